@@ -1,0 +1,45 @@
+"""Helpers to load tests/golden/*.npz (written by tools/make_golden.py from the real reference)."""
+import ast
+import os
+
+import numpy as np
+import torch
+
+from oracle import refil_oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["refil_tiny", "qmix_atten_tiny", "refil_abs_masked", "refil_odd", "refil_mid"]
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    case = ast.literal_eval(str(z["case"]))
+    cfg = orc.Cfg(
+        n_agents=case["na"], n_entities=case["ne"], n_actions=case["A"], entity_shape=case["ed"],
+        attn_embed_dim=case["d"], attn_n_heads=case["heads"], rnn_hidden_dim=case["H"],
+        hypernet_embed=case["h"], mixing_embed_dim=case["M"],
+        entity_last_action=case.get("entity_last_action", True),
+        softmax_mixing_weights=case.get("softmax_mixing_weights", True),
+        mixer_non_lin=case.get("mixer_non_lin", "elu"), imagine=case["imagine"],
+        double_q=case.get("double_q", True), lmbda=case.get("lmbda", 0.5),
+        grad_norm_clip=case.get("grad_norm_clip", 10),
+    )
+
+    def group(prefix):
+        return {k[len(prefix):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(prefix)}
+
+    return {
+        "z": z, "case": case, "cfg": cfg,
+        "batch": group("in."),
+        "agent": {k: v for k, v in group("agent0.").items() if "scale_factor" not in k},
+        "mixer": {k: v for k, v in group("mixer0.").items() if "scale_factor" not in k},
+        "tagent": {k: v for k, v in group("tagent.").items() if "scale_factor" not in k},
+        "tmixer": {k: v for k, v in group("tmixer.").items() if "scale_factor" not in k},
+        "bits": torch.from_numpy(z["group_bits"].copy()),
+    }
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()

@@ -1,0 +1,201 @@
+"""Generate tests/golden/*.npz by running the REAL reference learner (imported from /root/reference,
+which exists only in the build container) on seeded synthetic replay batches.
+
+The fixtures are plain arrays: inputs, initial weights (by state_dict name), the partition bits,
+and the reference's outputs (per-agent Q, chosen-action Q, q_tot, targets, loss, grads, post-step
+params, RMSprop square_avg). No reference source/bytecode is stored.
+
+Harness-side shim: the reference passes uint8 masks to masked_fill, which torch>=2 rejects
+(SURVEY.md section 8c); we cast to bool in a wrapper. No reference file is modified.
+
+Usage:  python tools/make_golden.py            (writes tests/golden/)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch as th
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+REF = "/root/reference/src"
+
+_orig_mf, _orig_mf_ = th.Tensor.masked_fill, th.Tensor.masked_fill_
+
+
+def _mf(self, mask, value):
+    return _orig_mf(self, mask.bool() if mask.dtype == th.uint8 else mask, value)
+
+
+def _mf_(self, mask, value):
+    return _orig_mf_(self, mask.bool() if mask.dtype == th.uint8 else mask, value)
+
+
+def import_reference():
+    th.Tensor.masked_fill, th.Tensor.masked_fill_ = _mf, _mf_
+    sys.path.insert(0, REF)
+    from learners import REGISTRY as le_REGISTRY          # noqa
+    from controllers import REGISTRY as mac_REGISTRY      # noqa
+    from components.episode_buffer import EpisodeBatch    # noqa
+    from components.transforms import OneHot              # noqa
+    return le_REGISTRY, mac_REGISTRY, EpisodeBatch, OneHot
+
+
+class _Logger:
+    def __init__(self):
+        self.stats = {}
+        self.console_logger = types.SimpleNamespace(info=lambda *a, **k: None)
+
+    def log_stat(self, key, value, t):
+        self.stats[key] = float(value)
+
+
+def ref_args(case):
+    a = types.SimpleNamespace(
+        agent="imagine_entity_attend_rnn" if case["imagine"] else "entity_attend_rnn",
+        mac="entity_mac", learner="q_learner", mixer="flex_qmix", agent_output_type="q",
+        action_selector="epsilon_greedy", epsilon_start=1.0, epsilon_finish=0.05, epsilon_anneal_time=500000,
+        n_agents=case["na"], n_actions=case["A"], n_entities=case["ne"], entity_shape=case["ed"],
+        entity_scheme=True, entity_last_action=case.get("entity_last_action", True), gt_mask_avail=False,
+        attn_embed_dim=case["d"], attn_n_heads=case["heads"], rnn_hidden_dim=case["H"],
+        hypernet_embed=case["h"], mixing_embed_dim=case["M"],
+        softmax_mixing_weights=case.get("softmax_mixing_weights", True), pooling_type=None,
+        double_q=case.get("double_q", True), gamma=0.99, lmbda=case.get("lmbda", 0.5), lr=0.0005, optim_alpha=0.99,
+        optim_eps=0.00001, weight_decay=0, grad_norm_clip=case.get("grad_norm_clip", 10),
+        target_update_interval=200, learner_log_interval=1,
+        train_gt_factors=False, train_rand_gt_factors=False, test_gt_factors=False, obs_last_action=False,
+        obs_agent_id=False, device="cpu",
+    )
+    if "mixer_non_lin" in case:
+        a.mixer_non_lin = case["mixer_non_lin"]
+    return a
+
+
+def run_case(name, case, out_dir):
+    from refil_amd.synthetic import make_batch
+    le_REGISTRY, mac_REGISTRY, EpisodeBatch, OneHot = import_reference()
+    args = ref_args(case)
+    B, T = case["B"], case["T"]
+    data = make_batch(B, T, case["ne"], seed=case["seed"], na=case["na"], A=case["A"], ed=case["ed"],
+                      min_active=case.get("min_active", 1), death_p=case.get("death_p", 0.05))
+    scheme = {
+        "entities": {"vshape": case["ed"], "group": "entities"},
+        "obs_mask": {"vshape": case["ne"], "group": "entities", "dtype": th.uint8},
+        "entity_mask": {"vshape": case["ne"], "dtype": th.uint8},
+        "actions": {"vshape": (1,), "group": "agents", "dtype": th.long},
+        "avail_actions": {"vshape": (case["A"],), "group": "agents", "dtype": th.int},
+        "reward": {"vshape": (1,)},
+        "terminated": {"vshape": (1,), "dtype": th.uint8},
+    }
+    groups = {"agents": case["na"], "entities": case["ne"]}
+    preprocess = {"actions": ("actions_onehot", [OneHot(out_dim=case["A"])])}
+    batch = EpisodeBatch(scheme, groups, B, T + 1, preprocess=preprocess, device="cpu")
+    for k, v in data.items():
+        batch.data.transition_data[k] = v.clone()
+    batch.data.transition_data["actions_onehot"] = OneHot(case["A"]).transform(data["actions"])
+
+    th.manual_seed(case["seed"] + 1000)
+    mac = mac_REGISTRY[args.mac](batch.scheme, groups, args)
+    logger = _Logger()
+    learner = le_REGISTRY[args.learner](mac, batch.scheme, logger, args)
+    # make the target nets differ from the live nets so the target path is really exercised
+    with th.no_grad():
+        for p in list(learner.target_mac.parameters()) + list(learner.target_mixer.parameters()):
+            p.add_(0.05 * th.randn_like(p))
+
+    rec = {}
+    for k, v in data.items():
+        rec["in." + k] = v.numpy()
+    for k, v in mac.agent.state_dict().items():
+        rec["agent0." + k] = v.numpy().copy()
+    for k, v in learner.mixer.state_dict().items():
+        rec["mixer0." + k] = v.numpy().copy()
+    for k, v in learner.target_mac.agent.state_dict().items():
+        rec["tagent." + k] = v.numpy().copy()
+    for k, v in learner.target_mixer.state_dict().items():
+        rec["tmixer." + k] = v.numpy().copy()
+
+    cap = {"mixer_calls": []}
+    mac.agent.register_forward_hook(lambda m, i, o: cap.__setitem__("agent_out", o))
+    learner.target_mac.agent.register_forward_hook(lambda m, i, o: cap.__setitem__("tagent_out", o))
+    learner.mixer.register_forward_hook(lambda m, i, o: cap["mixer_calls"].append((i, o)))
+    learner.target_mixer.register_forward_hook(lambda m, i, o: cap.__setitem__("tmixer", (i, o)))
+
+    # the partition draw = the first two calls on the default CPU generator inside train()
+    # (entity_rnn_agent.py:94-96); reproduce them from the same seed to store the bits.
+    draw_seed = case["seed"] + 7
+    th.manual_seed(draw_seed)
+    probs = th.rand(B, 1, 1).repeat(1, 1, case["ne"])
+    bits = th.bernoulli(probs).to(th.uint8).reshape(B, case["ne"])
+    th.manual_seed(draw_seed)
+    learner.train(batch, t_env=0, episode_num=0)
+
+    rec["group_bits"] = bits.numpy()
+    q_all = cap["agent_out"][0].detach()
+    G = 3 if case["imagine"] else 1
+    rec["q"] = q_all.reshape(G, B, T + 1, case["na"], case["A"]).numpy()
+    if case["imagine"]:
+        Wm = cap["agent_out"][2][0][:, 0]
+        inact = data["entity_mask"][:, 0].bool()
+        act_pair = (~inact)[:, :, None] & (~inact)[:, None, :]
+        same = act_pair & (bits.bool()[:, :, None] == bits.bool()[:, None, :])
+        assert th.equal(Wm.bool(), ~same), "stored partition bits do not reproduce the reference's W mask"
+        rec["Wmask_noobs"] = Wm.numpy()
+        rec["Imask_noobs"] = cap["agent_out"][2][1][:, 0].numpy()
+    rec["tq"] = cap["tagent_out"][0].detach().numpy()
+    (i0, o0) = cap["mixer_calls"][0]
+    rec["chosen_q_real"] = i0[0].detach().numpy()
+    rec["q_tot"] = o0.detach().numpy()
+    if case["imagine"]:
+        (i1, o1) = cap["mixer_calls"][1]
+        rec["chosen_q_imagine"] = i1[0].detach().numpy()
+        rec["q_tot_imagine"] = o1.detach().numpy()
+    rec["target_max_q"] = cap["tmixer"][0][0].detach().numpy()
+    rec["target_q_tot"] = cap["tmixer"][1].detach().numpy()
+    for k, v in logger.stats.items():
+        rec["stat." + k] = np.float64(v)
+    gn = logger.stats["grad_norm"]
+    coef = min(1.0, args.grad_norm_clip / (gn + 1e-6))
+    rec["clip_coef"] = np.float64(coef)
+    full = case.get("store_grads", True)
+    names = [("agent", k, p) for k, p in mac.agent.named_parameters()] + \
+            [("mixer", k, p) for k, p in learner.mixer.named_parameters()]
+    for which, k, p in names:
+        g = p.grad.detach() / coef          # p.grad was scaled in place by clip_grad_norm_
+        if full:
+            rec[f"grad.{which}.{k}"] = g.numpy()
+            rec[f"post.{which}.{k}"] = p.detach().numpy().copy()
+            rec[f"sq.{which}.{k}"] = learner.optimiser.state[p]["square_avg"].numpy().copy()
+        else:
+            rec[f"gradnorm.{which}.{k}"] = np.float64(g.double().norm().item())
+            rec[f"postsum.{which}.{k}"] = np.float64(p.detach().double().sum().item())
+    rec["case"] = np.array(repr(case))
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: loss={logger.stats['loss']:.6f} grad_norm={gn:.5f} clip_coef={coef:.4f} -> {path} "
+          f"({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+CASES = {
+    # tiny REFIL case: padded agents/enemies, deaths, softmax mixing weights
+    "refil_tiny": dict(imagine=True, B=3, T=5, ne=6, na=3, A=5, ed=9, d=16, heads=4, H=64, h=16, M=32, seed=11),
+    # qmix_atten (no imagination, G=1)
+    "qmix_atten_tiny": dict(imagine=False, B=3, T=4, ne=6, na=3, A=5, ed=9, d=16, heads=2, H=64, h=16, M=32, seed=12),
+    # abs mixing weights + heavy padding/deaths so fully-masked attention rows occur, clipping active
+    "refil_abs_masked": dict(imagine=True, B=4, T=6, ne=8, na=4, A=6, ed=11, d=16, heads=4, H=64, h=32, M=32,
+                             seed=13, softmax_mixing_weights=False, death_p=0.25, grad_norm_clip=0.05),
+    # odd sizes (ne not multiple of 4, na != ne/2, M != 32), no last-action input, no double-Q
+    "refil_odd": dict(imagine=True, B=2, T=3, ne=7, na=5, A=4, ed=10, d=24, heads=3, H=64, h=12, M=16, seed=14,
+                      entity_last_action=False, double_q=False, lmbda=0.3),
+    # mid-size, SC2 shape law (cfg-2-like entity sizes); weights stored, grads as per-tensor norms only
+    "refil_mid": dict(imagine=True, B=4, T=12, ne=16, na=8, A=14, ed=38, d=64, heads=4, H=64, h=64, M=32, seed=15,
+                      store_grads=False, min_active=3, death_p=0.02),
+}
+
+if __name__ == "__main__":
+    out = os.path.join(REPO, "tests", "golden")
+    only = sys.argv[1:] or list(CASES)
+    for nm in only:
+        run_case(nm, CASES[nm], out)
