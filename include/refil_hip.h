@@ -1,0 +1,266 @@
+/* refil_hip.h -- C ABI of the MI355X-native REFIL learner hot path (librefil_hip.so).
+ *
+ * The reference (shariqiqbal2810/REFIL) has no FFI: its hot path is the Python call
+ *     QLearner.train(batch, t_env, episode_num)            src/learners/q_learner.py:66-201
+ * issuing stock PyTorch ops. This library is what a native replacement of that call binds to:
+ * plain device pointers + sizes + a HIP stream, no torch types. Every entry point
+ *   - borrows (never owns) the caller's device memory,
+ *   - enqueues work on `stream` (a hipStream_t passed as void*; NULL = default stream) and returns
+ *     without synchronising,
+ *   - returns 0 on success, non-zero on error (message via refil_last_error(), thread-local).
+ * All floating-point data is fp32 (the reference's dtype); masks are uint8 {0,1} with 1 = masked /
+ * inactive; actions int64; avail_actions int32; filled int64 (src/run.py:178-192 scheme).
+ *
+ * Layout of this header:
+ *   1. problem dimensions + flat parameter layout
+ *   2. the learner step      (replaces q_learner.py:66-178)
+ *   3. MAC / mixer forwards  (replace basic_controller.py:28-67, flex_qmix.py:79-121)
+ *   4. building-block operators (exported for tests and for composing new paths)
+ */
+#ifndef REFIL_HIP_H
+#define REFIL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* 1. dimensions and parameter layout                                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Hyper-parameters the path reads from `args` (src/config/default.yaml:35-58, algs/refil.yaml:3-33;
+ * runtime-injected n_agents/n_actions/n_entities/entity_shape: src/run.py:152-176). */
+typedef struct refil_dims {
+    int32_t B;            /* episodes in the (per-rank) minibatch                                  */
+    int32_t T1;           /* stored timesteps = transitions + 1 (batch.max_seq_length)            */
+    int32_t ne;           /* n_entities (<= 64)                                                    */
+    int32_t na;           /* n_agents = first na entities                                          */
+    int32_t ed;           /* entity_shape (raw feature width)                                      */
+    int32_t A;            /* n_actions                                                             */
+    int32_t d;            /* attn_embed_dim (agent)                                                */
+    int32_t heads;        /* attn_n_heads                                                          */
+    int32_t H;            /* rnn_hidden_dim (must be 64)                                           */
+    int32_t hyp;          /* hypernet_embed                                                        */
+    int32_t M;            /* mixing_embed_dim (<= 64)                                              */
+    int32_t entity_last_action;      /* append one-hot previous action to agent entities          */
+    int32_t imagine;                 /* 1: REFIL ('imagine' in args.agent), 0: qmix_atten          */
+    int32_t softmax_mixing_weights;  /* 1: softmax, 0: abs      (flex_qmix.py:102-113)            */
+    int32_t mixer_tanh;              /* 0: elu, 1: tanh         (flex_qmix.py:75-77)              */
+    int32_t double_q;                /* q_learner.py:121-128                                       */
+    float gamma;
+    float lmbda;
+} refil_dims;
+
+/* Offsets (in floats) of every tensor inside the flat parameter buffer the library works on.
+ * One buffer holds the agent (EntityAttentionRNNAgent, entity_rnn_agent.py:8-25) followed by the
+ * FlexQMixer (flex_qmix.py:61-73). Mixer tensors of the four hypernets are stored net-major per
+ * field in the order hyper_w_1, hyper_w_final, hyper_b_1, V, so that field f of net n lives at
+ * mix_<f> + n * mix_<f>_stride and the four fc1 weights form one [4*hyp, E] matrix.
+ * Weights keep PyTorch's [out, in] row-major layout. */
+typedef struct refil_param_layout {
+    int64_t total;                    /* floats in the flat buffer (multiple of 4)                 */
+    int64_t agent_total;              /* floats of the agent part (mixer part starts here)         */
+    int64_t ag_fc1_w, ag_fc1_b, ag_in_w, ag_out_w, ag_out_b, ag_fc2_w, ag_fc2_b;
+    int64_t ag_w_ih, ag_w_hh, ag_b_ih, ag_b_hh, ag_fc3_w, ag_fc3_b;
+    int64_t mix_fc1_w, mix_fc1_b, mix_in_w, mix_out_w, mix_out_b, mix_fc2_w, mix_fc2_b;
+    int64_t mix_fc1_w_stride, mix_fc1_b_stride, mix_in_w_stride, mix_out_w_stride, mix_out_b_stride,
+            mix_fc2_w_stride, mix_fc2_b_stride;
+} refil_param_layout;
+
+int refil_get_param_layout(const refil_dims* dims, refil_param_layout* out);
+
+/* ------------------------------------------------------------------------------------------ */
+/* 2. learner step                                                                             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* One sampled replay minibatch = the EpisodeBatch fields QLearner.train reads
+ * (q_learner.py:68-73, entity_controller.py:11-30). Leading dims are [B, T1]; sB/sT are the strides
+ * (in ELEMENTS of that field) of those two dims, inner dims are contiguous -- so a time-truncated
+ * view batch[:, :max_t_filled] (run.py:269-270) can be passed without a copy. */
+typedef struct refil_batch {
+    const float*   entities;      int64_t ent_sB, ent_sT;     /* [B,T1,ne,ed]   */
+    const uint8_t* obs_mask;      int64_t om_sB, om_sT;       /* [B,T1,ne,ne]   */
+    const uint8_t* entity_mask;   int64_t em_sB, em_sT;       /* [B,T1,ne]      */
+    const int64_t* actions;       int64_t ac_sB, ac_sT;       /* [B,T1,na,1]    */
+    const int32_t* avail_actions; int64_t av_sB, av_sT;       /* [B,T1,na,A]    */
+    const float*   reward;        int64_t rw_sB, rw_sT;       /* [B,T1,1]       */
+    const uint8_t* terminated;    int64_t tm_sB, tm_sT;       /* [B,T1,1]       */
+    const int64_t* filled;        int64_t fl_sB, fl_sT;       /* [B,T1,1]       */
+    const uint8_t* group_bits;    /* [B,ne] the random 2-way entity split (entity_rnn_agent.py:94-96);
+                                     drawn by the host so that seeds reproduce the reference's masks.
+                                     Ignored when dims.imagine == 0. */
+} refil_batch;
+
+/* Scalars produced by a step, as a device array of REFIL_NSTAT floats (sums over this rank's shard,
+ * un-normalised, so that they can be all-reduced together with the gradients). */
+enum {
+    REFIL_STAT_MASK_SUM = 0,   /* sum(mask)                          q_learner.py:165 normaliser    */
+    REFIL_STAT_TD_SQ,          /* sum((mask*td)^2)                   -> q loss numerator            */
+    REFIL_STAT_IM_TD_SQ,       /* sum((mask*td_imagine)^2)           -> im_loss numerator           */
+    REFIL_STAT_TD_ABS,         /* sum(|mask*td|)                     q_learner.py:193               */
+    REFIL_STAT_QTOT_SUM,       /* sum(q_tot*mask)                    q_learner.py:194               */
+    REFIL_STAT_TARGET_SUM,     /* sum(targets*mask)                  q_learner.py:195               */
+    REFIL_STAT_GRAD_NORM,      /* written by refil_clip_rmsprop_step q_learner.py:177               */
+    REFIL_STAT_RESERVED,
+    REFIL_NSTAT
+};
+
+/* Optional copies of intermediates for parity tests (any pointer may be NULL). */
+typedef struct refil_debug_out {
+    float* q;              /* [G,B,T1,na,A] live per-agent Q (G = 3 if imagine else 1)             */
+    float* chosen_q;       /* [G,B,T,na]    Q of the taken actions (q_learner.py:91,109)           */
+    float* target_max_q;   /* [B,T,na]      (q_learner.py:121-128)                                 */
+    float* q_tot;          /* [B,T]                                                                */
+    float* q_tot_imagine;  /* [B,T]                                                                */
+    float* target_q_tot;   /* [B,T]                                                                */
+    float* targets;        /* [B,T]         (q_learner.py:157)                                     */
+} refil_debug_out;
+
+/* Bytes of scratch HBM refil_learner_forward_backward needs for `dims` (0 on invalid dims). */
+size_t refil_learner_workspace_bytes(const refil_dims* dims);
+
+/* Forward (live + target nets, mixers, TD loss) and the full hand-written backward.
+ * Replaces q_learner.py:66-176 (everything up to and including loss.backward()).
+ *   params_live / params_target : flat buffers laid out by refil_get_param_layout
+ *   grads  : [layout.total + REFIL_NSTAT] floats. grads[0:total] receives d(SUM-loss)/d(param),
+ *            i.e. the gradient of (1-lmbda)*sum(td^2) + lmbda*sum(td_im^2) WITHOUT the 1/sum(mask)
+ *            normaliser; grads[total:] receives the REFIL_STAT_* sums. Under data parallelism the
+ *            caller all-reduces (SUM) this one buffer; refil_clip_rmsprop_step then applies
+ *            1/sum(mask) -- exactly the reference's global-mean loss (q_learner.py:165,171). */
+int refil_learner_forward_backward(const refil_dims* dims, const refil_batch* batch,
+                                   const float* params_live, const float* params_target,
+                                   float* grads, void* workspace, size_t workspace_bytes,
+                                   const refil_debug_out* debug, void* stream);
+
+/* clip_grad_norm_ + RMSprop.step on the flat buffers (q_learner.py:37-38,177-178):
+ *   g = grads[0:n] / grads[n + REFIL_STAT_MASK_SUM];  norm = ||g||_2  (stored to grads[n+GRAD_NORM]);
+ *   g *= min(1, clip / (norm + 1e-6));  g += weight_decay * p;
+ *   sq = alpha*sq + (1-alpha)*g^2;  p -= lr * g / (sqrt(sq) + eps).
+ * scratch: >= 4096 bytes of device memory. */
+int refil_clip_rmsprop_step(float* params, const float* grads, float* square_avg, int64_t n,
+                            float lr, float alpha, float eps, float weight_decay, float grad_norm_clip,
+                            float* grads_stats, void* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* 3. forwards used outside the learner                                                        */
+/* ------------------------------------------------------------------------------------------ */
+
+/* BasicMAC.forward / EntityMAC._build_inputs / (Imagine)EntityAttentionRNNAgent.forward
+ * (basic_controller.py:28-67, entity_controller.py:11-30, entity_rnn_agent.py:31-64,87-126).
+ * Runs T1 = dims.T1 steps starting from hidden state h0.
+ *   prev_actions : actions of the step BEFORE each stored step: prev_actions[b,t] is the action whose
+ *                  one-hot is appended at step t; pass `actions` shifted by the caller, or set
+ *                  first_step_zero=1 to use actions[b,t-1] with zeros at t=0 (the t=None case).
+ *   h0    : [G,B,na,H] or NULL for zeros;   h_out : [G,B,na,H] final hidden state (may be NULL)
+ *   q_out : [G,B,T1,na,A] */
+size_t refil_agent_workspace_bytes(const refil_dims* dims);
+int refil_agent_forward(const refil_dims* dims, const refil_batch* batch, int32_t first_step_zero,
+                        const float* params, const float* h0, float* h_out, float* q_out,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* FlexQMixer.forward (flex_qmix.py:79-121) over steps [t0, t0+T) of the batch.
+ *   agent_qs [B,T,na]; agent_qs_imagine [B,T,2*na] or NULL; q_tot / q_tot_imagine [B,T]. */
+size_t refil_mixer_workspace_bytes(const refil_dims* dims);
+int refil_mixer_forward(const refil_dims* dims, const refil_batch* batch, int32_t t0, int32_t T,
+                        const float* params, const float* agent_qs, const float* agent_qs_imagine,
+                        float* q_tot, float* q_tot_imagine,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* 4. building-block operators                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+
+/* physical row of logical row r = (r / grp) * gstride + (r % grp) + off   (grp == 0: identity) */
+typedef struct refil_rowmap { int32_t grp, gstride, off; } refil_rowmap;
+
+enum {
+    REFIL_GEMM_RELU       = 1,   /* C = max(C, 0)                                                   */
+    REFIL_GEMM_RELU_BWD   = 2,   /* C *= (aux > 0), aux indexed like C                              */
+    REFIL_GEMM_ACCUM      = 4,   /* C += result                                                     */
+    REFIL_GEMM_A_OUTC     = 8,   /* A element (m,k) at A[k*lda + m] instead of A[m*lda + k]         */
+    REFIL_GEMM_B_OUTC     = 16,  /* B element (n,k) at B[k*ldb + n] instead of B[n*ldb + k]         */
+    REFIL_GEMM_COLSUM_A   = 32   /* also emit sum_k A(m,k) -> colsum[m] (bias gradients)            */
+};
+
+/* C[M,N] = epilogue( sum_k A(m,k) * B(n,k) ) on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+ * nn.Linear forward is A=x [rows,in], B=W [out,in]; dX = dY W uses B_OUTC; dW = dY^T X uses
+ * A_OUTC|B_OUTC with the row dimension as the reduction. `batch` independent problems are addressed
+ * with the s* strides. splits > 1 cuts the reduction into `splits` deterministic partial sums which a
+ * second kernel adds up (partials live in `partial`, >= batch*splits*M*N floats (+ batch*splits*M for colsum)). */
+typedef struct refil_gemm_desc {
+    const float* A; const float* B; float* C;
+    const float* bias;            /* [N] added to every row, or NULL                               */
+    const float* aux;             /* RELU_BWD source (same ld / rowmap as C), or NULL              */
+    const uint8_t* rowmask;       /* rowmask[r % rowmask_mod] != 0 -> row r of C is zeroed; or NULL */
+    float* colsum;                /* COLSUM_A output [M]                                           */
+    float* partial;               /* split-K scratch                                               */
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc;
+    int64_t sA, sB, sC, sBias, sColsum;   /* per-batch strides in floats                           */
+    refil_rowmap a_map, b_map, c_map;     /* applied to the MEMORY row index of A / B / C          */
+    int32_t rowmask_mod;
+    int32_t batch, splits, flags;
+} refil_gemm_desc;
+
+int refil_gemm(const refil_gemm_desc* desc, void* stream);
+
+/* pre-softmax mask variants of the entity attention (closed forms: SURVEY.md section 8a-5)           */
+enum {
+    REFIL_MASK_OBS = 0,        /* obs_mask[b,t,i,j]                           entity_rnn_agent.py:39-45 */
+    REFIL_MASK_OBS_WITHIN,     /* !same(i,j) | obs_mask                       entity_rnn_agent.py:116   */
+    REFIL_MASK_OBS_INTERACT,   /*  same(i,j) | obs_mask                       entity_rnn_agent.py:117   */
+    REFIL_MASK_ENTITY,         /* inactive_i(t) | inactive_j(t)               flex_qmix.py:43-46        */
+    REFIL_MASK_WITHIN,         /* !same(i,j)                                  entity_rnn_agent.py:111   */
+    REFIL_MASK_INTERACT        /*  same(i,j) | inactive0_i | inactive0_j      entity_rnn_agent.py:112   */
+};
+
+/* Multi-head masked attention core of EntityAttentionLayer (attention.py:48-64) for `nvar` mask
+ * variants sharing Q/K/V: logits = QK^T / sqrt(hd), mask -> -inf, softmax over entities, fully
+ * masked row -> 0, times V, heads merged. One (row, head) per workgroup. Backward recomputes the
+ * softmax and accumulates dQ/dK/dV over the variants. */
+typedef struct refil_attn_desc {
+    const float* Q;  int32_t ldq;          /* [R*na, >=w]   row r*na+i                             */
+    const float* K;  const float* V; int32_t ldkv;   /* [R*ne, ...] row r*ne+j                     */
+    float* O;        int64_t sO;  int32_t ldo;       /* variant v at O + v*sO, [R*na, w]           */
+    const float* dO;                                  /* backward: same layout as O                */
+    float* dQ; float* dK; float* dV;                  /* backward outputs, same layouts as Q/K/V   */
+    int32_t R, T1, ne, na, heads, hd;                 /* row r -> episode b = r / T1               */
+    int32_t nvar; int32_t var[3];
+    const uint8_t* obs_mask; int64_t om_sB, om_sT;    /* [B,T1,ne,ne]                              */
+    const uint8_t* ent_mask;                          /* contiguous [R,ne]                         */
+    const uint8_t* ent_mask0;                         /* [B,ne] entity_mask at t=0                 */
+    const uint8_t* group_bits;                        /* [B,ne]                                    */
+} refil_attn_desc;
+
+int refil_attn_forward(const refil_attn_desc* desc, void* stream);
+int refil_attn_backward(const refil_attn_desc* desc, void* stream);
+
+/* nn.GRUCell unrolled over T1 steps (entity_rnn_agent.py:49-55) as ONE persistent kernel per
+ * 16-row tile, W_hh fragments resident in registers. Logical row r in [0,NR) = (gb, i) with
+ * gb = r / na; time-major storage inside each gb:
+ *   gi   [(gb*T1 + t)*na + i, 3H]   = x_t W_ih^T + b_ih (precomputed by refil_gemm)
+ *   hsx  [(gb*(T1+1) + t)*na + i, H]  slot 0 = h0 (read), slot t+1 = h_t (written)
+ *   save_r/z/n/ghn [(gb*T1+t)*na+i, H] gates kept for the backward (NULL: inference)            */
+typedef struct refil_gru_desc {
+    const float* gi; float* hsx;
+    const float* w_hh; const float* b_hh;
+    float* save_r; float* save_z; float* save_n; float* save_ghn;
+    /* backward */
+    const float* dhs;        /* [(gb*T1+t)*na+i, H] external gradient on h_t (from fc3)           */
+    float* dgi; float* dgh;  /* [(gb*T1+t)*na+i, 3H] outputs                                      */
+    int32_t NR, T1, na, H;
+} refil_gru_desc;
+
+int refil_gru_forward(const refil_gru_desc* desc, void* stream);
+int refil_gru_backward(const refil_gru_desc* desc, void* stream);
+
+const char* refil_last_error(void);
+int refil_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REFIL_HIP_H */

@@ -1,0 +1,188 @@
+"""ctypes binding of librefil_hip.so (C ABI declared in include/refil_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, a RuntimeError is
+raised. PyTorch is used by the callers only to own device memory and streams; everything crossing
+this boundary is a raw pointer, a size or a plain C struct.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librefil_hip.so")
+
+REFIL_NSTAT = 8
+STAT_MASK_SUM, STAT_TD_SQ, STAT_IM_TD_SQ, STAT_TD_ABS, STAT_QTOT_SUM, STAT_TARGET_SUM, STAT_GRAD_NORM = range(7)
+
+GEMM_RELU, GEMM_RELU_BWD, GEMM_ACCUM, GEMM_A_OUTC, GEMM_B_OUTC, GEMM_COLSUM_A = 1, 2, 4, 8, 16, 32
+MASK_OBS, MASK_OBS_WITHIN, MASK_OBS_INTERACT, MASK_ENTITY, MASK_WITHIN, MASK_INTERACT = range(6)
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "B", "T1", "ne", "na", "ed", "A", "d", "heads", "H", "hyp", "M", "entity_last_action", "imagine",
+        "softmax_mixing_weights", "mixer_tanh", "double_q")] + [("gamma", C.c_float), ("lmbda", C.c_float)]
+
+
+class ParamLayout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "total", "agent_total",
+        "ag_fc1_w", "ag_fc1_b", "ag_in_w", "ag_out_w", "ag_out_b", "ag_fc2_w", "ag_fc2_b",
+        "ag_w_ih", "ag_w_hh", "ag_b_ih", "ag_b_hh", "ag_fc3_w", "ag_fc3_b",
+        "mix_fc1_w", "mix_fc1_b", "mix_in_w", "mix_out_w", "mix_out_b", "mix_fc2_w", "mix_fc2_b",
+        "mix_fc1_w_stride", "mix_fc1_b_stride", "mix_in_w_stride", "mix_out_w_stride", "mix_out_b_stride",
+        "mix_fc2_w_stride", "mix_fc2_b_stride")]
+
+
+class Batch(C.Structure):
+    _fields_ = [
+        ("entities", C.c_void_p), ("ent_sB", C.c_int64), ("ent_sT", C.c_int64),
+        ("obs_mask", C.c_void_p), ("om_sB", C.c_int64), ("om_sT", C.c_int64),
+        ("entity_mask", C.c_void_p), ("em_sB", C.c_int64), ("em_sT", C.c_int64),
+        ("actions", C.c_void_p), ("ac_sB", C.c_int64), ("ac_sT", C.c_int64),
+        ("avail_actions", C.c_void_p), ("av_sB", C.c_int64), ("av_sT", C.c_int64),
+        ("reward", C.c_void_p), ("rw_sB", C.c_int64), ("rw_sT", C.c_int64),
+        ("terminated", C.c_void_p), ("tm_sB", C.c_int64), ("tm_sT", C.c_int64),
+        ("filled", C.c_void_p), ("fl_sB", C.c_int64), ("fl_sT", C.c_int64),
+        ("group_bits", C.c_void_p),
+    ]
+
+
+class DebugOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "q", "chosen_q", "target_max_q", "q_tot", "q_tot_imagine", "target_q_tot", "targets")]
+
+
+class RowMap(C.Structure):
+    _fields_ = [("grp", C.c_int32), ("gstride", C.c_int32), ("off", C.c_int32)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("aux", C.c_void_p),
+        ("rowmask", C.c_void_p), ("colsum", C.c_void_p), ("partial", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+        ("sA", C.c_int64), ("sB", C.c_int64), ("sC", C.c_int64), ("sBias", C.c_int64), ("sColsum", C.c_int64),
+        ("a_map", RowMap), ("b_map", RowMap), ("c_map", RowMap),
+        ("rowmask_mod", C.c_int32), ("batch", C.c_int32), ("splits", C.c_int32), ("flags", C.c_int32),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("Q", C.c_void_p), ("ldq", C.c_int32),
+        ("K", C.c_void_p), ("V", C.c_void_p), ("ldkv", C.c_int32),
+        ("O", C.c_void_p), ("sO", C.c_int64), ("ldo", C.c_int32),
+        ("dO", C.c_void_p), ("dQ", C.c_void_p), ("dK", C.c_void_p), ("dV", C.c_void_p),
+        ("R", C.c_int32), ("T1", C.c_int32), ("ne", C.c_int32), ("na", C.c_int32), ("heads", C.c_int32), ("hd", C.c_int32),
+        ("nvar", C.c_int32), ("var", C.c_int32 * 3),
+        ("obs_mask", C.c_void_p), ("om_sB", C.c_int64), ("om_sT", C.c_int64),
+        ("ent_mask", C.c_void_p), ("ent_mask0", C.c_void_p), ("group_bits", C.c_void_p),
+    ]
+
+
+class GruDesc(C.Structure):
+    _fields_ = [
+        ("gi", C.c_void_p), ("hsx", C.c_void_p), ("w_hh", C.c_void_p), ("b_hh", C.c_void_p),
+        ("save_r", C.c_void_p), ("save_z", C.c_void_p), ("save_n", C.c_void_p), ("save_ghn", C.c_void_p),
+        ("dhs", C.c_void_p), ("dgi", C.c_void_p), ("dgh", C.c_void_p),
+        ("NR", C.c_int32), ("T1", C.c_int32), ("na", C.c_int32), ("H", C.c_int32),
+    ]
+
+
+# every symbol include/refil_hip.h declares (tests/test_abi.py checks the library exports them all)
+EXPORTS = [
+    "refil_get_param_layout", "refil_learner_workspace_bytes", "refil_learner_forward_backward",
+    "refil_clip_rmsprop_step", "refil_agent_workspace_bytes", "refil_agent_forward",
+    "refil_mixer_workspace_bytes", "refil_mixer_forward", "refil_gemm", "refil_attn_forward",
+    "refil_attn_backward", "refil_gru_forward", "refil_gru_backward", "refil_last_error", "refil_version",
+]
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle. Raises if the HIP library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -m refil_amd.build` (hipcc, gfx950). "
+            "refil_amd has no CPU/PyTorch fallback for the learner hot path.")
+    L = C.CDLL(LIB_PATH)
+    L.refil_last_error.restype = C.c_char_p
+    L.refil_version.restype = C.c_int
+    for name in ("refil_learner_workspace_bytes", "refil_agent_workspace_bytes", "refil_mixer_workspace_bytes"):
+        getattr(L, name).restype = C.c_size_t
+        getattr(L, name).argtypes = [C.POINTER(Dims)]
+    L.refil_get_param_layout.argtypes = [C.POINTER(Dims), C.POINTER(ParamLayout)]
+    L.refil_learner_forward_backward.argtypes = [
+        C.POINTER(Dims), C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+        C.POINTER(DebugOut), C.c_void_p]
+    L.refil_clip_rmsprop_step.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+        C.c_void_p, C.c_void_p, C.c_void_p]
+    L.refil_agent_forward.argtypes = [
+        C.POINTER(Dims), C.POINTER(Batch), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_size_t, C.c_void_p]
+    L.refil_mixer_forward.argtypes = [
+        C.POINTER(Dims), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.refil_gemm.argtypes = [C.POINTER(GemmDesc), C.c_void_p]
+    L.refil_attn_forward.argtypes = [C.POINTER(AttnDesc), C.c_void_p]
+    L.refil_attn_backward.argtypes = [C.POINTER(AttnDesc), C.c_void_p]
+    L.refil_gru_forward.argtypes = [C.POINTER(GruDesc), C.c_void_p]
+    L.refil_gru_backward.argtypes = [C.POINTER(GruDesc), C.c_void_p]
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {lib().refil_last_error().decode()}")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor, None -> NULL."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_dims(**kw) -> Dims:
+    d = Dims()
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d
+
+
+def param_layout(dims: Dims) -> ParamLayout:
+    out = ParamLayout()
+    check(lib().refil_get_param_layout(C.byref(dims), C.byref(out)), "refil_get_param_layout")
+    return out
+
+
+def make_batch(fields: dict, group_bits=None) -> Batch:
+    """fields: name -> tensor [B,T1,...] (any batch/time strides, inner dims contiguous)."""
+    b = Batch()
+    names = {"entities": "ent", "obs_mask": "om", "entity_mask": "em", "actions": "ac", "avail_actions": "av",
+             "reward": "rw", "terminated": "tm", "filled": "fl"}
+    for name, short in names.items():
+        t = fields.get(name)
+        if t is None:
+            continue
+        inner = t[0, 0]
+        if not inner.is_contiguous():
+            raise ValueError(f"batch field {name}: inner dims must be contiguous")
+        setattr(b, name, t.data_ptr())
+        setattr(b, short + "_sB", t.stride(0))
+        setattr(b, short + "_sT", t.stride(1))
+    if group_bits is not None:
+        b.group_bits = group_bits.data_ptr()
+    return b

@@ -1,0 +1,56 @@
+// Shared device/host helpers for the REFIL gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+namespace refil {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WAVE = 64;
+
+// thread-local error string returned by refil_last_error()
+void set_error(const char* fmt, ...);
+
+#define REFIL_CHECK(cond, ...)                    \
+    do {                                          \
+        if (!(cond)) {                            \
+            refil::set_error(__VA_ARGS__);        \
+            return 1;                             \
+        }                                         \
+    } while (0)
+
+#define REFIL_HIP(call)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            refil::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return 2;                                                                     \
+        }                                                                                 \
+    } while (0)
+
+#define REFIL_LAUNCH_CHECK()                                                              \
+    do {                                                                                  \
+        hipError_t e_ = hipGetLastError();                                                \
+        if (e_ != hipSuccess) {                                                           \
+            refil::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return 2;                                                                     \
+        }                                                                                 \
+    } while (0)
+
+__host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ inline long cdivl(long a, long b) { return (a + b - 1) / b; }
+
+// physical memory row of logical row r:  (r / grp) * gstride + (r % grp) + off   (grp == 0: identity)
+struct RowMap {
+    int grp, gstride, off;
+    __host__ __device__ inline long operator()(int r) const {
+        return grp ? (long)(r / grp) * gstride + (r % grp) + off : (long)r;
+    }
+};
+
+__device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+}  // namespace refil

@@ -1,0 +1,305 @@
+// fp32 matrix-core GEMM for the REFIL projections (nn.Linear forward, dX, dW) on gfx950.
+//
+//   C[M,N] = epilogue( sum_k A(m,k) * B(n,k) )
+//
+// * v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD): 4 waves per workgroup, each wave owns a
+//   (32*TM) x (32*TN) block of C in accumulator VGPRs.
+// * K is consumed in tiles of 32 staged through LDS. An operand whose reduction index is contiguous
+//   in memory ("RED": x [rows,in], W [out,in]) is stored [out][32+4] and read with one ds_read_b128
+//   per 4 MFMAs (conflict-free: 36*r mod 64 is a bijection on r mod 16); an operand whose OUTPUT
+//   index is contiguous ("OUTC": W in dX = dY W, both operands of dW = dY^T X) is stored
+//   [32][out+4] and read with conflict-free ds_read_b32. The MFMA k order is permuted identically
+//   for A and B (virtual k of MFMA j in group g, lane half hf  ->  k = 8g + 4hf + j).
+// * global loads are 16 B per lane and coalesced along whichever index is contiguous; the next
+//   K tile is prefetched into registers while the current one is multiplied.
+// * the reduction can be split across workgroups (dW: reduction = rows, tens of thousands) into
+//   deterministic partial sums that reduce_partials_kernel adds up -- no atomics, bit-reproducible.
+//
+// Replaces the implicit aten::mm / addmm calls of the reference.
+#include "common.h"
+#include "../../include/refil_hip.h"
+
+namespace refil {
+
+struct GemmK {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* aux; const uint8_t* rowmask; float* colsum; float* partial;
+    int M, N, K, lda, ldb, ldc;
+    long sA, sB, sC, sBias, sColsum;
+    RowMap amap, bmap, cmap;
+    int rowmask_mod, batch, splits, flags;
+    int vecA, vecB;   // 16-byte global loads legal for this operand
+};
+
+constexpr int BK = 32;
+constexpr int PITCH_RED = BK + 4;   // floats
+
+template <int ROWS, bool OUTC>
+struct Tile {
+    static constexpr int NV = ROWS * BK / 4 / 256;           // float4 per thread
+    static constexpr int PITCH = OUTC ? ROWS + 4 : PITCH_RED;
+    static constexpr int FLOATS = OUTC ? BK * (ROWS + 4) : ROWS * PITCH_RED;
+
+    // global -> registers. `o0` first output index of the tile, `k0` first reduction index,
+    // OUT/kend bounds. Element (o,k) lives at base[map(o)*ld + k] (RED) or base[map(k)*ld + o] (OUTC).
+    __device__ static inline void load(float4 (&v)[NV], const float* __restrict__ base, int ld, const RowMap& map,
+                                       int o0, int OUT, int k0, int kend, int vec, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + i * 256;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!OUTC) {
+                const int row = f >> 3, c4 = f & 7;
+                const int o = o0 + row, k = k0 + c4 * 4;
+                if (o < OUT && k < kend) {
+                    const float* p = base + map(o) * (long)ld + k;
+                    if (vec && k + 3 < kend) {
+                        r = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        r.x = p[0];
+                        if (k + 1 < kend) r.y = p[1];
+                        if (k + 2 < kend) r.z = p[2];
+                        if (k + 3 < kend) r.w = p[3];
+                    }
+                }
+            } else {
+                constexpr int O4 = ROWS / 4;
+                const int red = f / O4, o4 = f % O4;
+                const int k = k0 + red, o = o0 + o4 * 4;
+                if (k < kend && o < OUT) {
+                    const float* p = base + map(k) * (long)ld + o;
+                    if (vec && o + 3 < OUT) {
+                        r = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        r.x = p[0];
+                        if (o + 1 < OUT) r.y = p[1];
+                        if (o + 2 < OUT) r.z = p[2];
+                        if (o + 3 < OUT) r.w = p[3];
+                    }
+                }
+            }
+            v[i] = r;
+        }
+    }
+
+    __device__ static inline void store(const float4 (&v)[NV], float* lds, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + i * 256;
+            if (!OUTC) {
+                const int row = f >> 3, c4 = f & 7;
+                *reinterpret_cast<float4*>(lds + row * PITCH_RED + c4 * 4) = v[i];
+            } else {
+                constexpr int O4 = ROWS / 4;
+                const int red = f / O4, o4 = f % O4;
+                *reinterpret_cast<float4*>(lds + red * (ROWS + 4) + o4 * 4) = v[i];
+            }
+        }
+    }
+
+    // the 4 operand values of k-group g for the 32 outputs starting at `ob` (lane = l&31, half = l>>5)
+    __device__ static inline float4 frag(const float* lds, int ob, int g, int lane31, int hf) {
+        if (!OUTC) {
+            return *reinterpret_cast<const float4*>(lds + (ob + lane31) * PITCH_RED + g * 8 + hf * 4);
+        } else {
+            const float* p = lds + (g * 8 + hf * 4) * (ROWS + 4) + ob + lane31;
+            return make_float4(p[0], p[ROWS + 4], p[2 * (ROWS + 4)], p[3 * (ROWS + 4)]);
+        }
+    }
+};
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_OUTC, bool B_OUTC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
+    constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
+    using TA = Tile<BM, A_OUTC>;
+    using TB = Tile<BN, B_OUTC>;
+    __shared__ __attribute__((aligned(16))) float lds[TA::FLOATS + TB::FLOATS];
+    float* As = lds;
+    float* Bs = lds + TA::FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lane31 = lane & 31, hf = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int bz = blockIdx.z / p.splits, sp = blockIdx.z % p.splits;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    const float* A = p.A + bz * p.sA;
+    const float* B = p.B + bz * p.sB;
+
+    const int kchunk = cdiv(cdiv(p.K, p.splits), BK) * BK;
+    const int kbeg = sp * kchunk;
+    const int kend = min(p.K, kbeg + kchunk);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float csum = 0.f;
+    const bool do_colsum = (p.flags & REFIL_GEMM_COLSUM_A) && blockIdx.x == 0;
+
+    float4 va[TA::NV], vb[TB::NV];
+    if (kbeg < kend) {
+        TA::load(va, A, p.lda, p.amap, m0, p.M, kbeg, kend, p.vecA, tid);
+        TB::load(vb, B, p.ldb, p.bmap, n0, p.N, kbeg, kend, p.vecB, tid);
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        TA::store(va, As, tid);
+        TB::store(vb, Bs, tid);
+        __syncthreads();
+        if (k0 + BK < kend) {
+            TA::load(va, A, p.lda, p.amap, m0, p.M, k0 + BK, kend, p.vecA, tid);
+            TB::load(vb, B, p.ldb, p.bmap, n0, p.N, k0 + BK, kend, p.vecB, tid);
+        }
+        if (do_colsum && tid < BM) {
+            float s = 0.f;
+            if (A_OUTC) {
+#pragma unroll 8
+                for (int k = 0; k < BK; ++k) s += As[k * (BM + 4) + tid];
+            } else {
+#pragma unroll 8
+                for (int k = 0; k < BK; ++k) s += As[tid * PITCH_RED + k];
+            }
+            csum += s;
+        }
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = TA::frag(As, (wm * TM + i) * 32, g, lane31, hf);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = TB::frag(Bs, (wn * TN + j) * 32, g, lane31, hf);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    const bool split = p.splits > 1;
+    if (do_colsum && tid < BM && m0 + tid < p.M) {
+        if (split) p.partial[(long)p.batch * p.splits * p.M * p.N + ((long)bz * p.splits + sp) * p.M + m0 + tid] = csum;
+        else p.colsum[bz * p.sColsum + m0 + tid] = csum;
+    }
+    float* Cb = split ? p.partial + ((long)bz * p.splits + sp) * p.M * p.N : p.C + bz * p.sC;
+    const float* bias = (!split && p.bias) ? p.bias + bz * p.sBias : nullptr;
+    const float* aux = (!split && p.aux) ? p.aux + bz * p.sC : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + lane31;
+            if (n >= p.N) continue;
+            const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r];
+                if (split) {
+                    Cb[(long)m * p.N + n] = v;
+                    continue;
+                }
+                const long off = p.cmap(m) * (long)p.ldc + n;
+                v += bv;
+                if (p.flags & REFIL_GEMM_RELU) v = fmaxf(v, 0.f);
+                if (p.flags & REFIL_GEMM_RELU_BWD) v = aux[off] > 0.f ? v : 0.f;
+                if (p.rowmask && p.rowmask[m % p.rowmask_mod]) v = 0.f;
+                if (p.flags & REFIL_GEMM_ACCUM) v += Cb[off];
+                Cb[off] = v;
+            }
+        }
+    }
+}
+
+// sum the split partials; applies the (bias/accum-free) epilogue for split GEMMs: plain store or +=.
+__global__ void reduce_partials_kernel(GemmK p) {
+    const long total = (long)p.batch * p.M * p.N;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int b = idx / ((long)p.M * p.N);
+        const long rem = idx - (long)b * p.M * p.N;
+        const int m = rem / p.N, n = rem % p.N;
+        const float* src = p.partial + ((long)b * p.splits * p.M + m) * p.N + n;
+        float s = 0.f;
+        for (int sp = 0; sp < p.splits; ++sp) s += src[(long)sp * p.M * p.N];
+        float* dst = p.C + b * p.sC + p.cmap(m) * (long)p.ldc + n;
+        if (p.flags & REFIL_GEMM_ACCUM) s += *dst;
+        *dst = s;
+    }
+    if (p.flags & REFIL_GEMM_COLSUM_A) {
+        const long tot2 = (long)p.batch * p.M;
+        const float* cs = p.partial + (long)p.batch * p.splits * p.M * p.N;
+        for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < tot2; idx += stride) {
+            const int b = idx / p.M, m = idx % p.M;
+            float s = 0.f;
+            for (int sp = 0; sp < p.splits; ++sp) s += cs[((long)b * p.splits + sp) * p.M + m];
+            p.colsum[b * p.sColsum + m] = s;
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+static void launch_cfg(const GemmK& k, hipStream_t st) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    dim3 grid(cdiv(k.N, BN), cdiv(k.M, BM), k.batch * k.splits);
+    const bool ao = k.flags & REFIL_GEMM_A_OUTC, bo = k.flags & REFIL_GEMM_B_OUTC;
+    if (!ao && !bo) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, false, false>), grid, dim3(256), 0, st, k);
+    else if (!ao && bo) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, false, true>), grid, dim3(256), 0, st, k);
+    else if (ao && bo) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, true, true>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, true, false>), grid, dim3(256), 0, st, k);
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
+    REFIL_CHECK(d.A && d.B && d.C, "refil_gemm: null operand");
+    REFIL_CHECK(d.M > 0 && d.N > 0 && d.K > 0, "refil_gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
+    REFIL_CHECK(d.batch >= 1 && d.splits >= 1, "refil_gemm: batch/splits must be >= 1");
+    REFIL_CHECK(d.splits == 1 || d.partial, "refil_gemm: splits > 1 needs a partial buffer");
+    REFIL_CHECK(d.splits == 1 || !(d.flags & (REFIL_GEMM_RELU | REFIL_GEMM_RELU_BWD)) , "refil_gemm: split GEMM has no activation epilogue");
+    REFIL_CHECK(d.splits == 1 || (!d.bias && !d.rowmask), "refil_gemm: split GEMM supports no bias / rowmask");
+    REFIL_CHECK(!(d.flags & REFIL_GEMM_RELU_BWD) || d.aux, "refil_gemm: RELU_BWD needs aux");
+    REFIL_CHECK(!(d.flags & REFIL_GEMM_COLSUM_A) || d.colsum, "refil_gemm: COLSUM_A needs colsum");
+    REFIL_CHECK(!d.rowmask || d.rowmask_mod > 0, "refil_gemm: rowmask_mod must be > 0");
+    GemmK k;
+    k.A = d.A; k.B = d.B; k.C = d.C; k.bias = d.bias; k.aux = d.aux; k.rowmask = d.rowmask;
+    k.colsum = d.colsum; k.partial = d.partial;
+    k.M = d.M; k.N = d.N; k.K = d.K; k.lda = d.lda; k.ldb = d.ldb; k.ldc = d.ldc;
+    k.sA = d.sA; k.sB = d.sB; k.sC = d.sC; k.sBias = d.sBias; k.sColsum = d.sColsum;
+    k.amap = RowMap{d.a_map.grp, d.a_map.gstride, d.a_map.off};
+    k.bmap = RowMap{d.b_map.grp, d.b_map.gstride, d.b_map.off};
+    k.cmap = RowMap{d.c_map.grp, d.c_map.gstride, d.c_map.off};
+    k.rowmask_mod = d.rowmask_mod; k.batch = d.batch; k.splits = d.splits; k.flags = d.flags;
+    k.vecA = aligned16(d.A) && (d.lda % 4 == 0) && (d.sA % 4 == 0);
+    k.vecB = aligned16(d.B) && (d.ldb % 4 == 0) && (d.sB % 4 == 0);
+    if (d.N > 64) launch_cfg<2, 2, 2, 2>(k, st);
+    else if (d.N > 32) launch_cfg<4, 1, 1, 2>(k, st);
+    else launch_cfg<4, 1, 1, 1>(k, st);
+    REFIL_LAUNCH_CHECK();
+    if (d.splits > 1) {
+        const long total = (long)d.batch * d.M * d.N;
+        const int blocks = (int)min((long)2048, cdivl(total, 256));
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, k);
+        REFIL_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // namespace refil
+
+extern "C" int refil_gemm(const refil_gemm_desc* desc, void* stream) {
+    REFIL_CHECK(desc, "refil_gemm: null desc");
+    return refil::gemm_launch(*desc, (hipStream_t)stream);
+}

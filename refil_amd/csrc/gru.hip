@@ -1,0 +1,249 @@
+// Persistent GRU (nn.GRUCell unrolled over the episode) forward + BPTT for gfx950.
+//
+// Restates the hot loop of EntityAttentionRNNAgent.forward (reference:
+// src/modules/agents/entity_rnn_agent.py:49-55): T1 dependent GRUCell steps on [G*B*na, H] rows.
+// The reference issues 81 cell launches forward (+81 backward); here ONE kernel walks all steps:
+//
+//  * rows are independent, so a workgroup (4 waves) owns a tile of 16 rows for the whole episode --
+//    no grid sync. The input projection x_t W_ih^T + b_ih for ALL steps is one big GEMM done
+//    beforehand (refil_gemm); only the recurrent h W_hh^T stays in the loop.
+//  * per step each wave computes a 16x16 block of each gate with v_mfma_f32_16x16x4_f32: wave w owns
+//    hidden columns [16w,16w+16) of r, z and n, so the gate math for a column is lane-local.
+//    Its 3x16 B-fragments of W_hh (48 VGPRs) are loaded ONCE and stay in registers for all T1 steps;
+//    backward keeps the 48 fragments of W_hh^T the same way.
+//  * the new hidden tile is exchanged between the 4 waves through a double-buffered 16x64 LDS tile
+//    (pitch 66 floats: the strided ds_read_b32 A-fragment reads are conflict-free) -- one barrier
+//    per step.
+//  * gi (forward) / saved gates (backward) of step t+1 are prefetched into registers while step t
+//    is in the matrix pipe.
+//
+// MFMA fragment maps (v_mfma_f32_16x16x4_f32): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
+// D[row=4*(l>>4)+reg][col=l&15]. The k order is permuted (k = 4s + (l>>4)) identically for A and B.
+#include "common.h"
+#include "../../include/refil_hip.h"
+
+namespace refil {
+
+constexpr int GH = 64;        // hidden size (rnn_hidden_dim of every shipped config)
+constexpr int GROWS = 16;     // rows per workgroup
+constexpr int HP = GH + 2;    // LDS pitch of the h tile
+constexpr int GP = 3 * GH + 2;  // LDS pitch of the dgh tile
+
+struct GruK {
+    const float* gi; float* hsx; const float* w_hh; const float* b_hh;
+    float* save_r; float* save_z; float* save_n; float* save_ghn;
+    const float* dhs; float* dgi; float* dgh;
+    int NR, T1, na;
+};
+
+template <bool SAVE>
+__global__ __launch_bounds__(256) void gru_fwd_kernel(GruK p) {
+    __shared__ float hbuf[2][GROWS * HP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, c16 = lane & 15;
+    const int c = wave * 16 + c16;           // hidden column owned by this lane
+    const int r0 = blockIdx.x * GROWS;
+
+    // W_hh fragments: bw[g][s] = W_hh[g*64 + c][4s + q]
+    float bw[3][16];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) bw[g][s] = p.w_hh[(long)(g * GH + c) * GH + 4 * s + q];
+    const float bhr = p.b_hh[c], bhz = p.b_hh[GH + c], bhn = p.b_hh[2 * GH + c];
+
+    long gi_base[4], hs_base[4];
+    bool valid[4];
+    float hold[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int rr = r0 + 4 * q + reg;
+        valid[reg] = rr < p.NR;
+        const int gb = valid[reg] ? rr / p.na : 0, i = valid[reg] ? rr % p.na : 0;
+        gi_base[reg] = (long)gb * p.T1 * p.na + i;
+        hs_base[reg] = (long)gb * (p.T1 + 1) * p.na + i;
+        hold[reg] = valid[reg] ? p.hsx[hs_base[reg] * GH + c] : 0.f;
+        hbuf[0][(4 * q + reg) * HP + c] = hold[reg];
+    }
+    float gcur[4][3], gnext[4][3];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+            gcur[reg][g] = valid[reg] ? p.gi[gi_base[reg] * (3 * GH) + g * GH + c] : 0.f;
+    __syncthreads();
+
+    for (int t = 0; t < p.T1; ++t) {
+        const float* hb = hbuf[t & 1];
+        float* hn = hbuf[(t + 1) & 1];
+        if (t + 1 < p.T1) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    gnext[reg][g] = valid[reg] ? p.gi[(gi_base[reg] + (long)(t + 1) * p.na) * (3 * GH) + g * GH + c] : 0.f;
+        }
+        float a[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) a[s] = hb[c16 * HP + 4 * s + q];
+        f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[0][s], ar, 0, 0, 0);
+            az = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[1][s], az, 0, 0, 0);
+            an = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[2][s], an, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float rg = sigmoidf_(gcur[reg][0] + ar[reg] + bhr);
+            const float zg = sigmoidf_(gcur[reg][1] + az[reg] + bhz);
+            const float ghn = an[reg] + bhn;
+            const float ng = tanhf(gcur[reg][2] + rg * ghn);
+            const float hnew = (1.0f - zg) * ng + zg * hold[reg];
+            hold[reg] = hnew;
+            hn[(4 * q + reg) * HP + c] = hnew;
+            if (valid[reg]) {
+                p.hsx[(hs_base[reg] + (long)(t + 1) * p.na) * GH + c] = hnew;
+                if (SAVE) {
+                    const long o = (gi_base[reg] + (long)t * p.na) * GH + c;
+                    p.save_r[o] = rg; p.save_z[o] = zg; p.save_n[o] = ng; p.save_ghn[o] = ghn;
+                }
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gcur[reg][g] = gnext[reg][g];
+        __syncthreads();
+    }
+}
+
+// BPTT. For t = T1-1 .. 0:
+//   dh = carry + dhs[t];  dn = dh (1-z);  dz = dh (h_{t-1} - n);  carry' = dh z
+//   dn_pre = dn (1-n^2);  dr = dn_pre ghn;  dgh_n = dn_pre r
+//   dr_pre = dr r (1-r);  dz_pre = dz z (1-z)
+//   dgi[t] = (dr_pre, dz_pre, dn_pre);  dgh[t] = (dr_pre, dz_pre, dgh_n);  carry' += dgh[t] W_hh
+__global__ __launch_bounds__(256) void gru_bwd_kernel(GruK p) {
+    __shared__ float gbuf[2][GROWS * GP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, c16 = lane & 15;
+    const int c = wave * 16 + c16;
+    const int r0 = blockIdx.x * GROWS;
+
+    // W_hh^T fragments: carry[row][c] += sum_k dgh[row][k] W_hh[k][c];  bw[s] = W_hh[4s+q][c]
+    float bw[48];
+#pragma unroll
+    for (int s = 0; s < 48; ++s) bw[s] = p.w_hh[(long)(4 * s + q) * GH + c];
+
+    long gi_base[4], hs_base[4];
+    bool valid[4];
+    float carry[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int rr = r0 + 4 * q + reg;
+        valid[reg] = rr < p.NR;
+        const int gb = valid[reg] ? rr / p.na : 0, i = valid[reg] ? rr % p.na : 0;
+        gi_base[reg] = (long)gb * p.T1 * p.na + i;
+        hs_base[reg] = (long)gb * (p.T1 + 1) * p.na + i;
+        carry[reg] = 0.f;
+    }
+    // per-step inputs: 0 dhs, 1 r, 2 z, 3 n, 4 ghn, 5 h_{t-1}
+    float cur[4][6], nxt[4][6];
+    auto fetch = [&](float (&dst)[4][6], int t) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            if (valid[reg]) {
+                const long o = (gi_base[reg] + (long)t * p.na) * GH + c;
+                dst[reg][0] = p.dhs[o];
+                dst[reg][1] = p.save_r[o];
+                dst[reg][2] = p.save_z[o];
+                dst[reg][3] = p.save_n[o];
+                dst[reg][4] = p.save_ghn[o];
+                dst[reg][5] = p.hsx[(hs_base[reg] + (long)t * p.na) * GH + c];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) dst[reg][k] = 0.f;
+            }
+        }
+    };
+    fetch(cur, p.T1 - 1);
+    int it = 0;
+    for (int t = p.T1 - 1; t >= 0; --t, ++it) {
+        float* gb_w = gbuf[it & 1];
+        if (t > 0) fetch(nxt, t - 1);
+        float dhz[4];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float dh = carry[reg] + cur[reg][0];
+            const float rg = cur[reg][1], zg = cur[reg][2], ng = cur[reg][3], ghn = cur[reg][4], hp = cur[reg][5];
+            const float dn = dh * (1.0f - zg);
+            const float dz = dh * (hp - ng);
+            dhz[reg] = dh * zg;
+            const float dn_pre = dn * (1.0f - ng * ng);
+            const float dr = dn_pre * ghn;
+            const float dghn = dn_pre * rg;
+            const float dr_pre = dr * rg * (1.0f - rg);
+            const float dz_pre = dz * zg * (1.0f - zg);
+            float* row = gb_w + (4 * q + reg) * GP;
+            row[c] = dr_pre; row[GH + c] = dz_pre; row[2 * GH + c] = dghn;
+            if (valid[reg]) {
+                const long o = (gi_base[reg] + (long)t * p.na) * (3 * GH) + c;
+                p.dgi[o] = dr_pre; p.dgi[o + GH] = dz_pre; p.dgi[o + 2 * GH] = dn_pre;
+                p.dgh[o] = dr_pre; p.dgh[o + GH] = dz_pre; p.dgh[o + 2 * GH] = dghn;
+            }
+        }
+        __syncthreads();
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+#pragma unroll
+        for (int s = 0; s < 48; s += 3) {
+            const float x0 = gb_w[c16 * GP + 4 * s + q];
+            const float x1 = gb_w[c16 * GP + 4 * (s + 1) + q];
+            const float x2 = gb_w[c16 * GP + 4 * (s + 2) + q];
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, bw[s], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, bw[s + 1], a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x2, bw[s + 2], a2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            carry[reg] = dhz[reg] + (a0[reg] + a1[reg] + a2[reg]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cur[reg][k] = nxt[reg][k];
+        }
+    }
+}
+
+int gru_forward_launch(const refil_gru_desc& d, hipStream_t st) {
+    REFIL_CHECK(d.H == GH, "refil_gru: rnn_hidden_dim must be %d (got %d)", GH, d.H);
+    REFIL_CHECK(d.gi && d.hsx && d.w_hh && d.b_hh, "refil_gru_forward: null pointer");
+    REFIL_CHECK(d.NR > 0 && d.T1 > 0 && d.na > 0, "refil_gru_forward: bad sizes");
+    GruK k{d.gi, d.hsx, d.w_hh, d.b_hh, d.save_r, d.save_z, d.save_n, d.save_ghn, d.dhs, d.dgi, d.dgh, d.NR, d.T1, d.na};
+    const bool save = d.save_r != nullptr;
+    REFIL_CHECK(!save || (d.save_z && d.save_n && d.save_ghn), "refil_gru_forward: all four save buffers or none");
+    dim3 grid(cdiv(d.NR, GROWS));
+    if (save) hipLaunchKernelGGL(gru_fwd_kernel<true>, grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL(gru_fwd_kernel<false>, grid, dim3(256), 0, st, k);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
+int gru_backward_launch(const refil_gru_desc& d, hipStream_t st) {
+    REFIL_CHECK(d.H == GH, "refil_gru: rnn_hidden_dim must be %d (got %d)", GH, d.H);
+    REFIL_CHECK(d.hsx && d.w_hh && d.save_r && d.save_z && d.save_n && d.save_ghn && d.dhs && d.dgi && d.dgh,
+                "refil_gru_backward: null pointer");
+    REFIL_CHECK(d.NR > 0 && d.T1 > 0 && d.na > 0, "refil_gru_backward: bad sizes");
+    GruK k{d.gi, d.hsx, d.w_hh, d.b_hh, d.save_r, d.save_z, d.save_n, d.save_ghn, d.dhs, d.dgi, d.dgh, d.NR, d.T1, d.na};
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv(d.NR, GROWS)), dim3(256), 0, st, k);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace refil
+
+extern "C" int refil_gru_forward(const refil_gru_desc* desc, void* stream) {
+    REFIL_CHECK(desc, "refil_gru_forward: null desc");
+    return refil::gru_forward_launch(*desc, (hipStream_t)stream);
+}
+extern "C" int refil_gru_backward(const refil_gru_desc* desc, void* stream) {
+    REFIL_CHECK(desc, "refil_gru_backward: null desc");
+    return refil::gru_backward_launch(*desc, (hipStream_t)stream);
+}

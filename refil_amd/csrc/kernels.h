@@ -1,0 +1,76 @@
+// Internal launch API shared by the .hip translation units (not part of the C ABI).
+#pragma once
+#include "common.h"
+#include "../../include/refil_hip.h"
+
+namespace refil {
+
+int gemm_launch(const refil_gemm_desc& d, hipStream_t st);
+int attn_forward_launch(const refil_attn_desc& d, hipStream_t st);
+int attn_backward_launch(const refil_attn_desc& d, hipStream_t st);
+int gru_forward_launch(const refil_gru_desc& d, hipStream_t st);
+int gru_backward_launch(const refil_gru_desc& d, hipStream_t st);
+
+// entities || one-hot(prev action) -> xe [R*ne, Ep]; contiguous copies of the masks
+struct PrepArgs {
+    refil_batch b;
+    int B, T1, ne, na, ed, A, Ep, last_action, first_step_zero;
+    float* xe; uint8_t* emc; uint8_t* amask; uint8_t* em0;
+};
+int prep_launch(const PrepArgs& a, hipStream_t st);
+
+// hsx slot 0 <- h0 (or zeros)
+int set_h0_launch(float* hsx, const float* h0, int GB, int T1, int na, int H, hipStream_t st);
+// h_out[gb,i,:] <- hsx slot T1
+int get_hT_launch(const float* hsx, float* h_out, int GB, int T1, int na, int H, hipStream_t st);
+
+struct QSelArgs {
+    const float* q;        // [G, B*T1*na, A] live agent Q (inactive agents zeroed)
+    const float* tq;       // [B*T1*na, A] target agent Q
+    const int64_t* actions; long ac_sB, ac_sT;
+    const int32_t* avail; long av_sB, av_sT;
+    float* chosen;         // [G,B,T,na]
+    float* tmax;           // [B,T,na]
+    int G, B, T1, na, A, double_q;
+};
+int qselect_launch(const QSelArgs& a, hipStream_t st);
+
+struct QSelBwdArgs {
+    const float* dchosen;  // [G,B,T,na]
+    const int64_t* actions; long ac_sB, ac_sT;
+    const uint8_t* amask;  // [B*T1*na]
+    float* dq;             // [G, B*T1*na, A]
+    int G, B, T1, na, A;
+};
+int qselect_bwd_launch(const QSelBwdArgs& a, hipStream_t st);
+
+// FlexQMixer monotonic mixing on top of the hypernet outputs (flex_qmix.py:96-121)
+struct MixArgs {
+    const float* x_w1; long s_var;   // [nvar][R*na, M] masked fc2 outputs of hyper_w_1 (variant stride)
+    const float* x_wf; const float* x_b1; const float* x_v;   // [R*na, M]
+    const float* qs; long s_qs_g;    // [G][B,T,na] chosen agent Qs (copy stride)
+    float* q_tot; float* q_tot_im;   // [B,T]
+    // backward
+    const float* gc_real; const float* gc_im;   // [B,T] dL/dq_tot
+    float* dx_w1; float* dx_wf; float* dx_b1; float* dx_v;   // same layouts as x_*
+    float* dqs;                       // [G][B,T,na]
+    const uint8_t* amask;             // [R*na]
+    int B, T1, T, t_off, na, M, imagine, softmax_w, tanh_nl;
+};
+int mix_forward_launch(const MixArgs& a, hipStream_t st);
+int mix_backward_launch(const MixArgs& a, hipStream_t st);
+
+struct TdArgs {
+    const float* q_tot; const float* q_tot_im; const float* tq_tot;
+    const float* reward; long rw_sB, rw_sT;
+    const uint8_t* terminated; long tm_sB, tm_sT;
+    const int64_t* filled; long fl_sB, fl_sT;
+    float* gc_real; float* gc_im; float* targets; float* stats;
+    int B, T, imagine; float gamma, lmbda;
+};
+int td_loss_launch(const TdArgs& a, hipStream_t st);
+
+int clip_rmsprop_launch(float* params, const float* grads, float* sq, long n, float lr, float alpha, float eps,
+                        float wd, float clip, float* stats, float* scratch, hipStream_t st);
+
+}  // namespace refil

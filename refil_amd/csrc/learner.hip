@@ -1,0 +1,672 @@
+// The REFIL learner step as an explicit forward + backward schedule of the gfx950 kernels
+// (no autograd graph). Restates QLearner.train up to loss.backward()
+// (reference: src/learners/q_learner.py:66-176) and the module forwards below it:
+//   EntityMAC._build_inputs            src/controllers/entity_controller.py:11-30
+//   ImagineEntityAttentionRNNAgent     src/modules/agents/entity_rnn_agent.py:31-64,87-126
+//   EntityAttentionLayer               src/modules/layers/attention.py:24-79
+//   AttentionHyperNet / FlexQMixer     src/modules/mixers/flex_qmix.py:40-57,79-121
+//
+// Work the reference repeats is done once: fc1/K/V are shared by the three "imagine" copies (the
+// reference triples the batch, entity_rnn_agent.py:119-124), the entity||last-action tensor is
+// built once for MAC and mixer (entity_controller.py:13-27 and q_learner.py:50-60 build it twice),
+// the four hypernet fc1 layers are ONE [E -> 4*hyp] GEMM, and hyper_b_1 / hyper_w_final / V are
+// evaluated once for the real and the imagined mix (q_learner.py:134-150 evaluates them twice).
+//
+// Activations live in a caller-provided workspace arena (sized for 288 GB HBM parts: nothing is
+// recomputed except the attention softmax).
+#include <stdarg.h>
+#include <string.h>
+
+#include "kernels.h"
+
+namespace refil {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static inline long rup(long x, long m) { return (x + m - 1) / m * m; }
+
+static int check_dims(const refil_dims& d) {
+    REFIL_CHECK(d.B > 0 && d.T1 > 0, "refil: B and T1 must be > 0 (B=%d T1=%d)", d.B, d.T1);
+    REFIL_CHECK(d.ne >= 1 && d.ne <= 64 && d.na >= 1 && d.na <= d.ne, "refil: need 1 <= n_agents <= n_entities <= 64");
+    REFIL_CHECK(d.ed > 0 && d.A > 0, "refil: entity_shape and n_actions must be > 0");
+    REFIL_CHECK(d.heads > 0 && d.d % d.heads == 0 && d.hyp % d.heads == 0, "refil: embed dims must be divisible by attn_n_heads");
+    REFIL_CHECK((d.d / d.heads) % 4 == 0 && (d.hyp / d.heads) % 4 == 0, "refil: head dim must be a multiple of 4");
+    REFIL_CHECK(d.H == 64, "refil: rnn_hidden_dim must be 64 (got %d)", d.H);
+    REFIL_CHECK(d.M >= 1 && d.M <= 64, "refil: mixing_embed_dim must be in [1,64]");
+    return 0;
+}
+
+static inline int in_dim(const refil_dims& d) { return d.ed + (d.entity_last_action ? d.A : 0); }
+
+// ------------------------------------------------------------------------------------------------
+// flat parameter layout
+// ------------------------------------------------------------------------------------------------
+static void param_layout(const refil_dims& d, refil_param_layout& L) {
+    const long E = in_dim(d), dd = d.d, H = d.H, A = d.A, h = d.hyp, M = d.M;
+    long o = 0;
+    auto take = [&](long n) { long r = o; o = rup(o + n, 4); return r; };
+    L.ag_fc1_w = take(dd * E); L.ag_fc1_b = take(dd);
+    L.ag_in_w = take(3 * dd * dd);
+    L.ag_out_w = take(dd * dd); L.ag_out_b = take(dd);
+    L.ag_fc2_w = take(H * dd); L.ag_fc2_b = take(H);
+    L.ag_w_ih = take(3 * H * H); L.ag_w_hh = take(3 * H * H);
+    L.ag_b_ih = take(3 * H); L.ag_b_hh = take(3 * H);
+    L.ag_fc3_w = take(A * H); L.ag_fc3_b = take(A);
+    L.agent_total = o;
+    L.mix_fc1_w_stride = h * E; L.mix_fc1_w = take(4 * h * E);
+    L.mix_fc1_b_stride = h; L.mix_fc1_b = take(4 * h);
+    L.mix_in_w_stride = 3 * h * h; L.mix_in_w = take(4 * 3 * h * h);
+    L.mix_out_w_stride = h * h; L.mix_out_w = take(4 * h * h);
+    L.mix_out_b_stride = h; L.mix_out_b = take(4 * h);
+    L.mix_fc2_w_stride = M * h; L.mix_fc2_w = take(4 * M * h);
+    L.mix_fc2_b_stride = M; L.mix_fc2_b = take(4 * M);
+    L.total = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace arena
+// ------------------------------------------------------------------------------------------------
+struct Arena {
+    char* base; size_t cap; size_t off; bool overflow;
+    template <typename T> T* take(long n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = reinterpret_cast<T*>(base + off);
+        off += (size_t)n * sizeof(T);
+        if (base && off > cap) overflow = true;
+        return p;
+    }
+};
+
+constexpr long PARTIAL_FLOATS = 40L << 20;   // split-K scratch (160 MiB)
+
+struct AgentBufs {     // one entity-attention recurrent agent evaluation (G mask variants)
+    float *x1, *kv, *q, *ao, *x2, *x3, *gi, *hsx, *sr, *sz, *sn, *sg, *qv;
+};
+struct HyperBufs {     // the four attention hypernets (NV variant evaluations in total)
+    float *x1, *kv, *q, *ao, *x2, *x3;
+};
+struct Work {
+    float* xe; uint8_t *emc, *amask, *em0;
+    AgentBufs la, ta;
+    HyperBufs lh, th;
+    float *chosen, *tmax, *q_tot, *q_tot_im, *tq_tot, *gc_real, *gc_im, *targets;
+    // backward
+    float *dx3h, *dchosen, *dx2h, *daoh, *dqh, *dkvh, *dx1h;
+    float *dqva, *dhs, *dgi, *dgh, *dx3a, *dx2a, *daoa, *dqa, *dkva, *dx1a;
+    float* partial;
+};
+
+struct Sizes {
+    long R, NE, NA; int G, nv0, NV, E, Ep;
+};
+static Sizes sizes_of(const refil_dims& d) {
+    Sizes s;
+    s.R = (long)d.B * d.T1; s.NE = s.R * d.ne; s.NA = s.R * d.na;
+    s.G = d.imagine ? 3 : 1; s.nv0 = s.G; s.NV = s.nv0 + 3;
+    s.E = in_dim(d); s.Ep = (int)rup(s.E, 4);
+    return s;
+}
+
+static void carve_agent(Arena& a, const refil_dims& d, const Sizes& s, int G, bool save, AgentBufs& b) {
+    b.x1 = a.take<float>(s.NE * d.d);
+    b.kv = a.take<float>(s.NE * 2 * d.d);
+    b.q = a.take<float>(s.NA * d.d);
+    b.ao = a.take<float>((long)G * s.NA * d.d);
+    b.x2 = a.take<float>((long)G * s.NA * d.d);
+    b.x3 = a.take<float>((long)G * s.NA * d.H);
+    b.gi = a.take<float>((long)G * s.NA * 3 * d.H);
+    b.hsx = a.take<float>((long)G * d.B * (d.T1 + 1) * d.na * d.H);
+    b.sr = b.sz = b.sn = b.sg = nullptr;
+    if (save) {
+        b.sr = a.take<float>((long)G * s.NA * d.H); b.sz = a.take<float>((long)G * s.NA * d.H);
+        b.sn = a.take<float>((long)G * s.NA * d.H); b.sg = a.take<float>((long)G * s.NA * d.H);
+    }
+    b.qv = a.take<float>((long)G * s.NA * d.A);
+}
+static void carve_hyper(Arena& a, const refil_dims& d, const Sizes& s, int NV, HyperBufs& b) {
+    b.x1 = a.take<float>(s.NE * 4 * d.hyp);
+    b.kv = a.take<float>(4 * s.NE * 2 * d.hyp);
+    b.q = a.take<float>(4 * s.NA * d.hyp);
+    b.ao = a.take<float>((long)NV * s.NA * d.hyp);
+    b.x2 = a.take<float>((long)NV * s.NA * d.hyp);
+    b.x3 = a.take<float>((long)NV * s.NA * d.M);
+}
+
+enum CarveMode { CARVE_LEARNER, CARVE_AGENT_FWD, CARVE_MIXER_FWD };
+
+static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
+    const Sizes s = sizes_of(d);
+    const long BT = (long)d.B * (d.T1 > 1 ? d.T1 - 1 : 1);
+    memset(&w, 0, sizeof(w));
+    w.xe = a.take<float>(s.NE * s.Ep);
+    w.emc = a.take<uint8_t>(s.NE); w.amask = a.take<uint8_t>(s.NA); w.em0 = a.take<uint8_t>((long)d.B * d.ne);
+    if (mode == CARVE_AGENT_FWD) { carve_agent(a, d, s, s.G, false, w.la); return; }
+    if (mode == CARVE_MIXER_FWD) {
+        carve_hyper(a, d, s, s.NV, w.lh);
+        return;
+    }
+    carve_agent(a, d, s, s.G, true, w.la);
+    carve_agent(a, d, s, 1, false, w.ta);
+    carve_hyper(a, d, s, s.NV, w.lh);
+    carve_hyper(a, d, s, 4, w.th);
+    w.chosen = a.take<float>((long)s.G * BT * d.na);
+    w.tmax = a.take<float>(BT * d.na);
+    w.q_tot = a.take<float>(BT); w.q_tot_im = a.take<float>(BT); w.tq_tot = a.take<float>(BT);
+    w.gc_real = a.take<float>(BT); w.gc_im = a.take<float>(BT); w.targets = a.take<float>(BT);
+    w.dx3h = a.take<float>((long)s.NV * s.NA * d.M);
+    w.dchosen = a.take<float>((long)s.G * BT * d.na);
+    w.dx2h = a.take<float>((long)s.NV * s.NA * d.hyp);
+    w.daoh = a.take<float>((long)s.NV * s.NA * d.hyp);
+    w.dqh = a.take<float>(4 * s.NA * d.hyp);
+    w.dkvh = a.take<float>(4 * s.NE * 2 * d.hyp);
+    w.dx1h = a.take<float>(s.NE * 4 * d.hyp);
+    w.dqva = a.take<float>((long)s.G * s.NA * d.A);
+    w.dhs = a.take<float>((long)s.G * s.NA * d.H);
+    w.dgi = a.take<float>((long)s.G * s.NA * 3 * d.H);
+    w.dgh = a.take<float>((long)s.G * s.NA * 3 * d.H);
+    w.dx3a = a.take<float>((long)s.G * s.NA * d.H);
+    w.dx2a = a.take<float>((long)s.G * s.NA * d.d);
+    w.daoa = a.take<float>((long)s.G * s.NA * d.d);
+    w.dqa = a.take<float>(s.NA * d.d);
+    w.dkva = a.take<float>(s.NE * 2 * d.d);
+    w.dx1a = a.take<float>(s.NE * d.d);
+    w.partial = a.take<float>(PARTIAL_FLOATS);
+}
+
+static size_t workspace_bytes(const refil_dims& d, CarveMode mode) {
+    Arena a{nullptr, 0, 0, false};
+    Work w;
+    carve(a, d, w, mode);
+    return a.off + 256;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM helpers
+// ------------------------------------------------------------------------------------------------
+static refil_gemm_desc G0() {
+    refil_gemm_desc g;
+    memset(&g, 0, sizeof(g));
+    g.batch = 1; g.splits = 1;
+    return g;
+}
+// y[M,N] = x[M,K] W[N,K]^T (+bias)
+static refil_gemm_desc linear(const float* x, int ldx, const float* W, int ldw, const float* bias, float* y, int ldy,
+                              long M, int N, int K, int flags) {
+    refil_gemm_desc g = G0();
+    g.A = x; g.lda = ldx; g.B = W; g.ldb = ldw; g.bias = bias; g.C = y; g.ldc = ldy;
+    g.M = (int)M; g.N = N; g.K = K; g.flags = flags;
+    return g;
+}
+// dx[M,K] = dy[M,N] W[N,K]
+static refil_gemm_desc linear_dx(const float* dy, int lddy, const float* W, int ldw, float* dx, int lddx, long M, int N,
+                                 int K, int flags) {
+    refil_gemm_desc g = G0();
+    g.A = dy; g.lda = lddy; g.B = W; g.ldb = ldw; g.C = dx; g.ldc = lddx;
+    g.M = (int)M; g.N = K; g.K = N; g.flags = flags | REFIL_GEMM_B_OUTC;
+    return g;
+}
+// dW[N,K] = dy[R,N]^T x[R,K]; db[N] = colsum(dy)  (reduction over the R rows, split deterministically)
+static refil_gemm_desc linear_dw(const float* dy, int lddy, const float* x, int ldx, float* dW, int lddw, float* db,
+                                 long R, int N, int K, float* partial, int batch) {
+    refil_gemm_desc g = G0();
+    g.A = dy; g.lda = lddy; g.B = x; g.ldb = ldx; g.C = dW; g.ldc = lddw;
+    g.M = N; g.N = K; g.K = (int)R;
+    g.flags = REFIL_GEMM_A_OUTC | REFIL_GEMM_B_OUTC | (db ? REFIL_GEMM_COLSUM_A : 0);
+    g.colsum = db; g.partial = partial; g.batch = batch;
+    const int bn = K > 64 ? 128 : (K > 32 ? 64 : 32);
+    const long tiles = (long)cdiv(N, 128) * cdiv(K, bn) * batch;
+    long splits = 1024 / tiles;
+    splits = min(splits, cdivl(R, 256));
+    splits = max(splits, 1L);
+    while (splits > 1 && (long)batch * splits * ((long)N * K + N) > PARTIAL_FLOATS) --splits;
+    g.splits = (int)splits;
+    return g;
+}
+
+#define RUN(x) do { if (int e_ = (x)) return e_; } while (0)
+
+struct Ctx {
+    refil_dims d; Sizes s; refil_batch b; refil_param_layout L; Work w; hipStream_t st;
+};
+
+static refil_rowmap agent_rows(const Ctx& c) { return refil_rowmap{c.d.na, c.d.ne, 0}; }
+static refil_rowmap hs_rows(const Ctx& c, int off) { return refil_rowmap{c.d.T1 * c.d.na, (c.d.T1 + 1) * c.d.na, off}; }
+
+static refil_attn_desc attn_base(const Ctx& c, int w) {
+    refil_attn_desc a;
+    memset(&a, 0, sizeof(a));
+    a.R = (int)c.s.R; a.T1 = c.d.T1; a.ne = c.d.ne; a.na = c.d.na; a.heads = c.d.heads; a.hd = w / c.d.heads;
+    a.obs_mask = c.b.obs_mask; a.om_sB = c.b.om_sB; a.om_sT = c.b.om_sT;
+    a.ent_mask = c.w.emc; a.ent_mask0 = c.w.em0; a.group_bits = c.b.group_bits;
+    a.ldq = w; a.ldkv = 2 * w; a.ldo = w;
+    return a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// agent forward (entity_rnn_agent.py:31-64 with the G mask variants of :116-124)
+// ------------------------------------------------------------------------------------------------
+static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G, const float* h0) {
+    const refil_dims& d = c.d; const Sizes& s = c.s; const refil_param_layout& L = c.L;
+    const int dd = d.d, H = d.H;
+    // x1 = relu(fc1(entities))                                       :38
+    RUN(gemm_launch(linear(c.w.xe, s.Ep, P + L.ag_fc1_w, s.E, P + L.ag_fc1_b, b.x1, dd, s.NE, dd, s.E, REFIL_GEMM_RELU), c.st));
+    // K,V for all entities; Q for the agents only                    attention.py:46-48
+    RUN(gemm_launch(linear(b.x1, dd, P + L.ag_in_w + (long)dd * dd, dd, nullptr, b.kv, 2 * dd, s.NE, 2 * dd, dd, 0), c.st));
+    {
+        refil_gemm_desc g = linear(b.x1, dd, P + L.ag_in_w, dd, nullptr, b.q, dd, s.NA, dd, dd, 0);
+        g.a_map = agent_rows(c);
+        RUN(gemm_launch(g, c.st));
+    }
+    {
+        refil_attn_desc a = attn_base(c, dd);
+        a.Q = b.q; a.K = b.kv; a.V = b.kv + dd; a.O = b.ao; a.sO = s.NA * dd;
+        a.nvar = G; a.var[0] = REFIL_MASK_OBS; a.var[1] = REFIL_MASK_OBS_WITHIN; a.var[2] = REFIL_MASK_OBS_INTERACT;
+        RUN(attn_forward_launch(a, c.st));
+    }
+    // x2 = out_trans(attn) with inactive agents zeroed                attention.py:65-67
+    {
+        refil_gemm_desc g = linear(b.ao, dd, P + L.ag_out_w, dd, P + L.ag_out_b, b.x2, dd, (long)G * s.NA, dd, dd, 0);
+        g.rowmask = c.w.amask; g.rowmask_mod = (int)s.NA;
+        RUN(gemm_launch(g, c.st));
+    }
+    // x3 = relu(fc2(x2))                                              :46
+    RUN(gemm_launch(linear(b.x2, dd, P + L.ag_fc2_w, dd, P + L.ag_fc2_b, b.x3, H, (long)G * s.NA, H, dd, REFIL_GEMM_RELU), c.st));
+    // gi = x3 W_ih^T + b_ih for all steps, then the persistent recurrence   :49-55
+    RUN(gemm_launch(linear(b.x3, H, P + L.ag_w_ih, H, P + L.ag_b_ih, b.gi, 3 * H, (long)G * s.NA, 3 * H, H, 0), c.st));
+    RUN(set_h0_launch(b.hsx, h0, G * d.B, d.T1, d.na, H, c.st));
+    {
+        refil_gru_desc g;
+        memset(&g, 0, sizeof(g));
+        g.gi = b.gi; g.hsx = b.hsx; g.w_hh = P + L.ag_w_hh; g.b_hh = P + L.ag_b_hh;
+        g.save_r = b.sr; g.save_z = b.sz; g.save_n = b.sn; g.save_ghn = b.sg;
+        g.NR = G * d.B * d.na; g.T1 = d.T1; g.na = d.na; g.H = H;
+        RUN(gru_forward_launch(g, c.st));
+    }
+    // q = fc3(h), zero for inactive agents                            :57-60
+    {
+        refil_gemm_desc g = linear(b.hsx, H, P + L.ag_fc3_w, H, P + L.ag_fc3_b, b.qv, d.A, (long)G * s.NA, d.A, H, 0);
+        g.a_map = hs_rows(c, d.na);
+        g.rowmask = c.w.amask; g.rowmask_mod = (int)s.NA;
+        RUN(gemm_launch(g, c.st));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the four attention hypernets up to the masked fc2 output (flex_qmix.py:41-50)
+// variant order in ao/x2/x3: hyper_w_1 under nv0 masks, then hyper_w_final, hyper_b_1, V
+// ------------------------------------------------------------------------------------------------
+static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int nv0) {
+    const refil_dims& d = c.d; const Sizes& s = c.s; const refil_param_layout& L = c.L;
+    const int h = d.hyp, M = d.M;
+    RUN(gemm_launch(linear(c.w.xe, s.Ep, P + L.mix_fc1_w, s.E, P + L.mix_fc1_b, b.x1, 4 * h, s.NE, 4 * h, s.E, REFIL_GEMM_RELU), c.st));
+    {
+        refil_gemm_desc g = linear(b.x1, 4 * h, P + L.mix_in_w + (long)h * h, h, nullptr, b.kv, 2 * h, s.NE, 2 * h, h, 0);
+        g.batch = 4; g.sA = h; g.sB = L.mix_in_w_stride; g.sC = s.NE * 2 * h;
+        RUN(gemm_launch(g, c.st));
+    }
+    {
+        refil_gemm_desc g = linear(b.x1, 4 * h, P + L.mix_in_w, h, nullptr, b.q, h, s.NA, h, h, 0);
+        g.a_map = agent_rows(c);
+        g.batch = 4; g.sA = h; g.sB = L.mix_in_w_stride; g.sC = s.NA * h;
+        RUN(gemm_launch(g, c.st));
+    }
+    for (int n = 0; n < 4; ++n) {
+        refil_attn_desc a = attn_base(c, h);
+        a.Q = b.q + (long)n * s.NA * h; a.K = b.kv + (long)n * s.NE * 2 * h; a.V = a.K + h;
+        a.O = b.ao + (long)(n == 0 ? 0 : nv0 + n - 1) * s.NA * h; a.sO = s.NA * h;
+        a.nvar = n == 0 ? nv0 : 1;
+        a.var[0] = REFIL_MASK_ENTITY; a.var[1] = REFIL_MASK_WITHIN; a.var[2] = REFIL_MASK_INTERACT;
+        RUN(attn_forward_launch(a, c.st));
+    }
+    // out_trans and fc2, both with inactive agents zeroed (attention.py:65-67, flex_qmix.py:49-50)
+    for (int part = 0; part < 2; ++part) {
+        const long M_rows = part == 0 ? nv0 * s.NA : s.NA;
+        const int batch = part == 0 ? 1 : 3;
+        const long voff = part == 0 ? 0 : nv0;
+        const int net0 = part == 0 ? 0 : 1;
+        refil_gemm_desc g = linear(b.ao + voff * s.NA * h, h, P + L.mix_out_w + net0 * L.mix_out_w_stride, h,
+                                   P + L.mix_out_b + net0 * L.mix_out_b_stride, b.x2 + voff * s.NA * h, h, M_rows, h, h, 0);
+        g.batch = batch; g.sA = s.NA * h; g.sB = L.mix_out_w_stride; g.sBias = L.mix_out_b_stride; g.sC = s.NA * h;
+        g.rowmask = c.w.amask; g.rowmask_mod = (int)s.NA;
+        RUN(gemm_launch(g, c.st));
+        refil_gemm_desc f = linear(b.x2 + voff * s.NA * h, h, P + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h,
+                                   P + L.mix_fc2_b + net0 * L.mix_fc2_b_stride, b.x3 + voff * s.NA * M, M, M_rows, M, h, 0);
+        f.batch = batch; f.sA = s.NA * h; f.sB = L.mix_fc2_w_stride; f.sBias = L.mix_fc2_b_stride; f.sC = s.NA * M;
+        f.rowmask = c.w.amask; f.rowmask_mod = (int)s.NA;
+        RUN(gemm_launch(f, c.st));
+    }
+    return 0;
+}
+
+static MixArgs mix_args(const Ctx& c, const HyperBufs& b, int nv0, const float* qs, int G_qs, int t_off, int T) {
+    const refil_dims& d = c.d; const Sizes& s = c.s;
+    MixArgs m;
+    memset(&m, 0, sizeof(m));
+    m.x_w1 = b.x3; m.s_var = s.NA * d.M;
+    m.x_wf = b.x3 + (long)(nv0 + 0) * s.NA * d.M;
+    m.x_b1 = b.x3 + (long)(nv0 + 1) * s.NA * d.M;
+    m.x_v = b.x3 + (long)(nv0 + 2) * s.NA * d.M;
+    m.qs = qs; m.s_qs_g = (long)d.B * T * d.na;
+    m.amask = c.w.amask;
+    m.B = d.B; m.T1 = d.T1; m.T = T; m.t_off = t_off; m.na = d.na; m.M = d.M;
+    m.imagine = (nv0 == 3 && G_qs == 3) ? 1 : 0;
+    m.softmax_w = d.softmax_mixing_weights; m.tanh_nl = d.mixer_tanh;
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of one attention block: given d(x2) (already row-masked) produce dW_out, db_out, then
+// through the attention core and in_trans down to d(x1) (ReLU-masked). Shared by agent + hypernets.
+// ------------------------------------------------------------------------------------------------
+struct AttnBlockBwd {
+    int w;                    // embed width
+    int nets;                 // 1 (agent) or 4 (hypernets)
+    int nv0;                  // mask variants of net 0
+    const float* P; float* Gr;          // params / grads flat buffers
+    long in_w, in_w_stride, out_w, out_w_stride, out_b, out_b_stride;
+    const float *x1, *kv, *q, *ao;      // forward activations (x1 [NE, nets*w], kv [nets][NE,2w], q [nets][NA,w], ao [NV][NA,w])
+    const float* dx2;                    // [NV][NA,w]
+    float *dao, *dq, *dkv, *dx1;         // scratch / outputs
+    int var_first[3];                    // mask codes of net 0's variants
+    int var_rest;                        // mask code of nets 1..3
+};
+
+static int attn_block_backward(const Ctx& c, const AttnBlockBwd& k) {
+    const Sizes& s = c.s; const refil_dims& d = c.d;
+    const int w = k.w;
+    const long ldx1 = (long)k.nets * w;
+    for (int part = 0; part < (k.nets > 1 ? 2 : 1); ++part) {
+        const long rows = part == 0 ? k.nv0 * s.NA : s.NA;
+        const int batch = part == 0 ? 1 : k.nets - 1;
+        const long voff = part == 0 ? 0 : k.nv0;
+        const int net0 = part == 0 ? 0 : 1;
+        // dW_out = dx2^T ao ; db_out = colsum(dx2)
+        refil_gemm_desc gw = linear_dw(k.dx2 + voff * s.NA * w, w, k.ao + voff * s.NA * w, w,
+                                       k.Gr + k.out_w + net0 * k.out_w_stride, w, k.Gr + k.out_b + net0 * k.out_b_stride,
+                                       rows, w, w, c.w.partial, batch);
+        gw.sA = s.NA * w; gw.sB = s.NA * w; gw.sC = k.out_w_stride; gw.sColsum = k.out_b_stride;
+        RUN(gemm_launch(gw, c.st));
+        // d(attn_out) = dx2 W_out
+        refil_gemm_desc gx = linear_dx(k.dx2 + voff * s.NA * w, w, k.P + k.out_w + net0 * k.out_w_stride, w,
+                                       k.dao + voff * s.NA * w, w, rows, w, w, 0);
+        gx.batch = batch; gx.sA = s.NA * w; gx.sB = k.out_w_stride; gx.sC = s.NA * w;
+        RUN(gemm_launch(gx, c.st));
+    }
+    for (int n = 0; n < k.nets; ++n) {
+        refil_attn_desc a = attn_base(c, w);
+        a.Q = k.q + (long)n * s.NA * w; a.K = k.kv + (long)n * s.NE * 2 * w; a.V = a.K + w;
+        a.dO = k.dao + (long)(n == 0 ? 0 : k.nv0 + n - 1) * s.NA * w; a.sO = s.NA * w;
+        a.dQ = k.dq + (long)n * s.NA * w; a.dK = k.dkv + (long)n * s.NE * 2 * w; a.dV = a.dK + w;
+        a.nvar = n == 0 ? k.nv0 : 1;
+        if (n == 0) { a.var[0] = k.var_first[0]; a.var[1] = k.var_first[1]; a.var[2] = k.var_first[2]; }
+        else a.var[0] = k.var_rest;
+        RUN(attn_backward_launch(a, c.st));
+    }
+    // dW_in rows [w,3w) = dKV^T x1 ; rows [0,w) = dQ^T x1[agent rows]
+    {
+        refil_gemm_desc g = linear_dw(k.dkv, 2 * w, k.x1, (int)ldx1, k.Gr + k.in_w + (long)w * w, w, nullptr, s.NE, 2 * w, w,
+                                      c.w.partial, k.nets);
+        g.sA = s.NE * 2 * w; g.sB = w; g.sC = k.in_w_stride;
+        RUN(gemm_launch(g, c.st));
+        refil_gemm_desc q = linear_dw(k.dq, w, k.x1, (int)ldx1, k.Gr + k.in_w, w, nullptr, s.NA, w, w, c.w.partial, k.nets);
+        q.b_map = refil_rowmap{d.na, d.ne, 0};
+        q.sA = s.NA * w; q.sB = w; q.sC = k.in_w_stride;
+        RUN(gemm_launch(q, c.st));
+    }
+    // dx1 = relu'(x1) * (dKV W_kv + scatter(dQ W_q))
+    {
+        refil_gemm_desc g = linear_dx(k.dkv, 2 * w, k.P + k.in_w + (long)w * w, w, k.dx1, (int)ldx1, s.NE, 2 * w, w, REFIL_GEMM_RELU_BWD);
+        g.aux = k.x1; g.batch = k.nets; g.sA = s.NE * 2 * w; g.sB = k.in_w_stride; g.sC = w;
+        RUN(gemm_launch(g, c.st));
+        refil_gemm_desc q = linear_dx(k.dq, w, k.P + k.in_w, w, k.dx1, (int)ldx1, s.NA, w, w, REFIL_GEMM_RELU_BWD | REFIL_GEMM_ACCUM);
+        q.aux = k.x1; q.c_map = refil_rowmap{d.na, d.ne, 0};
+        q.batch = k.nets; q.sA = s.NA * w; q.sB = k.in_w_stride; q.sC = w;
+        RUN(gemm_launch(q, c.st));
+    }
+    return 0;
+}
+
+static int copy_out(float* dst, const float* src, long n, hipStream_t st) {
+    if (!dst) return 0;
+    REFIL_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, void* ws, size_t ws_bytes, CarveMode mode, void* stream) {
+    REFIL_CHECK(dims && batch && ws, "refil: null dims/batch/workspace");
+    if (int e = check_dims(*dims)) return e;
+    c.d = *dims; c.s = sizes_of(*dims); c.b = *batch; c.st = (hipStream_t)stream;
+    param_layout(c.d, c.L);
+    REFIL_CHECK(batch->entities && batch->entity_mask, "refil: batch.entities / entity_mask missing");
+    REFIL_CHECK(!dims->entity_last_action || batch->actions, "refil: batch.actions missing");
+    REFIL_CHECK((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "refil: workspace must be 256-byte aligned");
+    Arena a{(char*)ws, ws_bytes, 0, false};
+    carve(a, c.d, c.w, mode);
+    REFIL_CHECK(!a.overflow && a.off <= ws_bytes, "refil: workspace too small (%zu < %zu bytes)", ws_bytes, a.off);
+    return 0;
+}
+
+static int run_prep(const Ctx& c, int first_step_zero) {
+    PrepArgs p;
+    p.b = c.b; p.B = c.d.B; p.T1 = c.d.T1; p.ne = c.d.ne; p.na = c.d.na; p.ed = c.d.ed; p.A = c.d.A; p.Ep = c.s.Ep;
+    p.last_action = c.d.entity_last_action; p.first_step_zero = first_step_zero;
+    p.xe = c.w.xe; p.emc = c.w.emc; p.amask = c.w.amask; p.em0 = c.w.em0;
+    return prep_launch(p, c.st);
+}
+
+}  // namespace refil
+
+using namespace refil;
+
+extern "C" const char* refil_last_error(void) { return g_err; }
+extern "C" int refil_version(void) { return 1; }
+
+extern "C" int refil_get_param_layout(const refil_dims* dims, refil_param_layout* out) {
+    REFIL_CHECK(dims && out, "refil_get_param_layout: null argument");
+    if (int e = check_dims(*dims)) return e;
+    param_layout(*dims, *out);
+    return 0;
+}
+
+extern "C" size_t refil_learner_workspace_bytes(const refil_dims* dims) {
+    if (!dims || check_dims(*dims)) return 0;
+    return workspace_bytes(*dims, CARVE_LEARNER);
+}
+
+extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refil_batch* batch, const float* params_live,
+                                              const float* params_target, float* grads, void* workspace,
+                                              size_t workspace_bytes_, const refil_debug_out* debug, void* stream) {
+    Ctx c;
+    if (int e = make_ctx(c, dims, batch, workspace, workspace_bytes_, CARVE_LEARNER, stream)) return e;
+    REFIL_CHECK(params_live && params_target && grads, "refil_learner_forward_backward: null parameter/grad buffer");
+    REFIL_CHECK(dims->T1 >= 2, "refil_learner_forward_backward: need at least one transition (T1 >= 2)");
+    REFIL_CHECK(batch->obs_mask && batch->actions && batch->avail_actions && batch->reward && batch->terminated && batch->filled,
+                "refil_learner_forward_backward: incomplete batch");
+    REFIL_CHECK(!dims->imagine || batch->group_bits, "refil_learner_forward_backward: group_bits required when imagine=1");
+    const refil_dims& d = c.d; const Sizes& s = c.s; const refil_param_layout& L = c.L; Work& w = c.w;
+    const int T = d.T1 - 1, G = s.G, nv0 = s.nv0, H = d.H, h = d.hyp, M = d.M, dd = d.d;
+    const long BT = (long)d.B * T;
+    float* stats = grads + L.total;
+    REFIL_HIP(hipMemsetAsync(grads, 0, (L.total + REFIL_NSTAT) * sizeof(float), c.st));
+
+    // ---------------- forward ----------------
+    RUN(run_prep(c, 1));
+    RUN(agent_forward(c, params_live, w.la, G, nullptr));                         // q_learner.py:86-89 / 107
+    RUN(agent_forward(c, params_target, w.ta, 1, nullptr));                       // :111-113
+    {
+        QSelArgs q;
+        q.q = w.la.qv; q.tq = w.ta.qv; q.actions = c.b.actions; q.ac_sB = c.b.ac_sB; q.ac_sT = c.b.ac_sT;
+        q.avail = c.b.avail_actions; q.av_sB = c.b.av_sB; q.av_sT = c.b.av_sT;
+        q.chosen = w.chosen; q.tmax = w.tmax; q.G = G; q.B = d.B; q.T1 = d.T1; q.na = d.na; q.A = d.A; q.double_q = d.double_q;
+        RUN(qselect_launch(q, c.st));                                             // :91-96,115-128
+    }
+    RUN(hyper_forward(c, params_live, w.lh, nv0));   // live mixer hypernets
+    RUN(hyper_forward(c, params_target, w.th, 1));                                // target mixer hypernets
+    MixArgs ml = mix_args(c, w.lh, nv0, w.chosen, G, 0, T);
+    ml.q_tot = w.q_tot; ml.q_tot_im = w.q_tot_im;
+    RUN(mix_forward_launch(ml, c.st));                                            // :134-152
+    MixArgs mt = mix_args(c, w.th, 1, w.tmax, 1, 1, T);
+    mt.q_tot = w.tq_tot; mt.q_tot_im = nullptr;
+    RUN(mix_forward_launch(mt, c.st));                                            // :154
+    {
+        TdArgs t;
+        t.q_tot = w.q_tot; t.q_tot_im = w.q_tot_im; t.tq_tot = w.tq_tot;
+        t.reward = c.b.reward; t.rw_sB = c.b.rw_sB; t.rw_sT = c.b.rw_sT;
+        t.terminated = c.b.terminated; t.tm_sB = c.b.tm_sB; t.tm_sT = c.b.tm_sT;
+        t.filled = c.b.filled; t.fl_sB = c.b.fl_sB; t.fl_sT = c.b.fl_sT;
+        t.gc_real = w.gc_real; t.gc_im = w.gc_im; t.targets = w.targets; t.stats = stats;
+        t.B = d.B; t.T = T; t.imagine = d.imagine; t.gamma = d.gamma; t.lmbda = d.lmbda;
+        RUN(td_loss_launch(t, c.st));                                             // :157-172
+    }
+    if (debug) {
+        RUN(copy_out(debug->q, w.la.qv, (long)G * s.NA * d.A, c.st));
+        RUN(copy_out(debug->chosen_q, w.chosen, (long)G * BT * d.na, c.st));
+        RUN(copy_out(debug->target_max_q, w.tmax, BT * d.na, c.st));
+        RUN(copy_out(debug->q_tot, w.q_tot, BT, c.st));
+        if (d.imagine) RUN(copy_out(debug->q_tot_imagine, w.q_tot_im, BT, c.st));
+        RUN(copy_out(debug->target_q_tot, w.tq_tot, BT, c.st));
+        RUN(copy_out(debug->targets, w.targets, BT, c.st));
+    }
+
+    // ---------------- backward (q_learner.py:176, hand-scheduled) ----------------
+    ml.gc_real = w.gc_real; ml.gc_im = w.gc_im;
+    ml.dx_w1 = w.dx3h;
+    ml.dx_wf = w.dx3h + (long)(nv0 + 0) * s.NA * M;
+    ml.dx_b1 = w.dx3h + (long)(nv0 + 1) * s.NA * M;
+    ml.dx_v = w.dx3h + (long)(nv0 + 2) * s.NA * M;
+    ml.dqs = w.dchosen;
+    RUN(mix_backward_launch(ml, c.st));
+    // hypernet tails: fc2 (flex_qmix.py:49)
+    for (int part = 0; part < 2; ++part) {
+        const long rows = part == 0 ? nv0 * s.NA : s.NA;
+        const int batch = part == 0 ? 1 : 3;
+        const long voff = part == 0 ? 0 : nv0;
+        const int net0 = part == 0 ? 0 : 1;
+        refil_gemm_desc gw = linear_dw(w.dx3h + voff * s.NA * M, M, w.lh.x2 + voff * s.NA * h, h,
+                                       grads + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h,
+                                       grads + L.mix_fc2_b + net0 * L.mix_fc2_b_stride, rows, M, h, w.partial, batch);
+        gw.sA = s.NA * M; gw.sB = s.NA * h; gw.sC = L.mix_fc2_w_stride; gw.sColsum = L.mix_fc2_b_stride;
+        RUN(gemm_launch(gw, c.st));
+        refil_gemm_desc gx = linear_dx(w.dx3h + voff * s.NA * M, M, params_live + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h,
+                                       w.dx2h + voff * s.NA * h, h, rows, M, h, 0);
+        gx.batch = batch; gx.sA = s.NA * M; gx.sB = L.mix_fc2_w_stride; gx.sC = s.NA * h;
+        gx.rowmask = w.amask; gx.rowmask_mod = (int)s.NA;
+        RUN(gemm_launch(gx, c.st));
+    }
+    {
+        AttnBlockBwd k;
+        k.w = h; k.nets = 4; k.nv0 = nv0; k.P = params_live; k.Gr = grads;
+        k.in_w = L.mix_in_w; k.in_w_stride = L.mix_in_w_stride; k.out_w = L.mix_out_w; k.out_w_stride = L.mix_out_w_stride;
+        k.out_b = L.mix_out_b; k.out_b_stride = L.mix_out_b_stride;
+        k.x1 = w.lh.x1; k.kv = w.lh.kv; k.q = w.lh.q; k.ao = w.lh.ao; k.dx2 = w.dx2h;
+        k.dao = w.daoh; k.dq = w.dqh; k.dkv = w.dkvh; k.dx1 = w.dx1h;
+        k.var_first[0] = REFIL_MASK_ENTITY; k.var_first[1] = REFIL_MASK_WITHIN; k.var_first[2] = REFIL_MASK_INTERACT;
+        k.var_rest = REFIL_MASK_ENTITY;
+        RUN(attn_block_backward(c, k));
+        // the four hypernet fc1 layers: dW = dx1^T xe (one [4h,E] GEMM), db = colsum(dx1)
+        refil_gemm_desc g = linear_dw(w.dx1h, 4 * h, w.xe, s.Ep, grads + L.mix_fc1_w, s.E, grads + L.mix_fc1_b, s.NE, 4 * h, s.E,
+                                      w.partial, 1);
+        RUN(gemm_launch(g, c.st));
+    }
+    // agent: chosen-Q gather + inactive-agent fill, then fc3
+    {
+        QSelBwdArgs q;
+        q.dchosen = w.dchosen; q.actions = c.b.actions; q.ac_sB = c.b.ac_sB; q.ac_sT = c.b.ac_sT; q.amask = w.amask;
+        q.dq = w.dqva; q.G = G; q.B = d.B; q.T1 = d.T1; q.na = d.na; q.A = d.A;
+        RUN(qselect_bwd_launch(q, c.st));
+        const long rows = (long)G * s.NA;
+        refil_gemm_desc gw = linear_dw(w.dqva, d.A, w.la.hsx, H, grads + L.ag_fc3_w, H, grads + L.ag_fc3_b, rows, d.A, H, w.partial, 1);
+        gw.b_map = hs_rows(c, d.na);
+        RUN(gemm_launch(gw, c.st));
+        RUN(gemm_launch(linear_dx(w.dqva, d.A, params_live + L.ag_fc3_w, H, w.dhs, H, rows, d.A, H, 0), c.st));
+        // BPTT
+        refil_gru_desc g;
+        memset(&g, 0, sizeof(g));
+        g.hsx = w.la.hsx; g.w_hh = params_live + L.ag_w_hh; g.b_hh = params_live + L.ag_b_hh;
+        g.save_r = w.la.sr; g.save_z = w.la.sz; g.save_n = w.la.sn; g.save_ghn = w.la.sg;
+        g.dhs = w.dhs; g.dgi = w.dgi; g.dgh = w.dgh; g.NR = G * d.B * d.na; g.T1 = d.T1; g.na = d.na; g.H = H;
+        RUN(gru_backward_launch(g, c.st));
+        refil_gemm_desc ghh = linear_dw(w.dgh, 3 * H, w.la.hsx, H, grads + L.ag_w_hh, H, grads + L.ag_b_hh, rows, 3 * H, H, w.partial, 1);
+        ghh.b_map = hs_rows(c, 0);
+        RUN(gemm_launch(ghh, c.st));
+        RUN(gemm_launch(linear_dw(w.dgi, 3 * H, w.la.x3, H, grads + L.ag_w_ih, H, grads + L.ag_b_ih, rows, 3 * H, H, w.partial, 1), c.st));
+        refil_gemm_desc gx3 = linear_dx(w.dgi, 3 * H, params_live + L.ag_w_ih, H, w.dx3a, H, rows, 3 * H, H, REFIL_GEMM_RELU_BWD);
+        gx3.aux = w.la.x3;
+        RUN(gemm_launch(gx3, c.st));
+        // fc2
+        RUN(gemm_launch(linear_dw(w.dx3a, H, w.la.x2, dd, grads + L.ag_fc2_w, dd, grads + L.ag_fc2_b, rows, H, dd, w.partial, 1), c.st));
+        refil_gemm_desc gx2 = linear_dx(w.dx3a, H, params_live + L.ag_fc2_w, dd, w.dx2a, dd, rows, H, dd, 0);
+        gx2.rowmask = w.amask; gx2.rowmask_mod = (int)s.NA;
+        RUN(gemm_launch(gx2, c.st));
+        AttnBlockBwd k;
+        k.w = dd; k.nets = 1; k.nv0 = G; k.P = params_live; k.Gr = grads;
+        k.in_w = L.ag_in_w; k.in_w_stride = 0; k.out_w = L.ag_out_w; k.out_w_stride = 0; k.out_b = L.ag_out_b; k.out_b_stride = 0;
+        k.x1 = w.la.x1; k.kv = w.la.kv; k.q = w.la.q; k.ao = w.la.ao; k.dx2 = w.dx2a;
+        k.dao = w.daoa; k.dq = w.dqa; k.dkv = w.dkva; k.dx1 = w.dx1a;
+        k.var_first[0] = REFIL_MASK_OBS; k.var_first[1] = REFIL_MASK_OBS_WITHIN; k.var_first[2] = REFIL_MASK_OBS_INTERACT;
+        k.var_rest = REFIL_MASK_OBS;
+        RUN(attn_block_backward(c, k));
+        RUN(gemm_launch(linear_dw(w.dx1a, dd, w.xe, s.Ep, grads + L.ag_fc1_w, s.E, grads + L.ag_fc1_b, s.NE, dd, s.E, w.partial, 1), c.st));
+    }
+    return 0;
+}
+
+extern "C" int refil_agent_forward(const refil_dims* dims, const refil_batch* batch, int32_t first_step_zero,
+                                   const float* params, const float* h0, float* h_out, float* q_out, void* workspace,
+                                   size_t workspace_bytes_, void* stream) {
+    Ctx c;
+    if (int e = make_ctx(c, dims, batch, workspace, workspace_bytes_, CARVE_AGENT_FWD, stream)) return e;
+    REFIL_CHECK(params && q_out, "refil_agent_forward: null params / q_out");
+    REFIL_CHECK(batch->obs_mask, "refil_agent_forward: obs_mask missing");
+    REFIL_CHECK(!dims->imagine || batch->group_bits, "refil_agent_forward: group_bits required when imagine=1");
+    RUN(run_prep(c, first_step_zero));
+    RUN(agent_forward(c, params, c.w.la, c.s.G, h0));
+    RUN(copy_out(q_out, c.w.la.qv, (long)c.s.G * c.s.NA * c.d.A, c.st));
+    if (h_out) RUN(get_hT_launch(c.w.la.hsx, h_out, c.s.G * c.d.B, c.d.T1, c.d.na, c.d.H, c.st));
+    return 0;
+}
+
+extern "C" size_t refil_agent_workspace_bytes(const refil_dims* dims) {
+    if (!dims || check_dims(*dims)) return 0;
+    return workspace_bytes(*dims, CARVE_AGENT_FWD);
+}
+extern "C" size_t refil_mixer_workspace_bytes(const refil_dims* dims) {
+    if (!dims || check_dims(*dims)) return 0;
+    return workspace_bytes(*dims, CARVE_MIXER_FWD);
+}
+
+extern "C" int refil_mixer_forward(const refil_dims* dims, const refil_batch* batch, int32_t t0, int32_t T,
+                                   const float* params, const float* agent_qs, const float* agent_qs_imagine,
+                                   float* q_tot, float* q_tot_imagine, void* workspace, size_t workspace_bytes_, void* stream) {
+    Ctx c;
+    if (int e = make_ctx(c, dims, batch, workspace, workspace_bytes_, CARVE_MIXER_FWD, stream)) return e;
+    REFIL_CHECK(params && agent_qs && q_tot, "refil_mixer_forward: null pointer");
+    REFIL_CHECK(t0 >= 0 && T > 0 && t0 + T <= dims->T1, "refil_mixer_forward: step range [%d,%d) outside the batch", t0, t0 + T);
+    const bool im = agent_qs_imagine != nullptr;
+    REFIL_CHECK(!im || (batch->group_bits && q_tot_imagine && dims->imagine), "refil_mixer_forward: imagined mix needs imagine=1, group_bits and q_tot_imagine");
+    RUN(run_prep(c, 1));
+    const int nv0 = im ? 3 : 1;
+    RUN(hyper_forward(c, params, c.w.lh, nv0));
+    // chosen-Q layout expected by the mix kernel: [G][B,T,na]; the ABI hands real [B,T,na] and
+    // imagined [B,T,2na] = cat(W, I) (q_learner.py:96): de-interleave into scratch (reuse lh.q)
+    float* qs = c.w.lh.q;
+    const long BTn = (long)dims->B * T * dims->na;
+    REFIL_HIP(hipMemcpyAsync(qs, agent_qs, BTn * sizeof(float), hipMemcpyDeviceToDevice, c.st));
+    if (im) {
+        REFIL_HIP(hipMemcpy2DAsync(qs + BTn, dims->na * sizeof(float), agent_qs_imagine, 2 * dims->na * sizeof(float),
+                                   dims->na * sizeof(float), (size_t)dims->B * T, hipMemcpyDeviceToDevice, c.st));
+        REFIL_HIP(hipMemcpy2DAsync(qs + 2 * BTn, dims->na * sizeof(float), agent_qs_imagine + dims->na, 2 * dims->na * sizeof(float),
+                                   dims->na * sizeof(float), (size_t)dims->B * T, hipMemcpyDeviceToDevice, c.st));
+    }
+    MixArgs m = mix_args(c, c.w.lh, nv0, qs, im ? 3 : 1, t0, T);
+    m.q_tot = q_tot; m.q_tot_im = q_tot_imagine;
+    RUN(mix_forward_launch(m, c.st));
+    return 0;
+}

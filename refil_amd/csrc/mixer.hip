@@ -1,0 +1,435 @@
+// Small HBM-bound kernels of the REFIL learner step: input assembly, chosen-action / double-Q
+// selection, FlexQMixer monotonic mixing (forward + backward), TD loss, clip + RMSprop.
+// Each cites the reference lines it restates. All are coalesced grid-stride / wave-per-row kernels;
+// none of them is large enough to matter next to the projections, they exist so that no
+// intermediate ever leaves the GPU or goes through a generic framework op.
+#include "kernels.h"
+
+namespace refil {
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prep: entities || one-hot(previous action)  (entity_controller.py:13-27 == q_learner.py:50-60)
+// ------------------------------------------------------------------------------------------------
+__global__ void prep_kernel(PrepArgs a) {
+    const long R = (long)a.B * a.T1;
+    const long total = R * a.ne * a.Ep;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int c = idx % a.Ep;
+        const long row = idx / a.Ep;
+        const int e = row % a.ne;
+        const long r = row / a.ne;
+        const int b = r / a.T1, t = r % a.T1;
+        float v = 0.f;
+        if (c < a.ed) {
+            v = a.b.entities[b * a.b.ent_sB + t * a.b.ent_sT + (long)e * a.ed + c];
+        } else if (a.last_action && c < a.ed + a.A && e < a.na) {
+            // first_step_zero: one-hot of actions[b,t-1] with zeros at t=0 (the t=None forward);
+            // otherwise the caller passes actions already shifted by one step (acting, t=int)
+            const int tp = a.first_step_zero ? t - 1 : t;
+            if (tp >= 0) {
+                const int64_t act = a.b.actions[b * a.b.ac_sB + tp * a.b.ac_sT + e];
+                v = (act == (int64_t)(c - a.ed)) ? 1.f : 0.f;
+            }
+        }
+        a.xe[idx] = v;
+    }
+    const long tot2 = R * a.ne;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < tot2; idx += stride) {
+        const int e = idx % a.ne;
+        const long r = idx / a.ne;
+        const int b = r / a.T1, t = r % a.T1;
+        const uint8_t m = a.b.entity_mask[b * a.b.em_sB + t * a.b.em_sT + e];
+        a.emc[idx] = m;
+        if (e < a.na) a.amask[r * a.na + e] = m;
+        if (t == 0) a.em0[(long)b * a.ne + e] = m;
+    }
+}
+
+int prep_launch(const PrepArgs& a, hipStream_t st) {
+    const long total = (long)a.B * a.T1 * a.ne * a.Ep;
+    const int blocks = (int)min((long)4096, cdivl(total, 256));
+    hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, st, a);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void set_h0_kernel(float* hsx, const float* h0, int GB, int T1, int na, int H) {
+    const long total = (long)GB * na * H;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long gb = idx / ((long)na * H), rem = idx % ((long)na * H);
+        hsx[gb * (long)(T1 + 1) * na * H + rem] = h0 ? h0[idx] : 0.f;
+    }
+}
+int set_h0_launch(float* hsx, const float* h0, int GB, int T1, int na, int H, hipStream_t st) {
+    const long total = (long)GB * na * H;
+    hipLaunchKernelGGL(set_h0_kernel, dim3((int)min((long)1024, cdivl(total, 256))), dim3(256), 0, st, hsx, h0, GB, T1, na, H);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void get_hT_kernel(const float* hsx, float* h_out, int GB, int T1, int na, int H) {
+    const long total = (long)GB * na * H;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long gb = idx / ((long)na * H), rem = idx % ((long)na * H);
+        h_out[idx] = hsx[(gb * (long)(T1 + 1) + T1) * na * H + rem];
+    }
+}
+int get_hT_launch(const float* hsx, float* h_out, int GB, int T1, int na, int H, hipStream_t st) {
+    const long total = (long)GB * na * H;
+    hipLaunchKernelGGL(get_hT_kernel, dim3((int)min((long)1024, cdivl(total, 256))), dim3(256), 0, st, hsx, h_out, GB, T1, na, H);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// chosen-action Q + double-Q target selection (q_learner.py:91,109,115-128)
+// ------------------------------------------------------------------------------------------------
+constexpr float NEG_UNAVAIL = -9999999.0f;
+
+__global__ void qselect_kernel(QSelArgs a) {
+    const int T = a.T1 - 1;
+    const long total = (long)a.B * T * a.na;
+    const long NA = (long)a.B * a.T1 * a.na;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int i = idx % a.na;
+        const long bt = idx / a.na;
+        const int b = bt / T, t = bt % T;
+        const long row = ((long)b * a.T1 + t) * a.na + i;
+        const int64_t act = a.actions[b * a.ac_sB + t * a.ac_sT + i];
+        for (int g = 0; g < a.G; ++g) a.chosen[(long)g * total + idx] = a.q[((long)g * NA + row) * a.A + act];
+        if (a.tq) {
+            const long row1 = row + a.na;   // step t+1
+            const int32_t* av = a.avail + b * a.av_sB + (t + 1) * a.av_sT + (long)i * a.A;
+            const float* tq = a.tq + row1 * a.A;
+            float out;
+            if (a.double_q) {
+                const float* ql = a.q + row1 * a.A;   // live copy 0
+                float best = av[0] == 0 ? NEG_UNAVAIL : ql[0];
+                int arg = 0;
+                for (int k = 1; k < a.A; ++k) {
+                    const float v = av[k] == 0 ? NEG_UNAVAIL : ql[k];
+                    if (v > best) { best = v; arg = k; }   // first maximal index on ties
+                }
+                out = av[arg] == 0 ? NEG_UNAVAIL : tq[arg];
+            } else {
+                out = av[0] == 0 ? NEG_UNAVAIL : tq[0];
+                for (int k = 1; k < a.A; ++k) out = fmaxf(out, av[k] == 0 ? NEG_UNAVAIL : tq[k]);
+            }
+            a.tmax[idx] = out;
+        }
+    }
+}
+int qselect_launch(const QSelArgs& a, hipStream_t st) {
+    const long total = (long)a.B * (a.T1 - 1) * a.na;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(qselect_kernel, dim3((int)min((long)2048, cdivl(total, 256))), dim3(256), 0, st, a);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
+// d(chosen)/d(q): scatter through the gather (q_learner.py:91) and the inactive-agent zero fill
+// (entity_rnn_agent.py:60); dense [G*R*na, A] so that the fc3 dW/dX GEMMs can consume it.
+__global__ void qselect_bwd_kernel(QSelBwdArgs a) {
+    const int T = a.T1 - 1;
+    const long NA = (long)a.B * a.T1 * a.na;
+    const long total = (long)a.G * NA * a.A;
+    const long BTn = (long)a.B * T * a.na;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int k = idx % a.A;
+        const long grow = idx / a.A;
+        const int g = grow / NA;
+        const long row = grow % NA;
+        const int i = row % a.na;
+        const long r = row / a.na;
+        const int b = r / a.T1, t = r % a.T1;
+        float v = 0.f;
+        if (t < T && !a.amask[row]) {
+            const int64_t act = a.actions[b * a.ac_sB + t * a.ac_sT + i];
+            if (act == k) v = a.dchosen[(long)g * BTn + ((long)b * T + t) * a.na + i];
+        }
+        a.dq[idx] = v;
+    }
+}
+int qselect_bwd_launch(const QSelBwdArgs& a, hipStream_t st) {
+    const long total = (long)a.G * a.B * a.T1 * a.na * a.A;
+    hipLaunchKernelGGL(qselect_bwd_kernel, dim3((int)min((long)4096, cdivl(total, 256))), dim3(256), 0, st, a);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FlexQMixer mixing (flex_qmix.py:96-121). One wave per (b,t); lane m owns mixing unit m (< M <= 64).
+//   w1 = softmax_M / abs (hyper_w_1 [na(,2na), M]);  b1 = mean_agents(hyper_b_1);
+//   hidden = elu(qs . w1 + b1);  w_final = softmax_M / abs (mean_agents(hyper_w_final));
+//   v = mean_{agents,M}(V);  q_tot = hidden . w_final + v
+// ------------------------------------------------------------------------------------------------
+struct MixRow {
+    float b1, wf, wf_raw, v, pre_r, hid_r, pre_i, hid_i;
+};
+
+__device__ inline float mix_weight(float x, bool act, int softmax_w) {
+    if (softmax_w) {
+        const float mx = wave_max(act ? x : -INFINITY);
+        const float e = act ? expf(x - mx) : 0.f;
+        const float s = wave_sum(e);
+        return e / s;
+    }
+    return act ? fabsf(x) : 0.f;
+}
+__device__ inline float nonlin(float x, int tanh_nl) { return tanh_nl ? tanhf(x) : (x > 0.f ? x : expf(x) - 1.0f); }
+__device__ inline float nonlin_grad(float pre, float hid, int tanh_nl) {
+    return tanh_nl ? 1.0f - hid * hid : (pre > 0.f ? 1.0f : expf(pre));
+}
+
+__device__ inline MixRow mix_row_forward(const MixArgs& a, long base, long qbase, long BTn, int m, bool act) {
+    MixRow o;
+    float acc_r = 0.f, acc_i = 0.f, b1 = 0.f, wfr = 0.f, vs = 0.f;
+    for (int i = 0; i < a.na; ++i) {
+        const long o_im = base + (long)i * a.M + m;
+        const float x0 = act ? a.x_w1[o_im] : 0.f;
+        acc_r = fmaf(a.qs[qbase + i], mix_weight(x0, act, a.softmax_w), acc_r);
+        if (a.imagine) {
+            const float xw = act ? a.x_w1[a.s_var + o_im] : 0.f;
+            const float xi = act ? a.x_w1[2 * a.s_var + o_im] : 0.f;
+            acc_i = fmaf(a.qs[a.s_qs_g + qbase + i], mix_weight(xw, act, a.softmax_w), acc_i);
+            acc_i = fmaf(a.qs[2 * a.s_qs_g + qbase + i], mix_weight(xi, act, a.softmax_w), acc_i);
+        }
+        if (act) { b1 += a.x_b1[o_im]; wfr += a.x_wf[o_im]; vs += a.x_v[o_im]; }
+    }
+    o.b1 = b1 / (float)a.na;
+    o.wf_raw = wfr / (float)a.na;
+    o.wf = mix_weight(o.wf_raw, act, a.softmax_w);
+    o.v = wave_sum(vs) / (float)(a.na * a.M);
+    o.pre_r = acc_r + o.b1;
+    o.hid_r = nonlin(o.pre_r, a.tanh_nl);
+    o.pre_i = acc_i + o.b1;
+    o.hid_i = nonlin(o.pre_i, a.tanh_nl);
+    return o;
+}
+
+__global__ __launch_bounds__(64) void mix_fwd_kernel(MixArgs a) {
+    const int bt = blockIdx.x;
+    const int b = bt / a.T, t = bt % a.T;
+    const int m = threadIdx.x;
+    const bool act = m < a.M;
+    const long rr = (long)b * a.T1 + t + a.t_off;
+    const long base = rr * a.na * a.M;
+    const long qbase = (long)bt * a.na;
+    const long BTn = (long)a.B * a.T * a.na;
+    const MixRow o = mix_row_forward(a, base, qbase, BTn, m, act);
+    const float qt = wave_sum(act ? o.hid_r * o.wf : 0.f) + o.v;
+    if (m == 0) a.q_tot[bt] = qt;
+    if (a.imagine) {
+        const float qi = wave_sum(act ? o.hid_i * o.wf : 0.f) + o.v;
+        if (m == 0) a.q_tot_im[bt] = qi;
+    }
+}
+
+__device__ inline float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(64) void mix_bwd_kernel(MixArgs a) {
+    // grid = B*T1 rows of the R space: rows outside [t_off, t_off+T) get zero gradients
+    const int r = blockIdx.x;
+    const int b = r / a.T1, tt = r % a.T1;
+    const int m = threadIdx.x;
+    const bool act = m < a.M;
+    const long base = (long)r * a.na * a.M;
+    const int t = tt - a.t_off;
+    const int nvar = a.imagine ? 3 : 1;
+    if (t < 0 || t >= a.T) {
+        if (act) {
+            for (int i = 0; i < a.na; ++i) {
+                const long o = base + (long)i * a.M + m;
+                for (int v = 0; v < nvar; ++v) a.dx_w1[v * a.s_var + o] = 0.f;
+                a.dx_wf[o] = 0.f; a.dx_b1[o] = 0.f; a.dx_v[o] = 0.f;
+            }
+        }
+        return;
+    }
+    const int bt = b * a.T + t;
+    const long qbase = (long)bt * a.na;
+    const long BTn = (long)a.B * a.T * a.na;
+    const MixRow o = mix_row_forward(a, base, qbase, BTn, m, act);
+    const float g_r = a.gc_real[bt];
+    const float g_i = a.imagine ? a.gc_im[bt] : 0.f;
+    // q_tot = sum_m hid*wf + v
+    const float dv = (g_r + g_i) / (float)(a.na * a.M);
+    const float dwf = g_r * o.hid_r + g_i * o.hid_i;
+    float dwf_raw;
+    if (a.softmax_w) {
+        const float dot = wave_sum(act ? o.wf * dwf : 0.f);
+        dwf_raw = o.wf * (dwf - dot);
+    } else {
+        dwf_raw = sgn(o.wf_raw) * dwf;
+    }
+    dwf_raw /= (float)a.na;
+    const float dpre_r = g_r * o.wf * nonlin_grad(o.pre_r, o.hid_r, a.tanh_nl);
+    const float dpre_i = g_i * o.wf * nonlin_grad(o.pre_i, o.hid_i, a.tanh_nl);
+    const float db1 = (dpre_r + dpre_i) / (float)a.na;
+    for (int i = 0; i < a.na; ++i) {
+        const long oo = base + (long)i * a.M + m;
+        const bool dead = a.amask[(long)r * a.na + i];
+        for (int v = 0; v < nvar; ++v) {
+            const float x = act ? a.x_w1[v * a.s_var + oo] : 0.f;
+            const float w = mix_weight(x, act, a.softmax_w);
+            const float dpre = v == 0 ? dpre_r : dpre_i;
+            const float q = a.qs[v * a.s_qs_g + qbase + i];
+            const float dq = wave_sum(act ? dpre * w : 0.f);
+            if (m == 0) a.dqs[(long)v * BTn + qbase + i] = dq;
+            const float dw = q * dpre;
+            float dx;
+            if (a.softmax_w) {
+                const float dot = wave_sum(act ? w * dw : 0.f);
+                dx = w * (dw - dot);
+            } else {
+                dx = sgn(x) * dw;
+            }
+            if (act) a.dx_w1[v * a.s_var + oo] = dead ? 0.f : dx;
+        }
+        if (act) {
+            a.dx_wf[oo] = dead ? 0.f : dwf_raw;
+            a.dx_b1[oo] = dead ? 0.f : db1;
+            a.dx_v[oo] = dead ? 0.f : dv;
+        }
+    }
+}
+
+static int mix_check(const MixArgs& a) {
+    REFIL_CHECK(a.M >= 1 && a.M <= 64, "refil mix: mixing_embed_dim %d must be in [1,64]", a.M);
+    REFIL_CHECK(a.x_w1 && a.x_wf && a.x_b1 && a.x_v && a.qs, "refil mix: null input");
+    return 0;
+}
+int mix_forward_launch(const MixArgs& a, hipStream_t st) {
+    if (int e = mix_check(a)) return e;
+    if (a.B * a.T <= 0) return 0;
+    hipLaunchKernelGGL(mix_fwd_kernel, dim3(a.B * a.T), dim3(64), 0, st, a);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+int mix_backward_launch(const MixArgs& a, hipStream_t st) {
+    if (int e = mix_check(a)) return e;
+    hipLaunchKernelGGL(mix_bwd_kernel, dim3(a.B * a.T1), dim3(64), 0, st, a);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// TD targets + masked squared error (q_learner.py:68-72,157-172). Single workgroup: B*T <= ~10^4.
+//   L_sum = (1-lmbda) sum (mask td)^2 + lmbda sum (mask td_im)^2      (1/sum(mask) applied later)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void td_loss_kernel(TdArgs a) {
+    __shared__ float red[6][16];
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int total = a.B * a.T;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const int b = idx / a.T, t = idx % a.T;
+        float mask = (float)a.filled[b * a.fl_sB + t * a.fl_sT];
+        if (t > 0) mask *= 1.0f - (float)a.terminated[b * a.tm_sB + (t - 1) * a.tm_sT];
+        const float term = (float)a.terminated[b * a.tm_sB + t * a.tm_sT];
+        const float target = a.reward[b * a.rw_sB + t * a.rw_sT] + a.gamma * (1.0f - term) * a.tq_tot[idx];
+        const float td = (a.q_tot[idx] - target) * mask;
+        const float wr = a.imagine ? 1.0f - a.lmbda : 1.0f;
+        a.gc_real[idx] = 2.0f * wr * td * mask;
+        s[0] += mask; s[1] += td * td; s[3] += fabsf(td); s[4] += a.q_tot[idx] * mask; s[5] += target * mask;
+        if (a.imagine) {
+            const float tdi = (a.q_tot_im[idx] - target) * mask;
+            a.gc_im[idx] = 2.0f * a.lmbda * tdi * mask;
+            s[2] += tdi * tdi;
+        }
+        if (a.targets) a.targets[idx] = target;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float v = wave_sum(s[k]);
+        if (lane == 0) red[k][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += red[threadIdx.x][w];
+        a.stats[threadIdx.x] = v;
+    }
+    if (threadIdx.x == 6) a.stats[REFIL_STAT_GRAD_NORM] = 0.f;
+    if (threadIdx.x == 7) a.stats[REFIL_STAT_RESERVED] = 0.f;
+}
+int td_loss_launch(const TdArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(1024), 0, st, a);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// clip_grad_norm_ + RMSprop on the flat buffers (q_learner.py:37-38,177-178)
+// ------------------------------------------------------------------------------------------------
+constexpr int OPT_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, float* partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) s = fmaf(g[i], g[i], s);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void rmsprop_kernel(float* p, const float* g, float* sq, long n, float lr, float alpha,
+                                                      float eps, float wd, float clip, float* stats, const float* partial) {
+    __shared__ float red[4];
+    __shared__ float s_scale;
+    float s = partial[threadIdx.x];   // OPT_BLOCKS == blockDim
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float msum = stats[REFIL_STAT_MASK_SUM];
+        const float inv = 1.0f / msum;                                       // the loss normaliser (q_learner.py:165)
+        const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]) * inv;
+        const float coef = fminf(1.0f, clip / (norm + 1e-6f));               // torch clip_grad_norm_
+        s_scale = inv * coef;
+        if (blockIdx.x == 0) stats[REFIL_STAT_GRAD_NORM] = norm;
+    }
+    __syncthreads();
+    const float scale = s_scale;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float gi = g[i] * scale;
+        float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        const float v = alpha * sq[i] + (1.0f - alpha) * gi * gi;            // torch.optim.RMSprop, no momentum
+        sq[i] = v;
+        p[i] = pi - lr * gi / (sqrtf(v) + eps);
+    }
+}
+
+int clip_rmsprop_launch(float* params, const float* grads, float* sq, long n, float lr, float alpha, float eps,
+                        float wd, float clip, float* stats, float* scratch, hipStream_t st) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(OPT_BLOCKS), dim3(256), 0, st, grads, n, scratch);
+    REFIL_LAUNCH_CHECK();
+    const int blocks = (int)min((long)1024, cdivl(n, 256));
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(blocks), dim3(256), 0, st, params, grads, sq, n, lr, alpha, eps, wd, clip, stats, scratch);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace refil
+
+extern "C" int refil_clip_rmsprop_step(float* params, const float* grads, float* square_avg, int64_t n, float lr,
+                                       float alpha, float eps, float weight_decay, float grad_norm_clip,
+                                       float* grads_stats, void* scratch, void* stream) {
+    REFIL_CHECK(params && grads && square_avg && grads_stats && scratch, "refil_clip_rmsprop_step: null pointer");
+    REFIL_CHECK(n > 0, "refil_clip_rmsprop_step: n must be > 0");
+    return refil::clip_rmsprop_launch(params, grads, square_avg, n, lr, alpha, eps, weight_decay, grad_norm_clip,
+                                      grads_stats, (float*)scratch, (hipStream_t)stream);
+}

@@ -1,0 +1,75 @@
+"""Thin torch-tensor wrappers around the C ABI for the GPU tests (all calls go through ctypes)."""
+import ctypes as C
+
+import torch
+
+from refil_amd import _lib
+from refil_amd._lib import AttnDesc, GemmDesc, GruDesc, RowMap, check, lib, ptr
+
+
+def _stream():
+    return _lib.current_stream_ptr()
+
+
+def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, flags=0, bias=None, aux=None, rowmask=None, rowmask_mod=0,
+         colsum=None, partial=None, batch=1, splits=1, sA=0, sB=0, sC=0, sBias=0, sColsum=0,
+         a_map=(0, 0, 0), b_map=(0, 0, 0), c_map=(0, 0, 0)):
+    d = GemmDesc()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C_out.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.aux = aux.data_ptr() if aux is not None else None
+    d.rowmask = rowmask.data_ptr() if rowmask is not None else None
+    d.colsum = colsum.data_ptr() if colsum is not None else None
+    d.partial = partial.data_ptr() if partial is not None else None
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, ldb, ldc
+    d.sA, d.sB, d.sC, d.sBias, d.sColsum = sA, sB, sC, sBias, sColsum
+    d.a_map, d.b_map, d.c_map = RowMap(*a_map), RowMap(*b_map), RowMap(*c_map)
+    d.rowmask_mod, d.batch, d.splits, d.flags = rowmask_mod, batch, splits, flags
+    check(lib().refil_gemm(C.byref(d), _stream()), "refil_gemm")
+
+
+def attn_desc(Q, K, V, ldq, ldkv, R, T1, ne, na, heads, hd, variants, obs_mask=None, ent_mask=None, ent_mask0=None,
+              group_bits=None):
+    d = AttnDesc()
+    d.Q, d.K, d.V, d.ldq, d.ldkv = Q.data_ptr(), K.data_ptr(), V.data_ptr(), ldq, ldkv
+    d.R, d.T1, d.ne, d.na, d.heads, d.hd = R, T1, ne, na, heads, hd
+    d.nvar = len(variants)
+    for i, v in enumerate(variants):
+        d.var[i] = v
+    if obs_mask is not None:
+        d.obs_mask, d.om_sB, d.om_sT = obs_mask.data_ptr(), obs_mask.stride(0), obs_mask.stride(1)
+    d.ent_mask = ent_mask.data_ptr() if ent_mask is not None else None
+    d.ent_mask0 = ent_mask0.data_ptr() if ent_mask0 is not None else None
+    d.group_bits = group_bits.data_ptr() if group_bits is not None else None
+    return d
+
+
+def attn_forward(d: AttnDesc, O, ldo, sO):
+    d.O, d.ldo, d.sO = O.data_ptr(), ldo, sO
+    check(lib().refil_attn_forward(C.byref(d), _stream()), "refil_attn_forward")
+
+
+def attn_backward(d: AttnDesc, dO, ldo, sO, dQ, dK, dV):
+    d.dO, d.ldo, d.sO = dO.data_ptr(), ldo, sO
+    d.dQ, d.dK, d.dV = dQ.data_ptr(), dK.data_ptr(), dV.data_ptr()
+    check(lib().refil_attn_backward(C.byref(d), _stream()), "refil_attn_backward")
+
+
+def gru_desc(gi, hsx, w_hh, b_hh, NR, T1, na, H=64, saves=None, dhs=None, dgi=None, dgh=None):
+    d = GruDesc()
+    d.gi = gi.data_ptr() if gi is not None else None
+    d.hsx, d.w_hh, d.b_hh = hsx.data_ptr(), w_hh.data_ptr(), b_hh.data_ptr()
+    if saves is not None:
+        d.save_r, d.save_z, d.save_n, d.save_ghn = [s.data_ptr() for s in saves]
+    if dhs is not None:
+        d.dhs, d.dgi, d.dgh = dhs.data_ptr(), dgi.data_ptr(), dgh.data_ptr()
+    d.NR, d.T1, d.na, d.H = NR, T1, na, H
+    return d
+
+
+def gru_forward(d):
+    check(lib().refil_gru_forward(C.byref(d), _stream()), "refil_gru_forward")
+
+
+def gru_backward(d):
+    check(lib().refil_gru_backward(C.byref(d), _stream()), "refil_gru_backward")

@@ -1,0 +1,190 @@
+"""GPU parity of the whole learner step (through the C ABI) against (a) the golden vectors produced
+by the real reference and (b) the CPU oracle at larger sizes / via size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from golden_util import CASES, load, rel_err
+from oracle import refil_oracle as orc
+
+DEV = "cuda"
+TOL_FWD = 1e-4      # north_star: loss / chosen-action Q within 1e-4 relative
+TOL_GRAD = 2e-4
+
+
+def _dims(cfg, B, T1):
+    from refil_amd import _lib
+    return _lib.make_dims(B=B, T1=T1, ne=cfg.n_entities, na=cfg.n_agents, ed=cfg.entity_shape, A=cfg.n_actions,
+                          d=cfg.attn_embed_dim, heads=cfg.attn_n_heads, H=cfg.rnn_hidden_dim, hyp=cfg.hypernet_embed,
+                          M=cfg.mixing_embed_dim, entity_last_action=int(cfg.entity_last_action), imagine=int(cfg.imagine),
+                          softmax_mixing_weights=int(cfg.softmax_mixing_weights), mixer_tanh=int(cfg.mixer_non_lin == "tanh"),
+                          double_q=int(cfg.double_q), gamma=cfg.gamma, lmbda=cfg.lmbda)
+
+
+def run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, debug=True, step=True):
+    from refil_amd import _lib, flat
+    from refil_amd.engine import LearnerEngine
+    B, T1 = batch["entities"].shape[:2]
+    dims = _dims(cfg, B, T1)
+    eng = LearnerEngine(DEV)
+    live = flat.pack(dims, agent, mixer, DEV)
+    targ = flat.pack(dims, tagent, tmixer, DEV)
+    n = flat.total(dims)
+    grads = torch.full((n + _lib.REFIL_NSTAT,), float("nan"), device=DEV)
+    fields = {k: v.to(DEV) for k, v in batch.items()}
+    out = eng.forward_backward(dims, fields, bits.to(DEV) if bits is not None else None, live, targ, grads, debug=debug)
+    torch.cuda.synchronize()
+    stats = grads[n:].cpu().double()
+    g_agent, g_mixer = flat.views(grads[:n].clone(), dims)
+    res = {"dims": dims, "out": {k: v.cpu() for k, v in out.items()}, "stats": stats, "n": n,
+           "grads": {**{"agent." + k: v.cpu() for k, v in g_agent.items()}, **{"mixer." + k: v.cpu() for k, v in g_mixer.items()}}}
+    if step:
+        sq = torch.zeros(n, device=DEV)
+        eng.clip_rmsprop(live, grads, sq, n, cfg.lr, cfg.optim_alpha, cfg.optim_eps, cfg.weight_decay, cfg.grad_norm_clip)
+        torch.cuda.synchronize()
+        pa, pm = flat.views(live, dims)
+        sa, sm = flat.views(sq, dims)
+        res["post"] = {**{"agent." + k: v.cpu() for k, v in pa.items()}, **{"mixer." + k: v.cpu() for k, v in pm.items()}}
+        res["sq"] = {**{"agent." + k: v.cpu() for k, v in sa.items()}, **{"mixer." + k: v.cpu() for k, v in sm.items()}}
+        res["grad_norm"] = grads[n + _lib.STAT_GRAD_NORM].item()
+    return res
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_learner_step_matches_reference_golden(name):
+    g = load(name)
+    z, cfg, case = g["z"], g["cfg"], g["case"]
+    r = run_hip_step(cfg, g["batch"], g["bits"], g["agent"], g["mixer"], g["tagent"], g["tmixer"])
+    o, st = r["out"], r["stats"]
+    B, T = case["B"], case["T"]
+    assert rel_err(o["q"], z["q"]) < TOL_FWD
+    assert rel_err(o["chosen_q"][0], z["chosen_q_real"]) < TOL_FWD
+    assert rel_err(o["target_max_q"], z["target_max_q"]) < TOL_FWD
+    assert rel_err(o["q_tot"], z["q_tot"][..., 0]) < TOL_FWD
+    assert rel_err(o["target_q_tot"], z["target_q_tot"][..., 0]) < TOL_FWD
+    msum = st[0].item()
+    q_loss = st[1].item() / msum
+    if cfg.imagine:
+        caq_im = torch.cat([o["chosen_q"][1], o["chosen_q"][2]], dim=2)
+        assert rel_err(caq_im, z["chosen_q_imagine"]) < TOL_FWD
+        assert rel_err(o["q_tot_imagine"], z["q_tot_imagine"][..., 0]) < TOL_FWD
+        im_loss = st[2].item() / msum
+        assert abs(im_loss - float(z["stat.im_loss"])) < TOL_FWD * abs(float(z["stat.im_loss"]))
+        loss = (1 - cfg.lmbda) * q_loss + cfg.lmbda * im_loss
+    else:
+        loss = q_loss
+    assert abs(loss - float(z["stat.loss"])) < TOL_FWD * abs(float(z["stat.loss"])), (loss, float(z["stat.loss"]))
+    assert abs(st[3].item() / msum - float(z["stat.td_error_abs"])) < 1e-4 * abs(float(z["stat.td_error_abs"]))
+    assert abs(r["grad_norm"] - float(z["stat.grad_norm"])) < TOL_GRAD * float(z["stat.grad_norm"])
+    gmax = max((v / msum).abs().max().item() for v in r["grads"].values())
+    for k, gv in r["grads"].items():
+        gv = gv / msum                                   # the library returns SUM-loss grads (see refil_hip.h)
+        if ("grad." + k) in z.files:
+            ref = torch.from_numpy(z["grad." + k])
+            assert (gv - ref).abs().max().item() < TOL_GRAD * gmax, k
+            assert (r["post"][k] - torch.from_numpy(z["post." + k])).abs().max().item() < 5e-6, k
+            assert rel_err(r["sq"][k], z["sq." + k]) < 1e-3 or torch.from_numpy(z["sq." + k]).abs().max() < 1e-12, k
+        else:
+            refn = float(z["gradnorm." + k])
+            assert abs(gv.double().norm().item() - refn) < TOL_GRAD * max(refn, 1e-6), k
+
+
+def _oracle_case(B, T, ne, seed, imagine=True, d=64, h=64, heads=4):
+    from refil_amd.synthetic import make_batch_fast, sc2_shape_law
+    law = sc2_shape_law(ne)
+    cfg = orc.Cfg(n_agents=law["n_agents"], n_entities=ne, n_actions=law["n_actions"], entity_shape=law["entity_shape"],
+                  attn_embed_dim=d, attn_n_heads=heads, hypernet_embed=h, imagine=imagine)
+    batch = make_batch_fast(B, T, ne, seed=seed)
+    agent = orc.init_params(orc.agent_param_shapes(cfg), seed + 1)
+    mixer = orc.init_params(orc.mixer_param_shapes(cfg), seed + 2)
+    tagent = orc.init_params(orc.agent_param_shapes(cfg), seed + 3)
+    tmixer = orc.init_params(orc.mixer_param_shapes(cfg), seed + 4)
+    torch.manual_seed(seed)
+    bits = orc.draw_partition_bits(B, ne)
+    return cfg, batch, bits, agent, mixer, tagent, tmixer
+
+
+@pytest.mark.parametrize("B,T,ne,imagine,d", [(4, 10, 16, True, 64), (3, 7, 32, True, 128), (4, 9, 16, False, 128)])
+def test_learner_step_matches_oracle(B, T, ne, imagine, d):
+    cfg, batch, bits, agent, mixer, tagent, tmixer = _oracle_case(B, T, ne, seed=100 + B, imagine=imagine, d=d, h=d)
+    r = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer)
+    a2, m2 = dict(agent), dict(mixer)
+    out, grads, gnorm = orc.train_step(cfg, a2, m2, tagent, tmixer, batch, bits)
+    o, st = r["out"], r["stats"]
+    assert rel_err(o["q"], out.q.detach()) < TOL_FWD
+    assert rel_err(o["chosen_q"], out.chosen_q.detach()) < TOL_FWD
+    assert rel_err(o["q_tot"], out.q_tot.detach()[..., 0]) < TOL_FWD
+    assert rel_err(o["targets"], out.targets[..., 0]) < TOL_FWD
+    msum = st[0].item()
+    assert abs(msum - out.mask.sum().item()) < 1e-6
+    assert abs(st[1].item() / msum - out.q_loss.item()) < TOL_FWD * out.q_loss.item()
+    if imagine:
+        assert abs(st[2].item() / msum - out.im_loss.item()) < TOL_FWD * out.im_loss.item()
+    assert abs(r["grad_norm"] - gnorm) < TOL_GRAD * gnorm
+    gmax = max(v.abs().max().item() for v in grads.values())
+    for k, ref in grads.items():
+        assert (r["grads"][k] / msum - ref).abs().max().item() < TOL_GRAD * gmax, k
+    for k in a2:
+        assert (r["post"]["agent." + k] - a2[k]).abs().max().item() < 5e-6, k
+    for k in m2:
+        assert (r["post"]["mixer." + k] - m2[k]).abs().max().item() < 5e-6, k
+
+
+def test_time_truncated_strided_batch_equals_contiguous():
+    """batch[:, :max_t] views (run.py:269-270) are consumed in place through the stride arguments."""
+    cfg, batch, bits, agent, mixer, tagent, tmixer = _oracle_case(3, 8, 16, seed=7)
+    big = {k: torch.cat([v, torch.zeros_like(v[:, :5])], dim=1) for k, v in batch.items()}
+    from refil_amd import _lib, flat
+    from refil_amd.engine import LearnerEngine
+    dims = _dims(cfg, 3, 9)
+    eng = LearnerEngine(DEV)
+    live = flat.pack(dims, agent, mixer, DEV)
+    targ = flat.pack(dims, tagent, tmixer, DEV)
+    n = flat.total(dims)
+    res = []
+    for fields in ({k: v.to(DEV) for k, v in batch.items()}, {k: v.to(DEV)[:, :9] for k, v in big.items()}):
+        grads = torch.zeros(n + _lib.REFIL_NSTAT, device=DEV)
+        eng.forward_backward(dims, fields, bits.to(DEV), live, targ, grads)
+        torch.cuda.synchronize()
+        res.append(grads.cpu())
+    assert torch.equal(res[0], res[1])
+
+
+def test_full_size_properties():
+    """cfg-T sized step (B=32,T=80,ne=32,d=128): finite outputs, determinism, gradient linearity in lmbda
+    (grads are affine in lmbda: g(lmbda) = (1-lmbda) g_q + lmbda g_im), and data-parallel additivity:
+    SUM-loss grads of two half-batches add up to the full-batch grads."""
+    from refil_amd import _lib, flat
+    from refil_amd.engine import LearnerEngine, clone_dims
+    B, T, ne = 32, 80, 32
+    cfg, batch, bits, agent, mixer, tagent, tmixer = _oracle_case(B, T, ne, seed=3, d=128, h=128)
+    dims = _dims(cfg, B, T + 1)
+    eng = LearnerEngine(DEV)
+    live = flat.pack(dims, agent, mixer, DEV)
+    targ = flat.pack(dims, tagent, tmixer, DEV)
+    n = flat.total(dims)
+    fields = {k: v.to(DEV) for k, v in batch.items()}
+    bd = bits.to(DEV)
+
+    def run(dm, f, b):
+        g = torch.zeros(n + _lib.REFIL_NSTAT, device=DEV)
+        eng.forward_backward(dm, f, b, live, targ, g)
+        torch.cuda.synchronize()
+        return g
+
+    g_half = run(dims, fields, bd)
+    assert torch.isfinite(g_half).all()
+    assert torch.equal(g_half, run(dims, fields, bd)), "step is not deterministic"
+    g0 = run(clone_dims(dims, lmbda=0.0), fields, bd)[:n]
+    g1 = run(clone_dims(dims, lmbda=1.0), fields, bd)[:n]
+    mix = 0.5 * g0 + 0.5 * g1
+    assert (mix - g_half[:n]).abs().max().item() < 1e-4 * g_half[:n].abs().max().item()
+    h = B // 2
+    dh = clone_dims(dims, B=h)
+    ga = run(dh, {k: v[:h] for k, v in fields.items()}, bd[:h].contiguous())
+    gb = run(dh, {k: v[h:] for k, v in fields.items()}, bd[h:].contiguous())
+    tot = ga + gb
+    assert (tot[:n] - g_half[:n]).abs().max().item() < 1e-4 * g_half[:n].abs().max().item()
+    assert abs(tot[n].item() - g_half[n].item()) < 1e-3

@@ -1,0 +1,241 @@
+"""GPU parity tests of the building-block kernels, called through the C ABI, against plain fp32
+torch CPU math of the same op. Run on the MI355X box with `pytest -m gpu`."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from refil_amd._lib import (GEMM_A_OUTC, GEMM_ACCUM, GEMM_B_OUTC, GEMM_COLSUM_A, GEMM_RELU, GEMM_RELU_BWD, MASK_ENTITY,
+                            MASK_INTERACT, MASK_OBS, MASK_OBS_INTERACT, MASK_OBS_WITHIN, MASK_WITHIN)
+
+DEV = "cuda"
+
+
+def _close(a, b, tol=2e-5, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    ref = max(b.abs().max().item(), 1e-6)
+    assert err <= tol * ref, f"{what}: max abs err {err:.3e} vs ref max {ref:.3e} (tol {tol})"
+
+
+def _rowmap(r, grp, gstride, off):
+    return (r // grp) * gstride + (r % grp) + off if grp else r
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,pad", [(1000, 128, 84, 4), (300, 64, 128, 0), (777, 22, 64, 0), (130, 384, 128, 0),
+                                       (257, 40, 10, 1), (64, 32, 33, 3)])
+def test_gemm_linear_forward(M, N, K, pad):
+    import hip_ops
+    torch.manual_seed(M + N + K)
+    lda = K + pad
+    x = torch.randn(M, lda)
+    W = torch.randn(N, K) / math.sqrt(K)
+    b = torch.randn(N)
+    mask = (torch.rand(50) < 0.3).to(torch.uint8)
+    ref = torch.relu(x[:, :K] @ W.t() + b)
+    ref[mask[torch.arange(M) % 50].bool()] = 0
+    y = torch.full((M, N), float("nan"), device=DEV)
+    hip_ops.gemm(x.to(DEV), W.to(DEV), y, M, N, K, lda, K, N, flags=GEMM_RELU, bias=b.to(DEV), rowmask=mask.to(DEV),
+                 rowmask_mod=50)
+    _close(y, ref, what="linear fwd")
+
+
+def test_gemm_row_remap_and_batch():
+    import hip_ops
+    torch.manual_seed(1)
+    na, ne, R, w, nets = 3, 7, 41, 16, 4
+    x1 = torch.randn(R * ne, nets * w)
+    W = torch.randn(nets, w, w)
+    ref = torch.stack([x1.view(R, ne, nets * w)[:, :na, n * w:(n + 1) * w].reshape(R * na, w) @ W[n].t() for n in range(nets)])
+    y = torch.zeros(nets, R * na, w, device=DEV)
+    hip_ops.gemm(x1.to(DEV), W.to(DEV), y, R * na, w, w, nets * w, w, w, batch=nets, sA=w, sB=w * w, sC=R * na * w,
+                 a_map=(na, ne, 0))
+    _close(y, ref, what="Q projection (agent rows, batched)")
+
+
+def test_gemm_dx_relu_bwd_accum_cmap():
+    import hip_ops
+    torch.manual_seed(2)
+    na, ne, R, w = 3, 5, 37, 24
+    dkv = torch.randn(R * ne, 2 * w)
+    dq = torch.randn(R * na, w)
+    Win = torch.randn(3 * w, w) / 5
+    x1 = torch.randn(R * ne, w)
+    ref = dkv @ Win[w:]
+    refq = dq @ Win[:w]
+    ref.view(R, ne, w)[:, :na] += refq.view(R, na, w)
+    ref = ref * (x1 > 0)
+    dx1 = torch.full((R * ne, w), float("nan"), device=DEV)
+    Wd, x1d = Win.to(DEV), x1.to(DEV)
+    hip_ops.gemm(dkv.to(DEV), Wd[w:], dx1, R * ne, w, 2 * w, 2 * w, w, w, flags=GEMM_B_OUTC | GEMM_RELU_BWD, aux=x1d)
+    hip_ops.gemm(dq.to(DEV), Wd, dx1, R * na, w, w, w, w, w, flags=GEMM_B_OUTC | GEMM_RELU_BWD | GEMM_ACCUM, aux=x1d,
+                 c_map=(na, ne, 0))
+    _close(dx1, ref, what="dx1")
+
+
+@pytest.mark.parametrize("Rr,N,K,splits,batch", [(5000, 128, 84, 7, 1), (3000, 22, 64, 5, 1), (2000, 96, 48, 1, 2),
+                                                 (4097, 192, 64, 16, 3)])
+def test_gemm_dw_split_colsum(Rr, N, K, splits, batch):
+    import hip_ops
+    torch.manual_seed(Rr)
+    dy = torch.randn(batch, Rr, N)
+    x = torch.randn(batch, Rr, K)
+    ref_w = torch.einsum("brn,brk->bnk", dy, x)
+    ref_b = dy.sum(1)
+    dW = torch.full((batch, N, K), float("nan"), device=DEV)
+    db = torch.full((batch, N), float("nan"), device=DEV)
+    partial = torch.empty(batch * splits * (N * K + N) + 16, device=DEV)
+    hip_ops.gemm(dy.to(DEV), x.to(DEV), dW, N, K, Rr, N, K, K, flags=GEMM_A_OUTC | GEMM_B_OUTC | GEMM_COLSUM_A, colsum=db,
+                 partial=partial, batch=batch, splits=splits, sA=Rr * N, sB=Rr * K, sC=N * K, sColsum=N)
+    _close(dW, ref_w, tol=5e-5, what="dW")
+    _close(db, ref_b, tol=5e-5, what="db")
+
+
+def test_gemm_dw_bmap_hprev():
+    """dW_hh = dgh^T h_prev with h_prev read from the [gb, T1+1, na, H] buffer through a row map."""
+    import hip_ops
+    torch.manual_seed(5)
+    GB, T1, na, H = 3, 6, 4, 64
+    hsx = torch.randn(GB, T1 + 1, na, H)
+    dgh = torch.randn(GB * T1 * na, 3 * H)
+    hprev = hsx[:, :T1].reshape(-1, H)
+    ref = dgh.t() @ hprev
+    dW = torch.zeros(3 * H, H, device=DEV)
+    partial = torch.empty(4 * (3 * H * H + 3 * H), device=DEV)
+    hip_ops.gemm(dgh.to(DEV), hsx.to(DEV), dW, 3 * H, H, GB * T1 * na, 3 * H, H, H, flags=GEMM_A_OUTC | GEMM_B_OUTC,
+                 partial=partial, splits=4, b_map=(T1 * na, (T1 + 1) * na, 0))
+    _close(dW, ref, tol=5e-5, what="dW_hh")
+
+
+# ------------------------------------------------------------------------------------------------
+# attention core
+# ------------------------------------------------------------------------------------------------
+def _masks(code, obs, em_t, em0, gb, na):
+    """bool [B,T1,na,ne] pre-mask for a variant code (closed forms of SURVEY.md section 8a-5)."""
+    B, T1, ne, _ = obs.shape
+    inact0 = em0.bool()
+    act_pair = (~inact0)[:, :, None] & (~inact0)[:, None, :]
+    same = (act_pair & (gb.bool()[:, :, None] == gb.bool()[:, None, :]))[:, None, :na, :].expand(B, T1, na, ne)
+    in0 = (~act_pair)[:, None, :na, :].expand(B, T1, na, ne)
+    om = obs.bool()[:, :, :na, :]
+    emt = em_t.bool()
+    ent = emt[:, :, :na, None] | emt[:, :, None, :]
+    return {MASK_OBS: om, MASK_OBS_WITHIN: ~same | om, MASK_OBS_INTERACT: same | om, MASK_ENTITY: ent,
+            MASK_WITHIN: ~same, MASK_INTERACT: same | in0}[code]
+
+
+def _attn_ref(q, k, v, masks, heads):
+    """q [R,na,w], k,v [R,ne,w], masks list of bool [R,na,ne] -> list of [R,na,w] (attention.py:48-64)."""
+    R, na, w = q.shape
+    ne = k.shape[1]
+    hd = w // heads
+    qh = q.reshape(R, na, heads, hd).permute(0, 2, 1, 3)
+    kh = k.reshape(R, ne, heads, hd).permute(0, 2, 3, 1)
+    vh = v.reshape(R, ne, heads, hd).permute(0, 2, 1, 3)
+    logits = (qh @ kh) / torch.tensor(float(hd)).sqrt()
+    outs = []
+    for m in masks:
+        ml = logits.masked_fill(m[:, None], float("-inf"))
+        wts = torch.softmax(ml, dim=3)
+        wts = torch.where(torch.isnan(wts), torch.zeros_like(wts), wts)
+        outs.append((wts @ vh).permute(0, 2, 1, 3).reshape(R, na, w))
+    return outs
+
+
+@pytest.mark.parametrize("ne,na,heads,hd,variants", [
+    (32, 16, 4, 32, [MASK_OBS, MASK_OBS_WITHIN, MASK_OBS_INTERACT]),
+    (16, 8, 4, 16, [MASK_ENTITY, MASK_WITHIN, MASK_INTERACT]),
+    (7, 5, 3, 8, [MASK_OBS, MASK_OBS_WITHIN, MASK_OBS_INTERACT]),
+    (6, 3, 2, 4, [MASK_ENTITY]),
+    (48, 24, 4, 32, [MASK_ENTITY, MASK_WITHIN, MASK_INTERACT]),
+    (64, 32, 2, 32, [MASK_OBS]),
+])
+def test_attention_forward_backward(ne, na, heads, hd, variants):
+    import hip_ops
+    torch.manual_seed(ne * 100 + na)
+    B, T1 = 3, 4
+    R, w = B * T1, heads * hd
+    q = torch.randn(R, na, w, requires_grad=True)
+    kv = torch.randn(R, ne, 2 * w, requires_grad=True)
+    obs = (torch.rand(B, T1, ne, ne) < 0.4).to(torch.uint8)
+    em_t = (torch.rand(B, T1, ne) < 0.3).to(torch.uint8)
+    obs[0, 0, 0, :] = 1          # a fully masked row
+    em_t[1, :, :] = 1            # an episode with every entity inactive
+    em0 = em_t[:, 0].contiguous()
+    gb = (torch.rand(B, ne) < 0.5).to(torch.uint8)
+    masks = [_masks(c, obs, em_t, em0, gb, na).reshape(R, na, ne) for c in variants]
+    outs = _attn_ref(q, kv[:, :, :w], kv[:, :, w:], masks, heads)
+    nv = len(variants)
+    dO = torch.randn(nv, R, na, w)
+    loss = sum((o * dO[i]).sum() for i, o in enumerate(outs))
+    loss.backward()
+
+    qd, kvd = q.detach().reshape(R * na, w).to(DEV), kv.detach().reshape(R * ne, 2 * w).to(DEV)
+    d = hip_ops.attn_desc(qd, kvd, kvd[:, w:], w, 2 * w, R, T1, ne, na, heads, hd, variants, obs_mask=obs.to(DEV),
+                          ent_mask=em_t.reshape(R, ne).to(DEV), ent_mask0=em0.to(DEV), group_bits=gb.to(DEV))
+    O = torch.full((nv, R * na, w), float("nan"), device=DEV)
+    hip_ops.attn_forward(d, O, w, R * na * w)
+    for i in range(nv):
+        _close(O[i].reshape(R, na, w), outs[i], what=f"attn fwd variant {i}")
+    dQ = torch.full((R * na, w), float("nan"), device=DEV)
+    dKV = torch.full((R * ne, 2 * w), float("nan"), device=DEV)
+    hip_ops.attn_backward(d, dO.reshape(nv, R * na, w).to(DEV), w, R * na * w, dQ, dKV, dKV[:, w:])
+    _close(dQ.reshape(R, na, w), q.grad, tol=5e-5, what="dQ")
+    _close(dKV.reshape(R, ne, 2 * w), kv.grad, tol=5e-5, what="dKV")
+    assert torch.isfinite(O).all() and torch.isfinite(dQ).all() and torch.isfinite(dKV).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# persistent GRU
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("GB,T1,na", [(6, 9, 16), (5, 4, 3), (2, 1, 8), (3, 21, 5)])
+def test_gru_forward_backward(GB, T1, na):
+    import hip_ops
+    from oracle.refil_oracle import gru_cell
+    torch.manual_seed(GB * 7 + T1)
+    H = 64
+    NR = GB * na
+    w_ih = (torch.randn(3 * H, H) / 8).requires_grad_(True)
+    w_hh = (torch.randn(3 * H, H) / 8).requires_grad_(True)
+    b_ih = (torch.randn(3 * H) / 8).requires_grad_(True)
+    b_hh = (torch.randn(3 * H) / 8).requires_grad_(True)
+    x = torch.randn(GB, T1, na, H, requires_grad=True)
+    h0 = torch.randn(GB, na, H) / 2
+    h = h0.reshape(NR, H)
+    hs = []
+    for t in range(T1):
+        h = gru_cell(x[:, t].reshape(NR, H), h, w_ih, w_hh, b_ih, b_hh)
+        hs.append(h.reshape(GB, na, H))
+    hs = torch.stack(hs, 1)
+    dhs = torch.randn(GB, T1, na, H)
+    (hs * dhs).sum().backward()
+
+    gi = (x.detach().reshape(-1, H) @ w_ih.detach().t() + b_ih.detach()).to(DEV)
+    hsx = torch.full((GB, T1 + 1, na, H), float("nan"), device=DEV)
+    hsx[:, 0] = h0.to(DEV)
+    saves = [torch.full((GB * T1 * na, H), float("nan"), device=DEV) for _ in range(4)]
+    whh, bhh = w_hh.detach().to(DEV), b_hh.detach().to(DEV)
+    d = hip_ops.gru_desc(gi, hsx, whh, bhh, NR, T1, na, saves=saves)
+    hip_ops.gru_forward(d)
+    _close(hsx[:, 1:], hs, what="gru hs")
+    dgi = torch.full((GB * T1 * na, 3 * H), float("nan"), device=DEV)
+    dgh = torch.full((GB * T1 * na, 3 * H), float("nan"), device=DEV)
+    d = hip_ops.gru_desc(gi, hsx, whh, bhh, NR, T1, na, saves=saves, dhs=dhs.to(DEV), dgi=dgi, dgh=dgh)
+    hip_ops.gru_backward(d)
+    dgi_c, dgh_c = dgi.cpu(), dgh.cpu()
+    _close(dgi_c.sum(0), b_ih.grad, tol=1e-4, what="db_ih")
+    _close(dgh_c.sum(0), b_hh.grad, tol=1e-4, what="db_hh")
+    _close(dgi_c.t() @ x.detach().reshape(-1, H), w_ih.grad, tol=1e-4, what="dW_ih")
+    hprev = hsx[:, :T1].reshape(-1, H).cpu()
+    _close(dgh_c.t() @ hprev, w_hh.grad, tol=1e-4, what="dW_hh")
+    _close((dgi_c @ w_ih.detach()).reshape(GB, T1, na, H), x.grad, tol=1e-4, what="dx")
+    # inference variant (no saves) gives the same hidden states
+    hsx2 = torch.zeros_like(hsx)
+    hsx2[:, 0] = h0.to(DEV)
+    hip_ops.gru_forward(hip_ops.gru_desc(gi, hsx2, whh, bhh, NR, T1, na))
+    assert torch.equal(hsx2[:, 1:], hsx[:, 1:])
