@@ -1,0 +1,252 @@
+"""Learner-throughput bench of the MI355X-native REFIL hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one full QLearner.train() (reference: src/learners/q_learner.py:66-201) on a synthetic
+replay minibatch resident in HBM: live + target agent forward, mixers, TD loss, hand-written backward,
+(all-reduce when N > 1), clip + RMSprop, periodic target sync. Workload = the north-star shape
+(B=32 episodes per GPU, T=80 transitions, n_entities=32, attn/hypernet dim 128, REFIL); weak scaling:
+per-GPU batch fixed, value = transitions/s summed over all GPUs.
+
+Prints ONE JSON line (rank 0). Extra objects:
+  roofline     -- the kernel symbol with the largest share of GPU time, timed with HIP events on the
+                  launch stream by the library's profiler over K steps right after the timed region
+                  (events are kept out of the timed region itself so they cannot perturb `value`);
+                  achieved = algorithmic FLOPs per launch / mean launch duration; peak = 157.3 TFLOP/s
+                  (fp32 MFMA, MI355X_MICROARCH.md).
+  cpu_baseline -- oracle/refil_oracle.py (a fixture-pinned CPU port of the reference learner) timed on
+                  this box's host cores on a bounded sample of the same workload (N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_FP32_MFMA_TFLOPS = 157.3
+WORKLOAD = dict(B=32, T=80, ne=32, d=128, h=128, heads=4, H=64, M=32)
+
+
+def algorithmic_flops(B, T, ne, na, E, A, d, h, H, M, G):
+    """SURVEY.md section 8d closed form (2mnk per GEMM, backward 2x / first layers 1x, targets forward-only)."""
+    T1 = T + 1
+
+    def net(rows, w, V, tail, first_layer_bwd=True):
+        fc1 = 2 * ne * E * w
+        qkv = 2 * na * w * w + 4 * ne * w * w
+        core = 4 * na * ne * w
+        out = 2 * na * w * w
+        fwd = rows * (fc1 + qkv + V * (core + out + tail))
+        bwd = rows * (fc1 + 2 * qkv + V * 2 * (core + out + tail))
+        return fwd, bwd
+    tail_a = 2 * na * d * H + 12 * na * H * H + 2 * na * H * A
+    tail_h = 2 * na * h * M
+    la_f, la_b = net(B * T1, d, G, tail_a)
+    ta_f, _ = net(B * T1, d, 1, tail_a)
+    lm = [net(B * T, h, G, tail_h)] + [net(B * T, h, 1, tail_h) for _ in range(3)]
+    tm = [net(B * T, h, 1, tail_h) for _ in range(4)]
+    return la_f + la_b + ta_f + sum(f + b for f, b in lm) + sum(f for f, _ in tm)
+
+
+def make_args(dims):
+    return types.SimpleNamespace(
+        agent="imagine_entity_attend_rnn", mac="entity_mac", learner="q_learner", mixer="flex_qmix", agent_output_type="q",
+        action_selector="epsilon_greedy", epsilon_start=1.0, epsilon_finish=0.05, epsilon_anneal_time=500000,
+        n_agents=dims["na"], n_actions=dims["A"], n_entities=dims["ne"], entity_shape=dims["ed"], entity_scheme=True,
+        entity_last_action=True, gt_mask_avail=False, attn_embed_dim=dims["d"], attn_n_heads=dims["heads"],
+        rnn_hidden_dim=dims["H"], hypernet_embed=dims["h"], mixing_embed_dim=dims["M"], softmax_mixing_weights=True,
+        pooling_type=None, double_q=True, gamma=0.99, lmbda=0.5, lr=0.0005, optim_alpha=0.99, optim_eps=0.00001,
+        weight_decay=0, grad_norm_clip=10, target_update_interval=200, learner_log_interval=10 ** 9, device="cuda",
+        use_cuda=True)
+
+
+class _Logger:
+    def __init__(self):
+        self.console_logger = types.SimpleNamespace(info=lambda *a, **k: None)
+
+    def log_stat(self, *a):
+        pass
+
+
+def build(dims, B, T, seed, device):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from refil_amd.components.episode_buffer import EpisodeBatch
+    from refil_amd.components.transforms import OneHot
+    from refil_amd.controllers import REGISTRY as mac_REGISTRY
+    from refil_amd.learners import REGISTRY as le_REGISTRY
+    from refil_amd.synthetic import make_batch_fast
+    args = make_args(dims)
+    data = make_batch_fast(B, T, dims["ne"], seed=seed)
+    scheme = {
+        "entities": {"vshape": dims["ed"], "group": "entities"},
+        "obs_mask": {"vshape": dims["ne"], "group": "entities", "dtype": torch.uint8},
+        "entity_mask": {"vshape": dims["ne"], "dtype": torch.uint8},
+        "actions": {"vshape": (1,), "group": "agents", "dtype": torch.long},
+        "avail_actions": {"vshape": (dims["A"],), "group": "agents", "dtype": torch.int},
+        "reward": {"vshape": (1,)},
+        "terminated": {"vshape": (1,), "dtype": torch.uint8},
+    }
+    groups = {"agents": dims["na"], "entities": dims["ne"]}
+    batch = EpisodeBatch(scheme, groups, B, T + 1, preprocess={"actions": ("actions_onehot", [OneHot(dims["A"])])}, device=device)
+    batch.update({k: v for k, v in data.items() if k != "filled"}, mark_filled=False)
+    batch.data.transition_data["filled"].copy_(data["filled"])
+    torch.manual_seed(0)                                   # identical replicas on every rank
+    mac = mac_REGISTRY[args.mac](batch.scheme, groups, args)
+    learner = le_REGISTRY[args.learner](mac, batch.scheme, _Logger(), args)
+    learner.cuda()
+    learner.generator = torch.Generator().manual_seed(1234 + seed)
+    return args, batch, learner, data
+
+
+def cpu_baseline(dims, data_full, target_seconds=20.0):
+    """Time the CPU oracle (port of the reference learner) on a bounded sample of the same workload."""
+    from oracle import refil_oracle as orc
+    cfg = orc.Cfg(n_agents=dims["na"], n_entities=dims["ne"], n_actions=dims["A"], entity_shape=dims["ed"],
+                  attn_embed_dim=dims["d"], attn_n_heads=dims["heads"], hypernet_embed=dims["h"], imagine=True)
+    agent = orc.init_params(orc.agent_param_shapes(cfg), 1)
+    mixer = orc.init_params(orc.mixer_param_shapes(cfg), 2)
+    tagent = orc.init_params(orc.agent_param_shapes(cfg), 3)
+    tmixer = orc.init_params(orc.mixer_param_shapes(cfg), 4)
+    threads = torch.get_num_threads()
+    T = data_full["entities"].shape[1] - 1
+
+    def run(Bs, n):
+        batch = {k: v[:Bs].contiguous() for k, v in data_full.items()}
+        torch.manual_seed(0)
+        bits = orc.draw_partition_bits(Bs, dims["ne"])
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            orc.train_step(cfg, dict(agent), dict(mixer), tagent, tmixer, batch, bits)
+            ts.append(time.perf_counter() - t0)
+        return ts
+    probe = run(4, 2)[-1]                                  # includes warm-up of the thread pool
+    per_ep = probe / 4
+    Bs = 32
+    while Bs > 4 and per_ep * Bs * 3 > target_seconds:
+        Bs //= 2
+    ts = run(Bs, 3)
+    best = sorted(ts)[len(ts) // 2]
+    return {"value": round(Bs * T / best, 1), "unit": "transitions/s", "cores": threads, "kind": "port",
+            "sample": f"median of 3 oracle train steps on B={Bs} of the bench batch (T={T}, ne={dims['ne']}, d={dims['d']}), "
+                      f"fp32 torch CPU, {threads} threads", "ms_per_step": round(best * 1e3, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    from refil_amd import _lib
+    from refil_amd.synthetic import sc2_shape_law
+    W = WORKLOAD
+    law = sc2_shape_law(W["ne"])
+    dims = dict(ne=W["ne"], na=law["n_agents"], A=law["n_actions"], ed=law["entity_shape"], d=W["d"], h=W["h"],
+                heads=W["heads"], H=W["H"], M=W["M"])
+    B, T = W["B"], W["T"]
+    args, batch, learner, data = build(dims, B, T, seed=100 + rank, device=device)
+
+    def step(i):
+        learner.train(batch, t_env=0, episode_num=i)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = elapsed / a.steps * 1e3
+    value = world * B * T * a.steps / elapsed
+
+    E = dims["ed"] + dims["A"]
+    flops_step = algorithmic_flops(B, T, dims["ne"], dims["na"], E, dims["A"], dims["d"], dims["h"], dims["H"], dims["M"], 3)
+    roofline = None
+    kernels = None
+    if rank == 0 and not a.no_profile:
+        _lib.profile_enable(True)
+        nprof = max(3, min(a.steps, 10))
+        for i in range(nprof):
+            step(a.warmup + a.steps + i)
+        ents = _lib.profile_collect()
+        _lib.profile_enable(False)
+        ents.sort(key=lambda e: -e["total_ms"])
+        tot = sum(e["total_ms"] for e in ents)
+        kernels = [{"name": e["name"], "launches_per_step": e["launches"] // nprof, "ms_per_step": round(e["total_ms"] / nprof, 4),
+                    "avg_us": round(1e3 * e["total_ms"] / e["launches"], 2),
+                    "tflops": round(e["flops"] / (e["total_ms"] * 1e-3) / 1e12, 2) if e["flops"] > 0 else None}
+                   for e in ents[:8]]
+        dom = ents[0]
+        ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+        roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": dom["launches"] // nprof,
+                    "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
+                    "flops_per_launch": dom["flops"] / dom["launches"],
+                    "share_of_gpu_time": round(dom["total_ms"] / tot, 3),
+                    "gpu_ms_per_step_all_kernels": round(tot / nprof, 3),
+                    "step_frac_of_mfma_roofline": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "measured": f"HIP events on the launch stream, {nprof} steps right after the timed region"}
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(dims, data)
+
+    if rank == 0:
+        out = {
+            "metric": "learner transitions/sec (B x T per full QLearner.train step)", "value": round(value, 1),
+            "unit": "transitions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic replay (B={B}/GPU, T={T}, n_entities={dims['ne']}, n_agents={dims['na']}, "
+                                   f"d={dims['d']}, hypernet={dims['h']}), refil learner (imagine agent + flex_qmix), "
+                                   f"BASELINE.json north-star shape",
+                       "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
+                       "algorithmic_gflop_per_step_per_gpu": round(flops_step / 1e9, 2)},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        if cpu:
+            out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

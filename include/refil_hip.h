@@ -257,6 +257,20 @@ typedef struct refil_gru_desc {
 int refil_gru_forward(const refil_gru_desc* desc, void* stream);
 int refil_gru_backward(const refil_gru_desc* desc, void* stream);
 
+/* Optional per-kernel timing (HIP events recorded on the launch stream around every kernel the
+ * library launches, aggregated per kernel symbol). bench.py uses it for the roofline fraction.
+ * refil_profile_collect synchronises the device and returns MINUS the number of entries written
+ * (so 0 / positive values keep meaning "error code"). flops/bytes are ALGORITHMIC totals. */
+typedef struct refil_profile_entry {
+    char name[96];          /* kernel symbol, e.g. "gemm_kernel<2,2,2,2,false,false>"             */
+    int64_t launches;
+    double total_ms;
+    double flops;
+    double bytes;
+} refil_profile_entry;
+int refil_profile_enable(int on);
+int refil_profile_collect(refil_profile_entry* out, int max_entries);
+
 const char* refil_last_error(void);
 int refil_version(void);
 

@@ -92,12 +92,18 @@ class GruDesc(C.Structure):
     ]
 
 
+class ProfileEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
 # every symbol include/refil_hip.h declares (tests/test_abi.py checks the library exports them all)
 EXPORTS = [
     "refil_get_param_layout", "refil_learner_workspace_bytes", "refil_learner_forward_backward",
     "refil_clip_rmsprop_step", "refil_agent_workspace_bytes", "refil_agent_forward",
     "refil_mixer_workspace_bytes", "refil_mixer_forward", "refil_gemm", "refil_attn_forward",
     "refil_attn_backward", "refil_gru_forward", "refil_gru_backward", "refil_last_error", "refil_version",
+    "refil_profile_enable", "refil_profile_collect",
 ]
 
 _lib = None
@@ -136,8 +142,24 @@ def lib():
     L.refil_attn_backward.argtypes = [C.POINTER(AttnDesc), C.c_void_p]
     L.refil_gru_forward.argtypes = [C.POINTER(GruDesc), C.c_void_p]
     L.refil_gru_backward.argtypes = [C.POINTER(GruDesc), C.c_void_p]
+    L.refil_profile_enable.argtypes = [C.c_int]
+    L.refil_profile_collect.argtypes = [C.POINTER(ProfileEntry), C.c_int]
     _lib = L
     return L
+
+
+def profile_enable(on: bool):
+    check(lib().refil_profile_enable(int(on)), "refil_profile_enable")
+
+
+def profile_collect():
+    """[{name, launches, total_ms, flops, bytes}] aggregated per kernel symbol since profile_enable(True)."""
+    buf = (ProfileEntry * 64)()
+    n = lib().refil_profile_collect(buf, 64)
+    if n > 0:
+        check(n, "refil_profile_collect")
+    return [dict(name=buf[i].name.decode(), launches=buf[i].launches, total_ms=buf[i].total_ms, flops=buf[i].flops,
+                 bytes=buf[i].bytes) for i in range(-n)]
 
 
 def check(rc: int, what: str):

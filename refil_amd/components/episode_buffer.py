@@ -1,0 +1,184 @@
+"""Scheme-driven episode storage with the reference's API (src/components/episode_buffer.py:6-246):
+EpisodeBatch = dict of dense tensors [B, T, (group), *vshape] plus a `filled` mask; ReplayBuffer = ring
+of episodes with uniform sampling. Kept device-resident so that a sampled, time-truncated view is
+handed to the HIP learner without copies (the C ABI takes batch/time strides)."""
+from types import SimpleNamespace
+
+import numpy as np
+import torch as th
+
+
+def _as_tuple(v):
+    return (v,) if isinstance(v, int) else tuple(v)
+
+
+class EpisodeBatch:
+    def __init__(self, scheme, groups, batch_size, max_seq_length, data=None, preprocess=None, device="cpu"):
+        self.scheme = dict(scheme)
+        self.groups = groups
+        self.batch_size = batch_size
+        self.max_seq_length = max_seq_length
+        self.preprocess = {} if preprocess is None else preprocess
+        self.device = device
+        if data is not None:
+            self.data = data
+            return
+        self.data = SimpleNamespace(transition_data={}, episode_data={})
+        self._allocate(self.scheme, groups, batch_size, max_seq_length, self.preprocess)
+
+    # -- construction -------------------------------------------------------------------------
+    def _allocate(self, scheme, groups, batch_size, max_seq_length, preprocess):
+        for key, (new_key, transforms) in (preprocess or {}).items():
+            assert key in scheme, f"preprocess source {key} not in scheme"
+            vshape, dtype = self.scheme[key]["vshape"], self.scheme[key].get("dtype", th.float32)
+            for tr in transforms:
+                vshape, dtype = tr.infer_output_info(vshape, dtype)
+            entry = {"vshape": vshape, "dtype": dtype}
+            for inherit in ("group", "episode_const"):
+                if inherit in self.scheme[key]:
+                    entry[inherit] = self.scheme[key][inherit]
+            self.scheme[new_key] = entry
+        assert "filled" not in scheme, '"filled" is reserved for the validity mask'
+        scheme["filled"] = {"vshape": (1,), "dtype": th.long}
+        self.scheme.setdefault("filled", scheme["filled"])
+        for key, info in scheme.items():
+            assert "vshape" in info, f"scheme entry {key} needs a vshape"
+            shape = _as_tuple(info["vshape"])
+            group = info.get("group")
+            if group:
+                assert group in groups, f"group {group} has no size"
+                shape = (groups[group],) + shape
+            dtype = info.get("dtype", th.float32)
+            if info.get("episode_const", False):
+                self.data.episode_data[key] = th.zeros((batch_size,) + shape, dtype=dtype, device=self.device)
+            else:
+                self.data.transition_data[key] = th.zeros((batch_size, max_seq_length) + shape, dtype=dtype, device=self.device)
+
+    def extend(self, scheme, groups=None):
+        self._allocate(scheme, self.groups if groups is None else groups, self.batch_size, self.max_seq_length, None)
+
+    def to(self, device):
+        for store in (self.data.transition_data, self.data.episode_data):
+            for k in store:
+                store[k] = store[k].to(device)
+        self.device = device
+
+    # -- writes -------------------------------------------------------------------------------
+    def update(self, data, bs=slice(None), ts=slice(None), mark_filled=True):
+        sl = self._parse_slices((bs, ts))
+        for k, v in data.items():
+            if k in self.data.transition_data:
+                store, where = self.data.transition_data, sl
+                if mark_filled:
+                    store["filled"][sl] = 1
+                    mark_filled = False
+            elif k in self.data.episode_data:
+                store, where = self.data.episode_data, sl[0]
+            else:
+                raise KeyError(f"{k} not found in transition or episode data")
+            dtype = self.scheme[k].get("dtype", th.float32)
+            v = v.to(device=self.device, dtype=dtype) if isinstance(v, th.Tensor) else th.tensor(v, dtype=dtype, device=self.device)
+            dest = store[k][where]
+            self._check_safe_view(v, dest)
+            store[k][where] = v.view_as(dest)
+            if k in self.preprocess:
+                new_k, transforms = self.preprocess[k]
+                out = store[k][where]
+                for tr in transforms:
+                    out = tr.transform(out)
+                store[new_k][where] = out.view_as(store[new_k][where])
+
+    @staticmethod
+    def _check_safe_view(v, dest):
+        idx = v.dim() - 1
+        for s in reversed(dest.shape):
+            if idx >= 0 and v.shape[idx] == s:
+                idx -= 1
+            elif s != 1:
+                raise ValueError(f"Unsafe reshape of {tuple(v.shape)} to {tuple(dest.shape)}")
+
+    # -- reads --------------------------------------------------------------------------------
+    def __getitem__(self, item):
+        if isinstance(item, str):
+            if item in self.data.episode_data:
+                return self.data.episode_data[item]
+            if item in self.data.transition_data:
+                return self.data.transition_data[item]
+            raise ValueError(item)
+        if isinstance(item, tuple) and all(isinstance(it, str) for it in item):
+            new = SimpleNamespace(transition_data={}, episode_data={})
+            for key in item:
+                if key in self.data.transition_data:
+                    new.transition_data[key] = self.data.transition_data[key]
+                elif key in self.data.episode_data:
+                    new.episode_data[key] = self.data.episode_data[key]
+                else:
+                    raise KeyError(f"Unrecognised key {key}")
+            scheme = {k: self.scheme[k] for k in item}
+            groups = {self.scheme[k]["group"]: self.groups[self.scheme[k]["group"]] for k in item if "group" in self.scheme[k]}
+            return EpisodeBatch(scheme, groups, self.batch_size, self.max_seq_length, data=new, device=self.device)
+        sl = self._parse_slices(item)
+        new = SimpleNamespace(transition_data={k: v[sl] for k, v in self.data.transition_data.items()},
+                              episode_data={k: v[sl[0]] for k, v in self.data.episode_data.items()})
+        return EpisodeBatch(self.scheme, self.groups, self._count(sl[0], self.batch_size),
+                            self._count(sl[1], self.max_seq_length), data=new, device=self.device)
+
+    @staticmethod
+    def _count(idx, size):
+        if isinstance(idx, (list, np.ndarray)):
+            return len(idx)
+        if isinstance(idx, th.Tensor):
+            return idx.numel()
+        lo, hi, step = idx.indices(size)
+        return 1 + (hi - lo - 1) // step
+
+    @staticmethod
+    def _parse_slices(items):
+        if isinstance(items, (slice, int, list, np.ndarray, th.Tensor)):
+            items = (items, slice(None))
+        if isinstance(items[1], list):
+            raise IndexError("Indexing across Time must be contiguous")
+        return tuple(slice(it, it + 1) if isinstance(it, int) else it for it in items)
+
+    def max_t_filled(self):
+        return th.sum(self.data.transition_data["filled"], 1).max(0)[0]
+
+    def __repr__(self):
+        return (f"EpisodeBatch. Batch Size:{self.batch_size} Max_seq_len:{self.max_seq_length} "
+                f"Keys:{self.scheme.keys()} Groups:{self.groups.keys()}")
+
+
+class ReplayBuffer(EpisodeBatch):
+    def __init__(self, scheme, groups, buffer_size, max_seq_length, preprocess=None, device="cpu"):
+        super().__init__(scheme, groups, buffer_size, max_seq_length, preprocess=preprocess, device=device)
+        self.buffer_size = buffer_size
+        self.buffer_index = 0
+        self.episodes_in_buffer = 0
+
+    def insert_episode_batch(self, ep_batch):
+        n = ep_batch.batch_size
+        if self.buffer_index + n > self.buffer_size:                       # wrap around the ring
+            left = self.buffer_size - self.buffer_index
+            self.insert_episode_batch(ep_batch[0:left, :])
+            self.insert_episode_batch(ep_batch[left:, :])
+            return
+        where = slice(self.buffer_index, self.buffer_index + n)
+        self.update(ep_batch.data.transition_data, where, slice(0, ep_batch.max_seq_length), mark_filled=False)
+        self.update(ep_batch.data.episode_data, where)
+        self.buffer_index += n
+        self.episodes_in_buffer = max(self.episodes_in_buffer, self.buffer_index)
+        self.buffer_index %= self.buffer_size
+
+    def can_sample(self, batch_size):
+        return self.episodes_in_buffer >= batch_size
+
+    def sample(self, batch_size):
+        assert self.can_sample(batch_size)
+        if self.episodes_in_buffer == batch_size:
+            return self[:batch_size]
+        ep_ids = np.random.choice(self.episodes_in_buffer, batch_size, replace=False)     # uniform, w/o replacement
+        return self[ep_ids]
+
+    def __repr__(self):
+        return (f"ReplayBuffer. {self.episodes_in_buffer}/{self.buffer_size} episodes. "
+                f"Keys:{self.scheme.keys()} Groups:{self.groups.keys()}")

@@ -19,6 +19,7 @@
 //  * backward recomputes the softmax from Q,K (no [G,R,heads,na,ne] weights tensor is stored) and
 //    accumulates dQ/dK/dV over the variants in LDS before one coalesced store.
 #include "common.h"
+#include "profile.h"
 #include "../../include/refil_hip.h"
 
 namespace refil {
@@ -299,6 +300,9 @@ int attn_forward_launch(const refil_attn_desc& d, hipStream_t st) {
     AttnK k;
     if (int e = fill(d, k, false)) return e;
     const size_t smem = attn_smem_bytes(d.ne, d.na, d.hd, false);
+    const double unit = (double)d.R * d.heads * d.na * d.ne * d.hd;
+    ProfScope prof("attn_fwd_kernel", unit * (2.0 + 2.0 * d.nvar),
+                   4.0 * d.R * d.heads * d.hd * (d.na * (1.0 + d.nvar) + 2.0 * d.ne), st);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(d.R, d.heads), dim3(ANT), smem, st, k);
     REFIL_LAUNCH_CHECK();
     return 0;
@@ -312,6 +316,9 @@ int attn_backward_launch(const refil_attn_desc& d, hipStream_t st) {
     if (smem > 64 * 1024) {
         REFIL_HIP(hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
+    const double unit = (double)d.R * d.heads * d.na * d.ne * d.hd;
+    ProfScope prof("attn_bwd_kernel", unit * (2.0 + 8.0 * d.nvar),
+                   4.0 * d.R * d.heads * d.hd * (d.na * (2.0 + d.nvar) + 4.0 * d.ne), st);
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(d.R, d.heads), dim3(ANT), smem, st, k);
     REFIL_LAUNCH_CHECK();
     return 0;

@@ -17,6 +17,7 @@
 //
 // Replaces the implicit aten::mm / addmm calls of the reference.
 #include "common.h"
+#include "profile.h"
 #include "../../include/refil_hip.h"
 
 namespace refil {
@@ -250,11 +251,22 @@ __global__ void reduce_partials_kernel(GemmK p) {
     }
 }
 
+static const char* gemm_name(int wm, int tm, int tn, bool ao, bool bo) {
+    static const char* names[3][4] = {
+        {"gemm_kernel<2,2,2,2,false,false>", "gemm_kernel<2,2,2,2,false,true>", "gemm_kernel<2,2,2,2,true,false>", "gemm_kernel<2,2,2,2,true,true>"},
+        {"gemm_kernel<4,1,1,2,false,false>", "gemm_kernel<4,1,1,2,false,true>", "gemm_kernel<4,1,1,2,true,false>", "gemm_kernel<4,1,1,2,true,true>"},
+        {"gemm_kernel<4,1,1,1,false,false>", "gemm_kernel<4,1,1,1,false,true>", "gemm_kernel<4,1,1,1,true,false>", "gemm_kernel<4,1,1,1,true,true>"}};
+    const int c = wm == 2 ? 0 : (tn == 2 ? 1 : 2);
+    return names[c][(ao ? 2 : 0) + (bo ? 1 : 0)];
+}
+
 template <int WM, int WN, int TM, int TN>
 static void launch_cfg(const GemmK& k, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     dim3 grid(cdiv(k.N, BN), cdiv(k.M, BM), k.batch * k.splits);
     const bool ao = k.flags & REFIL_GEMM_A_OUTC, bo = k.flags & REFIL_GEMM_B_OUTC;
+    ProfScope prof(gemm_name(WM, TM, TN, ao, bo), 2.0 * k.M * k.N * k.K * k.batch,
+                   4.0 * k.batch * ((double)k.M * k.K + (double)k.N * k.K + (double)k.M * k.N), st);
     if (!ao && !bo) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, false, false>), grid, dim3(256), 0, st, k);
     else if (!ao && bo) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, false, true>), grid, dim3(256), 0, st, k);
     else if (ao && bo) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, true, true>), grid, dim3(256), 0, st, k);
@@ -291,6 +303,7 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
     if (d.splits > 1) {
         const long total = (long)d.batch * d.M * d.N;
         const int blocks = (int)min((long)2048, cdivl(total, 256));
+        ProfScope prof("reduce_partials_kernel", 0.0, 4.0 * total * (d.splits + 1), st);
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, k);
         REFIL_LAUNCH_CHECK();
     }

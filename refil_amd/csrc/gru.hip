@@ -20,6 +20,7 @@
 // MFMA fragment maps (v_mfma_f32_16x16x4_f32): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
 // D[row=4*(l>>4)+reg][col=l&15]. The k order is permuted (k = 4s + (l>>4)) identically for A and B.
 #include "common.h"
+#include "profile.h"
 #include "../../include/refil_hip.h"
 
 namespace refil {
@@ -220,6 +221,8 @@ int gru_forward_launch(const refil_gru_desc& d, hipStream_t st) {
     const bool save = d.save_r != nullptr;
     REFIL_CHECK(!save || (d.save_z && d.save_n && d.save_ghn), "refil_gru_forward: all four save buffers or none");
     dim3 grid(cdiv(d.NR, GROWS));
+    ProfScope prof(save ? "gru_fwd_kernel<true>" : "gru_fwd_kernel<false>", 2.0 * d.NR * d.T1 * GH * 3 * GH,
+                   4.0 * d.NR * d.T1 * GH * (save ? 8.0 : 4.0), st);
     if (save) hipLaunchKernelGGL(gru_fwd_kernel<true>, grid, dim3(256), 0, st, k);
     else hipLaunchKernelGGL(gru_fwd_kernel<false>, grid, dim3(256), 0, st, k);
     REFIL_LAUNCH_CHECK();
@@ -232,6 +235,7 @@ int gru_backward_launch(const refil_gru_desc& d, hipStream_t st) {
                 "refil_gru_backward: null pointer");
     REFIL_CHECK(d.NR > 0 && d.T1 > 0 && d.na > 0, "refil_gru_backward: bad sizes");
     GruK k{d.gi, d.hsx, d.w_hh, d.b_hh, d.save_r, d.save_z, d.save_n, d.save_ghn, d.dhs, d.dgi, d.dgh, d.NR, d.T1, d.na};
+    ProfScope prof("gru_bwd_kernel", 2.0 * d.NR * d.T1 * GH * 3 * GH, 4.0 * d.NR * d.T1 * GH * 12.0, st);
     hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv(d.NR, GROWS)), dim3(256), 0, st, k);
     REFIL_LAUNCH_CHECK();
     return 0;

@@ -1,0 +1,58 @@
+#include "profile.h"
+
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "../../include/refil_hip.h"
+
+namespace refil {
+
+struct Rec { const char* name; double flops, bytes; hipEvent_t e0, e1; };
+static bool g_on = false;
+static std::vector<Rec> g_recs;
+
+bool prof_enabled() { return g_on; }
+
+void prof_begin(const char* kernel, double flops, double bytes, hipStream_t st) {
+    Rec r{kernel, flops, bytes, nullptr, nullptr};
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    hipEventRecord(r.e0, st);
+    g_recs.push_back(r);
+}
+void prof_end(hipStream_t st) {
+    if (!g_recs.empty()) hipEventRecord(g_recs.back().e1, st);
+}
+
+}  // namespace refil
+
+using namespace refil;
+
+extern "C" int refil_profile_enable(int on) {
+    for (auto& r : g_recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    g_recs.clear();
+    g_on = on != 0;
+    return 0;
+}
+
+extern "C" int refil_profile_collect(refil_profile_entry* out, int max_entries) {
+    REFIL_CHECK(out && max_entries > 0, "refil_profile_collect: bad arguments");
+    REFIL_HIP(hipDeviceSynchronize());
+    std::map<std::string, refil_profile_entry> agg;
+    for (auto& r : g_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        auto& e = agg[r.name];
+        if (e.launches == 0) { memset(&e, 0, sizeof(e)); strncpy(e.name, r.name, sizeof(e.name) - 1); }
+        e.launches += 1; e.total_ms += ms; e.flops += r.flops; e.bytes += r.bytes;
+    }
+    int n = 0;
+    for (auto& kv : agg) {
+        if (n >= max_entries) break;
+        out[n++] = kv.second;
+    }
+    return n < 0 ? 0 : -n;   // negative count on success so that 0/positive keep the error convention
+}

@@ -1,0 +1,202 @@
+"""QLearner with the reference's plugin surface (reference: src/learners/q_learner.py:10-229) driving
+the MI355X-native step: one C-ABI call for forward+backward, one flat RCCL all-reduce under data
+parallelism, one C-ABI call for clip + RMSprop. No autograd, no torch.optim.
+"""
+from __future__ import annotations
+
+import copy
+
+import torch as th
+import torch.distributed as dist
+
+from .. import _lib
+from ..engine import LearnerEngine, dims_from_args
+from ..modules.mixers.flex_qmix import FlexQMixer
+
+
+class QLearner:
+    def __init__(self, mac, scheme, logger, args):
+        self.args = args
+        self.mac = mac
+        self.logger = logger
+        self.last_target_update_episode = 0
+        self.mixer = None
+        if args.mixer is not None:
+            if args.mixer == "flex_qmix":
+                assert args.entity_scheme, "FlexQMixer only available with entity scheme"
+                self.mixer = FlexQMixer(args)
+            elif args.mixer in ("vdn", "qmix", "lin_flex_qmix"):
+                raise NotImplementedError(f"mixer {args.mixer} is outside the REFIL hot path built so far (SURVEY.md 8f4)")
+            else:
+                raise ValueError("Mixer {} not recognised.".format(args.mixer))
+        else:
+            raise NotImplementedError("mixer-less learning is outside the REFIL hot path")
+        self.params = list(mac.parameters()) + list(self.mixer.parameters())      # q_learner.py:16,34 order
+        self.target_mixer = copy.deepcopy(self.mixer)
+        self.target_mac = copy.deepcopy(mac)
+        self.log_stats_t = -self.args.learner_log_interval - 1
+        self._step_count = 0
+        self._engine = None
+        self._flat_ready = False
+        self.generator = None      # optional torch.Generator for the partition draw (defaults to the global CPU RNG)
+
+    # ------------------------------------------------------------------------------------------
+    def _setup_flat(self):
+        """[agent | mixer] flat buffers for live / target nets, RMSprop state and gradients."""
+        dev = next(self.mac.agent.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("refil_amd.QLearner runs on the GPU only: call learner.cuda() first (no CPU fallback)")
+        self._engine = LearnerEngine(dev)
+        d0 = dims_from_args(self.args, 1, 2)
+        L = _lib.param_layout(d0)
+        self._L, self._n, self._na = L, int(L.total), int(L.agent_total)
+        self.flat_live = th.zeros(self._n, dtype=th.float32, device=dev)
+        self.flat_target = th.zeros(self._n, dtype=th.float32, device=dev)
+        self.square_avg = th.zeros(self._n, dtype=th.float32, device=dev)
+        self.grads = th.zeros(self._n + _lib.REFIL_NSTAT, dtype=th.float32, device=dev)
+        self.mac.agent.adopt(self.flat_live[:self._na])
+        self.mixer.adopt(self.flat_live[self._na:])
+        self.target_mac.agent.adopt(self.flat_target[:self._na])
+        self.target_mixer.adopt(self.flat_target[self._na:])
+        self.params = list(self.mac.parameters()) + list(self.mixer.parameters())
+        g_agent = self.grads[:self._na]
+        g_mixer = self.grads[self._na:self._n]
+        for mod, g in ((self.mac.agent, g_agent), (self.mixer, g_mixer)):      # expose .grad as views of the flat grads
+            named = dict(mod.named_parameters())
+            for name, off, shape in mod._fields():
+                n = 1
+                for s in shape:
+                    n *= s
+                named[name].grad = g[off:off + n].view(*shape)
+        self._bits_host = None
+        self._flat_ready = True
+
+    def _check_flat(self):
+        if not self._flat_ready:
+            self._setup_flat()
+            return
+        for mod, st in ((self.mac.agent, self.flat_live[:self._na]), (self.mixer, self.flat_live[self._na:]),
+                        (self.target_mac.agent, self.flat_target[:self._na]), (self.target_mixer, self.flat_target[self._na:])):
+            if getattr(mod, "_flat", None) is None or mod._flat.data_ptr() != st.data_ptr() or not mod._is_flat():
+                mod.adopt(st)
+
+    def _draw_partition(self, B, ne, device):
+        """entity_rnn_agent.py:94-96: p = rand(B,1,1); groupA = bernoulli(p.repeat(1,1,ne)) -- drawn with the
+        CPU generator (same two calls, same stream as the reference's CPU run) and shipped to the device."""
+        p = th.rand(B, 1, 1, generator=self.generator).repeat(1, 1, ne)
+        bits = th.bernoulli(p, generator=self.generator).to(th.uint8).reshape(B, ne)
+        if self._bits_host is None or self._bits_host.shape != bits.shape:
+            self._bits_host = th.empty_like(bits).pin_memory()
+        self._bits_host.copy_(bits)
+        return self._bits_host.to(device, non_blocking=True)
+
+    def _fields(self, batch):
+        names = ["entities", "obs_mask", "entity_mask", "actions", "avail_actions", "reward", "terminated", "filled"]
+        out = {}
+        for k in names:
+            v = batch[k]
+            if not v[0, 0].is_contiguous():
+                v = v.contiguous()
+            out[k] = v
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def train(self, batch, t_env: int, episode_num: int, group_bits=None):
+        self._check_flat()
+        args = self.args
+        B, T1 = batch.batch_size, batch.max_seq_length
+        dims = dims_from_args(args, B, T1)
+        fields = self._fields(batch)
+        dev = self.flat_live.device
+        bits = None
+        if dims.imagine:
+            bits = group_bits.to(dev).to(th.uint8).contiguous() if group_bits is not None else \
+                self._draw_partition(B, args.n_entities, dev)
+        self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # data parallel over episodes: ONE all-reduce(SUM) of [grads | stat sums]; the global
+            # sum(mask) normaliser is applied afterwards by the optimiser kernel (q_learner.py:165)
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
+        self._engine.clip_rmsprop(self.flat_live, self.grads, self.square_avg, self._n, args.lr, args.optim_alpha,
+                                  args.optim_eps, args.weight_decay, args.grad_norm_clip)
+        self._step_count += 1
+
+        if (episode_num - self.last_target_update_episode) / args.target_update_interval >= 1.0:
+            self._update_targets()
+            self.last_target_update_episode = episode_num
+
+        if t_env - self.log_stats_t >= args.learner_log_interval:
+            st = self.grads[self._n:].tolist()                         # the only host sync, on log steps
+            msum = st[_lib.STAT_MASK_SUM]
+            q_loss = st[_lib.STAT_TD_SQ] / msum
+            if dims.imagine:
+                im_loss = st[_lib.STAT_IM_TD_SQ] / msum
+                self.logger.log_stat("loss", (1 - args.lmbda) * q_loss + args.lmbda * im_loss, t_env)   # :172,185
+                self.logger.log_stat("im_loss", im_loss, t_env)
+            else:
+                self.logger.log_stat("loss", q_loss, t_env)
+            self.logger.log_stat("grad_norm", st[_lib.STAT_GRAD_NORM], t_env)
+            self.logger.log_stat("td_error_abs", st[_lib.STAT_TD_ABS] / msum, t_env)
+            self.logger.log_stat("q_taken_mean", st[_lib.STAT_QTOT_SUM] / (msum * args.n_agents), t_env)    # :194 quirk kept
+            self.logger.log_stat("target_mean", st[_lib.STAT_TARGET_SUM] / (msum * args.n_agents), t_env)
+            self.log_stats_t = t_env
+
+    def _update_targets(self):
+        self._check_flat()
+        self.flat_target.copy_(self.flat_live)          # one flat D2D copy (q_learner.py:203-207)
+        self.logger.console_logger.info("Updated target network")
+
+    def cuda(self):
+        self.mac.cuda()
+        self.target_mac.cuda()
+        self.mixer.cuda()
+        self.target_mixer.cuda()
+        self._flat_ready = False
+
+    # -- checkpoints in the reference's format (agent.th / mixer.th / opt.th) -------------------
+    def _opt_state_dict(self):
+        self._check_flat()
+        state = {}
+        idx = 0
+        for mod, base in ((self.mac.agent, 0), (self.mixer, self._na)):
+            offs = {name: (off, shape) for name, off, shape in mod._fields()}
+            for name, _ in mod.named_parameters():
+                off, shape = offs[name]
+                n = 1
+                for s in shape:
+                    n *= s
+                state[idx] = {"step": self._step_count,
+                              "square_avg": self.square_avg[base + off:base + off + n].view(*shape).clone()}
+                idx += 1
+        group = {"lr": self.args.lr, "momentum": 0, "alpha": self.args.optim_alpha, "eps": self.args.optim_eps,
+                 "centered": False, "weight_decay": self.args.weight_decay, "params": list(range(idx))}
+        return {"state": state, "param_groups": [group]}
+
+    def _load_opt_state_dict(self, sd):
+        self._check_flat()
+        idx = 0
+        for mod, base in ((self.mac.agent, 0), (self.mixer, self._na)):
+            offs = {name: (off, shape) for name, off, shape in mod._fields()}
+            for name, _ in mod.named_parameters():
+                off, shape = offs[name]
+                n = 1
+                for s in shape:
+                    n *= s
+                st = sd["state"].get(idx)
+                if st is not None:
+                    self.square_avg[base + off:base + off + n].view(*shape).copy_(st["square_avg"])
+                    step = st.get("step", 0)
+                    self._step_count = int(step.item() if hasattr(step, "item") else step)
+                idx += 1
+
+    def save_models(self, path):
+        self.mac.save_models(path)
+        th.save(self.mixer.state_dict(), "{}/mixer.th".format(path))
+        th.save(self._opt_state_dict(), "{}/opt.th".format(path))
+
+    def load_models(self, path, evaluate=False):
+        self.mac.load_models(path)
+        self.target_mac.load_models(path)       # like the reference: targets are not checkpointed (:224-225)
+        if not evaluate:
+            self.mixer.load_state_dict(th.load("{}/mixer.th".format(path), map_location=lambda storage, loc: storage))
+            self._load_opt_state_dict(th.load("{}/opt.th".format(path), map_location=lambda storage, loc: storage))

@@ -1,0 +1,114 @@
+"""FlexQMixer behind the reference's mixer interface (reference: src/modules/mixers/flex_qmix.py:7-121).
+Parameter holder + marshalling to refil_mixer_forward; no PyTorch math."""
+from __future__ import annotations
+
+import torch as th
+import torch.nn as nn
+
+from ... import _lib
+from ...engine import LearnerEngine, dims_from_args
+from ..agents.entity_rnn_agent import _InTrans
+from ..flat_module import FlatParamModule
+
+HYPERNETS = ("hyper_w_1", "hyper_w_final", "hyper_b_1", "V")
+
+
+class AttentionHyperNet(nn.Module):
+    """fc1 -> entity attention -> fc2 (flex_qmix.py:15-38); mode only matters inside the kernels."""
+
+    def __init__(self, args, mode="matrix"):
+        super().__init__()
+        self.mode = mode
+        E = args.entity_shape + (args.n_actions if args.entity_last_action else 0)
+        h = args.hypernet_embed
+        assert getattr(args, "pooling_type", None) is None, "EntityPoolingLayer is out of scope"
+        self.fc1 = nn.Linear(E, h)
+        self.attn = _InTrans(h)
+        self.attn.register_buffer("scale_factor", th.scalar_tensor(h // args.attn_n_heads).sqrt())
+        self.fc2 = nn.Linear(h, args.mixing_embed_dim)
+
+
+class FlexQMixer(FlatParamModule):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.n_agents = args.n_agents
+        self.embed_dim = args.mixing_embed_dim
+        self.hyper_w_1 = AttentionHyperNet(args, mode="matrix")
+        self.hyper_w_final = AttentionHyperNet(args, mode="vector")
+        self.hyper_b_1 = AttentionHyperNet(args, mode="vector")
+        self.V = AttentionHyperNet(args, mode="scalar")
+        self._engine = None
+
+    def _dims(self, B=1, T1=2):
+        return dims_from_args(self.args, B, T1)
+
+    def _layout(self):
+        return _lib.param_layout(self._dims())
+
+    def _fields(self):
+        L = self._layout()
+        a = self.args
+        h, M = a.hypernet_embed, a.mixing_embed_dim
+        E = a.entity_shape + (a.n_actions if a.entity_last_action else 0)
+        base = L.agent_total
+        out = []
+        for n, net in enumerate(HYPERNETS):
+            out += [(f"{net}.fc1.weight", L.mix_fc1_w + n * L.mix_fc1_w_stride - base, (h, E)),
+                    (f"{net}.fc1.bias", L.mix_fc1_b + n * L.mix_fc1_b_stride - base, (h,)),
+                    (f"{net}.attn.in_trans.weight", L.mix_in_w + n * L.mix_in_w_stride - base, (3 * h, h)),
+                    (f"{net}.attn.out_trans.weight", L.mix_out_w + n * L.mix_out_w_stride - base, (h, h)),
+                    (f"{net}.attn.out_trans.bias", L.mix_out_b + n * L.mix_out_b_stride - base, (h,)),
+                    (f"{net}.fc2.weight", L.mix_fc2_w + n * L.mix_fc2_w_stride - base, (M, h)),
+                    (f"{net}.fc2.bias", L.mix_fc2_b + n * L.mix_fc2_b_stride - base, (M,))]
+        return out
+
+    def _flat_size(self):
+        L = self._layout()
+        return int(L.total - L.agent_total)
+
+    def engine(self):
+        if self._engine is None:
+            object.__setattr__(self, "_engine", LearnerEngine(self.V.fc1.weight.device))
+        return self._engine
+
+    def forward(self, agent_qs, inputs, imagine_groups=None):
+        """agent_qs [bs,T,na] (or [bs,T,2na] with imagine_groups); inputs = (entities||last-action
+        [bs,T,ne,E], entity_mask [bs,T,ne]) as built by QLearner._get_mixer_ins (q_learner.py:45-64).
+        imagine_groups: the [bs,ne] partition bits (uint8). The reference passes the derived
+        (Wmask, Imask) tensors; the kernels re-derive those masks from the bits in registers."""
+        entities, entity_mask = inputs
+        bs, T, ne, E = entities.shape
+        dims = self._dims(bs, T)
+        dims.ed, dims.entity_last_action = E, 0          # entities already carry the one-hots
+        fields = {"entities": entities.contiguous(), "entity_mask": entity_mask.contiguous()}
+        gb = None
+        qs_im = None
+        if imagine_groups is not None:
+            if isinstance(imagine_groups, (tuple, list)):
+                raise NotImplementedError("pass the [bs, ne] partition bits instead of (Wmask, Imask) tensors")
+            gb = imagine_groups.to(entities.device).to(th.uint8).contiguous()
+            qs_im = agent_qs.reshape(bs, T, 2 * self.n_agents).contiguous().float()
+            dims.imagine = 1
+        else:
+            dims.imagine = 0
+        L = self._layout()
+        flat = self.flat()
+        # the library indexes the mixer tensors at absolute offsets of the combined [agent|mixer] buffer
+        base_ptr = flat.data_ptr() - 4 * int(L.agent_total)
+        eng = self.engine()
+        import ctypes as C
+        nbytes = _lib.lib().refil_mixer_workspace_bytes(C.byref(dims))
+        wp, wsz = eng.ws.ptr_size(nbytes)
+        b = _lib.make_batch(fields, gb)
+        q_tot = th.empty(bs, T, dtype=th.float32, device=entities.device)
+        q_im = th.empty(bs, T, dtype=th.float32, device=entities.device) if qs_im is not None else None
+        if qs_im is not None:
+            real = th.zeros(bs, T, self.n_agents, dtype=th.float32, device=entities.device)
+        else:
+            real = agent_qs.reshape(bs, T, self.n_agents).contiguous().float()
+        _lib.check(_lib.lib().refil_mixer_forward(
+            C.byref(dims), C.byref(b), C.c_int32(0), C.c_int32(T), C.c_void_p(base_ptr), _lib.ptr(real),
+            _lib.ptr(qs_im), _lib.ptr(q_tot), _lib.ptr(q_im), wp, wsz, _lib.current_stream_ptr()), "refil_mixer_forward")
+        out = q_im if qs_im is not None else q_tot
+        return out.reshape(bs, T, 1)

@@ -41,6 +41,7 @@ def attn_desc(Q, K, V, ldq, ldkv, R, T1, ne, na, heads, hd, variants, obs_mask=N
     d.ent_mask = ent_mask.data_ptr() if ent_mask is not None else None
     d.ent_mask0 = ent_mask0.data_ptr() if ent_mask0 is not None else None
     d.group_bits = group_bits.data_ptr() if group_bits is not None else None
+    d._keep = [Q, K, V, obs_mask, ent_mask, ent_mask0, group_bits]   # the desc only holds raw addresses
     return d
 
 
@@ -50,6 +51,7 @@ def attn_forward(d: AttnDesc, O, ldo, sO):
 
 
 def attn_backward(d: AttnDesc, dO, ldo, sO, dQ, dK, dV):
+    d._keep.append(dO)
     d.dO, d.ldo, d.sO = dO.data_ptr(), ldo, sO
     d.dQ, d.dK, d.dV = dQ.data_ptr(), dK.data_ptr(), dV.data_ptr()
     check(lib().refil_attn_backward(C.byref(d), _stream()), "refil_attn_backward")
@@ -64,6 +66,7 @@ def gru_desc(gi, hsx, w_hh, b_hh, NR, T1, na, H=64, saves=None, dhs=None, dgi=No
     if dhs is not None:
         d.dhs, d.dgi, d.dgh = dhs.data_ptr(), dgi.data_ptr(), dgh.data_ptr()
     d.NR, d.T1, d.na, d.H = NR, T1, na, H
+    d._keep = [gi, hsx, w_hh, b_hh, saves, dhs, dgi, dgh]
     return d
 
 
