@@ -128,7 +128,17 @@ def cpu_baseline(dims, data_full, target_seconds=20.0):
             orc.train_step(cfg, dict(agent), dict(mixer), tagent, tmixer, batch, bits)
             ts.append(time.perf_counter() - t0)
         return ts
-    probe = run(4, 2)[-1]                                  # includes warm-up of the thread pool
+    # pick the thread count that makes the CPU port fastest on this host (all cores is not always best
+    # for these small GEMMs); `cores` reports the count actually used
+    ncpu = os.cpu_count() or 1
+    cands = sorted({c for c in (8, 16, 32, 64, threads, ncpu) if 1 <= c <= ncpu})
+    probe = None
+    for c in cands:
+        torch.set_num_threads(c)
+        t = run(4, 2)[-1]                                  # 2nd run: thread pool warm
+        if probe is None or t < probe:
+            threads, probe = c, t
+    torch.set_num_threads(threads)
     per_ep = probe / 4
     Bs = 32
     while Bs > 4 and per_ep * Bs * 3 > target_seconds:

@@ -109,8 +109,11 @@ struct Tile {
     }
 };
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_OUTC, bool B_OUTC>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
+// EPI: 0 = store act(acc + bias) (+ optional row mask), 1 = relu-backward (x aux>0, optional +=C),
+//      2 = raw partial store of a split reduction. Compile-time so that the epilogue is branch-free and
+//      its loads (mask bytes / aux / C) are issued in batches instead of one dependent load per element.
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_OUTC, bool B_OUTC, int EPI>
+__global__ __launch_bounds__(256, 3) void gemm_kernel(GemmK p) {
     constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
     using TA = Tile<BM, A_OUTC>;
     using TB = Tile<BN, B_OUTC>;
@@ -188,66 +191,132 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
     }
 
     // ---------------- epilogue ----------------
-    const bool split = p.splits > 1;
     if (do_colsum && tid < BM && m0 + tid < p.M) {
-        if (split) p.partial[(long)p.batch * p.splits * p.M * p.N + ((long)bz * p.splits + sp) * p.M + m0 + tid] = csum;
+        if (EPI == 2) p.partial[(long)p.batch * p.splits * p.M * p.N + ((long)bz * p.splits + sp) * p.M + m0 + tid] = csum;
         else p.colsum[bz * p.sColsum + m0 + tid] = csum;
     }
-    float* Cb = split ? p.partial + ((long)bz * p.splits + sp) * p.M * p.N : p.C + bz * p.sC;
-    const float* bias = (!split && p.bias) ? p.bias + bz * p.sBias : nullptr;
-    const float* aux = (!split && p.aux) ? p.aux + bz * p.sC : nullptr;
+    float* Cb = EPI == 2 ? p.partial + ((long)bz * p.splits + sp) * p.M * p.N : p.C + bz * p.sC;
+    const int ldc = EPI == 2 ? p.N : p.ldc;
+    int ncol[TN];
+    float bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        ncol[j] = n0 + (wn * TN + j) * 32 + lane31;
+        bv[j] = (EPI == 0 && p.bias && ncol[j] < p.N) ? p.bias[bz * p.sBias + ncol[j]] : 0.f;
+    }
+    const bool relu = p.flags & REFIL_GEMM_RELU;
+    const bool accum = p.flags & REFIL_GEMM_ACCUM;
+    const float* aux = EPI == 1 ? p.aux + bz * p.sC : nullptr;
+    // accumulator register r of a 32x32 tile holds row (r&3) + 8*(r>>2) + 4*hf: walk the 4 row quads
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + lane31;
-            if (n >= p.N) continue;
-            const float bv = bias ? bias[n] : 0.f;
+        for (int c = 0; c < 4; ++c) {
+            unsigned roff[4];   // element offsets fit 32 bits (checked on the host)
+            bool rok[4], dead[4];
+            uint8_t mb[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r];
-                if (split) {
-                    Cb[(long)m * p.N + n] = v;
-                    continue;
-                }
-                const long off = p.cmap(m) * (long)p.ldc + n;
-                v += bv;
-                if (p.flags & REFIL_GEMM_RELU) v = fmaxf(v, 0.f);
-                if (p.flags & REFIL_GEMM_RELU_BWD) v = aux[off] > 0.f ? v : 0.f;
-                if (p.rowmask && p.rowmask[m % p.rowmask_mod]) v = 0.f;
-                if (p.flags & REFIL_GEMM_ACCUM) v += Cb[off];
-                Cb[off] = v;
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + (wm * TM + i) * 32 + q + 8 * c + 4 * hf;
+                rok[q] = m < p.M;
+                roff[q] = (unsigned)((EPI == 2 ? (long)m : p.cmap(m)) * ldc);
+                mb[q] = (EPI == 0 && p.rowmask && rok[q]) ? p.rowmask[m % p.rowmask_mod] : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dead[q] = mb[q] != 0;
+            if (EPI == 1) {
+                float ax[TN][4], cx[TN][4];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool ok = rok[q] && ncol[j] < p.N;
+                        ax[j][q] = ok ? aux[roff[q] + ncol[j]] : 0.f;
+                        cx[j][q] = (ok && accum) ? Cb[roff[q] + ncol[j]] : 0.f;
+                    }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v = (ax[j][q] > 0.f ? acc[i][j][4 * c + q] : 0.f) + cx[j][q];
+                        if (rok[q] && ncol[j] < p.N) Cb[roff[q] + ncol[j]] = v;
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v = acc[i][j][4 * c + q];
+                        if (EPI == 0) {
+                            v += bv[j];
+                            v = relu ? fmaxf(v, 0.f) : v;
+                            v = dead[q] ? 0.f : v;
+                        }
+                        if (rok[q] && ncol[j] < p.N) Cb[roff[q] + ncol[j]] = v;
+                    }
             }
         }
     }
 }
 
-// sum the split partials; applies the (bias/accum-free) epilogue for split GEMMs: plain store or +=.
-__global__ void reduce_partials_kernel(GemmK p) {
-    const long total = (long)p.batch * p.M * p.N;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        const int b = idx / ((long)p.M * p.N);
-        const long rem = idx - (long)b * p.M * p.N;
-        const int m = rem / p.N, n = rem % p.N;
-        const float* src = p.partial + ((long)b * p.splits * p.M + m) * p.N + n;
+// sum the split partials (plain store or +=). 16 waves per workgroup: lane = output element (coalesced),
+// wave w adds splits w, w+16, ... (independent loads in flight), then a 16-way LDS reduction.
+constexpr int RED_WAVES = 16;
+__global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_kernel(GemmK p) {
+    __shared__ float red[RED_WAVES][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long MN = (long)p.M * p.N;
+    const long total = (long)p.batch * MN;
+    const long nchunk = cdivl(total, 64);
+    const bool with_cs = p.flags & REFIL_GEMM_COLSUM_A;
+    const long tot2 = with_cs ? (long)p.batch * p.M : 0;
+    const long nchunk2 = cdivl(tot2, 64);
+    for (long chunk = blockIdx.x; chunk < nchunk + nchunk2; chunk += gridDim.x) {
+        const bool cs = chunk >= nchunk;
+        const long idx = (cs ? chunk - nchunk : chunk) * 64 + lane;
+        const long lim = cs ? tot2 : total;
         float s = 0.f;
-        for (int sp = 0; sp < p.splits; ++sp) s += src[(long)sp * p.M * p.N];
-        float* dst = p.C + b * p.sC + p.cmap(m) * (long)p.ldc + n;
-        if (p.flags & REFIL_GEMM_ACCUM) s += *dst;
-        *dst = s;
-    }
-    if (p.flags & REFIL_GEMM_COLSUM_A) {
-        const long tot2 = (long)p.batch * p.M;
-        const float* cs = p.partial + (long)p.batch * p.splits * p.M * p.N;
-        for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < tot2; idx += stride) {
-            const int b = idx / p.M, m = idx % p.M;
-            float s = 0.f;
-            for (int sp = 0; sp < p.splits; ++sp) s += cs[((long)b * p.splits + sp) * p.M + m];
-            p.colsum[b * p.sColsum + m] = s;
+        int b = 0, m = 0, n = 0;
+        if (idx < lim) {
+            const float* src;
+            long sstride;
+            if (!cs) {
+                b = idx / MN;
+                const long rem = idx - (long)b * MN;
+                m = rem / p.N; n = rem % p.N;
+                src = p.partial + (long)b * p.splits * MN + rem;
+                sstride = MN;
+            } else {
+                b = idx / p.M; m = idx % p.M;
+                src = p.partial + (long)p.batch * p.splits * MN + (long)b * p.splits * p.M + m;
+                sstride = p.M;
+            }
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int sp = w;
+            for (; sp + 3 * RED_WAVES < p.splits; sp += 4 * RED_WAVES) {
+                s0 += src[(long)sp * sstride];
+                s1 += src[(long)(sp + RED_WAVES) * sstride];
+                s2 += src[(long)(sp + 2 * RED_WAVES) * sstride];
+                s3 += src[(long)(sp + 3 * RED_WAVES) * sstride];
+            }
+            for (; sp < p.splits; sp += RED_WAVES) s0 += src[(long)sp * sstride];
+            s = (s0 + s1) + (s2 + s3);
         }
+        red[w][lane] = s;
+        __syncthreads();
+        if (w == 0 && idx < lim) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < RED_WAVES; ++k) t += red[k][lane];
+            if (!cs) {
+                float* dst = p.C + b * p.sC + p.cmap(m) * (long)p.ldc + n;
+                if (p.flags & REFIL_GEMM_ACCUM) t += *dst;
+                *dst = t;
+            } else {
+                p.colsum[b * p.sColsum + m] = t;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -260,6 +329,15 @@ static const char* gemm_name(int wm, int tm, int tn, bool ao, bool bo) {
     return names[c][(ao ? 2 : 0) + (bo ? 1 : 0)];
 }
 
+template <int WM, int WN, int TM, int TN, int EPI>
+static void launch_epi(const GemmK& k, dim3 grid, hipStream_t st) {
+    const bool ao = k.flags & REFIL_GEMM_A_OUTC, bo = k.flags & REFIL_GEMM_B_OUTC;
+    if (!ao && !bo) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, false, false, EPI>), grid, dim3(256), 0, st, k);
+    else if (!ao && bo) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, false, true, EPI>), grid, dim3(256), 0, st, k);
+    else if (ao && bo) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, true, true, EPI>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, true, false, EPI>), grid, dim3(256), 0, st, k);
+}
+
 template <int WM, int WN, int TM, int TN>
 static void launch_cfg(const GemmK& k, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -267,10 +345,9 @@ static void launch_cfg(const GemmK& k, hipStream_t st) {
     const bool ao = k.flags & REFIL_GEMM_A_OUTC, bo = k.flags & REFIL_GEMM_B_OUTC;
     ProfScope prof(gemm_name(WM, TM, TN, ao, bo), 2.0 * k.M * k.N * k.K * k.batch,
                    4.0 * k.batch * ((double)k.M * k.K + (double)k.N * k.K + (double)k.M * k.N), st);
-    if (!ao && !bo) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, false, false>), grid, dim3(256), 0, st, k);
-    else if (!ao && bo) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, false, true>), grid, dim3(256), 0, st, k);
-    else if (ao && bo) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, true, true>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, true, false>), grid, dim3(256), 0, st, k);
+    if (k.splits > 1) launch_epi<WM, WN, TM, TN, 2>(k, grid, st);
+    else if (k.flags & REFIL_GEMM_RELU_BWD) launch_epi<WM, WN, TM, TN, 1>(k, grid, st);
+    else launch_epi<WM, WN, TM, TN, 0>(k, grid, st);
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -283,8 +360,16 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
     REFIL_CHECK(d.splits == 1 || !(d.flags & (REFIL_GEMM_RELU | REFIL_GEMM_RELU_BWD)) , "refil_gemm: split GEMM has no activation epilogue");
     REFIL_CHECK(d.splits == 1 || (!d.bias && !d.rowmask), "refil_gemm: split GEMM supports no bias / rowmask");
     REFIL_CHECK(!(d.flags & REFIL_GEMM_RELU_BWD) || d.aux, "refil_gemm: RELU_BWD needs aux");
+    REFIL_CHECK(d.splits > 1 || !(d.flags & REFIL_GEMM_ACCUM) || (d.flags & REFIL_GEMM_RELU_BWD),
+                "refil_gemm: ACCUM is supported with RELU_BWD or with a split reduction");
+    REFIL_CHECK(!(d.flags & REFIL_GEMM_RELU_BWD) || (!d.bias && !d.rowmask && !(d.flags & REFIL_GEMM_RELU)),
+                "refil_gemm: RELU_BWD excludes bias / rowmask / RELU");
     REFIL_CHECK(!(d.flags & REFIL_GEMM_COLSUM_A) || d.colsum, "refil_gemm: COLSUM_A needs colsum");
     REFIL_CHECK(!d.rowmask || d.rowmask_mod > 0, "refil_gemm: rowmask_mod must be > 0");
+    {
+        const long rows = d.c_map.grp ? ((long)(d.M - 1) / d.c_map.grp) * d.c_map.gstride + d.c_map.grp + d.c_map.off : d.M;
+        REFIL_CHECK(rows * (long)(d.splits > 1 ? d.N : d.ldc) < (1L << 32), "refil_gemm: C exceeds 2^32 elements per batch");
+    }
     GemmK k;
     k.A = d.A; k.B = d.B; k.C = d.C; k.bias = d.bias; k.aux = d.aux; k.rowmask = d.rowmask;
     k.colsum = d.colsum; k.partial = d.partial;
@@ -302,9 +387,9 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
     REFIL_LAUNCH_CHECK();
     if (d.splits > 1) {
         const long total = (long)d.batch * d.M * d.N;
-        const int blocks = (int)min((long)2048, cdivl(total, 256));
+        const int blocks = (int)min((long)2048, cdivl(total, 64) + cdivl((long)d.batch * d.M, 64));
         ProfScope prof("reduce_partials_kernel", 0.0, 4.0 * total * (d.splits + 1), st);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, st, k);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(64 * RED_WAVES), 0, st, k);
         REFIL_LAUNCH_CHECK();
     }
     return 0;
