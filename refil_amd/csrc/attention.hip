@@ -18,6 +18,8 @@
 //    (36*j mod 64 distinct for j mod 16).
 //  * backward recomputes the softmax from Q,K (no [G,R,heads,na,ne] weights tensor is stored) and
 //    accumulates dQ/dK/dV over the variants in LDS before one coalesced store.
+#include <stdlib.h>
+
 #include "common.h"
 #include "profile.h"
 #include "../../include/refil_hip.h"
@@ -296,9 +298,20 @@ static int fill(const refil_attn_desc& d, AttnK& k, bool bwd) {
     return 0;
 }
 
+int attn_mfma_launch(const refil_attn_desc& d, bool bwd, hipStream_t st);   // attention_mfma.hip; -1 = shape not instantiated
+
+static bool force_valu() {
+    const char* e = getenv("REFIL_ATTN_VALU");      // debugging / A-B switch: run the generic VALU kernels
+    return e && e[0] == '1';
+}
+
 int attn_forward_launch(const refil_attn_desc& d, hipStream_t st) {
     AttnK k;
     if (int e = fill(d, k, false)) return e;
+    if (!force_valu()) {
+        const int rc = attn_mfma_launch(d, false, st);
+        if (rc >= 0) return rc;
+    }
     const size_t smem = attn_smem_bytes(d.ne, d.na, d.hd, false);
     const double unit = (double)d.R * d.heads * d.na * d.ne * d.hd;
     ProfScope prof("attn_fwd_kernel", unit * (2.0 + 2.0 * d.nvar),
@@ -311,6 +324,10 @@ int attn_forward_launch(const refil_attn_desc& d, hipStream_t st) {
 int attn_backward_launch(const refil_attn_desc& d, hipStream_t st) {
     AttnK k;
     if (int e = fill(d, k, true)) return e;
+    if (!force_valu()) {
+        const int rc = attn_mfma_launch(d, true, st);
+        if (rc >= 0) return rc;
+    }
     const size_t smem = attn_smem_bytes(d.ne, d.na, d.hd, true);
     REFIL_CHECK(smem <= 160 * 1024, "refil_attn_backward: LDS need %zu B exceeds 160 KiB", smem);
     if (smem > 64 * 1024) {

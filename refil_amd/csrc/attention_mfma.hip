@@ -1,0 +1,379 @@
+// Matrix-core (v_mfma_f32_16x16x4_f32) version of the masked entity attention core, forward + backward.
+// Same math as attention.hip (reference: src/modules/layers/attention.py:48-64); that VALU kernel stays
+// as the generic fallback for tile shapes not instantiated here.
+//
+// One WAVE owns one (row=(b,t), head); a workgroup = 4 waves = 4 heads of the same row, so the mask
+// bytes of the row are fetched once. Q/K/V (and dO) head slices are staged in wave-private LDS
+// (pitch hd+2 floats: the strided b32 fragment reads are conflict-free), everything else lives in
+// registers. Key trick: compute the TRANSPOSED logits  S^T[key,agent] = K Q^T.  In the MFMA D layout a
+// lane then holds 4 consecutive keys of ONE agent, so
+//   * the softmax over keys is lane-local + 2 shuffles (lanes ^16, ^32),
+//   * the normalised weights are already the B operand (k = key) of  O^T = V^T P^T  -- no LDS
+//     round trip, no transposition,
+//   * the result lane holds 4 consecutive channels of one agent -> 16-byte stores.
+// The MFMA k order is a free permutation as long as A and B agree; every product here maps
+// virtual k (step s, lane group q) to the index the D registers of the previous product hold.
+// Backward needs products contracted over agents as well (dV, dK), for which the logits are
+// recomputed in the other orientation S[agent,key] too -- MFMA work is free here, the kernel is
+// bound by its HBM traffic.
+#include "common.h"
+#include "profile.h"
+#include "../../include/refil_hip.h"
+
+namespace refil {
+
+struct AttnM {
+    const float* Q; const float* K; const float* V; float* O; const float* dO;
+    float* dQ; float* dK; float* dV;
+    int ldq, ldkv, ldo; long sO;
+    int R, T1, ne, na, heads, hd, nvar; int var[3];
+    const uint8_t* obs_mask; long om_sB, om_sT;
+    const uint8_t* ent_mask; const uint8_t* ent_mask0; const uint8_t* group_bits;
+    int wave_floats;   // LDS floats per wave region
+};
+
+struct MaskLds { const uint8_t *emt, *em0, *gb, *om; };
+
+__device__ inline bool premask_m(int code, const MaskLds& s, int ne, int i, int j) {
+    const bool in0 = s.em0[i] | s.em0[j];
+    const bool same = !in0 && (s.gb[i] == s.gb[j]);
+    switch (code) {
+        case REFIL_MASK_OBS: return s.om[i * ne + j];
+        case REFIL_MASK_OBS_WITHIN: return !same || s.om[i * ne + j];
+        case REFIL_MASK_OBS_INTERACT: return same || s.om[i * ne + j];
+        case REFIL_MASK_ENTITY: return s.emt[i] | s.emt[j];
+        case REFIL_MASK_WITHIN: return !same;
+        default: return same || in0;
+    }
+}
+
+// stage `rows` x hd floats (row-major, ld) into wave-private LDS rows of pitch pd; rows [rows, rows_pad) zeroed
+__device__ inline void stage(float* dst, const float* src, long row0, int rows, int rows_pad, int ld, int col0, int hd, int pd, int lane) {
+    const int c4n = hd >> 2;
+    for (int idx = lane; idx < rows_pad * c4n; idx += 64) {
+        const int r = idx / c4n, c4 = idx % c4n;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows) v = *reinterpret_cast<const float4*>(src + (row0 + r) * (long)ld + col0 + c4 * 4);
+        float2* d = reinterpret_cast<float2*>(dst + r * pd + c4 * 4);
+        d[0] = make_float2(v.x, v.y);
+        d[1] = make_float2(v.z, v.w);
+    }
+}
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// D[rowtile x coltile] = sum_c X[rowbase + (l&15)][c] * Y[colbase + (l&15)][c]   (both operands [rows][hd] in LDS)
+__device__ inline f32x4 dot_tile(const float* X, int rowbase, const float* Y, int colbase, int hd, int pd, int l15, int q) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* xp = X + (rowbase + l15) * pd + q;
+    const float* yp = Y + (colbase + l15) * pd + q;
+    for (int s = 0; s < (hd >> 2); ++s) acc = MFMA16(xp[4 * s], yp[4 * s], acc);
+    return acc;
+}
+
+__device__ inline float group16_sum(float v) {   // sum over the 16 lanes sharing l>>4
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+__device__ inline float group16_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
+    v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
+    return v;
+}
+__device__ inline float cross4_sum(float v) {    // sum over the 4 lanes sharing l&15
+    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ inline float cross4_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+// masked softmax of transposed logits: st[jt][reg] = S^T[key 16jt+4q+reg][agent], in place -> P^T
+template <int NJT>
+__device__ inline void softmax_T(f32x4 (&st)[NJT], int code, const MaskLds& m, int ne, int na, int agent, int q, float inv_scale) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int key = 16 * jt + 4 * q + reg;
+            const bool masked = agent >= na || key >= ne || premask_m(code, m, ne, agent, key);
+            const float v = masked ? -INFINITY : st[jt][reg] * inv_scale;
+            st[jt][reg] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = cross4_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float e = st[jt][reg] == -INFINITY ? 0.f : expf(st[jt][reg] - mx);
+            st[jt][reg] = e;
+            sum += e;
+        }
+    sum = cross4_sum(sum);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) st[jt][reg] = sum > 0.f ? st[jt][reg] / sum : 0.f;
+    (void)inv;
+}
+
+// masked softmax of non-transposed logits: sn[jt][reg] = S[agent 16at+4q+reg][key 16jt + l15] -> P
+template <int NJT>
+__device__ inline void softmax_N(f32x4 (&sn)[NJT], int code, const MaskLds& m, int ne, int na, int agent0, int l15, float inv_scale) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int agent = agent0 + reg;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            const int key = 16 * jt + l15;
+            const bool masked = agent >= na || key >= ne || premask_m(code, m, ne, agent, key);
+            const float v = masked ? -INFINITY : sn[jt][reg] * inv_scale;
+            sn[jt][reg] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = group16_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            const float e = sn[jt][reg] == -INFINITY ? 0.f : expf(sn[jt][reg] - mx);
+            sn[jt][reg] = e;
+            sum += e;
+        }
+        sum = group16_sum(sum);
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) sn[jt][reg] = sum > 0.f ? sn[jt][reg] / sum : 0.f;
+    }
+}
+
+__device__ inline void load_masks(const AttnM& p, uint8_t* base, MaskLds& m, int r, int tid, int nthreads, bool need_obs) {
+    uint8_t* emt = base; uint8_t* em0 = base + p.ne; uint8_t* gb = base + 2 * p.ne; uint8_t* om = base + 3 * p.ne;
+    const int b = r / p.T1, t = r % p.T1;
+    for (int j = tid; j < p.ne; j += nthreads) {
+        emt[j] = p.ent_mask ? p.ent_mask[(long)r * p.ne + j] : 0;
+        em0[j] = p.ent_mask0 ? p.ent_mask0[(long)b * p.ne + j] : 0;
+        gb[j] = p.group_bits ? p.group_bits[(long)b * p.ne + j] : 0;
+    }
+    if (need_obs) {
+        const uint8_t* src = p.obs_mask + b * p.om_sB + t * p.om_sT;
+        for (int idx = tid; idx < p.na * p.ne; idx += nthreads) om[idx] = src[idx];
+    }
+    m.emt = emt; m.em0 = em0; m.gb = gb; m.om = om;
+}
+
+__device__ inline bool uses_obs_m(const AttnM& p) {
+    bool u = false;
+    for (int v = 0; v < p.nvar; ++v) u |= (p.var[v] <= REFIL_MASK_OBS_INTERACT);
+    return u;
+}
+
+// NJT/NAT/NCT: 16-tiles along keys / agents / head channels
+template <int NJT, int NAT, int NCT>
+__global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    const int r = blockIdx.x;
+    const int pd = p.hd + 2;
+    MaskLds m;
+    load_masks(p, reinterpret_cast<uint8_t*>(smem + 4 * p.wave_floats), m, r, tid, 256, uses_obs_m(p));
+    __syncthreads();
+    float* Qs = smem + wave * p.wave_floats;
+    float* Ks = Qs + NAT * 16 * pd;
+    float* Vs = Ks + NJT * 16 * pd;
+    const float inv_scale = 1.0f / sqrtf((float)p.hd);
+    const float scale = sqrtf((float)p.hd);
+    (void)inv_scale;
+    for (int head = wave; head < p.heads; head += 4) {
+        stage(Qs, p.Q, (long)r * p.na, p.na, NAT * 16, p.ldq, head * p.hd, p.hd, pd, lane);
+        stage(Ks, p.K, (long)r * p.ne, p.ne, NJT * 16, p.ldkv, head * p.hd, p.hd, pd, lane);
+        stage(Vs, p.V, (long)r * p.ne, p.ne, NJT * 16, p.ldkv, head * p.hd, p.hd, pd, lane);
+#pragma unroll
+        for (int at = 0; at < NAT; ++at) {
+            const int agent = 16 * at + l15;
+            f32x4 st0[NJT];
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) st0[jt] = dot_tile(Ks, 16 * jt, Qs, 16 * at, p.hd, pd, l15, q);
+            for (int v = 0; v < p.nvar; ++v) {
+                f32x4 pt[NJT];
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) pt[jt][reg] = st0[jt][reg] / scale;   // attention.py:54 divides
+                softmax_T<NJT>(pt, p.var[v], m, p.ne, p.na, agent, q, 1.0f);
+                float* O = p.O + v * p.sO;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    // O^T[c][agent] = sum_key V[key][c] P^T[key][agent]; virtual k (jt,reg | q) <-> key 16jt+4q+reg
+                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg)
+                            o = MFMA16(Vs[(16 * jt + 4 * q + reg) * pd + 16 * ct + l15], pt[jt][reg], o);
+                    const int c = 16 * ct + 4 * q;
+                    if (agent < p.na && c < p.hd)
+                        *reinterpret_cast<float4*>(O + ((long)r * p.na + agent) * p.ldo + head * p.hd + c) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+    }
+}
+
+template <int NJT, int NAT, int NCT>
+__global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, q = lane >> 4;
+    const int r = blockIdx.x;
+    const int pd = p.hd + 2;
+    MaskLds m;
+    load_masks(p, reinterpret_cast<uint8_t*>(smem + 4 * p.wave_floats), m, r, tid, 256, uses_obs_m(p));
+    __syncthreads();
+    float* Qs = smem + wave * p.wave_floats;
+    float* Ks = Qs + NAT * 16 * pd;
+    float* Vs = Ks + NJT * 16 * pd;
+    float* Ds = Vs + NJT * 16 * pd;          // dO of one (variant, agent tile): 16 rows
+    const float scale = sqrtf((float)p.hd);
+    for (int head = wave; head < p.heads; head += 4) {
+        stage(Qs, p.Q, (long)r * p.na, p.na, NAT * 16, p.ldq, head * p.hd, p.hd, pd, lane);
+        stage(Ks, p.K, (long)r * p.ne, p.ne, NJT * 16, p.ldkv, head * p.hd, p.hd, pd, lane);
+        stage(Vs, p.V, (long)r * p.ne, p.ne, NJT * 16, p.ldkv, head * p.hd, p.hd, pd, lane);
+        f32x4 dKt[NCT][NJT], dVt[NCT][NJT];     // [c 16ct+4q+reg][key 16jt+l15]
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                dKt[ct][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dVt[ct][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int at = 0; at < NAT; ++at) {
+            const int agentT = 16 * at + l15;        // agent of this lane in the transposed orientation
+            const int agentN0 = 16 * at + 4 * q;     // first agent of this lane in the normal orientation
+            f32x4 st0[NJT], sn0[NJT];
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                st0[jt] = dot_tile(Ks, 16 * jt, Qs, 16 * at, p.hd, pd, l15, q);   // S^T[key][agent]
+                sn0[jt] = dot_tile(Qs, 16 * at, Ks, 16 * jt, p.hd, pd, l15, q);   // S[agent][key]
+            }
+            f32x4 dQt[NCT];                           // [c][agent 16at+l15]
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) dQt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int v = 0; v < p.nvar; ++v) {
+                const int na_t = min(16, p.na - 16 * at);
+                stage(Ds, p.dO + v * p.sO, (long)r * p.na + 16 * at, na_t, 16, p.ldo, head * p.hd, p.hd, pd, lane);
+                f32x4 pt[NJT], pn[NJT];
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        pt[jt][reg] = st0[jt][reg] / scale;
+                        pn[jt][reg] = sn0[jt][reg] / scale;
+                    }
+                softmax_T<NJT>(pt, p.var[v], m, p.ne, p.na, agentT, q, 1.0f);
+                softmax_N<NJT>(pn, p.var[v], m, p.ne, p.na, agentN0, l15, 1.0f);
+                // dP^T[key][agent] = V dO^T ; dP[agent][key] = dO V^T ; dS = P (dP - sum_key P dP) / scale
+                f32x4 dst[NJT], dsn[NJT];
+                float rdT = 0.f, rdN[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    dst[jt] = dot_tile(Vs, 16 * jt, Ds, 0, p.hd, pd, l15, q);
+                    dsn[jt] = dot_tile(Ds, 0, Vs, 16 * jt, p.hd, pd, l15, q);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        rdT += pt[jt][reg] * dst[jt][reg];
+                        rdN[reg] += pn[jt][reg] * dsn[jt][reg];
+                    }
+                }
+                rdT = cross4_sum(rdT);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) rdN[reg] = group16_sum(rdN[reg]);
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        dst[jt][reg] = pt[jt][reg] * (dst[jt][reg] - rdT) / scale;
+                        dsn[jt][reg] = pn[jt][reg] * (dsn[jt][reg] - rdN[reg]) / scale;
+                    }
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+                    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            // contraction over agents: virtual k (reg | q) <-> agent 16at+4q+reg (rows of Ds / Qs)
+                            dVt[ct][jt] = MFMA16(Ds[(4 * q + reg) * pd + 16 * ct + l15], pn[jt][reg], dVt[ct][jt]);
+                            dKt[ct][jt] = MFMA16(Qs[(16 * at + 4 * q + reg) * pd + 16 * ct + l15], dsn[jt][reg], dKt[ct][jt]);
+                            // contraction over keys: virtual k (jt,reg | q) <-> key 16jt+4q+reg
+                            dQt[ct] = MFMA16(Ks[(16 * jt + 4 * q + reg) * pd + 16 * ct + l15], dst[jt][reg], dQt[ct]);
+                        }
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int c = 16 * ct + 4 * q;
+                if (agentT < p.na && c < p.hd)
+                    *reinterpret_cast<float4*>(p.dQ + ((long)r * p.na + agentT) * p.ldq + head * p.hd + c) =
+                        make_float4(dQt[ct][0], dQt[ct][1], dQt[ct][2], dQt[ct][3]);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                const int key = 16 * jt + l15, c = 16 * ct + 4 * q;
+                if (key < p.ne && c < p.hd) {
+                    const long off = ((long)r * p.ne + key) * p.ldkv + head * p.hd + c;
+                    *reinterpret_cast<float4*>(p.dK + off) = make_float4(dKt[ct][jt][0], dKt[ct][jt][1], dKt[ct][jt][2], dKt[ct][jt][3]);
+                    *reinterpret_cast<float4*>(p.dV + off) = make_float4(dVt[ct][jt][0], dVt[ct][jt][1], dVt[ct][jt][2], dVt[ct][jt][3]);
+                }
+            }
+    }
+}
+
+static inline int tiles16(int n) { return (n + 15) / 16; }
+
+template <int NJT, int NAT, int NCT>
+static int launch_pair(const AttnM& k, bool bwd, size_t smem, hipStream_t st) {
+    if (bwd) {
+        if (smem > 64 * 1024) REFIL_HIP(hipFuncSetAttribute((const void*)attn_bwd_mfma<NJT, NAT, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((attn_bwd_mfma<NJT, NAT, NCT>), dim3(k.R), dim3(256), smem, st, k);
+    } else {
+        if (smem > 64 * 1024) REFIL_HIP(hipFuncSetAttribute((const void*)attn_fwd_mfma<NJT, NAT, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((attn_fwd_mfma<NJT, NAT, NCT>), dim3(k.R), dim3(256), smem, st, k);
+    }
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
+// returns -1 when the tile shape is not instantiated (caller falls back to the VALU kernel)
+int attn_mfma_launch(const refil_attn_desc& d, bool bwd, hipStream_t st) {
+    const int njt = tiles16(d.ne), nat = tiles16(d.na), nct = tiles16(d.hd);
+    AttnM k;
+    k.Q = d.Q; k.K = d.K; k.V = d.V; k.O = d.O; k.dO = d.dO; k.dQ = d.dQ; k.dK = d.dK; k.dV = d.dV;
+    k.ldq = d.ldq; k.ldkv = d.ldkv; k.ldo = d.ldo; k.sO = d.sO;
+    k.R = d.R; k.T1 = d.T1; k.ne = d.ne; k.na = d.na; k.heads = d.heads; k.hd = d.hd; k.nvar = d.nvar;
+    for (int v = 0; v < 3; ++v) k.var[v] = d.var[v];
+    k.obs_mask = d.obs_mask; k.om_sB = d.om_sB; k.om_sT = d.om_sT;
+    k.ent_mask = d.ent_mask; k.ent_mask0 = d.ent_mask0; k.group_bits = d.group_bits;
+    const int pd = d.hd + 2;
+    // +16 floats of slack: fragment reads of a partial channel tile (hd < 16*nct) run past the last row
+    k.wave_floats = ((nat * 16 + 2 * njt * 16 + (bwd ? 16 : 0)) * pd + 16 + 3) & ~3;
+    const size_t smem = ((size_t)4 * k.wave_floats * 4 + 3 * (size_t)d.ne + (size_t)d.na * d.ne + 15) & ~(size_t)15;
+    if (smem > 160 * 1024) return -1;
+    const double unit = (double)d.R * d.heads * d.na * d.ne * d.hd;
+    ProfScope prof(bwd ? "attn_bwd_mfma" : "attn_fwd_mfma", unit * (bwd ? 2.0 + 8.0 * d.nvar : 2.0 + 2.0 * d.nvar),
+                   4.0 * d.R * d.heads * d.hd * (bwd ? d.na * (2.0 + d.nvar) + 4.0 * d.ne : d.na * (1.0 + d.nvar) + 2.0 * d.ne), st);
+#define CASE(J, A, C) if (njt == J && nat == A && nct == C) return launch_pair<J, A, C>(k, bwd, smem, st)
+    CASE(1, 1, 1); CASE(1, 1, 2); CASE(2, 1, 1); CASE(2, 1, 2); CASE(2, 2, 2); CASE(3, 2, 2); CASE(4, 2, 2);
+#undef CASE
+    return -1;
+}
+
+}  // namespace refil

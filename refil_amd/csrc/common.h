@@ -43,11 +43,13 @@ void set_error(const char* fmt, ...);
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ inline long cdivl(long a, long b) { return (a + b - 1) / b; }
 
-// physical memory row of logical row r:  (r / grp) * gstride + (r % grp) + off   (grp == 0: identity)
+// physical memory row of logical row r:  (r / grp) * gstride + (r % grp) + off.
+// Branch-free on purpose (it sits in the GEMM load path): the identity is encoded as grp = 2^30.
 struct RowMap {
     int grp, gstride, off;
     __host__ __device__ inline long operator()(int r) const {
-        return grp ? (long)(r / grp) * gstride + (r % grp) + off : (long)r;
+        const int q = r / grp;
+        return (long)q * gstride + (r - q * grp) + off;
     }
 };
 

@@ -30,6 +30,7 @@ struct GemmK {
     RowMap amap, bmap, cmap;
     int rowmask_mod, batch, splits, flags;
     int vecA, vecB;   // 16-byte global loads legal for this operand
+    int vecC;         // 16-byte stores (and aux / accumulate loads) legal for C
 };
 
 constexpr int BK = 32;
@@ -41,43 +42,48 @@ struct Tile {
     static constexpr int PITCH = OUTC ? ROWS + 4 : PITCH_RED;
     static constexpr int FLOATS = OUTC ? BK * (ROWS + 4) : ROWS * PITCH_RED;
 
-    // global -> registers. `o0` first output index of the tile, `k0` first reduction index,
-    // OUT/kend bounds. Element (o,k) lives at base[map(o)*ld + k] (RED) or base[map(k)*ld + o] (OUTC).
-    __device__ static inline void load(float4 (&v)[NV], const float* __restrict__ base, int ld, const RowMap& map,
-                                       int o0, int OUT, int k0, int kend, int vec, int tid) {
+    // Per-thread invariants of the NV loads of a tile: the position along the OUTPUT index never changes
+    // across K tiles, so its bounds check (and, for reduction-contiguous operands, the row map) is hoisted.
+    struct Pos {
+        long off[NV];    // RED: map(o)*ld ; OUTC: o
+        bool ok[NV];     // o < OUT
+    };
+    __device__ static inline void prepare(Pos& ps, int ld, const RowMap& map, int o0, int OUT, int tid) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int f = tid + i * 256;
-            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!OUTC) {
-                const int row = f >> 3, c4 = f & 7;
-                const int o = o0 + row, k = k0 + c4 * 4;
-                if (o < OUT && k < kend) {
-                    const float* p = base + map(o) * (long)ld + k;
-                    if (vec && k + 3 < kend) {
-                        r = *reinterpret_cast<const float4*>(p);
-                    } else {
-                        r.x = p[0];
-                        if (k + 1 < kend) r.y = p[1];
-                        if (k + 2 < kend) r.z = p[2];
-                        if (k + 3 < kend) r.w = p[3];
-                    }
-                }
+            const int o = OUTC ? o0 + (f % (ROWS / 4)) * 4 : o0 + (f >> 3);
+            ps.ok[i] = o < OUT;
+            const int oc = ps.ok[i] ? o : 0;
+            ps.off[i] = OUTC ? (long)oc : map(oc) * (long)ld;
+        }
+    }
+
+    // global -> registers, BRANCH-FREE: out-of-range elements read a clamped (valid) address and are
+    // zeroed by a select, so all NV loads of a tile issue back to back (a divergent if-ladder here
+    // serialised the loads: ~8 dependent HBM latencies per K tile). VEC: 16-byte loads are legal
+    // (aligned base, ld % 4 == 0, extent of the contiguous dim % 4 == 0); otherwise 4 scalar loads.
+    // Element (o,k) lives at base[map(o)*ld + k] (RED) or base[map(k)*ld + o] (OUTC).
+    template <bool VEC>
+    __device__ static inline void load(float4 (&v)[NV], const float* __restrict__ base, int ld, const RowMap& map,
+                                       const Pos& ps, int OUT, int k0, int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int f = tid + i * 256;
+            const int k = OUTC ? k0 + f / (ROWS / 4) : k0 + (f & 7) * 4;
+            const bool in = ps.ok[i] && (k < kend);
+            const int kc = in ? k : 0;
+            const float* p = OUTC ? base + map(kc) * (long)ld + (in ? ps.off[i] : 0) : base + (in ? ps.off[i] : 0) + kc;
+            float4 r;
+            if (VEC) {
+                r = *reinterpret_cast<const float4*>(p);
+                r.x = in ? r.x : 0.f; r.y = in ? r.y : 0.f; r.z = in ? r.z : 0.f; r.w = in ? r.w : 0.f;
             } else {
-                constexpr int O4 = ROWS / 4;
-                const int red = f / O4, o4 = f % O4;
-                const int k = k0 + red, o = o0 + o4 * 4;
-                if (k < kend && o < OUT) {
-                    const float* p = base + map(k) * (long)ld + o;
-                    if (vec && o + 3 < OUT) {
-                        r = *reinterpret_cast<const float4*>(p);
-                    } else {
-                        r.x = p[0];
-                        if (o + 1 < OUT) r.y = p[1];
-                        if (o + 2 < OUT) r.z = p[2];
-                        if (o + 3 < OUT) r.w = p[3];
-                    }
-                }
+                // tail of the contiguous dim: element e valid iff (contiguous index + e) < limit
+                const int c = OUTC ? (int)ps.off[i] : k, lim = OUTC ? OUT : kend;
+                const bool i1 = in && c + 1 < lim, i2 = in && c + 2 < lim, i3 = in && c + 3 < lim;
+                const float x0 = p[0], x1 = p[i1 ? 1 : 0], x2 = p[i2 ? 2 : 0], x3 = p[i3 ? 3 : 0];
+                r.x = in ? x0 : 0.f; r.y = i1 ? x1 : 0.f; r.z = i2 ? x2 : 0.f; r.w = i3 ? x3 : 0.f;
             }
             v[i] = r;
         }
@@ -112,12 +118,15 @@ struct Tile {
 // EPI: 0 = store act(acc + bias) (+ optional row mask), 1 = relu-backward (x aux>0, optional +=C),
 //      2 = raw partial store of a split reduction. Compile-time so that the epilogue is branch-free and
 //      its loads (mask bytes / aux / C) are issued in batches instead of one dependent load per element.
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_OUTC, bool B_OUTC, int EPI>
+// VEC: both operands admit 16-byte global loads (compile-time so that the loads stay straight-line code).
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_OUTC, bool B_OUTC, int EPI, bool VEC>
 __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmK p) {
     constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
     using TA = Tile<BM, A_OUTC>;
     using TB = Tile<BN, B_OUTC>;
-    __shared__ __attribute__((aligned(16))) float lds[TA::FLOATS + TB::FLOATS];
+    constexpr int SLAB_W = 32 * TN, SLAB_P = SLAB_W + 4;          // epilogue staging: one 32 x (32*TN) slab per wave
+    constexpr int LDS_FLOATS = (TA::FLOATS + TB::FLOATS) > 4 * 32 * SLAB_P ? (TA::FLOATS + TB::FLOATS) : 4 * 32 * SLAB_P;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     float* As = lds;
     float* Bs = lds + TA::FLOATS;
 
@@ -147,17 +156,23 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmK p) {
     const bool do_colsum = (p.flags & REFIL_GEMM_COLSUM_A) && blockIdx.x == 0;
 
     float4 va[TA::NV], vb[TB::NV];
+    typename TA::Pos pa;
+    typename TB::Pos pb;
+    TA::prepare(pa, p.lda, p.amap, m0, p.M, tid);
+    TB::prepare(pb, p.ldb, p.bmap, n0, p.N, tid);
     if (kbeg < kend) {
-        TA::load(va, A, p.lda, p.amap, m0, p.M, kbeg, kend, p.vecA, tid);
-        TB::load(vb, B, p.ldb, p.bmap, n0, p.N, kbeg, kend, p.vecB, tid);
+        TA::template load<VEC>(va, A, p.lda, p.amap, pa, p.M, kbeg, kend, tid);
+        TB::template load<VEC>(vb, B, p.ldb, p.bmap, pb, p.N, kbeg, kend, tid);
     }
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        TA::store(va, As, tid);
-        TB::store(vb, Bs, tid);
-        __syncthreads();
-        if (k0 + BK < kend) {
-            TA::load(va, A, p.lda, p.amap, m0, p.M, k0 + BK, kend, p.vecA, tid);
-            TB::load(vb, B, p.ldb, p.bmap, n0, p.N, k0 + BK, kend, p.vecB, tid);
+        if (!(p.flags & 1024) || k0 == kbeg) {
+            TA::store(va, As, tid);
+            TB::store(vb, Bs, tid);
+            __syncthreads();
+        }
+        if (k0 + BK < kend && !(p.flags & 512)) {
+            TA::template load<VEC>(va, A, p.lda, p.amap, pa, p.M, k0 + BK, kend, tid);
+            TB::template load<VEC>(vb, B, p.ldb, p.bmap, pb, p.N, k0 + BK, kend, tid);
         }
         if (do_colsum && tid < BM) {
             float s = 0.f;
@@ -187,73 +202,85 @@ __global__ __launch_bounds__(256, 3) void gemm_kernel(GemmK p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        __syncthreads();
+        if (!(p.flags & 1024)) __syncthreads();
     }
 
     // ---------------- epilogue ----------------
+    // The MFMA accumulator layout gives a lane ONE column and 16 rows of a 32x32 tile, i.e. 4-byte
+    // stores scattered over 16 rows; issued directly they are store-issue bound (measured: 71 -> 103
+    // TFLOP/s with the stores removed). So each wave transposes its 32 x (32*TN) slab through LDS and
+    // writes whole 16-byte vectors, 16 (TN=2) or 8 (TN=1) lanes per contiguous row segment; bias, ReLU,
+    // row masks and the ReLU-backward / accumulate reads are applied on that vector path (coalesced).
+    if ((p.flags & 256) && acc[0][0][0] != 123456.789f) return;   // ablation: skip the stores
     if (do_colsum && tid < BM && m0 + tid < p.M) {
         if (EPI == 2) p.partial[(long)p.batch * p.splits * p.M * p.N + ((long)bz * p.splits + sp) * p.M + m0 + tid] = csum;
         else p.colsum[bz * p.sColsum + m0 + tid] = csum;
     }
     float* Cb = EPI == 2 ? p.partial + ((long)bz * p.splits + sp) * p.M * p.N : p.C + bz * p.sC;
     const int ldc = EPI == 2 ? p.N : p.ldc;
-    int ncol[TN];
-    float bv[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        ncol[j] = n0 + (wn * TN + j) * 32 + lane31;
-        bv[j] = (EPI == 0 && p.bias && ncol[j] < p.N) ? p.bias[bz * p.sBias + ncol[j]] : 0.f;
-    }
+    const float* aux = EPI == 1 ? p.aux + bz * p.sC : nullptr;
     const bool relu = p.flags & REFIL_GEMM_RELU;
     const bool accum = p.flags & REFIL_GEMM_ACCUM;
-    const float* aux = EPI == 1 ? p.aux + bz * p.sC : nullptr;
-    // accumulator register r of a 32x32 tile holds row (r&3) + 8*(r>>2) + 4*hf: walk the 4 row quads
+    float* slab = lds + wave * 32 * SLAB_P;
+    constexpr int LPR = SLAB_W / 4;            // lanes per slab row (float4 each)
+    constexpr int RPP = 64 / LPR;              // rows per pass
+    const int c4 = lane % LPR, rsub = lane / LPR;
+    const int ncol = n0 + wn * SLAB_W + c4 * 4;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == 0 && p.bias) {
+        const float* bp = p.bias + bz * p.sBias;
+        bias4.x = ncol < p.N ? bp[ncol] : 0.f;
+        bias4.y = ncol + 1 < p.N ? bp[ncol + 1] : 0.f;
+        bias4.z = ncol + 2 < p.N ? bp[ncol + 2] : 0.f;
+        bias4.w = ncol + 3 < p.N ? bp[ncol + 3] : 0.f;
+    }
+    const bool vecc = p.vecC;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        if (i > 0) __syncthreads();             // the wave's slab is reused
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            unsigned roff[4];   // element offsets fit 32 bits (checked on the host)
-            bool rok[4], dead[4];
-            uint8_t mb[4];
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = m0 + (wm * TM + i) * 32 + q + 8 * c + 4 * hf;
-                rok[q] = m < p.M;
-                roff[q] = (unsigned)((EPI == 2 ? (long)m : p.cmap(m)) * ldc);
-                mb[q] = (EPI == 0 && p.rowmask && rok[q]) ? p.rowmask[m % p.rowmask_mod] : 0;
+            for (int r = 0; r < 16; ++r)
+                slab[((r & 3) + 8 * (r >> 2) + 4 * hf) * SLAB_P + j * 32 + lane31] = acc[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 32 / RPP; ++ps) {
+            const int rr = ps * RPP + rsub;
+            const int m = m0 + (wm * TM + i) * 32 + rr;
+            const bool rok = m < p.M;
+            float4 v = *reinterpret_cast<const float4*>(slab + rr * SLAB_P + c4 * 4);
+            const long off = (EPI == 2 ? (long)(rok ? m : 0) : p.cmap(rok ? m : 0)) * ldc + ncol;
+            if (EPI == 0) {
+                v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (p.rowmask) {
+                    const bool dead = rok && p.rowmask[m % p.rowmask_mod] != 0;
+                    if (dead) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dead[q] = mb[q] != 0;
-            if (EPI == 1) {
-                float ax[TN][4], cx[TN][4];
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bool ok = rok[q] && ncol[j] < p.N;
-                        ax[j][q] = ok ? aux[roff[q] + ncol[j]] : 0.f;
-                        cx[j][q] = (ok && accum) ? Cb[roff[q] + ncol[j]] : 0.f;
-                    }
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float v = (ax[j][q] > 0.f ? acc[i][j][4 * c + q] : 0.f) + cx[j][q];
-                        if (rok[q] && ncol[j] < p.N) Cb[roff[q] + ncol[j]] = v;
-                    }
+            if (vecc) {
+                const bool ok = rok && ncol < p.N;       // N % 4 == 0 on this path: a vector is all-in or all-out
+                if (EPI == 1) {
+                    float4 ax = make_float4(0.f, 0.f, 0.f, 0.f), cx = ax;
+                    if (ok) ax = *reinterpret_cast<const float4*>(aux + off);
+                    if (ok && accum) cx = *reinterpret_cast<const float4*>(Cb + off);
+                    v.x = (ax.x > 0.f ? v.x : 0.f) + cx.x; v.y = (ax.y > 0.f ? v.y : 0.f) + cx.y;
+                    v.z = (ax.z > 0.f ? v.z : 0.f) + cx.z; v.w = (ax.w > 0.f ? v.w : 0.f) + cx.w;
+                }
+                if (ok) *reinterpret_cast<float4*>(Cb + off) = v;
             } else {
+                float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float v = acc[i][j][4 * c + q];
-                        if (EPI == 0) {
-                            v += bv[j];
-                            v = relu ? fmaxf(v, 0.f) : v;
-                            v = dead[q] ? 0.f : v;
-                        }
-                        if (rok[q] && ncol[j] < p.N) Cb[roff[q] + ncol[j]] = v;
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = rok && ncol + e < p.N;
+                    if (EPI == 1) {
+                        const float a = ok ? aux[off + e] : 0.f;
+                        const float c = (ok && accum) ? Cb[off + e] : 0.f;
+                        vv[e] = (a > 0.f ? vv[e] : 0.f) + c;
                     }
+                    if (ok) Cb[off + e] = vv[e];
+                }
             }
         }
     }
@@ -329,25 +356,32 @@ static const char* gemm_name(int wm, int tm, int tn, bool ao, bool bo) {
     return names[c][(ao ? 2 : 0) + (bo ? 1 : 0)];
 }
 
-template <int WM, int WN, int TM, int TN, int EPI>
-static void launch_epi(const GemmK& k, dim3 grid, hipStream_t st) {
-    const bool ao = k.flags & REFIL_GEMM_A_OUTC, bo = k.flags & REFIL_GEMM_B_OUTC;
-    if (!ao && !bo) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, false, false, EPI>), grid, dim3(256), 0, st, k);
-    else if (!ao && bo) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, false, true, EPI>), grid, dim3(256), 0, st, k);
-    else if (ao && bo) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, true, true, EPI>), grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, true, false, EPI>), grid, dim3(256), 0, st, k);
+template <int WM, int WN, int TM, int TN, bool AO, bool BO, int EPI>
+static void launch_vec(const GemmK& k, dim3 grid, hipStream_t st) {
+    if (k.vecA && k.vecB) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, AO, BO, EPI, true>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, AO, BO, EPI, false>), grid, dim3(256), 0, st, k);
 }
 
+// Only the operand-layout x epilogue combinations the learner schedule uses are instantiated:
+//   x W^T (RED,RED): store | dY W (RED,OUTC): store, relu-bwd | dY^T X (OUTC,OUTC): split partial, store
 template <int WM, int WN, int TM, int TN>
-static void launch_cfg(const GemmK& k, hipStream_t st) {
+static int launch_cfg(const GemmK& k, hipStream_t st) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     dim3 grid(cdiv(k.N, BN), cdiv(k.M, BM), k.batch * k.splits);
     const bool ao = k.flags & REFIL_GEMM_A_OUTC, bo = k.flags & REFIL_GEMM_B_OUTC;
+    const int epi = k.splits > 1 ? 2 : ((k.flags & REFIL_GEMM_RELU_BWD) ? 1 : 0);
     ProfScope prof(gemm_name(WM, TM, TN, ao, bo), 2.0 * k.M * k.N * k.K * k.batch,
                    4.0 * k.batch * ((double)k.M * k.K + (double)k.N * k.K + (double)k.M * k.N), st);
-    if (k.splits > 1) launch_epi<WM, WN, TM, TN, 2>(k, grid, st);
-    else if (k.flags & REFIL_GEMM_RELU_BWD) launch_epi<WM, WN, TM, TN, 1>(k, grid, st);
-    else launch_epi<WM, WN, TM, TN, 0>(k, grid, st);
+    if (!ao && !bo && epi == 0) launch_vec<WM, WN, TM, TN, false, false, 0>(k, grid, st);
+    else if (!ao && bo && epi == 0) launch_vec<WM, WN, TM, TN, false, true, 0>(k, grid, st);
+    else if (!ao && bo && epi == 1) launch_vec<WM, WN, TM, TN, false, true, 1>(k, grid, st);
+    else if (ao && bo && epi == 2) launch_vec<WM, WN, TM, TN, true, true, 2>(k, grid, st);
+    else if (ao && bo && epi == 0) launch_vec<WM, WN, TM, TN, true, true, 0>(k, grid, st);
+    else {
+        set_error("refil_gemm: unsupported combination (A_OUTC=%d, B_OUTC=%d, epilogue=%d)", (int)ao, (int)bo, epi);
+        return 1;
+    }
+    return 0;
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -375,15 +409,22 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
     k.colsum = d.colsum; k.partial = d.partial;
     k.M = d.M; k.N = d.N; k.K = d.K; k.lda = d.lda; k.ldb = d.ldb; k.ldc = d.ldc;
     k.sA = d.sA; k.sB = d.sB; k.sC = d.sC; k.sBias = d.sBias; k.sColsum = d.sColsum;
-    k.amap = RowMap{d.a_map.grp, d.a_map.gstride, d.a_map.off};
-    k.bmap = RowMap{d.b_map.grp, d.b_map.gstride, d.b_map.off};
-    k.cmap = RowMap{d.c_map.grp, d.c_map.gstride, d.c_map.off};
+    auto mk = [](const refil_rowmap& m) { return m.grp ? RowMap{m.grp, m.gstride, m.off} : RowMap{1 << 30, 0, 0}; };
+    k.amap = mk(d.a_map); k.bmap = mk(d.b_map); k.cmap = mk(d.c_map);
     k.rowmask_mod = d.rowmask_mod; k.batch = d.batch; k.splits = d.splits; k.flags = d.flags;
-    k.vecA = aligned16(d.A) && (d.lda % 4 == 0) && (d.sA % 4 == 0);
-    k.vecB = aligned16(d.B) && (d.ldb % 4 == 0) && (d.sB % 4 == 0);
-    if (d.N > 64) launch_cfg<2, 2, 2, 2>(k, st);
-    else if (d.N > 32) launch_cfg<4, 1, 1, 2>(k, st);
-    else launch_cfg<4, 1, 1, 1>(k, st);
+    // 16-byte loads: aligned base/strides and the contiguous extent (K for reduction-contiguous operands,
+    // M resp. N for output-contiguous ones) a multiple of 4, so a float4 is never partially valid
+    const int extA = (d.flags & REFIL_GEMM_A_OUTC) ? d.M : d.K, extB = (d.flags & REFIL_GEMM_B_OUTC) ? d.N : d.K;
+    k.vecA = aligned16(d.A) && (d.lda % 4 == 0) && (d.sA % 4 == 0) && (extA % 4 == 0);
+    k.vecB = aligned16(d.B) && (d.ldb % 4 == 0) && (d.sB % 4 == 0) && (extB % 4 == 0);
+    if (d.splits > 1) k.vecC = aligned16(d.partial) && (d.N % 4 == 0) && (((long)d.M * d.N) % 4 == 0);
+    else k.vecC = aligned16(d.C) && (d.ldc % 4 == 0) && (d.sC % 4 == 0) && (d.N % 4 == 0) &&
+                  (!d.aux || aligned16(d.aux));
+    int rc;
+    if (d.N > 64) rc = launch_cfg<2, 2, 2, 2>(k, st);
+    else if (d.N > 32) rc = launch_cfg<4, 1, 1, 2>(k, st);
+    else rc = launch_cfg<4, 1, 1, 1>(k, st);
+    if (rc) return rc;
     REFIL_LAUNCH_CHECK();
     if (d.splits > 1) {
         const long total = (long)d.batch * d.M * d.N;

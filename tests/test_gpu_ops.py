@@ -154,9 +154,12 @@ def _attn_ref(q, k, v, masks, heads):
     (6, 3, 2, 4, [MASK_ENTITY]),
     (48, 24, 4, 32, [MASK_ENTITY, MASK_WITHIN, MASK_INTERACT]),
     (64, 32, 2, 32, [MASK_OBS]),
+    (40, 40, 1, 64, [MASK_ENTITY, MASK_WITHIN]),      # tile shape without a matrix-core instantiation -> VALU fallback
 ])
-def test_attention_forward_backward(ne, na, heads, hd, variants):
+@pytest.mark.parametrize("force_valu", [False, True])
+def test_attention_forward_backward(ne, na, heads, hd, variants, force_valu, monkeypatch):
     import hip_ops
+    monkeypatch.setenv("REFIL_ATTN_VALU", "1" if force_valu else "0")   # matrix-core kernel vs generic VALU fallback
     torch.manual_seed(ne * 100 + na)
     B, T1 = 3, 4
     R, w = B * T1, heads * hd
