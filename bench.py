@@ -131,7 +131,7 @@ def cpu_baseline(dims, data_full, target_seconds=20.0):
     # pick the thread count that makes the CPU port fastest on this host (all cores is not always best
     # for these small GEMMs); `cores` reports the count actually used
     ncpu = os.cpu_count() or 1
-    cands = sorted({c for c in (8, 16, 32, 64, threads, ncpu) if 1 <= c <= ncpu})
+    cands = sorted({c for c in (8, 16, 32) if 1 <= c <= ncpu}) or [1]   # more threads only slow these small ops down
     probe = None
     for c in cands:
         torch.set_num_threads(c)

@@ -1,0 +1,47 @@
+"""Data-parallel plumbing of the learner step (one process per GPU, torch.distributed; backend "nccl" is
+RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+The path shards over EPISODES: every op of the step is independent across
+batch rows, the only cross-rank quantity is the loss normaliser sum(mask) (q_learner.py:165,171).
+Recipe: each rank back-propagates the UN-normalised loss of its shard; ONE all-reduce(SUM) of the flat
+buffer [gradients | stat sums] then yields both the global gradient sum and the global sum(mask); the
+optimiser kernel divides by it. Replicas stay bit-identical (same reduced buffer, same update), so no
+parameter broadcast is needed after step 0. The message is small (1.74 MB at the north-star shape), i.e.
+latency-bound on xGMI: one collective per step, never one per tensor.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
+    """In-place SUM over ranks of the flat [grads | stats] buffer (no-op for a single process)."""
+    if world() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+def shard_episodes(fields: Dict[str, torch.Tensor], r: int, n: int) -> Dict[str, torch.Tensor]:
+    """Rank r of n takes episodes [r*B/n, (r+1)*B/n) of the sampled minibatch (views, no copies)."""
+    B = next(iter(fields.values())).shape[0]
+    assert B % n == 0, f"batch of {B} episodes does not shard over {n} ranks"
+    per = B // n
+    return {k: v[r * per:(r + 1) * per] for k, v in fields.items()}
+
+
+def shard_bits(bits: torch.Tensor, r: int, n: int) -> torch.Tensor:
+    """The partition bits are drawn ONCE for the global batch (shared seed) and sliced per rank, so the
+    union over ranks equals the single-GPU draw exactly."""
+    per = bits.shape[0] // n
+    return bits[r * per:(r + 1) * per].contiguous()

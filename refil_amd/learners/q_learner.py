@@ -7,9 +7,7 @@ from __future__ import annotations
 import copy
 
 import torch as th
-import torch.distributed as dist
-
-from .. import _lib
+from .. import _lib, dp
 from ..engine import LearnerEngine, dims_from_args
 from ..modules.mixers.flex_qmix import FlexQMixer
 
@@ -113,10 +111,9 @@ class QLearner:
             bits = group_bits.to(dev).to(th.uint8).contiguous() if group_bits is not None else \
                 self._draw_partition(B, args.n_entities, dev)
         self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            # data parallel over episodes: ONE all-reduce(SUM) of [grads | stat sums]; the global
-            # sum(mask) normaliser is applied afterwards by the optimiser kernel (q_learner.py:165)
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
+        # data parallel over episodes: ONE all-reduce(SUM) of [grads | stat sums]; the global
+        # sum(mask) normaliser is applied afterwards by the optimiser kernel (q_learner.py:165)
+        dp.allreduce_sum_(self.grads)
         self._engine.clip_rmsprop(self.flat_live, self.grads, self.square_avg, self._n, args.lr, args.optim_alpha,
                                   args.optim_eps, args.weight_decay, args.grad_norm_clip)
         self._step_count += 1
