@@ -15,6 +15,7 @@
 // Activations live in a caller-provided workspace arena (sized for 288 GB HBM parts: nothing is
 // recomputed except the attention softmax).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "kernels.h"
@@ -100,6 +101,7 @@ struct Work {
     float *dx3h, *dchosen, *dx2h, *daoh, *dqh, *dkvh, *dx1h;
     float *dqva, *dhs, *dgi, *dgh, *dx3a, *dx2a, *daoa, *dqa, *dkva, *dx1a;
     float* partial;
+    float* partial2;   // split-K scratch of the side (agent-chain) stream
 };
 
 struct Sizes {
@@ -177,6 +179,7 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     w.dkva = a.take<float>(s.NE * 2 * d.d);
     w.dx1a = a.take<float>(s.NE * d.d);
     w.partial = a.take<float>(PARTIAL_FLOATS);
+    w.partial2 = a.take<float>(PARTIAL_FLOATS);
 }
 
 static size_t workspace_bytes(const refil_dims& d, CarveMode mode) {
@@ -230,6 +233,32 @@ static refil_gemm_desc linear_dw(const float* dy, int lddy, const float* x, int 
 }
 
 #define RUN(x) do { if (int e_ = (x)) return e_; } while (0)
+
+// The step has two independent chains between its join points: the agent chain (3-variant live agent,
+// target agent, GRUs -- latency-bound, few workgroups) and the hypernet chain (throughput-bound GEMMs).
+// They run on two HIP streams (fork/join with events, graph-capturable) so that the persistent GRU's 96
+// workgroups do not leave the other 160 CUs idle. REFIL_NO_OVERLAP=1 serialises everything on one stream.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ok = false;
+};
+static int side_stream(SideStream*& out) {
+    static thread_local SideStream sd;
+    if (!sd.ok) {
+        int lo = 0, hi = 0;
+        REFIL_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        REFIL_HIP(hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, hi));   // latency-bound chain: high priority
+        for (auto& e : sd.ev) REFIL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        sd.ok = true;
+    }
+    out = &sd;
+    return 0;
+}
+static bool overlap_enabled() {
+    const char* e = getenv("REFIL_NO_OVERLAP");
+    return !(e && e[0] == '1');
+}
 
 struct Ctx {
     refil_dims d; Sizes s; refil_batch b; refil_param_layout L; Work w; hipStream_t st;
@@ -498,17 +527,28 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
 
     // ---------------- forward ----------------
     RUN(run_prep(c, 1));
-    RUN(agent_forward(c, params_live, w.la, G, nullptr));                         // q_learner.py:86-89 / 107
-    RUN(agent_forward(c, params_target, w.ta, 1, nullptr));                       // :111-113
+    Ctx ca = c;                       // agent chain context (side stream + its own split-K scratch)
+    SideStream* sd = nullptr;
+    const bool overlap = overlap_enabled();
+    if (overlap) {
+        RUN(side_stream(sd));
+        ca.st = sd->s; ca.w.partial = w.partial2;
+        REFIL_HIP(hipEventRecord(sd->ev[0], c.st));
+        REFIL_HIP(hipStreamWaitEvent(sd->s, sd->ev[0], 0));
+    }
+    RUN(agent_forward(ca, params_live, w.la, G, nullptr));                        // q_learner.py:86-89 / 107
+    RUN(agent_forward(ca, params_target, w.ta, 1, nullptr));                      // :111-113
     {
         QSelArgs q;
         q.q = w.la.qv; q.tq = w.ta.qv; q.actions = c.b.actions; q.ac_sB = c.b.ac_sB; q.ac_sT = c.b.ac_sT;
         q.avail = c.b.avail_actions; q.av_sB = c.b.av_sB; q.av_sT = c.b.av_sT;
         q.chosen = w.chosen; q.tmax = w.tmax; q.G = G; q.B = d.B; q.T1 = d.T1; q.na = d.na; q.A = d.A; q.double_q = d.double_q;
-        RUN(qselect_launch(q, c.st));                                             // :91-96,115-128
+        RUN(qselect_launch(q, ca.st));                                            // :91-96,115-128
     }
+    if (overlap) REFIL_HIP(hipEventRecord(sd->ev[1], sd->s));
     RUN(hyper_forward(c, params_live, w.lh, nv0));   // live mixer hypernets
     RUN(hyper_forward(c, params_target, w.th, 1));                                // target mixer hypernets
+    if (overlap) REFIL_HIP(hipStreamWaitEvent(c.st, sd->ev[1], 0));               // join: mixing needs the agents' Q
     MixArgs ml = mix_args(c, w.lh, nv0, w.chosen, G, 0, T);
     ml.q_tot = w.q_tot; ml.q_tot_im = w.q_tot_im;
     RUN(mix_forward_launch(ml, c.st));                                            // :134-152
@@ -543,6 +583,10 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
     ml.dx_v = w.dx3h + (long)(nv0 + 2) * s.NA * M;
     ml.dqs = w.dchosen;
     RUN(mix_backward_launch(ml, c.st));
+    if (overlap) {                                                                 // fork: agent backward chain
+        REFIL_HIP(hipEventRecord(sd->ev[2], c.st));
+        REFIL_HIP(hipStreamWaitEvent(sd->s, sd->ev[2], 0));
+    }
     // hypernet tails: fc2 (flex_qmix.py:49)
     for (int part = 0; part < 2; ++part) {
         const long rows = part == 0 ? nv0 * s.NA : s.NA;
@@ -580,31 +624,31 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
         QSelBwdArgs q;
         q.dchosen = w.dchosen; q.actions = c.b.actions; q.ac_sB = c.b.ac_sB; q.ac_sT = c.b.ac_sT; q.amask = w.amask;
         q.dq = w.dqva; q.G = G; q.B = d.B; q.T1 = d.T1; q.na = d.na; q.A = d.A;
-        RUN(qselect_bwd_launch(q, c.st));
+        RUN(qselect_bwd_launch(q, ca.st));
         const long rows = (long)G * s.NA;
-        refil_gemm_desc gw = linear_dw(w.dqva, d.A, w.la.hsx, H, grads + L.ag_fc3_w, H, grads + L.ag_fc3_b, rows, d.A, H, w.partial, 1);
+        refil_gemm_desc gw = linear_dw(w.dqva, d.A, w.la.hsx, H, grads + L.ag_fc3_w, H, grads + L.ag_fc3_b, rows, d.A, H, ca.w.partial, 1);
         gw.b_map = hs_rows(c, d.na);
-        RUN(gemm_launch(gw, c.st));
-        RUN(gemm_launch(linear_dx(w.dqva, d.A, params_live + L.ag_fc3_w, H, w.dhs, H, rows, d.A, H, 0), c.st));
+        RUN(gemm_launch(gw, ca.st));
+        RUN(gemm_launch(linear_dx(w.dqva, d.A, params_live + L.ag_fc3_w, H, w.dhs, H, rows, d.A, H, 0), ca.st));
         // BPTT
         refil_gru_desc g;
         memset(&g, 0, sizeof(g));
         g.hsx = w.la.hsx; g.w_hh = params_live + L.ag_w_hh; g.b_hh = params_live + L.ag_b_hh;
         g.save_r = w.la.sr; g.save_z = w.la.sz; g.save_n = w.la.sn; g.save_ghn = w.la.sg;
         g.dhs = w.dhs; g.dgi = w.dgi; g.dgh = w.dgh; g.NR = G * d.B * d.na; g.T1 = d.T1; g.na = d.na; g.H = H;
-        RUN(gru_backward_launch(g, c.st));
-        refil_gemm_desc ghh = linear_dw(w.dgh, 3 * H, w.la.hsx, H, grads + L.ag_w_hh, H, grads + L.ag_b_hh, rows, 3 * H, H, w.partial, 1);
+        RUN(gru_backward_launch(g, ca.st));
+        refil_gemm_desc ghh = linear_dw(w.dgh, 3 * H, w.la.hsx, H, grads + L.ag_w_hh, H, grads + L.ag_b_hh, rows, 3 * H, H, ca.w.partial, 1);
         ghh.b_map = hs_rows(c, 0);
-        RUN(gemm_launch(ghh, c.st));
-        RUN(gemm_launch(linear_dw(w.dgi, 3 * H, w.la.x3, H, grads + L.ag_w_ih, H, grads + L.ag_b_ih, rows, 3 * H, H, w.partial, 1), c.st));
+        RUN(gemm_launch(ghh, ca.st));
+        RUN(gemm_launch(linear_dw(w.dgi, 3 * H, w.la.x3, H, grads + L.ag_w_ih, H, grads + L.ag_b_ih, rows, 3 * H, H, ca.w.partial, 1), ca.st));
         refil_gemm_desc gx3 = linear_dx(w.dgi, 3 * H, params_live + L.ag_w_ih, H, w.dx3a, H, rows, 3 * H, H, REFIL_GEMM_RELU_BWD);
         gx3.aux = w.la.x3;
-        RUN(gemm_launch(gx3, c.st));
+        RUN(gemm_launch(gx3, ca.st));
         // fc2
-        RUN(gemm_launch(linear_dw(w.dx3a, H, w.la.x2, dd, grads + L.ag_fc2_w, dd, grads + L.ag_fc2_b, rows, H, dd, w.partial, 1), c.st));
+        RUN(gemm_launch(linear_dw(w.dx3a, H, w.la.x2, dd, grads + L.ag_fc2_w, dd, grads + L.ag_fc2_b, rows, H, dd, ca.w.partial, 1), ca.st));
         refil_gemm_desc gx2 = linear_dx(w.dx3a, H, params_live + L.ag_fc2_w, dd, w.dx2a, dd, rows, H, dd, 0);
         gx2.rowmask = w.amask; gx2.rowmask_mod = (int)s.NA;
-        RUN(gemm_launch(gx2, c.st));
+        RUN(gemm_launch(gx2, ca.st));
         AttnBlockBwd k;
         k.w = dd; k.nets = 1; k.nv0 = G; k.P = params_live; k.Gr = grads;
         k.in_w = L.ag_in_w; k.in_w_stride = 0; k.out_w = L.ag_out_w; k.out_w_stride = 0; k.out_b = L.ag_out_b; k.out_b_stride = 0;
@@ -612,8 +656,12 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
         k.dao = w.daoa; k.dq = w.dqa; k.dkv = w.dkva; k.dx1 = w.dx1a;
         k.var_first[0] = REFIL_MASK_OBS; k.var_first[1] = REFIL_MASK_OBS_WITHIN; k.var_first[2] = REFIL_MASK_OBS_INTERACT;
         k.var_rest = REFIL_MASK_OBS;
-        RUN(attn_block_backward(c, k));
-        RUN(gemm_launch(linear_dw(w.dx1a, dd, w.xe, s.Ep, grads + L.ag_fc1_w, s.E, grads + L.ag_fc1_b, s.NE, dd, s.E, w.partial, 1), c.st));
+        RUN(attn_block_backward(ca, k));
+        RUN(gemm_launch(linear_dw(w.dx1a, dd, w.xe, s.Ep, grads + L.ag_fc1_w, s.E, grads + L.ag_fc1_b, s.NE, dd, s.E, ca.w.partial, 1), ca.st));
+    }
+    if (overlap) {                                                                 // join
+        REFIL_HIP(hipEventRecord(sd->ev[3], sd->s));
+        REFIL_HIP(hipStreamWaitEvent(c.st, sd->ev[3], 0));
     }
     return 0;
 }

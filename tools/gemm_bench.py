@@ -11,7 +11,7 @@ import hip_ops
 from refil_amd._lib import GEMM_A_OUTC, GEMM_B_OUTC, GEMM_RELU
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-ABL = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+ABL = 0
 dev = "cuda"
 NE, NA = 82944, 41472
 
