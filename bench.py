@@ -194,6 +194,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
+    host_enqueue = time.perf_counter() - t0          # host time to enqueue K steps (no sync inside)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -242,7 +243,7 @@ def main():
         out = {
             "metric": "learner transitions/sec (B x T per full QLearner.train step)", "value": round(value, 1),
             "unit": "transitions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "host_enqueue_ms_per_step": round(host_enqueue / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic replay (B={B}/GPU, T={T}, n_entities={dims['ne']}, n_agents={dims['na']}, "
                                    f"d={dims['d']}, hypernet={dims['h']}), refil learner (imagine agent + flex_qmix), "

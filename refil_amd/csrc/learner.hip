@@ -587,38 +587,7 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
         REFIL_HIP(hipEventRecord(sd->ev[2], c.st));
         REFIL_HIP(hipStreamWaitEvent(sd->s, sd->ev[2], 0));
     }
-    // hypernet tails: fc2 (flex_qmix.py:49)
-    for (int part = 0; part < 2; ++part) {
-        const long rows = part == 0 ? nv0 * s.NA : s.NA;
-        const int batch = part == 0 ? 1 : 3;
-        const long voff = part == 0 ? 0 : nv0;
-        const int net0 = part == 0 ? 0 : 1;
-        refil_gemm_desc gw = linear_dw(w.dx3h + voff * s.NA * M, M, w.lh.x2 + voff * s.NA * h, h,
-                                       grads + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h,
-                                       grads + L.mix_fc2_b + net0 * L.mix_fc2_b_stride, rows, M, h, w.partial, batch);
-        gw.sA = s.NA * M; gw.sB = s.NA * h; gw.sC = L.mix_fc2_w_stride; gw.sColsum = L.mix_fc2_b_stride;
-        RUN(gemm_launch(gw, c.st));
-        refil_gemm_desc gx = linear_dx(w.dx3h + voff * s.NA * M, M, params_live + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h,
-                                       w.dx2h + voff * s.NA * h, h, rows, M, h, 0);
-        gx.batch = batch; gx.sA = s.NA * M; gx.sB = L.mix_fc2_w_stride; gx.sC = s.NA * h;
-        gx.rowmask = w.amask; gx.rowmask_mod = (int)s.NA;
-        RUN(gemm_launch(gx, c.st));
-    }
-    {
-        AttnBlockBwd k;
-        k.w = h; k.nets = 4; k.nv0 = nv0; k.P = params_live; k.Gr = grads;
-        k.in_w = L.mix_in_w; k.in_w_stride = L.mix_in_w_stride; k.out_w = L.mix_out_w; k.out_w_stride = L.mix_out_w_stride;
-        k.out_b = L.mix_out_b; k.out_b_stride = L.mix_out_b_stride;
-        k.x1 = w.lh.x1; k.kv = w.lh.kv; k.q = w.lh.q; k.ao = w.lh.ao; k.dx2 = w.dx2h;
-        k.dao = w.daoh; k.dq = w.dqh; k.dkv = w.dkvh; k.dx1 = w.dx1h;
-        k.var_first[0] = REFIL_MASK_ENTITY; k.var_first[1] = REFIL_MASK_WITHIN; k.var_first[2] = REFIL_MASK_INTERACT;
-        k.var_rest = REFIL_MASK_ENTITY;
-        RUN(attn_block_backward(c, k));
-        // the four hypernet fc1 layers: dW = dx1^T xe (one [4h,E] GEMM), db = colsum(dx1)
-        refil_gemm_desc g = linear_dw(w.dx1h, 4 * h, w.xe, s.Ep, grads + L.mix_fc1_w, s.E, grads + L.mix_fc1_b, s.NE, 4 * h, s.E,
-                                      w.partial, 1);
-        RUN(gemm_launch(g, c.st));
-    }
+    // (the agent chain is enqueued first: it is the latency-bound one and runs on the side stream)
     // agent: chosen-Q gather + inactive-agent fill, then fc3
     {
         QSelBwdArgs q;
@@ -658,6 +627,38 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
         k.var_rest = REFIL_MASK_OBS;
         RUN(attn_block_backward(ca, k));
         RUN(gemm_launch(linear_dw(w.dx1a, dd, w.xe, s.Ep, grads + L.ag_fc1_w, s.E, grads + L.ag_fc1_b, s.NE, dd, s.E, ca.w.partial, 1), ca.st));
+    }
+    // hypernet tails: fc2 (flex_qmix.py:49)
+    for (int part = 0; part < 2; ++part) {
+        const long rows = part == 0 ? nv0 * s.NA : s.NA;
+        const int batch = part == 0 ? 1 : 3;
+        const long voff = part == 0 ? 0 : nv0;
+        const int net0 = part == 0 ? 0 : 1;
+        refil_gemm_desc gw = linear_dw(w.dx3h + voff * s.NA * M, M, w.lh.x2 + voff * s.NA * h, h,
+                                       grads + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h,
+                                       grads + L.mix_fc2_b + net0 * L.mix_fc2_b_stride, rows, M, h, w.partial, batch);
+        gw.sA = s.NA * M; gw.sB = s.NA * h; gw.sC = L.mix_fc2_w_stride; gw.sColsum = L.mix_fc2_b_stride;
+        RUN(gemm_launch(gw, c.st));
+        refil_gemm_desc gx = linear_dx(w.dx3h + voff * s.NA * M, M, params_live + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h,
+                                       w.dx2h + voff * s.NA * h, h, rows, M, h, 0);
+        gx.batch = batch; gx.sA = s.NA * M; gx.sB = L.mix_fc2_w_stride; gx.sC = s.NA * h;
+        gx.rowmask = w.amask; gx.rowmask_mod = (int)s.NA;
+        RUN(gemm_launch(gx, c.st));
+    }
+    {
+        AttnBlockBwd k;
+        k.w = h; k.nets = 4; k.nv0 = nv0; k.P = params_live; k.Gr = grads;
+        k.in_w = L.mix_in_w; k.in_w_stride = L.mix_in_w_stride; k.out_w = L.mix_out_w; k.out_w_stride = L.mix_out_w_stride;
+        k.out_b = L.mix_out_b; k.out_b_stride = L.mix_out_b_stride;
+        k.x1 = w.lh.x1; k.kv = w.lh.kv; k.q = w.lh.q; k.ao = w.lh.ao; k.dx2 = w.dx2h;
+        k.dao = w.daoh; k.dq = w.dqh; k.dkv = w.dkvh; k.dx1 = w.dx1h;
+        k.var_first[0] = REFIL_MASK_ENTITY; k.var_first[1] = REFIL_MASK_WITHIN; k.var_first[2] = REFIL_MASK_INTERACT;
+        k.var_rest = REFIL_MASK_ENTITY;
+        RUN(attn_block_backward(c, k));
+        // the four hypernet fc1 layers: dW = dx1^T xe (one [4h,E] GEMM), db = colsum(dx1)
+        refil_gemm_desc g = linear_dw(w.dx1h, 4 * h, w.xe, s.Ep, grads + L.mix_fc1_w, s.E, grads + L.mix_fc1_b, s.NE, 4 * h, s.E,
+                                      w.partial, 1);
+        RUN(gemm_launch(g, c.st));
     }
     if (overlap) {                                                                 // join
         REFIL_HIP(hipEventRecord(sd->ev[3], sd->s));
