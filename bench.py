@@ -222,9 +222,18 @@ def main():
                     "tflops": round(e["flops"] / (e["total_ms"] * 1e-3) / 1e12, 2) if e["flops"] > 0 else None}
                    for e in ents[:8]]
         dom = ents[0]
+        traffic = None          # HBM bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 runs)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            key = dom["name"].split("<")[0] if dom["name"].startswith("attn_") else dom["name"]
+            traffic = pmc.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
         ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
         roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes/launch (PMC 2*FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+                    "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                     "launches_per_step": dom["launches"] // nprof,
                     "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
                     "flops_per_launch": dom["flops"] / dom["launches"],
