@@ -50,6 +50,12 @@ typedef struct refil_dims {
     int32_t softmax_mixing_weights;  /* 1: softmax, 0: abs      (flex_qmix.py:102-113)            */
     int32_t mixer_tanh;              /* 0: elu, 1: tanh         (flex_qmix.py:75-77)              */
     int32_t double_q;                /* q_learner.py:121-128                                       */
+    int32_t agent_ff;                /* 1: feed-forward agent fc1->relu(attn)->fc2 (entity_ff_agent.py:29-57),
+                                        0: recurrent agent (entity_rnn_agent.py:31-64)                */
+    int32_t mixer_lin;               /* 1: LinearFlexQMixer (flex_qmix.py:124-172), 0: FlexQMixer       */
+    int32_t gt_factors;              /* 1: imagine groups = ground-truth factors batch.gt_mask
+                                        (entity_ff_agent.py:93-95) instead of the random split       */
+    int32_t gt_obs_mask;             /* 1: batch.gt_mask replaces obs_mask (entity_ff_agent.py:34-35)   */
     float gamma;
     float lmbda;
 } refil_dims;
@@ -89,6 +95,8 @@ typedef struct refil_batch {
     const float*   reward;        int64_t rw_sB, rw_sT;       /* [B,T1,1]       */
     const uint8_t* terminated;    int64_t tm_sB, tm_sT;       /* [B,T1,1]       */
     const int64_t* filled;        int64_t fl_sB, fl_sT;       /* [B,T1,1]       */
+    const uint8_t* gt_mask;       int64_t gt_sB, gt_sT;       /* [B,T1,na,ne] ground-truth factor mask (group_matching env,
+                                                                 src/run.py:187-188); NULL unless gt_factors / gt_obs_mask */
     const uint8_t* group_bits;    /* [B,ne] the random 2-way entity split (entity_rnn_agent.py:94-96);
                                      drawn by the host so that seeds reproduce the reference's masks.
                                      Ignored when dims.imagine == 0. */
@@ -104,7 +112,8 @@ enum {
     REFIL_STAT_QTOT_SUM,       /* sum(q_tot*mask)                    q_learner.py:194               */
     REFIL_STAT_TARGET_SUM,     /* sum(targets*mask)                  q_learner.py:195               */
     REFIL_STAT_GRAD_NORM,      /* written by refil_clip_rmsprop_step q_learner.py:177               */
-    REFIL_STAT_RESERVED,
+    REFIL_STAT_INGROUP_SUM,    /* LinearFlexQMixer only: sum over (b,t) of the in-group mixing weight mass
+                                  sum_{i<na} w1[i] of the imagined mix (flex_qmix.py:166-170, unmasked rows)  */
     REFIL_NSTAT
 };
 
@@ -161,12 +170,13 @@ int refil_agent_forward(const refil_dims* dims, const refil_batch* batch, int32_
                         const float* params, const float* h0, float* h_out, float* q_out,
                         void* workspace, size_t workspace_bytes, void* stream);
 
-/* FlexQMixer.forward (flex_qmix.py:79-121) over steps [t0, t0+T) of the batch.
+/* FlexQMixer.forward (flex_qmix.py:79-121) / LinearFlexQMixer.forward (:136-172, dims.mixer_lin) over steps
+ * [t0, t0+T) of the batch. ingroup_sum (device float, may be NULL): LinearFlexQMixer's ret_ingroup_prop numerator.
  *   agent_qs [B,T,na]; agent_qs_imagine [B,T,2*na] or NULL; q_tot / q_tot_imagine [B,T]. */
 size_t refil_mixer_workspace_bytes(const refil_dims* dims);
 int refil_mixer_forward(const refil_dims* dims, const refil_batch* batch, int32_t t0, int32_t T,
                         const float* params, const float* agent_qs, const float* agent_qs_imagine,
-                        float* q_tot, float* q_tot_imagine,
+                        float* q_tot, float* q_tot_imagine, float* ingroup_sum,
                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -214,7 +224,13 @@ enum {
     REFIL_MASK_OBS_INTERACT,   /*  same(i,j) | obs_mask                       entity_rnn_agent.py:117   */
     REFIL_MASK_ENTITY,         /* inactive_i(t) | inactive_j(t)               flex_qmix.py:43-46        */
     REFIL_MASK_WITHIN,         /* !same(i,j)                                  entity_rnn_agent.py:111   */
-    REFIL_MASK_INTERACT        /*  same(i,j) | inactive0_i | inactive0_j      entity_rnn_agent.py:112   */
+    REFIL_MASK_INTERACT,       /*  same(i,j) | inactive0_i | inactive0_j      entity_rnn_agent.py:112   */
+    /* ground-truth factor variants (entity_ff_agent.py:93-95,117-121): gt = gt_mask[b,t,i,j]            */
+    REFIL_MASK_OBS_GTW,        /*  gt | obs_mask                                                        */
+    REFIL_MASK_OBS_GTI,        /* !gt | obs_mask                                                        */
+    REFIL_MASK_GTW,            /*  gt | inactive0_i | inactive0_j                                       */
+    REFIL_MASK_GTI,            /* !gt | inactive0_i | inactive0_j                                       */
+    REFIL_MASK_COUNT
 };
 
 /* Multi-head masked attention core of EntityAttentionLayer (attention.py:48-64) for `nvar` mask
@@ -233,6 +249,7 @@ typedef struct refil_attn_desc {
     const uint8_t* ent_mask;                          /* contiguous [R,ne]                         */
     const uint8_t* ent_mask0;                         /* [B,ne] entity_mask at t=0                 */
     const uint8_t* group_bits;                        /* [B,ne]                                    */
+    const uint8_t* gt_mask;  int64_t gt_sB, gt_sT;    /* [B,T1,na,ne], for the *_GT* variants      */
 } refil_attn_desc;
 
 int refil_attn_forward(const refil_attn_desc* desc, void* stream);

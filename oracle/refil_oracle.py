@@ -52,6 +52,9 @@ class Cfg:
     softmax_mixing_weights: bool = True
     mixer_non_lin: str = "elu"
     imagine: bool = True           # 'imagine' in args.agent  (q_learner.py:86)
+    agent_ff: bool = False         # entity_attend_ff agents (entity_ff_agent.py) instead of the recurrent ones
+    mixer_lin: bool = False        # lin_flex_qmix (flex_qmix.py:124-172) instead of flex_qmix
+    gt_obs_mask: bool = False      # entity_ff_agent.py:34-35
     double_q: bool = True
     gamma: float = 0.99
     lmbda: float = 0.5
@@ -67,6 +70,7 @@ class Cfg:
 
 
 HYPERNETS = ("hyper_w_1", "hyper_w_final", "hyper_b_1", "V")  # flex_qmix.py:69-73
+LIN_HYPERNETS = ("hyper_w_1", "V")                           # flex_qmix.py:133-134
 
 
 # --------------------------------------------------------------------------------------
@@ -75,6 +79,10 @@ HYPERNETS = ("hyper_w_1", "hyper_w_final", "hyper_b_1", "V")  # flex_qmix.py:69-
 def agent_param_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
     """state_dict layout of EntityAttentionRNNAgent (entity_rnn_agent.py:8-25)."""
     d, H, A, E = cfg.attn_embed_dim, cfg.rnn_hidden_dim, cfg.n_actions, cfg.in_dim
+    if cfg.agent_ff:                                  # EntityAttentionFFAgent (entity_ff_agent.py:8-23)
+        return {"fc1.weight": (d, E), "fc1.bias": (d,), "attn.in_trans.weight": (3 * d, d),
+                "attn.out_trans.weight": (d, d), "attn.out_trans.bias": (d,),
+                "fc2.weight": (A, d), "fc2.bias": (A,)}
     return {
         "fc1.weight": (d, E), "fc1.bias": (d,),
         "attn.in_trans.weight": (3 * d, d),
@@ -90,7 +98,7 @@ def mixer_param_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
     """state_dict layout of FlexQMixer (flex_qmix.py:28-38,69-73)."""
     h, M, E = cfg.hypernet_embed, cfg.mixing_embed_dim, cfg.in_dim
     out = {}
-    for net in HYPERNETS:
+    for net in (LIN_HYPERNETS if cfg.mixer_lin else HYPERNETS):
         out[f"{net}.fc1.weight"] = (h, E)
         out[f"{net}.fc1.bias"] = (h,)
         out[f"{net}.attn.in_trans.weight"] = (3 * h, h)
@@ -154,6 +162,24 @@ def imagine_masks(group_bits: Tensor, entity_mask0: Tensor) -> Tuple[Tensor, Ten
     return ~same, same | ~act_pair
 
 
+def group_masks(cfg: "Cfg", entity_mask: Tensor, group_bits: Optional[Tensor] = None,
+                gt_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    """(within, interact, active) bool [B,Tg,na,ne] for the query rows (agents):
+    random split (Tg = 1; entity_rnn_agent.py:97-108 == entity_ff_agent.py:98-109): within = not same,
+    interact = same; ground-truth factors (Tg = T1; entity_ff_agent.py:93-95): within = gt_mask,
+    interact = not gt_mask. active[i,j] = inactive0_i | inactive0_j (":91 activeattnmask")."""
+    na = cfg.n_agents
+    inact = entity_mask[:, 0].bool()
+    active = (inact[:, :na, None] | inact[:, None, :])[:, None]
+    if gt_mask is not None:
+        W = gt_mask.bool()
+        return W, ~W, active
+    Wm, _ = imagine_masks(group_bits, entity_mask[:, 0])
+    W = Wm[:, None, :na, :]
+    # NOTE: for the random split the reference's "interact" (before OR-ing active) is exactly `same`
+    return W, ~W, active
+
+
 # --------------------------------------------------------------------------------------
 # EntityAttentionLayer (attention.py:24-79) with several pre-masks sharing Q/K/V
 # --------------------------------------------------------------------------------------
@@ -196,33 +222,36 @@ def gru_cell(x: Tensor, h: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih: Tensor, b_h
 
 
 def agent_forward(cfg: Cfg, p: Dict[str, Tensor], xe: Tensor, obs_mask: Tensor, entity_mask: Tensor,
-                  h0: Optional[Tensor] = None, group_bits: Optional[Tensor] = None):
-    """Returns (q [G,B,T1,na,A], hs [G,B,T1,na,H], groups) where G = 3 with group_bits (imagine) else 1.
+                  h0: Optional[Tensor] = None, group_bits: Optional[Tensor] = None,
+                  gt_mask: Optional[Tensor] = None, use_gt_factors: bool = False):
+    """Returns (q [G,B,T1,na,A], hs, groups) where G = 3 when imagining (group_bits or use_gt_factors) else 1.
 
-    Copy 0 = real obs mask, copy 1 = within-group, copy 2 = between-group (entity_rnn_agent.py:116-124).
-    ``groups`` = (Wmask_noobs, Imask_noobs) bool [B,ne,ne] or None.
-    """
+    Copy 0 = real obs mask, copy 1 = within-group, copy 2 = between-group (entity_rnn_agent.py:116-124,
+    entity_ff_agent.py:122-129). ``groups`` = (Wmask_noobs, Imask_noobs) bool [B,Tg,na,ne] or None.
+    Recurrent agent: fc1 -> attn -> relu(fc2) -> GRU -> fc3; feed-forward agent (cfg.agent_ff,
+    entity_ff_agent.py:29-57): fc1 -> relu(attn) -> fc2."""
     B, T1, ne, E = xe.shape
     na, H = cfg.n_agents, cfg.rnn_hidden_dim
     R = B * T1
-    om = obs_mask.bool()[:, :, :na, :]                       # attention.py:44 slices to the queries
+    om = (gt_mask if cfg.gt_obs_mask else obs_mask).bool()[:, :, :na, :]      # attention.py:44 slices to the queries
     pre = [om]
     groups = None
-    if group_bits is not None:
-        Wm, Im = imagine_masks(group_bits, entity_mask[:, 0])
-        groups = (Wm, Im)
-        # entity_rnn_agent.py:116-117 use the masks *before* OR-ing "activeattnmask":
-        #   within = not same | obs ;  interact = same | obs
-        same = ~Wm
-        pre.append(Wm[:, None, :na, :] | om)
-        pre.append(same[:, None, :na, :] | om)
+    if group_bits is not None or use_gt_factors:
+        W, I, active = group_masks(cfg, entity_mask, group_bits, gt_mask if use_gt_factors else None)
+        groups = (W | active, I | active)
+        pre.append(W | om)
+        pre.append(I | om)
     agent_mask = entity_mask.bool()[:, :, :na]
     x1 = torch.relu(xe.reshape(R, ne, E) @ p["fc1.weight"].t() + p["fc1.bias"])           # :38
     x2s = attention_variants(x1, p["attn.in_trans.weight"], p["attn.out_trans.weight"],
                              p["attn.out_trans.bias"], cfg.attn_n_heads,
-                             [m.reshape(R, na, ne) for m in pre], agent_mask.reshape(R, na))
+                             [m.expand(B, T1, na, ne).reshape(R, na, ne) for m in pre], agent_mask.reshape(R, na))
     G = len(x2s)
     x2 = torch.stack(x2s, 0)                                                               # [G,R,na,d]
+    if cfg.agent_ff:
+        hs = torch.relu(x2).reshape(G, B, T1, na, -1)                                      # entity_ff_agent.py:44
+        q = hs @ p["fc2.weight"].t() + p["fc2.bias"]                                       # :49
+        return q.masked_fill(agent_mask[None, :, :, :, None], 0.0), hs, groups            # :52
     x3 = torch.relu(x2 @ p["fc2.weight"].t() + p["fc2.bias"]).reshape(G, B, T1, na, H)     # :46-47
     h = torch.zeros(G * B * na, H) if h0 is None else h0.reshape(G * B * na, H)
     hs = []
@@ -250,7 +279,7 @@ def hypernet_x3(cfg: Cfg, p: Dict[str, Tensor], net: str, xe: Tensor, entity_mas
     if attn_masks is None:
         pre = [am[:, :, None] | em[:, None, :]]                      # flex_qmix.py:43-46
     else:
-        pre = [m[:, :na, :] for m in attn_masks]
+        pre = [m[:, :na, :] for m in attn_masks]   # [R,na,ne] (or [R,ne,ne]: only the query rows are used)
     x1 = torch.relu(xe @ p[f"{net}.fc1.weight"].t() + p[f"{net}.fc1.bias"])
     x2s = attention_variants(x1, p[f"{net}.attn.in_trans.weight"], p[f"{net}.attn.out_trans.weight"],
                              p[f"{net}.attn.out_trans.bias"], cfg.attn_n_heads, pre, am)
@@ -271,34 +300,47 @@ def _non_lin(cfg: Cfg, x: Tensor) -> Tensor:
 
 def mixer_forward(cfg: Cfg, p: Dict[str, Tensor], agent_qs: Tensor, xe: Tensor, entity_mask: Tensor,
                   agent_qs_imagine: Optional[Tensor] = None,
-                  groups: Optional[Tuple[Tensor, Tensor]] = None):
-    """FlexQMixer.forward for the real call and (optionally) the imagined call, sharing b1/w_final/V.
+                  groups: Optional[Tuple[Tensor, Tensor]] = None, ret_ingroup_prop: bool = False):
+    """FlexQMixer.forward / LinearFlexQMixer.forward for the real call and (optionally) the imagined call.
 
     agent_qs [B,T,na]; xe [B,T,ne,E]; entity_mask [B,T,ne]; agent_qs_imagine [B,T,2na] = cat(caqW, caqI)
-    (q_learner.py:96); groups = (Wmask, Imask) bool [B,ne,ne] (time-constant, entity_rnn_agent.py:126).
-    Returns q_tot [B,T,1] (and q_tot_imagine)."""
+    (q_learner.py:96); groups = (Wmask, Imask) bool [B,Tg,na,ne], Tg in {1,T}.
+    Returns q_tot [B,T,1] (and q_tot_imagine (and ingroup_prop))."""
     B, T, ne, E = xe.shape
     na, M = cfg.n_agents, cfg.mixing_embed_dim
     R = B * T
     xr = xe.reshape(R, ne, E)
     em = entity_mask.reshape(R, ne).bool()
+    v = hypernet_x3(cfg, p, "V", xr, em)[0].mean(dim=(1, 2))                               # mode 'scalar' :55-56
+    em_d = (em[:, :na, None] | em[:, None, :])
+    masks = None
+    if agent_qs_imagine is not None:
+        masks = [em_d] + [m.expand(B, T, na, ne).reshape(R, na, ne) for m in groups]
+    w1s = hypernet_x3(cfg, p, "hyper_w_1", xr, em, masks)
+
+    if cfg.mixer_lin:                                                                      # flex_qmix.py:136-172
+        def lin(qs, w1):                      # w1: alt_vector mode = mean over the embedding dim (:53-54)
+            w = _mix_w(cfg, w1)
+            return ((qs * w).sum(dim=1) + v).reshape(B, T, 1), w
+        q_tot, _ = lin(agent_qs.reshape(R, na), w1s[0].mean(dim=2))
+        if agent_qs_imagine is None:
+            return q_tot
+        q_im, w = lin(agent_qs_imagine.reshape(R, 2 * na), torch.cat([w1s[1].mean(dim=2), w1s[2].mean(dim=2)], dim=1))
+        if ret_ingroup_prop:
+            return q_tot, q_im, w[:, :na].sum(dim=1).mean()                               # :166-170
+        return q_tot, q_im
+
     b1 = hypernet_x3(cfg, p, "hyper_b_1", xr, em)[0].mean(dim=1).reshape(R, 1, M)          # mode 'vector' :51-52
     w_final = _mix_w(cfg, hypernet_x3(cfg, p, "hyper_w_final", xr, em)[0].mean(dim=1)).reshape(R, M, 1)
-    v = hypernet_x3(cfg, p, "V", xr, em)[0].mean(dim=(1, 2)).reshape(R, 1, 1)              # mode 'scalar' :55-56
 
     def mix(qs, w1):
         hidden = _non_lin(cfg, torch.bmm(qs, _mix_w(cfg, w1)) + b1)                        # :107
-        return (torch.bmm(hidden, w_final) + v).reshape(B, T, 1)                           # :118-120
+        return (torch.bmm(hidden, w_final) + v.reshape(R, 1, 1)).reshape(B, T, 1)         # :118-120
 
+    q_tot = mix(agent_qs.reshape(R, 1, na), w1s[0])
     if agent_qs_imagine is None:
-        w1 = hypernet_x3(cfg, p, "hyper_w_1", xr, em)[0]
-        return mix(agent_qs.reshape(R, 1, na), w1)
-    Wm, Im = groups
-    masks = [m[:, None].expand(B, T, ne, ne).reshape(R, ne, ne) for m in (Wm, Im)]
-    em_d = em[:, :na, None] | em[:, None, :]
-    w1_real, w1_W, w1_I = hypernet_x3(cfg, p, "hyper_w_1", xr, em, [em_d.expand(R, na, ne)] + masks)
-    q_tot = mix(agent_qs.reshape(R, 1, na), w1_real)
-    q_tot_im = mix(agent_qs_imagine.reshape(R, 1, 2 * na), torch.cat([w1_W, w1_I], dim=1))  # :85-94
+        return q_tot
+    q_tot_im = mix(agent_qs_imagine.reshape(R, 1, 2 * na), torch.cat([w1s[1], w1s[2]], dim=1))  # :85-94
     return q_tot, q_tot_im
 
 
@@ -333,12 +375,13 @@ def learner_forward(cfg: Cfg, agent_p, mixer_p, tgt_agent_p, tgt_mixer_p, batch:
     xe = build_entity_inputs(cfg, batch["entities"], batch["actions"])
     out = StepOut()
 
+    gt = batch.get("gt_mask")
     q, _, groups = agent_forward(cfg, agent_p, xe, batch["obs_mask"], batch["entity_mask"],
-                                 group_bits=group_bits if cfg.imagine else None)
+                                 group_bits=group_bits if cfg.imagine else None, gt_mask=gt)
     G = q.shape[0]
     chosen = torch.gather(q[:, :, :-1], 4, actions[None].expand(G, -1, -1, -1, -1)).squeeze(4)   # :91,109
     with torch.no_grad():
-        tq, _, _ = agent_forward(cfg, tgt_agent_p, xe, batch["obs_mask"], batch["entity_mask"])
+        tq, _, _ = agent_forward(cfg, tgt_agent_p, xe, batch["obs_mask"], batch["entity_mask"], gt_mask=gt)
         tq = tq[0, :, 1:].clone()
         tq[avail[:, 1:] == 0] = NEG_UNAVAIL                                             # :118
         if cfg.double_q:
@@ -351,6 +394,7 @@ def learner_forward(cfg: Cfg, agent_p, mixer_p, tgt_agent_p, tgt_mixer_p, batch:
         tq_tot = mixer_forward(cfg, tgt_mixer_p, tmax, xe[:, 1:], batch["entity_mask"][:, 1:])   # :154
     if cfg.imagine:
         caq_im = torch.cat([chosen[1], chosen[2]], dim=2)                              # :96
+        groups = tuple(g if g.shape[1] == 1 else g[:, :-1] for g in groups)            # :137 "don't need last timestep"
         q_tot, q_tot_im = mixer_forward(cfg, mixer_p, chosen[0], xe[:, :-1], batch["entity_mask"][:, :-1],
                                         caq_im, groups)
     else:

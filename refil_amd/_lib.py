@@ -13,16 +13,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librefil_hip.so")
 
 REFIL_NSTAT = 8
-STAT_MASK_SUM, STAT_TD_SQ, STAT_IM_TD_SQ, STAT_TD_ABS, STAT_QTOT_SUM, STAT_TARGET_SUM, STAT_GRAD_NORM = range(7)
+STAT_MASK_SUM, STAT_TD_SQ, STAT_IM_TD_SQ, STAT_TD_ABS, STAT_QTOT_SUM, STAT_TARGET_SUM, STAT_GRAD_NORM, STAT_INGROUP_SUM = range(8)
 
 GEMM_RELU, GEMM_RELU_BWD, GEMM_ACCUM, GEMM_A_OUTC, GEMM_B_OUTC, GEMM_COLSUM_A = 1, 2, 4, 8, 16, 32
 MASK_OBS, MASK_OBS_WITHIN, MASK_OBS_INTERACT, MASK_ENTITY, MASK_WITHIN, MASK_INTERACT = range(6)
+MASK_OBS_GTW, MASK_OBS_GTI, MASK_GTW, MASK_GTI = 6, 7, 8, 9
 
 
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "B", "T1", "ne", "na", "ed", "A", "d", "heads", "H", "hyp", "M", "entity_last_action", "imagine",
-        "softmax_mixing_weights", "mixer_tanh", "double_q")] + [("gamma", C.c_float), ("lmbda", C.c_float)]
+        "softmax_mixing_weights", "mixer_tanh", "double_q", "agent_ff", "mixer_lin", "gt_factors", "gt_obs_mask")] + [("gamma", C.c_float), ("lmbda", C.c_float)]
 
 
 class ParamLayout(C.Structure):
@@ -45,6 +46,7 @@ class Batch(C.Structure):
         ("reward", C.c_void_p), ("rw_sB", C.c_int64), ("rw_sT", C.c_int64),
         ("terminated", C.c_void_p), ("tm_sB", C.c_int64), ("tm_sT", C.c_int64),
         ("filled", C.c_void_p), ("fl_sB", C.c_int64), ("fl_sT", C.c_int64),
+        ("gt_mask", C.c_void_p), ("gt_sB", C.c_int64), ("gt_sT", C.c_int64),
         ("group_bits", C.c_void_p),
     ]
 
@@ -80,6 +82,7 @@ class AttnDesc(C.Structure):
         ("nvar", C.c_int32), ("var", C.c_int32 * 3),
         ("obs_mask", C.c_void_p), ("om_sB", C.c_int64), ("om_sT", C.c_int64),
         ("ent_mask", C.c_void_p), ("ent_mask0", C.c_void_p), ("group_bits", C.c_void_p),
+        ("gt_mask", C.c_void_p), ("gt_sB", C.c_int64), ("gt_sT", C.c_int64),
     ]
 
 
@@ -136,7 +139,7 @@ def lib():
         C.c_void_p, C.c_size_t, C.c_void_p]
     L.refil_mixer_forward.argtypes = [
         C.POINTER(Dims), C.POINTER(Batch), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-        C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.refil_gemm.argtypes = [C.POINTER(GemmDesc), C.c_void_p]
     L.refil_attn_forward.argtypes = [C.POINTER(AttnDesc), C.c_void_p]
     L.refil_attn_backward.argtypes = [C.POINTER(AttnDesc), C.c_void_p]
@@ -194,7 +197,7 @@ def make_batch(fields: dict, group_bits=None) -> Batch:
     """fields: name -> tensor [B,T1,...] (any batch/time strides, inner dims contiguous)."""
     b = Batch()
     names = {"entities": "ent", "obs_mask": "om", "entity_mask": "em", "actions": "ac", "avail_actions": "av",
-             "reward": "rw", "terminated": "tm", "filled": "fl"}
+             "reward": "rw", "terminated": "tm", "filled": "fl", "gt_mask": "gt"}
     for name, short in names.items():
         t = fields.get(name)
         if t is None:

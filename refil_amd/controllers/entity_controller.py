@@ -8,7 +8,6 @@ class EntityMAC(BasicMAC):
         """The reference materialises entities || one-hot(previous action) here with zeros/cat
         (entity_controller.py:13-27). The HIP library builds that tensor itself, so only the raw
         slices travel: entities[:, t], the actions whose one-hots are appended, the masks."""
-        assert not getattr(self.args, "gt_mask_avail", False), "ground-truth factor masks are out of scope (SURVEY.md 8f4)"
         ents = batch["entities"][:, t]
         actions = None
         first_step_zero = True
@@ -18,7 +17,8 @@ class EntityMAC(BasicMAC):
             else:
                 actions = batch["actions"][:, slice(t.start - 1, t.stop - 1)]
                 first_step_zero = False
-        return EntityInputs(ents, actions, batch["obs_mask"][:, t], batch["entity_mask"][:, t], first_step_zero)
+        gt = batch["gt_mask"][:, t] if getattr(self.args, "gt_mask_avail", False) else None     # entity_controller.py:28-29
+        return EntityInputs(ents, actions, batch["obs_mask"][:, t], batch["entity_mask"][:, t], first_step_zero, gt)
 
     def _get_input_shape(self, scheme):
         shape = scheme["entities"]["vshape"]

@@ -35,12 +35,13 @@ struct AttnK {
     int R, T1, ne, na, heads, hd, nvar; int var[3];
     const uint8_t* obs_mask; long om_sB, om_sT;
     const uint8_t* ent_mask; const uint8_t* ent_mask0; const uint8_t* group_bits;
+    const uint8_t* gt_mask; long gt_sB, gt_sT;
     int nep;  // pow2 >= ne
 };
 
 struct AttnSmem {
     float *Qs, *Ks, *Vs, *S, *P, *dS, *dOs, *dQs, *dKs, *dVs;
-    uint8_t *emt, *em0, *gb, *om;
+    uint8_t *emt, *em0, *gb, *om, *gt;
 };
 
 __host__ __device__ inline int attn_pitch(int hd) { return hd + 4; }
@@ -49,7 +50,7 @@ __host__ __device__ inline size_t attn_smem_bytes(int ne, int na, int hd, bool b
     const int pd = attn_pitch(hd), ps = ne + 1;
     size_t f = (size_t)(na + 2 * ne) * pd + 2 * (size_t)na * ps;
     if (bwd) f += (size_t)na * ps + (size_t)na * pd + (size_t)(na + 2 * ne) * pd;
-    size_t bytes = f * 4 + 3 * (size_t)ne + (size_t)na * ne;
+    size_t bytes = f * 4 + 3 * (size_t)ne + 2 * (size_t)na * ne;
     return (bytes + 15) & ~(size_t)15;
 }
 
@@ -74,7 +75,8 @@ __device__ inline AttnSmem carve(float* base, int ne, int na, int hd, bool bwd) 
     s.emt = b; b += ne;
     s.em0 = b; b += ne;
     s.gb = b; b += ne;
-    s.om = b;
+    s.om = b; b += na * ne;
+    s.gt = b;
     return s;
 }
 
@@ -88,7 +90,11 @@ __device__ inline bool premask(int code, const AttnSmem& s, int ne, int i, int j
         case REFIL_MASK_OBS_INTERACT: return same || s.om[i * ne + j];
         case REFIL_MASK_ENTITY: return s.emt[i] | s.emt[j];
         case REFIL_MASK_WITHIN: return !same;
-        default: return same || in0;  // REFIL_MASK_INTERACT
+        case REFIL_MASK_INTERACT: return same || in0;
+        case REFIL_MASK_OBS_GTW: return s.gt[i * ne + j] || s.om[i * ne + j];
+        case REFIL_MASK_OBS_GTI: return !s.gt[i * ne + j] || s.om[i * ne + j];
+        case REFIL_MASK_GTW: return s.gt[i * ne + j] || in0;
+        default: return !s.gt[i * ne + j] || in0;  // REFIL_MASK_GTI
     }
 }
 
@@ -126,6 +132,10 @@ __device__ inline void load_common(const AttnK& p, const AttnSmem& s, int r, int
         const uint8_t* om = p.obs_mask + b * p.om_sB + t * p.om_sT;
         for (int idx = tid; idx < p.na * p.ne; idx += ANT) s.om[idx] = om[idx];
     }
+    if (p.gt_mask) {
+        const uint8_t* gt = p.gt_mask + b * p.gt_sB + t * p.gt_sT;
+        for (int idx = tid; idx < p.na * p.ne; idx += ANT) s.gt[idx] = gt[idx];
+    }
 }
 
 __device__ inline void compute_logits(const AttnK& p, const AttnSmem& s, int tid) {
@@ -139,7 +149,8 @@ __device__ inline void compute_logits(const AttnK& p, const AttnSmem& s, int tid
 
 __device__ inline bool uses_obs(const AttnK& p) {
     bool u = false;
-    for (int v = 0; v < p.nvar; ++v) u |= (p.var[v] <= REFIL_MASK_OBS_INTERACT);
+    for (int v = 0; v < p.nvar; ++v)
+        u |= (p.var[v] <= REFIL_MASK_OBS_INTERACT) || p.var[v] == REFIL_MASK_OBS_GTW || p.var[v] == REFIL_MASK_OBS_GTI;
     return u;
 }
 
@@ -274,13 +285,18 @@ static int fill(const refil_attn_desc& d, AttnK& k, bool bwd) {
     REFIL_CHECK(d.nvar >= 1 && d.nvar <= 3, "refil_attn: nvar must be 1..3");
     REFIL_CHECK(d.ldq % 4 == 0 && d.ldkv % 4 == 0 && d.ldo % 4 == 0, "refil_attn: leading dims must be multiples of 4");
     REFIL_CHECK(d.R > 0 && d.T1 > 0 && d.heads > 0, "refil_attn: bad R/T1/heads");
-    bool need_obs = false, need_grp = false, need_emt = false;
+    bool need_obs = false, need_grp = false, need_emt = false, need_gt = false, need_e0 = false;
     for (int v = 0; v < d.nvar; ++v) {
-        REFIL_CHECK(d.var[v] >= 0 && d.var[v] <= REFIL_MASK_INTERACT, "refil_attn: bad mask code %d", d.var[v]);
-        need_obs |= d.var[v] <= REFIL_MASK_OBS_INTERACT;
-        need_grp |= d.var[v] != REFIL_MASK_OBS && d.var[v] != REFIL_MASK_ENTITY;
+        REFIL_CHECK(d.var[v] >= 0 && d.var[v] < REFIL_MASK_COUNT, "refil_attn: bad mask code %d", d.var[v]);
+        const bool gtv = d.var[v] >= REFIL_MASK_OBS_GTW;
+        need_gt |= gtv;
+        need_obs |= d.var[v] <= REFIL_MASK_OBS_INTERACT || d.var[v] == REFIL_MASK_OBS_GTW || d.var[v] == REFIL_MASK_OBS_GTI;
+        need_grp |= !gtv && d.var[v] != REFIL_MASK_OBS && d.var[v] != REFIL_MASK_ENTITY;
+        need_e0 |= d.var[v] == REFIL_MASK_GTW || d.var[v] == REFIL_MASK_GTI;
         need_emt |= d.var[v] == REFIL_MASK_ENTITY;
     }
+    REFIL_CHECK(!need_gt || d.gt_mask, "refil_attn: gt_mask required by a ground-truth-factor mask variant");
+    REFIL_CHECK(!need_e0 || d.ent_mask0, "refil_attn: ent_mask0 required by a mask variant");
     REFIL_CHECK(!need_obs || d.obs_mask, "refil_attn: obs_mask required by a mask variant");
     REFIL_CHECK(!need_grp || (d.ent_mask0 && d.group_bits), "refil_attn: ent_mask0/group_bits required by a mask variant");
     REFIL_CHECK(!need_emt || d.ent_mask, "refil_attn: ent_mask required by a mask variant");
@@ -292,6 +308,7 @@ static int fill(const refil_attn_desc& d, AttnK& k, bool bwd) {
     for (int v = 0; v < 3; ++v) k.var[v] = d.var[v];
     k.obs_mask = d.obs_mask; k.om_sB = d.om_sB; k.om_sT = d.om_sT;
     k.ent_mask = d.ent_mask; k.ent_mask0 = d.ent_mask0; k.group_bits = d.group_bits;
+    k.gt_mask = d.gt_mask; k.gt_sB = d.gt_sB; k.gt_sT = d.gt_sT;
     int nep = 1;
     while (nep < d.ne) nep <<= 1;
     k.nep = nep;

@@ -29,10 +29,11 @@ struct AttnM {
     int R, T1, ne, na, heads, hd, nvar; int var[3];
     const uint8_t* obs_mask; long om_sB, om_sT;
     const uint8_t* ent_mask; const uint8_t* ent_mask0; const uint8_t* group_bits;
+    const uint8_t* gt_mask; long gt_sB, gt_sT;
     int wave_floats;   // LDS floats per wave region
 };
 
-struct MaskLds { const uint8_t *emt, *em0, *gb, *om; };
+struct MaskLds { const uint8_t *emt, *em0, *gb, *om, *gt; };
 
 __device__ inline bool premask_m(int code, const MaskLds& s, int ne, int i, int j) {
     const bool in0 = s.em0[i] | s.em0[j];
@@ -43,7 +44,11 @@ __device__ inline bool premask_m(int code, const MaskLds& s, int ne, int i, int 
         case REFIL_MASK_OBS_INTERACT: return same || s.om[i * ne + j];
         case REFIL_MASK_ENTITY: return s.emt[i] | s.emt[j];
         case REFIL_MASK_WITHIN: return !same;
-        default: return same || in0;
+        case REFIL_MASK_INTERACT: return same || in0;
+        case REFIL_MASK_OBS_GTW: return s.gt[i * ne + j] || s.om[i * ne + j];
+        case REFIL_MASK_OBS_GTI: return !s.gt[i * ne + j] || s.om[i * ne + j];
+        case REFIL_MASK_GTW: return s.gt[i * ne + j] || in0;
+        default: return !s.gt[i * ne + j] || in0;
     }
 }
 
@@ -153,6 +158,7 @@ __device__ inline void softmax_N(f32x4 (&sn)[NJT], int code, const MaskLds& m, i
 
 __device__ inline void load_masks(const AttnM& p, uint8_t* base, MaskLds& m, int r, int tid, int nthreads, bool need_obs) {
     uint8_t* emt = base; uint8_t* em0 = base + p.ne; uint8_t* gb = base + 2 * p.ne; uint8_t* om = base + 3 * p.ne;
+    uint8_t* gt = om + p.na * p.ne;
     const int b = r / p.T1, t = r % p.T1;
     for (int j = tid; j < p.ne; j += nthreads) {
         emt[j] = p.ent_mask ? p.ent_mask[(long)r * p.ne + j] : 0;
@@ -163,12 +169,17 @@ __device__ inline void load_masks(const AttnM& p, uint8_t* base, MaskLds& m, int
         const uint8_t* src = p.obs_mask + b * p.om_sB + t * p.om_sT;
         for (int idx = tid; idx < p.na * p.ne; idx += nthreads) om[idx] = src[idx];
     }
-    m.emt = emt; m.em0 = em0; m.gb = gb; m.om = om;
+    if (p.gt_mask) {
+        const uint8_t* src = p.gt_mask + b * p.gt_sB + t * p.gt_sT;
+        for (int idx = tid; idx < p.na * p.ne; idx += nthreads) gt[idx] = src[idx];
+    }
+    m.emt = emt; m.em0 = em0; m.gb = gb; m.om = om; m.gt = gt;
 }
 
 __device__ inline bool uses_obs_m(const AttnM& p) {
     bool u = false;
-    for (int v = 0; v < p.nvar; ++v) u |= (p.var[v] <= REFIL_MASK_OBS_INTERACT);
+    for (int v = 0; v < p.nvar; ++v)
+        u |= (p.var[v] <= REFIL_MASK_OBS_INTERACT) || p.var[v] == REFIL_MASK_OBS_GTW || p.var[v] == REFIL_MASK_OBS_GTI;
     return u;
 }
 
@@ -362,10 +373,11 @@ int attn_mfma_launch(const refil_attn_desc& d, bool bwd, hipStream_t st) {
     for (int v = 0; v < 3; ++v) k.var[v] = d.var[v];
     k.obs_mask = d.obs_mask; k.om_sB = d.om_sB; k.om_sT = d.om_sT;
     k.ent_mask = d.ent_mask; k.ent_mask0 = d.ent_mask0; k.group_bits = d.group_bits;
+    k.gt_mask = d.gt_mask; k.gt_sB = d.gt_sB; k.gt_sT = d.gt_sT;
     const int pd = d.hd + 2;
     // +16 floats of slack: fragment reads of a partial channel tile (hd < 16*nct) run past the last row
     k.wave_floats = ((nat * 16 + 2 * njt * 16 + (bwd ? 16 : 0)) * pd + 16 + 3) & ~3;
-    const size_t smem = ((size_t)4 * k.wave_floats * 4 + 3 * (size_t)d.ne + (size_t)d.na * d.ne + 15) & ~(size_t)15;
+    const size_t smem = ((size_t)4 * k.wave_floats * 4 + 3 * (size_t)d.ne + 2 * (size_t)d.na * d.ne + 15) & ~(size_t)15;
     if (smem > 160 * 1024) return -1;
     const double unit = (double)d.R * d.heads * d.na * d.ne * d.hd;
     ProfScope prof(bwd ? "attn_bwd_mfma" : "attn_fwd_mfma", unit * (bwd ? 2.0 + 8.0 * d.nvar : 2.0 + 2.0 * d.nvar),

@@ -56,6 +56,8 @@ struct MixArgs {
     float* dqs;                       // [G][B,T,na]
     const uint8_t* amask;             // [R*na]
     int B, T1, T, t_off, na, M, imagine, softmax_w, tanh_nl;
+    int lin;                          // LinearFlexQMixer (flex_qmix.py:136-172): x_wf/x_b1 unused
+    float* ingroup_rows;              // lin + imagine: per-(b,t) in-group weight mass sum_{i<na} w1[i] (or NULL)
 };
 int mix_forward_launch(const MixArgs& a, hipStream_t st);
 int mix_backward_launch(const MixArgs& a, hipStream_t st);
@@ -66,9 +68,12 @@ struct TdArgs {
     const uint8_t* terminated; long tm_sB, tm_sT;
     const int64_t* filled; long fl_sB, fl_sT;
     float* gc_real; float* gc_im; float* targets; float* stats;
+    const float* ingroup_rows;        // optional [B,T] -> stats[REFIL_STAT_INGROUP_SUM]
     int B, T, imagine; float gamma, lmbda;
 };
 int td_loss_launch(const TdArgs& a, hipStream_t st);
+
+int sum_launch(const float* x, long n, float* out, hipStream_t st);   // out[0] = sum(x)
 
 int clip_rmsprop_launch(float* params, const float* grads, float* sq, long n, float lr, float alpha, float eps,
                         float wd, float clip, float* stats, float* scratch, hipStream_t st);

@@ -38,7 +38,8 @@ static int check_dims(const refil_dims& d) {
     REFIL_CHECK(d.ed > 0 && d.A > 0, "refil: entity_shape and n_actions must be > 0");
     REFIL_CHECK(d.heads > 0 && d.d % d.heads == 0 && d.hyp % d.heads == 0, "refil: embed dims must be divisible by attn_n_heads");
     REFIL_CHECK((d.d / d.heads) % 4 == 0 && (d.hyp / d.heads) % 4 == 0, "refil: head dim must be a multiple of 4");
-    REFIL_CHECK(d.H == 64, "refil: rnn_hidden_dim must be 64 (got %d)", d.H);
+    REFIL_CHECK(d.agent_ff || d.H == 64, "refil: rnn_hidden_dim must be 64 (got %d)", d.H);
+    REFIL_CHECK(!d.mixer_lin || 2 * d.na <= 64, "refil: LinearFlexQMixer supports n_agents <= 32");
     REFIL_CHECK(d.M >= 1 && d.M <= 64, "refil: mixing_embed_dim must be in [1,64]");
     return 0;
 }
@@ -55,18 +56,24 @@ static void param_layout(const refil_dims& d, refil_param_layout& L) {
     L.ag_fc1_w = take(dd * E); L.ag_fc1_b = take(dd);
     L.ag_in_w = take(3 * dd * dd);
     L.ag_out_w = take(dd * dd); L.ag_out_b = take(dd);
-    L.ag_fc2_w = take(H * dd); L.ag_fc2_b = take(H);
-    L.ag_w_ih = take(3 * H * H); L.ag_w_hh = take(3 * H * H);
-    L.ag_b_ih = take(3 * H); L.ag_b_hh = take(3 * H);
-    L.ag_fc3_w = take(A * H); L.ag_fc3_b = take(A);
+    if (d.agent_ff) {      // EntityAttentionFFAgent: fc2 maps attn_embed_dim -> n_actions, no GRU / fc3
+        L.ag_fc2_w = take(A * dd); L.ag_fc2_b = take(A);
+        L.ag_w_ih = L.ag_w_hh = L.ag_b_ih = L.ag_b_hh = L.ag_fc3_w = L.ag_fc3_b = o;
+    } else {
+        L.ag_fc2_w = take(H * dd); L.ag_fc2_b = take(H);
+        L.ag_w_ih = take(3 * H * H); L.ag_w_hh = take(3 * H * H);
+        L.ag_b_ih = take(3 * H); L.ag_b_hh = take(3 * H);
+        L.ag_fc3_w = take(A * H); L.ag_fc3_b = take(A);
+    }
     L.agent_total = o;
-    L.mix_fc1_w_stride = h * E; L.mix_fc1_w = take(4 * h * E);
-    L.mix_fc1_b_stride = h; L.mix_fc1_b = take(4 * h);
-    L.mix_in_w_stride = 3 * h * h; L.mix_in_w = take(4 * 3 * h * h);
-    L.mix_out_w_stride = h * h; L.mix_out_w = take(4 * h * h);
-    L.mix_out_b_stride = h; L.mix_out_b = take(4 * h);
-    L.mix_fc2_w_stride = M * h; L.mix_fc2_w = take(4 * M * h);
-    L.mix_fc2_b_stride = M; L.mix_fc2_b = take(4 * M);
+    const long nn = d.mixer_lin ? 2 : 4;       // hypernets: (hyper_w_1, V) or (hyper_w_1, hyper_w_final, hyper_b_1, V)
+    L.mix_fc1_w_stride = h * E; L.mix_fc1_w = take(nn * h * E);
+    L.mix_fc1_b_stride = h; L.mix_fc1_b = take(nn * h);
+    L.mix_in_w_stride = 3 * h * h; L.mix_in_w = take(nn * 3 * h * h);
+    L.mix_out_w_stride = h * h; L.mix_out_w = take(nn * h * h);
+    L.mix_out_b_stride = h; L.mix_out_b = take(nn * h);
+    L.mix_fc2_w_stride = M * h; L.mix_fc2_w = take(nn * M * h);
+    L.mix_fc2_b_stride = M; L.mix_fc2_b = take(nn * M);
     L.total = o;
 }
 
@@ -96,7 +103,7 @@ struct Work {
     float* xe; uint8_t *emc, *amask, *em0;
     AgentBufs la, ta;
     HyperBufs lh, th;
-    float *chosen, *tmax, *q_tot, *q_tot_im, *tq_tot, *gc_real, *gc_im, *targets;
+    float *chosen, *tmax, *q_tot, *q_tot_im, *tq_tot, *gc_real, *gc_im, *targets, *ingroup;
     // backward
     float *dx3h, *dchosen, *dx2h, *daoh, *dqh, *dkvh, *dx1h;
     float *dqva, *dhs, *dgi, *dgh, *dx3a, *dx2a, *daoa, *dqa, *dkva, *dx1a;
@@ -105,12 +112,12 @@ struct Work {
 };
 
 struct Sizes {
-    long R, NE, NA; int G, nv0, NV, E, Ep;
+    long R, NE, NA; int G, nv0, NV, E, Ep, nets;
 };
 static Sizes sizes_of(const refil_dims& d) {
     Sizes s;
     s.R = (long)d.B * d.T1; s.NE = s.R * d.ne; s.NA = s.R * d.na;
-    s.G = d.imagine ? 3 : 1; s.nv0 = s.G; s.NV = s.nv0 + 3;
+    s.G = d.imagine ? 3 : 1; s.nv0 = s.G; s.nets = d.mixer_lin ? 2 : 4; s.NV = s.nv0 + s.nets - 1;
     s.E = in_dim(d); s.Ep = (int)rup(s.E, 4);
     return s;
 }
@@ -132,9 +139,9 @@ static void carve_agent(Arena& a, const refil_dims& d, const Sizes& s, int G, bo
     b.qv = a.take<float>((long)G * s.NA * d.A);
 }
 static void carve_hyper(Arena& a, const refil_dims& d, const Sizes& s, int NV, HyperBufs& b) {
-    b.x1 = a.take<float>(s.NE * 4 * d.hyp);
-    b.kv = a.take<float>(4 * s.NE * 2 * d.hyp);
-    b.q = a.take<float>(4 * s.NA * d.hyp);
+    b.x1 = a.take<float>(s.NE * s.nets * d.hyp);
+    b.kv = a.take<float>(s.nets * s.NE * 2 * d.hyp);
+    b.q = a.take<float>(s.nets * s.NA * d.hyp);
     b.ao = a.take<float>((long)NV * s.NA * d.hyp);
     b.x2 = a.take<float>((long)NV * s.NA * d.hyp);
     b.x3 = a.take<float>((long)NV * s.NA * d.M);
@@ -151,23 +158,24 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     if (mode == CARVE_AGENT_FWD) { carve_agent(a, d, s, s.G, false, w.la); return; }
     if (mode == CARVE_MIXER_FWD) {
         carve_hyper(a, d, s, s.NV, w.lh);
+        w.ingroup = a.take<float>(BT + d.B);
         return;
     }
     carve_agent(a, d, s, s.G, true, w.la);
     carve_agent(a, d, s, 1, false, w.ta);
     carve_hyper(a, d, s, s.NV, w.lh);
-    carve_hyper(a, d, s, 4, w.th);
+    carve_hyper(a, d, s, s.nets, w.th);
     w.chosen = a.take<float>((long)s.G * BT * d.na);
     w.tmax = a.take<float>(BT * d.na);
     w.q_tot = a.take<float>(BT); w.q_tot_im = a.take<float>(BT); w.tq_tot = a.take<float>(BT);
-    w.gc_real = a.take<float>(BT); w.gc_im = a.take<float>(BT); w.targets = a.take<float>(BT);
+    w.gc_real = a.take<float>(BT); w.gc_im = a.take<float>(BT); w.targets = a.take<float>(BT); w.ingroup = a.take<float>(BT);
     w.dx3h = a.take<float>((long)s.NV * s.NA * d.M);
     w.dchosen = a.take<float>((long)s.G * BT * d.na);
     w.dx2h = a.take<float>((long)s.NV * s.NA * d.hyp);
     w.daoh = a.take<float>((long)s.NV * s.NA * d.hyp);
-    w.dqh = a.take<float>(4 * s.NA * d.hyp);
-    w.dkvh = a.take<float>(4 * s.NE * 2 * d.hyp);
-    w.dx1h = a.take<float>(s.NE * 4 * d.hyp);
+    w.dqh = a.take<float>(s.nets * s.NA * d.hyp);
+    w.dkvh = a.take<float>(s.nets * s.NE * 2 * d.hyp);
+    w.dx1h = a.take<float>(s.NE * s.nets * d.hyp);
     w.dqva = a.take<float>((long)s.G * s.NA * d.A);
     w.dhs = a.take<float>((long)s.G * s.NA * d.H);
     w.dgi = a.take<float>((long)s.G * s.NA * 3 * d.H);
@@ -272,6 +280,8 @@ static refil_attn_desc attn_base(const Ctx& c, int w) {
     memset(&a, 0, sizeof(a));
     a.R = (int)c.s.R; a.T1 = c.d.T1; a.ne = c.d.ne; a.na = c.d.na; a.heads = c.d.heads; a.hd = w / c.d.heads;
     a.obs_mask = c.b.obs_mask; a.om_sB = c.b.om_sB; a.om_sT = c.b.om_sT;
+    if (c.d.gt_obs_mask) { a.obs_mask = c.b.gt_mask; a.om_sB = c.b.gt_sB; a.om_sT = c.b.gt_sT; }   // entity_ff_agent.py:34-35
+    a.gt_mask = c.b.gt_mask; a.gt_sB = c.b.gt_sB; a.gt_sT = c.b.gt_sT;
     a.ent_mask = c.w.emc; a.ent_mask0 = c.w.em0; a.group_bits = c.b.group_bits;
     a.ldq = w; a.ldkv = 2 * w; a.ldo = w;
     return a;
@@ -295,8 +305,20 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
     {
         refil_attn_desc a = attn_base(c, dd);
         a.Q = b.q; a.K = b.kv; a.V = b.kv + dd; a.O = b.ao; a.sO = s.NA * dd;
-        a.nvar = G; a.var[0] = REFIL_MASK_OBS; a.var[1] = REFIL_MASK_OBS_WITHIN; a.var[2] = REFIL_MASK_OBS_INTERACT;
+        a.nvar = G; a.var[0] = REFIL_MASK_OBS;
+        a.var[1] = d.gt_factors ? REFIL_MASK_OBS_GTW : REFIL_MASK_OBS_WITHIN;
+        a.var[2] = d.gt_factors ? REFIL_MASK_OBS_GTI : REFIL_MASK_OBS_INTERACT;
         RUN(attn_forward_launch(a, c.st));
+    }
+    if (d.agent_ff) {
+        // feed-forward agent (entity_ff_agent.py:40-52): x2 = relu(out_trans(attn)) (inactive agents zeroed), q = fc2(x2)
+        refil_gemm_desc g = linear(b.ao, dd, P + L.ag_out_w, dd, P + L.ag_out_b, b.x2, dd, (long)G * s.NA, dd, dd, REFIL_GEMM_RELU);
+        g.rowmask = c.w.amask; g.rowmask_mod = (int)s.NA;
+        RUN(gemm_launch(g, c.st));
+        refil_gemm_desc f = linear(b.x2, dd, P + L.ag_fc2_w, dd, P + L.ag_fc2_b, b.qv, d.A, (long)G * s.NA, d.A, dd, 0);
+        f.rowmask = c.w.amask; f.rowmask_mod = (int)s.NA;
+        RUN(gemm_launch(f, c.st));
+        return 0;
     }
     // x2 = out_trans(attn) with inactive agents zeroed                attention.py:65-67
     {
@@ -333,31 +355,33 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
 // ------------------------------------------------------------------------------------------------
 static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int nv0) {
     const refil_dims& d = c.d; const Sizes& s = c.s; const refil_param_layout& L = c.L;
-    const int h = d.hyp, M = d.M;
-    RUN(gemm_launch(linear(c.w.xe, s.Ep, P + L.mix_fc1_w, s.E, P + L.mix_fc1_b, b.x1, 4 * h, s.NE, 4 * h, s.E, REFIL_GEMM_RELU), c.st));
+    const int h = d.hyp, M = d.M, nets = s.nets;
+    RUN(gemm_launch(linear(c.w.xe, s.Ep, P + L.mix_fc1_w, s.E, P + L.mix_fc1_b, b.x1, nets * h, s.NE, nets * h, s.E, REFIL_GEMM_RELU), c.st));
     {
-        refil_gemm_desc g = linear(b.x1, 4 * h, P + L.mix_in_w + (long)h * h, h, nullptr, b.kv, 2 * h, s.NE, 2 * h, h, 0);
-        g.batch = 4; g.sA = h; g.sB = L.mix_in_w_stride; g.sC = s.NE * 2 * h;
+        refil_gemm_desc g = linear(b.x1, nets * h, P + L.mix_in_w + (long)h * h, h, nullptr, b.kv, 2 * h, s.NE, 2 * h, h, 0);
+        g.batch = nets; g.sA = h; g.sB = L.mix_in_w_stride; g.sC = s.NE * 2 * h;
         RUN(gemm_launch(g, c.st));
     }
     {
-        refil_gemm_desc g = linear(b.x1, 4 * h, P + L.mix_in_w, h, nullptr, b.q, h, s.NA, h, h, 0);
+        refil_gemm_desc g = linear(b.x1, nets * h, P + L.mix_in_w, h, nullptr, b.q, h, s.NA, h, h, 0);
         g.a_map = agent_rows(c);
-        g.batch = 4; g.sA = h; g.sB = L.mix_in_w_stride; g.sC = s.NA * h;
+        g.batch = nets; g.sA = h; g.sB = L.mix_in_w_stride; g.sC = s.NA * h;
         RUN(gemm_launch(g, c.st));
     }
-    for (int n = 0; n < 4; ++n) {
+    for (int n = 0; n < nets; ++n) {
         refil_attn_desc a = attn_base(c, h);
         a.Q = b.q + (long)n * s.NA * h; a.K = b.kv + (long)n * s.NE * 2 * h; a.V = a.K + h;
         a.O = b.ao + (long)(n == 0 ? 0 : nv0 + n - 1) * s.NA * h; a.sO = s.NA * h;
         a.nvar = n == 0 ? nv0 : 1;
-        a.var[0] = REFIL_MASK_ENTITY; a.var[1] = REFIL_MASK_WITHIN; a.var[2] = REFIL_MASK_INTERACT;
+        a.var[0] = REFIL_MASK_ENTITY;
+        a.var[1] = d.gt_factors ? REFIL_MASK_GTW : REFIL_MASK_WITHIN;
+        a.var[2] = d.gt_factors ? REFIL_MASK_GTI : REFIL_MASK_INTERACT;
         RUN(attn_forward_launch(a, c.st));
     }
     // out_trans and fc2, both with inactive agents zeroed (attention.py:65-67, flex_qmix.py:49-50)
     for (int part = 0; part < 2; ++part) {
         const long M_rows = part == 0 ? nv0 * s.NA : s.NA;
-        const int batch = part == 0 ? 1 : 3;
+        const int batch = part == 0 ? 1 : nets - 1;
         const long voff = part == 0 ? 0 : nv0;
         const int net0 = part == 0 ? 0 : 1;
         refil_gemm_desc g = linear(b.ao + voff * s.NA * h, h, P + L.mix_out_w + net0 * L.mix_out_w_stride, h,
@@ -379,9 +403,14 @@ static MixArgs mix_args(const Ctx& c, const HyperBufs& b, int nv0, const float* 
     MixArgs m;
     memset(&m, 0, sizeof(m));
     m.x_w1 = b.x3; m.s_var = s.NA * d.M;
-    m.x_wf = b.x3 + (long)(nv0 + 0) * s.NA * d.M;
-    m.x_b1 = b.x3 + (long)(nv0 + 1) * s.NA * d.M;
-    m.x_v = b.x3 + (long)(nv0 + 2) * s.NA * d.M;
+    m.lin = d.mixer_lin;
+    if (d.mixer_lin) {                                  // hypernets (hyper_w_1, V)
+        m.x_v = b.x3 + (long)(nv0 + 0) * s.NA * d.M;
+    } else {                                            // (hyper_w_1, hyper_w_final, hyper_b_1, V)
+        m.x_wf = b.x3 + (long)(nv0 + 0) * s.NA * d.M;
+        m.x_b1 = b.x3 + (long)(nv0 + 1) * s.NA * d.M;
+        m.x_v = b.x3 + (long)(nv0 + 2) * s.NA * d.M;
+    }
     m.qs = qs; m.s_qs_g = (long)d.B * T * d.na;
     m.amask = c.w.amask;
     m.B = d.B; m.T1 = d.T1; m.T = T; m.t_off = t_off; m.na = d.na; m.M = d.M;
@@ -518,7 +547,8 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
     REFIL_CHECK(dims->T1 >= 2, "refil_learner_forward_backward: need at least one transition (T1 >= 2)");
     REFIL_CHECK(batch->obs_mask && batch->actions && batch->avail_actions && batch->reward && batch->terminated && batch->filled,
                 "refil_learner_forward_backward: incomplete batch");
-    REFIL_CHECK(!dims->imagine || batch->group_bits, "refil_learner_forward_backward: group_bits required when imagine=1");
+    REFIL_CHECK(!dims->imagine || batch->group_bits || dims->gt_factors, "refil_learner_forward_backward: group_bits required when imagine=1");
+    REFIL_CHECK(!(dims->gt_factors || dims->gt_obs_mask) || batch->gt_mask, "refil_learner_forward_backward: gt_mask required by gt_factors / gt_obs_mask");
     const refil_dims& d = c.d; const Sizes& s = c.s; const refil_param_layout& L = c.L; Work& w = c.w;
     const int T = d.T1 - 1, G = s.G, nv0 = s.nv0, H = d.H, h = d.hyp, M = d.M, dd = d.d;
     const long BT = (long)d.B * T;
@@ -551,6 +581,7 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
     if (overlap) REFIL_HIP(hipStreamWaitEvent(c.st, sd->ev[1], 0));               // join: mixing needs the agents' Q
     MixArgs ml = mix_args(c, w.lh, nv0, w.chosen, G, 0, T);
     ml.q_tot = w.q_tot; ml.q_tot_im = w.q_tot_im;
+    ml.ingroup_rows = (d.mixer_lin && d.imagine) ? w.ingroup : nullptr;
     RUN(mix_forward_launch(ml, c.st));                                            // :134-152
     MixArgs mt = mix_args(c, w.th, 1, w.tmax, 1, 1, T);
     mt.q_tot = w.tq_tot; mt.q_tot_im = nullptr;
@@ -562,6 +593,7 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
         t.terminated = c.b.terminated; t.tm_sB = c.b.tm_sB; t.tm_sT = c.b.tm_sT;
         t.filled = c.b.filled; t.fl_sB = c.b.fl_sB; t.fl_sT = c.b.fl_sT;
         t.gc_real = w.gc_real; t.gc_im = w.gc_im; t.targets = w.targets; t.stats = stats;
+        t.ingroup_rows = ml.ingroup_rows;
         t.B = d.B; t.T = T; t.imagine = d.imagine; t.gamma = d.gamma; t.lmbda = d.lmbda;
         RUN(td_loss_launch(t, c.st));                                             // :157-172
     }
@@ -578,9 +610,13 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
     // ---------------- backward (q_learner.py:176, hand-scheduled) ----------------
     ml.gc_real = w.gc_real; ml.gc_im = w.gc_im;
     ml.dx_w1 = w.dx3h;
-    ml.dx_wf = w.dx3h + (long)(nv0 + 0) * s.NA * M;
-    ml.dx_b1 = w.dx3h + (long)(nv0 + 1) * s.NA * M;
-    ml.dx_v = w.dx3h + (long)(nv0 + 2) * s.NA * M;
+    if (d.mixer_lin) {
+        ml.dx_v = w.dx3h + (long)(nv0 + 0) * s.NA * M;
+    } else {
+        ml.dx_wf = w.dx3h + (long)(nv0 + 0) * s.NA * M;
+        ml.dx_b1 = w.dx3h + (long)(nv0 + 1) * s.NA * M;
+        ml.dx_v = w.dx3h + (long)(nv0 + 2) * s.NA * M;
+    }
     ml.dqs = w.dchosen;
     RUN(mix_backward_launch(ml, c.st));
     if (overlap) {                                                                 // fork: agent backward chain
@@ -595,35 +631,45 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
         q.dq = w.dqva; q.G = G; q.B = d.B; q.T1 = d.T1; q.na = d.na; q.A = d.A;
         RUN(qselect_bwd_launch(q, ca.st));
         const long rows = (long)G * s.NA;
-        refil_gemm_desc gw = linear_dw(w.dqva, d.A, w.la.hsx, H, grads + L.ag_fc3_w, H, grads + L.ag_fc3_b, rows, d.A, H, ca.w.partial, 1);
-        gw.b_map = hs_rows(c, d.na);
-        RUN(gemm_launch(gw, ca.st));
-        RUN(gemm_launch(linear_dx(w.dqva, d.A, params_live + L.ag_fc3_w, H, w.dhs, H, rows, d.A, H, 0), ca.st));
-        // BPTT
-        refil_gru_desc g;
-        memset(&g, 0, sizeof(g));
-        g.hsx = w.la.hsx; g.w_hh = params_live + L.ag_w_hh; g.b_hh = params_live + L.ag_b_hh;
-        g.save_r = w.la.sr; g.save_z = w.la.sz; g.save_n = w.la.sn; g.save_ghn = w.la.sg;
-        g.dhs = w.dhs; g.dgi = w.dgi; g.dgh = w.dgh; g.NR = G * d.B * d.na; g.T1 = d.T1; g.na = d.na; g.H = H;
-        RUN(gru_backward_launch(g, ca.st));
-        refil_gemm_desc ghh = linear_dw(w.dgh, 3 * H, w.la.hsx, H, grads + L.ag_w_hh, H, grads + L.ag_b_hh, rows, 3 * H, H, ca.w.partial, 1);
-        ghh.b_map = hs_rows(c, 0);
-        RUN(gemm_launch(ghh, ca.st));
-        RUN(gemm_launch(linear_dw(w.dgi, 3 * H, w.la.x3, H, grads + L.ag_w_ih, H, grads + L.ag_b_ih, rows, 3 * H, H, ca.w.partial, 1), ca.st));
-        refil_gemm_desc gx3 = linear_dx(w.dgi, 3 * H, params_live + L.ag_w_ih, H, w.dx3a, H, rows, 3 * H, H, REFIL_GEMM_RELU_BWD);
-        gx3.aux = w.la.x3;
-        RUN(gemm_launch(gx3, ca.st));
-        // fc2
-        RUN(gemm_launch(linear_dw(w.dx3a, H, w.la.x2, dd, grads + L.ag_fc2_w, dd, grads + L.ag_fc2_b, rows, H, dd, ca.w.partial, 1), ca.st));
-        refil_gemm_desc gx2 = linear_dx(w.dx3a, H, params_live + L.ag_fc2_w, dd, w.dx2a, dd, rows, H, dd, 0);
-        gx2.rowmask = w.amask; gx2.rowmask_mod = (int)s.NA;
-        RUN(gemm_launch(gx2, ca.st));
+        if (d.agent_ff) {
+            // feed-forward agent: q = fc2(x2), x2 = relu(masked out_trans)  (entity_ff_agent.py:44-52)
+            RUN(gemm_launch(linear_dw(w.dqva, d.A, w.la.x2, dd, grads + L.ag_fc2_w, dd, grads + L.ag_fc2_b, rows, d.A, dd, ca.w.partial, 1), ca.st));
+            refil_gemm_desc gx2 = linear_dx(w.dqva, d.A, params_live + L.ag_fc2_w, dd, w.dx2a, dd, rows, d.A, dd, REFIL_GEMM_RELU_BWD);
+            gx2.aux = w.la.x2;                 // x2 = 0 on inactive rows, so relu' also applies the row mask
+            RUN(gemm_launch(gx2, ca.st));
+        } else {
+            refil_gemm_desc gw = linear_dw(w.dqva, d.A, w.la.hsx, H, grads + L.ag_fc3_w, H, grads + L.ag_fc3_b, rows, d.A, H, ca.w.partial, 1);
+            gw.b_map = hs_rows(c, d.na);
+            RUN(gemm_launch(gw, ca.st));
+            RUN(gemm_launch(linear_dx(w.dqva, d.A, params_live + L.ag_fc3_w, H, w.dhs, H, rows, d.A, H, 0), ca.st));
+            // BPTT
+            refil_gru_desc g;
+            memset(&g, 0, sizeof(g));
+            g.hsx = w.la.hsx; g.w_hh = params_live + L.ag_w_hh; g.b_hh = params_live + L.ag_b_hh;
+            g.save_r = w.la.sr; g.save_z = w.la.sz; g.save_n = w.la.sn; g.save_ghn = w.la.sg;
+            g.dhs = w.dhs; g.dgi = w.dgi; g.dgh = w.dgh; g.NR = G * d.B * d.na; g.T1 = d.T1; g.na = d.na; g.H = H;
+            RUN(gru_backward_launch(g, ca.st));
+            refil_gemm_desc ghh = linear_dw(w.dgh, 3 * H, w.la.hsx, H, grads + L.ag_w_hh, H, grads + L.ag_b_hh, rows, 3 * H, H, ca.w.partial, 1);
+            ghh.b_map = hs_rows(c, 0);
+            RUN(gemm_launch(ghh, ca.st));
+            RUN(gemm_launch(linear_dw(w.dgi, 3 * H, w.la.x3, H, grads + L.ag_w_ih, H, grads + L.ag_b_ih, rows, 3 * H, H, ca.w.partial, 1), ca.st));
+            refil_gemm_desc gx3 = linear_dx(w.dgi, 3 * H, params_live + L.ag_w_ih, H, w.dx3a, H, rows, 3 * H, H, REFIL_GEMM_RELU_BWD);
+            gx3.aux = w.la.x3;
+            RUN(gemm_launch(gx3, ca.st));
+            // fc2
+            RUN(gemm_launch(linear_dw(w.dx3a, H, w.la.x2, dd, grads + L.ag_fc2_w, dd, grads + L.ag_fc2_b, rows, H, dd, ca.w.partial, 1), ca.st));
+            refil_gemm_desc gx2 = linear_dx(w.dx3a, H, params_live + L.ag_fc2_w, dd, w.dx2a, dd, rows, H, dd, 0);
+            gx2.rowmask = w.amask; gx2.rowmask_mod = (int)s.NA;
+            RUN(gemm_launch(gx2, ca.st));
+        }
         AttnBlockBwd k;
         k.w = dd; k.nets = 1; k.nv0 = G; k.P = params_live; k.Gr = grads;
         k.in_w = L.ag_in_w; k.in_w_stride = 0; k.out_w = L.ag_out_w; k.out_w_stride = 0; k.out_b = L.ag_out_b; k.out_b_stride = 0;
         k.x1 = w.la.x1; k.kv = w.la.kv; k.q = w.la.q; k.ao = w.la.ao; k.dx2 = w.dx2a;
         k.dao = w.daoa; k.dq = w.dqa; k.dkv = w.dkva; k.dx1 = w.dx1a;
-        k.var_first[0] = REFIL_MASK_OBS; k.var_first[1] = REFIL_MASK_OBS_WITHIN; k.var_first[2] = REFIL_MASK_OBS_INTERACT;
+        k.var_first[0] = REFIL_MASK_OBS;
+        k.var_first[1] = d.gt_factors ? REFIL_MASK_OBS_GTW : REFIL_MASK_OBS_WITHIN;
+        k.var_first[2] = d.gt_factors ? REFIL_MASK_OBS_GTI : REFIL_MASK_OBS_INTERACT;
         k.var_rest = REFIL_MASK_OBS;
         RUN(attn_block_backward(ca, k));
         RUN(gemm_launch(linear_dw(w.dx1a, dd, w.xe, s.Ep, grads + L.ag_fc1_w, s.E, grads + L.ag_fc1_b, s.NE, dd, s.E, ca.w.partial, 1), ca.st));
@@ -631,7 +677,7 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
     // hypernet tails: fc2 (flex_qmix.py:49)
     for (int part = 0; part < 2; ++part) {
         const long rows = part == 0 ? nv0 * s.NA : s.NA;
-        const int batch = part == 0 ? 1 : 3;
+        const int batch = part == 0 ? 1 : s.nets - 1;
         const long voff = part == 0 ? 0 : nv0;
         const int net0 = part == 0 ? 0 : 1;
         refil_gemm_desc gw = linear_dw(w.dx3h + voff * s.NA * M, M, w.lh.x2 + voff * s.NA * h, h,
@@ -647,16 +693,18 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
     }
     {
         AttnBlockBwd k;
-        k.w = h; k.nets = 4; k.nv0 = nv0; k.P = params_live; k.Gr = grads;
+        k.w = h; k.nets = s.nets; k.nv0 = nv0; k.P = params_live; k.Gr = grads;
         k.in_w = L.mix_in_w; k.in_w_stride = L.mix_in_w_stride; k.out_w = L.mix_out_w; k.out_w_stride = L.mix_out_w_stride;
         k.out_b = L.mix_out_b; k.out_b_stride = L.mix_out_b_stride;
         k.x1 = w.lh.x1; k.kv = w.lh.kv; k.q = w.lh.q; k.ao = w.lh.ao; k.dx2 = w.dx2h;
         k.dao = w.daoh; k.dq = w.dqh; k.dkv = w.dkvh; k.dx1 = w.dx1h;
-        k.var_first[0] = REFIL_MASK_ENTITY; k.var_first[1] = REFIL_MASK_WITHIN; k.var_first[2] = REFIL_MASK_INTERACT;
+        k.var_first[0] = REFIL_MASK_ENTITY;
+        k.var_first[1] = d.gt_factors ? REFIL_MASK_GTW : REFIL_MASK_WITHIN;
+        k.var_first[2] = d.gt_factors ? REFIL_MASK_GTI : REFIL_MASK_INTERACT;
         k.var_rest = REFIL_MASK_ENTITY;
         RUN(attn_block_backward(c, k));
         // the four hypernet fc1 layers: dW = dx1^T xe (one [4h,E] GEMM), db = colsum(dx1)
-        refil_gemm_desc g = linear_dw(w.dx1h, 4 * h, w.xe, s.Ep, grads + L.mix_fc1_w, s.E, grads + L.mix_fc1_b, s.NE, 4 * h, s.E,
+        refil_gemm_desc g = linear_dw(w.dx1h, s.nets * h, w.xe, s.Ep, grads + L.mix_fc1_w, s.E, grads + L.mix_fc1_b, s.NE, s.nets * h, s.E,
                                       w.partial, 1);
         RUN(gemm_launch(g, c.st));
     }
@@ -674,11 +722,12 @@ extern "C" int refil_agent_forward(const refil_dims* dims, const refil_batch* ba
     if (int e = make_ctx(c, dims, batch, workspace, workspace_bytes_, CARVE_AGENT_FWD, stream)) return e;
     REFIL_CHECK(params && q_out, "refil_agent_forward: null params / q_out");
     REFIL_CHECK(batch->obs_mask, "refil_agent_forward: obs_mask missing");
-    REFIL_CHECK(!dims->imagine || batch->group_bits, "refil_agent_forward: group_bits required when imagine=1");
+    REFIL_CHECK(!dims->imagine || batch->group_bits || dims->gt_factors, "refil_agent_forward: group_bits required when imagine=1");
+    REFIL_CHECK(!(dims->gt_factors || dims->gt_obs_mask) || batch->gt_mask, "refil_agent_forward: gt_mask required by gt_factors / gt_obs_mask");
     RUN(run_prep(c, first_step_zero));
     RUN(agent_forward(c, params, c.w.la, c.s.G, h0));
     RUN(copy_out(q_out, c.w.la.qv, (long)c.s.G * c.s.NA * c.d.A, c.st));
-    if (h_out) RUN(get_hT_launch(c.w.la.hsx, h_out, c.s.G * c.d.B, c.d.T1, c.d.na, c.d.H, c.st));
+    if (h_out && !c.d.agent_ff) RUN(get_hT_launch(c.w.la.hsx, h_out, c.s.G * c.d.B, c.d.T1, c.d.na, c.d.H, c.st));
     return 0;
 }
 
@@ -693,13 +742,16 @@ extern "C" size_t refil_mixer_workspace_bytes(const refil_dims* dims) {
 
 extern "C" int refil_mixer_forward(const refil_dims* dims, const refil_batch* batch, int32_t t0, int32_t T,
                                    const float* params, const float* agent_qs, const float* agent_qs_imagine,
-                                   float* q_tot, float* q_tot_imagine, void* workspace, size_t workspace_bytes_, void* stream) {
+                                   float* q_tot, float* q_tot_imagine, float* ingroup_sum, void* workspace,
+                                   size_t workspace_bytes_, void* stream) {
     Ctx c;
     if (int e = make_ctx(c, dims, batch, workspace, workspace_bytes_, CARVE_MIXER_FWD, stream)) return e;
     REFIL_CHECK(params && agent_qs && q_tot, "refil_mixer_forward: null pointer");
     REFIL_CHECK(t0 >= 0 && T > 0 && t0 + T <= dims->T1, "refil_mixer_forward: step range [%d,%d) outside the batch", t0, t0 + T);
     const bool im = agent_qs_imagine != nullptr;
-    REFIL_CHECK(!im || (batch->group_bits && q_tot_imagine && dims->imagine), "refil_mixer_forward: imagined mix needs imagine=1, group_bits and q_tot_imagine");
+    REFIL_CHECK(!im || ((batch->group_bits || dims->gt_factors) && q_tot_imagine && dims->imagine),
+                "refil_mixer_forward: imagined mix needs imagine=1, group_bits (or gt_factors) and q_tot_imagine");
+    REFIL_CHECK(!dims->gt_factors || batch->gt_mask, "refil_mixer_forward: gt_factors needs batch.gt_mask");
     RUN(run_prep(c, 1));
     const int nv0 = im ? 3 : 1;
     RUN(hyper_forward(c, params, c.w.lh, nv0));
@@ -716,6 +768,9 @@ extern "C" int refil_mixer_forward(const refil_dims* dims, const refil_batch* ba
     }
     MixArgs m = mix_args(c, c.w.lh, nv0, qs, im ? 3 : 1, t0, T);
     m.q_tot = q_tot; m.q_tot_im = q_tot_imagine;
+    const bool want_ing = ingroup_sum && im && dims->mixer_lin;
+    m.ingroup_rows = want_ing ? c.w.ingroup : nullptr;
     RUN(mix_forward_launch(m, c.st));
+    if (want_ing) RUN(sum_launch(c.w.ingroup, (long)dims->B * T, ingroup_sum, c.st));
     return 0;
 }

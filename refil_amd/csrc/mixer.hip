@@ -311,23 +311,120 @@ __global__ __launch_bounds__(64) void mix_bwd_kernel(MixArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LinearFlexQMixer (flex_qmix.py:136-172). One wave per (b,t); lane l owns mixing weight l:
+//   real:     w = softmax_na / abs ( mean_M hyper_w_1[default mask] ),          q_tot = sum_i q_i w_i + v
+//   imagined: w = softmax_2na / abs ( cat(mean_M hyper_w_1[W], mean_M hyper_w_1[I]) ), same with 2na Qs
+//   ingroup  = sum_{i<na} w_imagined[i]                                          (:166-170)
+// ------------------------------------------------------------------------------------------------
+struct LinRow { float a_r, w_r, a_i, w_i, v; };
+
+__device__ inline float lin_weight(float a, bool act, int softmax_w) {
+    if (softmax_w) {
+        const float mx = wave_max(act ? a : -INFINITY);
+        const float e = act ? expf(a - mx) : 0.f;
+        return e / wave_sum(e);
+    }
+    return act ? fabsf(a) : 0.f;
+}
+
+__device__ inline LinRow lin_row_forward(const MixArgs& a, long base, int l) {
+    LinRow o;
+    const int na = a.na;
+    float sr = 0.f, si = 0.f, sv = 0.f;
+    if (l < na) {
+        for (int m = 0; m < a.M; ++m) { sr += a.x_w1[base + (long)l * a.M + m]; sv += a.x_v[base + (long)l * a.M + m]; }
+    }
+    if (a.imagine && l < 2 * na) {
+        const float* x = a.x_w1 + (1 + l / na) * a.s_var + base + (long)(l % na) * a.M;
+        for (int m = 0; m < a.M; ++m) si += x[m];
+    }
+    o.a_r = sr / (float)a.M;                       // mode 'alt_vector': mean over the embedding dim (:53-54)
+    o.a_i = si / (float)a.M;
+    o.w_r = lin_weight(o.a_r, l < na, a.softmax_w);
+    o.w_i = a.imagine ? lin_weight(o.a_i, l < 2 * na, a.softmax_w) : 0.f;
+    o.v = wave_sum(sv) / (float)(na * a.M);
+    return o;
+}
+
+__global__ __launch_bounds__(64) void mix_lin_fwd_kernel(MixArgs a) {
+    const int bt = blockIdx.x, b = bt / a.T, t = bt % a.T, l = threadIdx.x;
+    const long base = ((long)b * a.T1 + t + a.t_off) * a.na * a.M;
+    const long qbase = (long)bt * a.na;
+    const LinRow o = lin_row_forward(a, base, l);
+    const float qr = l < a.na ? a.qs[qbase + l] : 0.f;
+    const float qt = wave_sum(qr * o.w_r) + o.v;
+    if (l == 0) a.q_tot[bt] = qt;
+    if (a.imagine) {
+        const float qi = l < 2 * a.na ? a.qs[(1 + l / a.na) * a.s_qs_g + qbase + l % a.na] : 0.f;
+        const float qti = wave_sum(qi * o.w_i) + o.v;
+        const float ing = wave_sum(l < a.na ? o.w_i : 0.f);
+        if (l == 0) { a.q_tot_im[bt] = qti; if (a.ingroup_rows) a.ingroup_rows[bt] = ing; }
+    }
+}
+
+__global__ __launch_bounds__(64) void mix_lin_bwd_kernel(MixArgs a) {
+    const int r = blockIdx.x, b = r / a.T1, tt = r % a.T1, l = threadIdx.x;
+    const int na = a.na, t = tt - a.t_off;
+    const long base = (long)r * na * a.M;
+    const int nvar = a.imagine ? 3 : 1;
+    const bool in_range = t >= 0 && t < a.T;
+    float da_r = 0.f, da_i = 0.f, dv = 0.f;
+    if (in_range) {
+        const int bt = b * a.T + t;
+        const long qbase = (long)bt * na;
+        const long BTn = (long)a.B * a.T * na;
+        const LinRow o = lin_row_forward(a, base, l);
+        const float g_r = a.gc_real[bt], g_i = a.imagine ? a.gc_im[bt] : 0.f;
+        dv = (g_r + g_i) / (float)(na * a.M);
+        const float qr = l < na ? a.qs[qbase + l] : 0.f;
+        const float dw_r = g_r * qr;
+        if (a.softmax_w) da_r = o.w_r * (dw_r - wave_sum(o.w_r * dw_r));
+        else da_r = sgn(o.a_r) * dw_r;
+        if (l < na) a.dqs[qbase + l] = g_r * o.w_r;
+        if (a.imagine) {
+            const float qi = l < 2 * na ? a.qs[(1 + l / na) * a.s_qs_g + qbase + l % na] : 0.f;
+            const float dw_i = g_i * qi;
+            if (a.softmax_w) da_i = o.w_i * (dw_i - wave_sum(o.w_i * dw_i));
+            else da_i = sgn(o.a_i) * dw_i;
+            if (l < 2 * na) a.dqs[(1 + l / na) * BTn + qbase + l % na] = g_i * o.w_i;
+        }
+    }
+    // mean over M backward: every embedding column gets da / M; inactive agents' rows were zero-filled
+    if (l < na) {
+        const bool dead = a.amask[(long)r * na + l];
+        for (int m = 0; m < a.M; ++m) {
+            a.dx_w1[base + (long)l * a.M + m] = dead ? 0.f : da_r / (float)a.M;
+            a.dx_v[base + (long)l * a.M + m] = dead ? 0.f : dv;
+        }
+    }
+    if (nvar == 3 && l < 2 * na) {
+        const bool dead = a.amask[(long)r * na + l % na];
+        float* dx = a.dx_w1 + (1 + l / na) * a.s_var + base + (long)(l % na) * a.M;
+        for (int m = 0; m < a.M; ++m) dx[m] = dead ? 0.f : da_i / (float)a.M;
+    }
+}
+
 static int mix_check(const MixArgs& a) {
     REFIL_CHECK(a.M >= 1 && a.M <= 64, "refil mix: mixing_embed_dim %d must be in [1,64]", a.M);
-    REFIL_CHECK(a.x_w1 && a.x_wf && a.x_b1 && a.x_v && a.qs, "refil mix: null input");
+    REFIL_CHECK(a.x_w1 && a.x_v && a.qs && (a.lin || (a.x_wf && a.x_b1)), "refil mix: null input");
+    REFIL_CHECK(!a.lin || 2 * a.na <= 64, "refil mix: LinearFlexQMixer supports n_agents <= 32");
     return 0;
 }
 int mix_forward_launch(const MixArgs& a, hipStream_t st) {
     if (int e = mix_check(a)) return e;
     if (a.B * a.T <= 0) return 0;
-    ProfScope prof_mix_fwd_kernel("mix_fwd_kernel", 0.0, 0.0, st);
-    hipLaunchKernelGGL(mix_fwd_kernel, dim3(a.B * a.T), dim3(64), 0, st, a);
+    ProfScope prof_mix_fwd_kernel(a.lin ? "mix_lin_fwd_kernel" : "mix_fwd_kernel", 0.0, 0.0, st);
+    if (a.lin) hipLaunchKernelGGL(mix_lin_fwd_kernel, dim3(a.B * a.T), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(mix_fwd_kernel, dim3(a.B * a.T), dim3(64), 0, st, a);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
 int mix_backward_launch(const MixArgs& a, hipStream_t st) {
     if (int e = mix_check(a)) return e;
-    ProfScope prof_mix_bwd_kernel("mix_bwd_kernel", 0.0, 0.0, st);
-    hipLaunchKernelGGL(mix_bwd_kernel, dim3(a.B * a.T1), dim3(64), 0, st, a);
+    ProfScope prof_mix_bwd_kernel(a.lin ? "mix_lin_bwd_kernel" : "mix_bwd_kernel", 0.0, 0.0, st);
+    if (a.lin) hipLaunchKernelGGL(mix_lin_bwd_kernel, dim3(a.B * a.T1), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(mix_bwd_kernel, dim3(a.B * a.T1), dim3(64), 0, st, a);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
@@ -337,8 +434,8 @@ int mix_backward_launch(const MixArgs& a, hipStream_t st) {
 //   L_sum = (1-lmbda) sum (mask td)^2 + lmbda sum (mask td_im)^2      (1/sum(mask) applied later)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void td_loss_kernel(TdArgs a) {
-    __shared__ float red[6][16];
-    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __shared__ float red[7][16];
+    float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int total = a.B * a.T;
     for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
         const int b = idx / a.T, t = idx % a.T;
@@ -356,10 +453,11 @@ __global__ __launch_bounds__(1024) void td_loss_kernel(TdArgs a) {
             s[2] += tdi * tdi;
         }
         if (a.targets) a.targets[idx] = target;
+        if (a.ingroup_rows) s[6] += a.ingroup_rows[idx];
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 7; ++k) {
         const float v = wave_sum(s[k]);
         if (lane == 0) red[k][wave] = v;
     }
@@ -369,12 +467,31 @@ __global__ __launch_bounds__(1024) void td_loss_kernel(TdArgs a) {
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += red[threadIdx.x][w];
         a.stats[threadIdx.x] = v;
     }
-    if (threadIdx.x == 6) a.stats[REFIL_STAT_GRAD_NORM] = 0.f;
-    if (threadIdx.x == 7) a.stats[REFIL_STAT_RESERVED] = 0.f;
+    if (threadIdx.x == 6) {
+        float v = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += red[6][w];
+        a.stats[REFIL_STAT_INGROUP_SUM] = v;
+    }
+    if (threadIdx.x == 7) a.stats[REFIL_STAT_GRAD_NORM] = 0.f;
 }
 int td_loss_launch(const TdArgs& a, hipStream_t st) {
     ProfScope prof_td_loss_kernel("td_loss_kernel", 0.0, 0.0, st);
     hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(1024), 0, st, a);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void sum_kernel(const float* x, long n, float* out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+int sum_launch(const float* x, long n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, x, n, out);
     REFIL_LAUNCH_CHECK();
     return 0;
 }

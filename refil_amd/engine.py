@@ -21,6 +21,8 @@ def dims_from_args(args, B: int, T1: int) -> Dims:
         M=args.mixing_embed_dim, entity_last_action=int(bool(args.entity_last_action)),
         imagine=int("imagine" in args.agent), softmax_mixing_weights=int(bool(args.softmax_mixing_weights)),
         mixer_tanh=int(getattr(args, "mixer_non_lin", "elu") == "tanh"), double_q=int(bool(args.double_q)),
+        agent_ff=int(args.agent.endswith("_ff")), mixer_lin=int(getattr(args, "mixer", None) == "lin_flex_qmix"),
+        gt_factors=0, gt_obs_mask=int(bool(getattr(args, "gt_obs_mask", False))),
         gamma=float(args.gamma), lmbda=float(getattr(args, "lmbda", 0.0)))
 
 
@@ -109,13 +111,18 @@ class LearnerEngine:
 
     # -- flex_qmix.py:79-121 -------------------------------------------------------------------
     def mixer_forward(self, dims: Dims, fields: Dict[str, torch.Tensor], group_bits, params: torch.Tensor,
-                      agent_qs: torch.Tensor, agent_qs_imagine: Optional[torch.Tensor], t0: int, T: int):
+                      agent_qs: torch.Tensor, agent_qs_imagine: Optional[torch.Tensor], t0: int, T: int,
+                      params_ptr: Optional[int] = None, want_ingroup: bool = False):
         nbytes = lib().refil_mixer_workspace_bytes(C.byref(dims))
         wp, wsz = self.ws.ptr_size(nbytes)
         b = _lib.make_batch(fields, group_bits)
         q_tot = torch.empty(dims.B, T, dtype=torch.float32, device=self.device)
         q_im = torch.empty(dims.B, T, dtype=torch.float32, device=self.device) if agent_qs_imagine is not None else None
-        check(lib().refil_mixer_forward(C.byref(dims), C.byref(b), C.c_int32(t0), C.c_int32(T), _lib.ptr(params),
+        ing = torch.zeros(1, dtype=torch.float32, device=self.device) if want_ingroup else None
+        pp = C.c_void_p(params_ptr) if params_ptr is not None else _lib.ptr(params)
+        check(lib().refil_mixer_forward(C.byref(dims), C.byref(b), C.c_int32(t0), C.c_int32(T), pp,
                                         _lib.ptr(agent_qs), _lib.ptr(agent_qs_imagine), _lib.ptr(q_tot), _lib.ptr(q_im),
-                                        wp, wsz, _lib.current_stream_ptr()), "refil_mixer_forward")
+                                        _lib.ptr(ing), wp, wsz, _lib.current_stream_ptr()), "refil_mixer_forward")
+        if want_ingroup:
+            return q_tot, q_im, ing
         return q_tot, q_im

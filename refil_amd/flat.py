@@ -41,6 +41,10 @@ _MIXER = [
 ]
 
 
+LIN_HYPERNETS = ("hyper_w_1", "V")                              # LinearFlexQMixer (flex_qmix.py:133-134)
+_AGENT_FF = _AGENT[:5] + [("fc2.weight", "ag_fc2_w", lambda c: (c["A"], c["d"])), ("fc2.bias", "ag_fc2_b", lambda c: (c["A"],))]
+
+
 def _consts(dims: _lib.Dims) -> Dict[str, int]:
     E = dims.ed + (dims.A if dims.entity_last_action else 0)
     return {"d": dims.d, "E": E, "H": dims.H, "A": dims.A, "h": dims.hyp, "M": dims.M}
@@ -52,14 +56,14 @@ def views(flat: torch.Tensor, dims: _lib.Dims) -> Tuple[Dict[str, torch.Tensor],
     c = _consts(dims)
     assert flat.numel() >= L.total and flat.is_contiguous()
     agent, mixer = {}, {}
-    for key, fld, shp in _AGENT:
+    for key, fld, shp in (_AGENT_FF if dims.agent_ff else _AGENT):
         s = shp(c)
         n = 1
         for x in s:
             n *= x
         o = getattr(L, fld)
         agent[key] = flat[o:o + n].view(*s)
-    for ni, net in enumerate(HYPERNETS):
+    for ni, net in enumerate(LIN_HYPERNETS if dims.mixer_lin else HYPERNETS):
         for key, fld, shp in _MIXER:
             s = shp(c)
             n = 1

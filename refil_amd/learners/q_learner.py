@@ -9,7 +9,7 @@ import copy
 import torch as th
 from .. import _lib, dp
 from ..engine import LearnerEngine, dims_from_args
-from ..modules.mixers.flex_qmix import FlexQMixer
+from ..modules.mixers.flex_qmix import FlexQMixer, LinearFlexQMixer
 
 
 class QLearner:
@@ -23,7 +23,10 @@ class QLearner:
             if args.mixer == "flex_qmix":
                 assert args.entity_scheme, "FlexQMixer only available with entity scheme"
                 self.mixer = FlexQMixer(args)
-            elif args.mixer in ("vdn", "qmix", "lin_flex_qmix"):
+            elif args.mixer == "lin_flex_qmix":
+                assert args.entity_scheme, "FlexQMixer only available with entity scheme"
+                self.mixer = LinearFlexQMixer(args)
+            elif args.mixer in ("vdn", "qmix"):
                 raise NotImplementedError(f"mixer {args.mixer} is outside the REFIL hot path built so far (SURVEY.md 8f4)")
             else:
                 raise ValueError("Mixer {} not recognised.".format(args.mixer))
@@ -90,6 +93,8 @@ class QLearner:
 
     def _fields(self, batch):
         names = ["entities", "obs_mask", "entity_mask", "actions", "avail_actions", "reward", "terminated", "filled"]
+        if getattr(self.args, "gt_mask_avail", False):
+            names.append("gt_mask")
         out = {}
         for k in names:
             v = batch[k]
@@ -104,8 +109,15 @@ class QLearner:
         args = self.args
         B, T1 = batch.batch_size, batch.max_seq_length
         dims = dims_from_args(args, B, T1)
+        if getattr(args, "train_rand_gt_factors", False):
+            raise NotImplementedError("train_rand_gt_factors is not built (entity_ff_agent.py:111-114)")
+        dims.gt_factors = int(bool(getattr(args, "train_gt_factors", False)))       # q_learner.py:88
         fields = self._fields(batch)
         dev = self.flat_live.device
+        will_log = t_env - self.log_stats_t >= args.learner_log_interval
+        gt_ingroup = None
+        if will_log and dims.imagine and getattr(args, "test_gt_factors", False):
+            gt_ingroup = self._gt_ingroup_prop(dims, fields, B, T1)                     # with the pre-update weights
         bits = None
         if dims.imagine:
             bits = group_bits.to(dev).to(th.uint8).contiguous() if group_bits is not None else \
@@ -132,11 +144,31 @@ class QLearner:
                 self.logger.log_stat("im_loss", im_loss, t_env)
             else:
                 self.logger.log_stat("loss", q_loss, t_env)
+            if getattr(args, "test_gt_factors", False) and dims.imagine:                # q_learner.py:188-190
+                self.logger.log_stat("ingroup_prop", st[_lib.STAT_INGROUP_SUM] / (B * (T1 - 1)), t_env)
+                self.logger.log_stat("gt_ingroup_prop", float(gt_ingroup), t_env)
             self.logger.log_stat("grad_norm", st[_lib.STAT_GRAD_NORM], t_env)
             self.logger.log_stat("td_error_abs", st[_lib.STAT_TD_ABS] / msum, t_env)
             self.logger.log_stat("q_taken_mean", st[_lib.STAT_QTOT_SUM] / (msum * args.n_agents), t_env)    # :194 quirk kept
             self.logger.log_stat("target_mean", st[_lib.STAT_TARGET_SUM] / (msum * args.n_agents), t_env)
             self.log_stats_t = t_env
+
+    def _gt_ingroup_prop(self, dims, fields, B, T1):
+        """Log-step-only diagnostic of refil_group_matching (q_learner.py:98-105,143-147): imagine with the
+        ground-truth factors and report the in-group mixing-weight mass of LinearFlexQMixer."""
+        from ..engine import clone_dims
+        if not dims.mixer_lin:
+            raise TypeError("test_gt_factors needs lin_flex_qmix (FlexQMixer.forward has no ret_ingroup_prop, flex_qmix.py:79)")
+        T = T1 - 1
+        dg = clone_dims(dims, gt_factors=1)
+        q, _ = self._engine.agent_forward(dg, fields, None, self.flat_live, None, first_step_zero=True)
+        acts = fields["actions"][:, :-1].long()
+        chosen = th.gather(q[:, :, :-1], 4, acts[None].expand(3, -1, -1, -1, -1)).squeeze(4)      # glue: [3,B,T,na]
+        caq_im = th.cat([chosen[1], chosen[2]], dim=2).contiguous()
+        mfields = {k: v[:, :-1] for k, v in fields.items()}
+        _, _, ing = self._engine.mixer_forward(clone_dims(dg, T1=T), mfields, None, self.flat_live, chosen[0].contiguous(),
+                                               caq_im, 0, T, want_ingroup=True)
+        return ing[0] / (B * T)
 
     def _update_targets(self):
         self._check_flat()

@@ -15,7 +15,19 @@ from ..flat_module import FlatParamModule
 
 # What EntityMAC._build_inputs hands to the agent. Raw batch fields instead of the materialised
 # entities||last-action tensor: the library builds that tensor itself (once, for MAC and mixer).
-EntityInputs = namedtuple("EntityInputs", ["entities", "actions", "obs_mask", "entity_mask", "first_step_zero"])
+EntityInputs = namedtuple("EntityInputs", ["entities", "actions", "obs_mask", "entity_mask", "first_step_zero", "gt_mask"],
+                          defaults=(None,))
+
+
+class ImagineGroups(tuple):
+    """(Wmask_noobs, Imask_noobs) like the reference returns (entity_rnn_agent.py:126, entity_ff_agent.py:135),
+    plus what the HIP mixers actually consume: the [bs,ne] partition bits or the ground-truth factor mask
+    (the kernels re-derive the masks in registers)."""
+
+    def __new__(cls, W, I, bits=None, gt_mask=None):
+        obj = super().__new__(cls, (W, I))
+        obj.bits, obj.gt_mask = bits, gt_mask
+        return obj
 
 
 class _InTrans(nn.Module):
@@ -79,10 +91,11 @@ class EntityAttentionRNNAgent(FlatParamModule):
             object.__setattr__(self, "_engine", LearnerEngine(self.fc1.weight.device))
         return self._engine
 
-    def _run(self, inputs, hidden_state, imagine, group_bits=None):
+    def _run(self, inputs, hidden_state, imagine, group_bits=None, use_gt_factors=False):
         na, H = self.args.n_agents, self.args.rnn_hidden_dim
+        gt_mask = None
         if isinstance(inputs, EntityInputs):
-            ents, obs_mask, entity_mask = inputs.entities, inputs.obs_mask, inputs.entity_mask
+            ents, obs_mask, entity_mask, gt_mask = inputs.entities, inputs.obs_mask, inputs.entity_mask, inputs.gt_mask
             fields = {"entities": ents, "obs_mask": obs_mask, "entity_mask": entity_mask}
             last_action = bool(self.args.entity_last_action)
             if last_action:
@@ -91,10 +104,15 @@ class EntityAttentionRNNAgent(FlatParamModule):
             fsz = inputs.first_step_zero
         else:   # the reference's tuple form: entities already carry the last-action one-hots
             ents, obs_mask, entity_mask = inputs[:3]
+            gt_mask = inputs[3] if len(inputs) > 3 else None
             fields = {"entities": ents, "obs_mask": obs_mask, "entity_mask": entity_mask}
             dims = self._dims(ents.shape[0], ents.shape[1], ed=ents.shape[3], last_action=False)
             fsz = True
         dims.imagine = int(imagine)
+        dims.gt_factors = int(bool(use_gt_factors))
+        if dims.gt_factors or dims.gt_obs_mask:
+            assert gt_mask is not None, "gt_mask needed (env must provide it: gt_mask_avail)"
+            fields["gt_mask"] = gt_mask
         bs, ts = ents.shape[0], ents.shape[1]
         G = 3 if imagine else 1
         fields = {k: (v if v[0, 0].is_contiguous() else v.contiguous()) for k, v in fields.items()}
@@ -104,7 +122,7 @@ class EntityAttentionRNNAgent(FlatParamModule):
             if imagine and h0.shape[0] == bs:
                 h0 = h0.repeat(3, 1, 1)                                   # entity_rnn_agent.py:124
             h0 = h0.reshape(G, bs, na, H).contiguous().float()
-        if imagine and group_bits is None:
+        if imagine and group_bits is None and not use_gt_factors:
             # the reference's two RNG calls (entity_rnn_agent.py:94-96), on the CPU generator so that a
             # seed reproduces the same partition as the reference's CPU run
             p = th.rand(bs, 1, 1).repeat(1, 1, self.args.n_entities)
@@ -136,4 +154,4 @@ class ImagineEntityAttentionRNNAgent(EntityAttentionRNNAgent):
         same = act_pair & (g[:, :, None] == g[:, None, :])
         Wm = (~same).to(th.uint8)[:, None].repeat(1, ts, 1, 1)              # :111,126
         Im = (same | ~act_pair).to(th.uint8)[:, None].repeat(1, ts, 1, 1)   # :112,126
-        return q.reshape(G * bs, ts, na, A), h.reshape(G * bs, 1, na, -1), (Wm, Im)
+        return q.reshape(G * bs, ts, na, A), h.reshape(G * bs, 1, na, -1), ImagineGroups(Wm, Im, bits=gb)

@@ -43,6 +43,9 @@ class FlexQMixer(FlatParamModule):
     def _dims(self, B=1, T1=2):
         return dims_from_args(self.args, B, T1)
 
+    def _nets(self):
+        return HYPERNETS
+
     def _layout(self):
         return _lib.param_layout(self._dims())
 
@@ -53,7 +56,7 @@ class FlexQMixer(FlatParamModule):
         E = a.entity_shape + (a.n_actions if a.entity_last_action else 0)
         base = L.agent_total
         out = []
-        for n, net in enumerate(HYPERNETS):
+        for n, net in enumerate(self._nets()):
             out += [(f"{net}.fc1.weight", L.mix_fc1_w + n * L.mix_fc1_w_stride - base, (h, E)),
                     (f"{net}.fc1.bias", L.mix_fc1_b + n * L.mix_fc1_b_stride - base, (h,)),
                     (f"{net}.attn.in_trans.weight", L.mix_in_w + n * L.mix_in_w_stride - base, (3 * h, h)),
@@ -72,43 +75,66 @@ class FlexQMixer(FlatParamModule):
             object.__setattr__(self, "_engine", LearnerEngine(self.V.fc1.weight.device))
         return self._engine
 
-    def forward(self, agent_qs, inputs, imagine_groups=None):
+    def _mix(self, agent_qs, inputs, imagine_groups, want_ingroup):
         """agent_qs [bs,T,na] (or [bs,T,2na] with imagine_groups); inputs = (entities||last-action
         [bs,T,ne,E], entity_mask [bs,T,ne]) as built by QLearner._get_mixer_ins (q_learner.py:45-64).
-        imagine_groups: the [bs,ne] partition bits (uint8). The reference passes the derived
-        (Wmask, Imask) tensors; the kernels re-derive those masks from the bits in registers."""
+        imagine_groups: what the imagine agents return (ImagineGroups carrying the partition bits or the
+        gt mask), or the [bs,ne] bits tensor itself; the kernels re-derive the masks in registers."""
+        from ..agents.entity_rnn_agent import ImagineGroups
         entities, entity_mask = inputs
         bs, T, ne, E = entities.shape
         dims = self._dims(bs, T)
         dims.ed, dims.entity_last_action = E, 0          # entities already carry the one-hots
         fields = {"entities": entities.contiguous(), "entity_mask": entity_mask.contiguous()}
-        gb = None
-        qs_im = None
+        gb = qs_im = None
+        dims.imagine = dims.gt_factors = 0
         if imagine_groups is not None:
-            if isinstance(imagine_groups, (tuple, list)):
-                raise NotImplementedError("pass the [bs, ne] partition bits instead of (Wmask, Imask) tensors")
-            gb = imagine_groups.to(entities.device).to(th.uint8).contiguous()
+            if isinstance(imagine_groups, ImagineGroups):
+                if imagine_groups.gt_mask is not None:
+                    gt = imagine_groups.gt_mask
+                    fields["gt_mask"] = (gt[:, :T] if gt.shape[1] != T else gt).contiguous()
+                    dims.gt_factors = 1
+                else:
+                    gb = imagine_groups.bits
+            elif isinstance(imagine_groups, (tuple, list)):
+                raise NotImplementedError("pass the agent's ImagineGroups (or the [bs, ne] partition bits), not bare mask tensors")
+            else:
+                gb = imagine_groups
+            if gb is not None:
+                gb = gb.to(entities.device).to(th.uint8).contiguous()
             qs_im = agent_qs.reshape(bs, T, 2 * self.n_agents).contiguous().float()
+            real = th.zeros(bs, T, self.n_agents, dtype=th.float32, device=entities.device)
             dims.imagine = 1
         else:
-            dims.imagine = 0
-        L = self._layout()
-        flat = self.flat()
-        # the library indexes the mixer tensors at absolute offsets of the combined [agent|mixer] buffer
-        base_ptr = flat.data_ptr() - 4 * int(L.agent_total)
-        eng = self.engine()
-        import ctypes as C
-        nbytes = _lib.lib().refil_mixer_workspace_bytes(C.byref(dims))
-        wp, wsz = eng.ws.ptr_size(nbytes)
-        b = _lib.make_batch(fields, gb)
-        q_tot = th.empty(bs, T, dtype=th.float32, device=entities.device)
-        q_im = th.empty(bs, T, dtype=th.float32, device=entities.device) if qs_im is not None else None
-        if qs_im is not None:
-            real = th.zeros(bs, T, self.n_agents, dtype=th.float32, device=entities.device)
-        else:
             real = agent_qs.reshape(bs, T, self.n_agents).contiguous().float()
-        _lib.check(_lib.lib().refil_mixer_forward(
-            C.byref(dims), C.byref(b), C.c_int32(0), C.c_int32(T), C.c_void_p(base_ptr), _lib.ptr(real),
-            _lib.ptr(qs_im), _lib.ptr(q_tot), _lib.ptr(q_im), wp, wsz, _lib.current_stream_ptr()), "refil_mixer_forward")
-        out = q_im if qs_im is not None else q_tot
-        return out.reshape(bs, T, 1)
+        L = self._layout()
+        # the library indexes the mixer tensors at absolute offsets of the combined [agent|mixer] buffer
+        base_ptr = self.flat().data_ptr() - 4 * int(L.agent_total)
+        out = self.engine().mixer_forward(dims, fields, gb, None, real, qs_im, 0, T, params_ptr=base_ptr,
+                                          want_ingroup=want_ingroup)
+        q = (out[1] if qs_im is not None else out[0]).reshape(bs, T, 1)
+        if want_ingroup:
+            return q, out[2][0] / (bs * T)
+        return q
+
+    def forward(self, agent_qs, inputs, imagine_groups=None):
+        return self._mix(agent_qs, inputs, imagine_groups, False)
+
+
+class LinearFlexQMixer(FlexQMixer):
+    """flex_qmix.py:124-172: q_tot = sum_i q_i * w1_i + V with w1 from an 'alt_vector' attention hypernet."""
+
+    def __init__(self, args):
+        FlatParamModule.__init__(self)
+        self.args = args
+        self.n_agents = args.n_agents
+        self.embed_dim = args.mixing_embed_dim
+        self.hyper_w_1 = AttentionHyperNet(args, mode="alt_vector")
+        self.V = AttentionHyperNet(args, mode="scalar")
+        self._engine = None
+
+    def _nets(self):
+        return ("hyper_w_1", "V")
+
+    def forward(self, agent_qs, inputs, imagine_groups=None, ret_ingroup_prop=False):
+        return self._mix(agent_qs, inputs, imagine_groups, bool(ret_ingroup_prop))

@@ -17,9 +17,11 @@ class RecLogger:
 
 def make_args(cfg, imagine=None, **over):
     imagine = cfg.imagine if imagine is None else imagine
+    kind = "ff" if cfg.agent_ff else "rnn"
     a = types.SimpleNamespace(
-        agent="imagine_entity_attend_rnn" if imagine else "entity_attend_rnn",
-        mac="entity_mac", learner="q_learner", mixer="flex_qmix", agent_output_type="q",
+        agent=("imagine_entity_attend_" if imagine else "entity_attend_") + kind,
+        mac="entity_mac", learner="q_learner", mixer="lin_flex_qmix" if cfg.mixer_lin else "flex_qmix", agent_output_type="q",
+        train_gt_factors=False, train_rand_gt_factors=False, test_gt_factors=False, gt_obs_mask=cfg.gt_obs_mask,
         action_selector="epsilon_greedy", epsilon_start=1.0, epsilon_finish=0.05, epsilon_anneal_time=500000,
         n_agents=cfg.n_agents, n_actions=cfg.n_actions, n_entities=cfg.n_entities, entity_shape=cfg.entity_shape,
         entity_scheme=True, entity_last_action=cfg.entity_last_action, gt_mask_avail=False,
@@ -49,6 +51,8 @@ def make_episode_batch(cfg, data, device="cpu"):
         "reward": {"vshape": (1,)},
         "terminated": {"vshape": (1,), "dtype": th.uint8},
     }
+    if "gt_mask" in data:                                  # src/run.py:187-188
+        scheme["gt_mask"] = {"vshape": cfg.n_entities, "group": "agents", "dtype": th.uint8}
     groups = {"agents": cfg.n_agents, "entities": cfg.n_entities}
     preprocess = {"actions": ("actions_onehot", [OneHot(out_dim=cfg.n_actions)])}
     batch = EpisodeBatch(scheme, groups, B, T1, preprocess=preprocess, device=device)

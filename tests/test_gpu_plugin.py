@@ -132,3 +132,30 @@ def test_target_update_copies_flat_buffer():
     assert any("Updated target network" in str(i) for i in logger.infos)
     for (k, a), (_, b) in zip(mac.agent.state_dict().items(), learner.target_mac.agent.state_dict().items()):
         assert th.equal(a, b), k
+
+
+def test_cfg1_group_matching_ff_agent_linear_mixer():
+    """BASELINE.json configs[0]: refil_group_matching (imagine_entity_attend_ff + lin_flex_qmix, test_gt_factors)
+    on real GroupMatching episodes, through the plugin surface, against the reference's own run."""
+    g, args, batch, mac, learner, logger = _build("gm_refil_ff_lin", gt_mask_avail=True, test_gt_factors=True)
+    z, case = g["z"], g["case"]
+    assert type(mac.agent).__name__ == "ImagineEntityAttentionFFAgent" and type(learner.mixer).__name__ == "LinearFlexQMixer"
+    th.manual_seed(case["seed"] + 7)
+    learner.train(batch, t_env=0, episode_num=0)
+    th.cuda.synchronize()
+    for k in ("loss", "im_loss", "grad_norm", "td_error_abs", "q_taken_mean", "target_mean", "ingroup_prop", "gt_ingroup_prop"):
+        ref = float(z["stat." + k])
+        assert abs(logger.stats[k] - ref) < 2e-4 * max(abs(ref), 1e-3), (k, logger.stats[k], ref)
+    sd = {**{"agent." + k: v for k, v in mac.agent.state_dict().items()},
+          **{"mixer." + k: v for k, v in learner.mixer.state_dict().items()}}
+    for k in z.files:
+        if k.startswith("post."):
+            assert (sd[k[5:]].cpu() - th.from_numpy(z[k])).abs().max().item() < 5e-6, k
+    # imagine forward with ground-truth factors through the MAC (q_learner.py:99)
+    g2, args2, batch2, mac2, learner2, _ = _build("gm_refil_ff_lin", gt_mask_avail=True)
+    mac2.init_hidden(batch2.batch_size)
+    q, groups = mac2.forward(batch2, t=None, imagine=True, use_gt_factors=True)
+    assert rel_err(q.reshape(3, batch2.batch_size, *q.shape[1:]).cpu(), z["q_gt"]) < 1e-4
+    mac2.init_hidden(batch2.batch_size)
+    acts = mac2.select_actions(batch2, t_ep=0, t_env=0, test_mode=True)
+    assert acts.shape == (batch2.batch_size, g["cfg"].n_agents)

@@ -5,12 +5,12 @@ import pytest
 import torch
 
 from oracle import refil_oracle as orc
-from golden_util import CASES, load, rel_err
+from golden_util import CASES, GM_CASES, load, rel_err
 
 TOL = 2e-5   # fp32, different op order than the reference (shared fc1/K/V, fused masks)
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + GM_CASES)
 def test_oracle_matches_reference(name):
     g = load(name)
     z, cfg, case = g["z"], g["cfg"], g["case"]
@@ -29,9 +29,13 @@ def test_oracle_matches_reference(name):
         assert rel_err(caq_im, z["chosen_q_imagine"]) < TOL
         assert rel_err(out.q_tot_imagine.detach(), z["q_tot_imagine"]) < TOL
         assert abs(out.im_loss.item() - float(z["stat.im_loss"])) < TOL * abs(float(z["stat.im_loss"]))
-        Wm, Im = orc.imagine_masks(g["bits"], g["batch"]["entity_mask"][:, 0])
-        assert np.array_equal(Wm.numpy().astype(np.uint8), z["Wmask_noobs"])
-        assert np.array_equal(Im.numpy().astype(np.uint8), z["Imask_noobs"])
+        if z["Wmask_noobs"].shape[-2] == cfg.n_entities:          # recurrent agent: full [ne,ne] masks
+            Wm, Im = orc.imagine_masks(g["bits"], g["batch"]["entity_mask"][:, 0])
+            assert np.array_equal(Wm.numpy().astype(np.uint8), z["Wmask_noobs"])
+            assert np.array_equal(Im.numpy().astype(np.uint8), z["Imask_noobs"])
+        W, I, act = orc.group_masks(cfg, g["batch"]["entity_mask"], g["bits"])
+        assert np.array_equal((W | act)[:, 0].numpy().astype(np.uint8), z["Wmask_noobs"][:, :cfg.n_agents])
+        assert np.array_equal((I | act)[:, 0].numpy().astype(np.uint8), z["Imask_noobs"][:, :cfg.n_agents])
     assert abs(gnorm - float(z["stat.grad_norm"])) < 1e-4 * float(z["stat.grad_norm"])
     for k in ("td_error_abs", "q_taken_mean", "target_mean"):
         assert abs(out.stats[k] - float(z["stat." + k])) < 1e-4 * max(abs(float(z["stat." + k])), 1e-3)
@@ -53,3 +57,28 @@ def test_partition_draw_matches_reference_rng_calls():
     torch.manual_seed(g["case"]["seed"] + 7)
     bits = orc.draw_partition_bits(g["case"]["B"], g["case"]["ne"])
     assert torch.equal(bits, g["bits"])
+
+
+@pytest.mark.parametrize("name", GM_CASES)
+def test_oracle_gt_factor_diagnostics(name):
+    """The log-step-only passes of cfg 1 (q_learner.py:98-105,138-147): imagine with ground-truth factors and
+    LinearFlexQMixer's ingroup_prop."""
+    g = load(name)
+    z, cfg = g["z"], g["cfg"]
+    b = g["batch"]
+    xe = orc.build_entity_inputs(cfg, b["entities"], b["actions"])
+    q_gt, _, groups = orc.agent_forward(cfg, g["agent"], xe, b["obs_mask"], b["entity_mask"], gt_mask=b["gt_mask"], use_gt_factors=True)
+    assert rel_err(q_gt, z["q_gt"]) < TOL
+    em = b["entity_mask"][:, :-1]
+    _, q_im, prop = orc.mixer_forward(cfg, g["mixer"], torch.from_numpy(z["chosen_q_real"]), xe[:, :-1], em,
+                                      torch.from_numpy(z["chosen_q_imagine"]),
+                                      tuple(m for m in orc.group_masks(cfg, b["entity_mask"], g["bits"])[:2]) and
+                                      tuple((m | orc.group_masks(cfg, b["entity_mask"], g["bits"])[2]) for m in orc.group_masks(cfg, b["entity_mask"], g["bits"])[:2]),
+                                      ret_ingroup_prop=True)
+    assert rel_err(q_im, z["q_tot_imagine"]) < TOL
+    assert abs(prop.item() - float(z["stat.ingroup_prop"])) < 1e-5
+    gtg = tuple(m[:, :-1] for m in groups)
+    _, q_im_gt, prop_gt = orc.mixer_forward(cfg, g["mixer"], torch.from_numpy(z["chosen_q_real"]), xe[:, :-1], em,
+                                            torch.from_numpy(z["chosen_q_imagine_gt"]), gtg, ret_ingroup_prop=True)
+    assert rel_err(q_im_gt, z["q_tot_imagine_gt"]) < TOL
+    assert abs(prop_gt.item() - float(z["stat.gt_ingroup_prop"])) < 1e-5

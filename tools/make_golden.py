@@ -178,6 +178,139 @@ def run_case(name, case, out_dir):
           f"({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def _import_group_matching():
+    """GroupMatching env of the reference without executing envs/__init__.py (which needs pysc2)."""
+    import importlib.util
+    pkg = types.ModuleType("envs")
+    pkg.__path__ = [os.path.join(REF, "envs")]
+    sys.modules.setdefault("envs", pkg)
+    sub = types.ModuleType("envs.group_matching")
+    sub.__path__ = [os.path.join(REF, "envs", "group_matching")]
+    sys.modules.setdefault("envs.group_matching", sub)
+    for name, rel in (("envs.multiagentenv", "envs/multiagentenv.py"),
+                      ("envs.group_matching.group_matching", "envs/group_matching/group_matching.py")):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+    return sys.modules["envs.group_matching.group_matching"].GroupMatching
+
+
+def group_matching_rollouts(case):
+    """Real episodes of the reference's GroupMatching env under a uniform random policy
+    (what EpisodeRunner.run stores: entities, masks, gt_mask, actions, reward, terminated)."""
+    GM = _import_group_matching()
+    B, T, na = case["B"], case["T"], case["na"]
+    env = GM(entity_scheme=True, n_agents=na, n_states=case["n_states"], n_groups=2, rand_trans=0.1,
+             episode_limit=T, fixed_scen=False, seed=case["seed"])
+    rng = np.random.RandomState(case["seed"] + 1)
+    ed = env.get_entity_size()
+    d = {"entities": np.zeros((B, T + 1, na, ed), np.float32), "obs_mask": np.zeros((B, T + 1, na, na), np.uint8),
+         "entity_mask": np.zeros((B, T + 1, na), np.uint8), "gt_mask": np.zeros((B, T + 1, na, na), np.uint8),
+         "actions": np.zeros((B, T + 1, na, 1), np.int64), "avail_actions": np.zeros((B, T + 1, na, 3), np.int32),
+         "reward": np.zeros((B, T + 1, 1), np.float32), "terminated": np.zeros((B, T + 1, 1), np.uint8),
+         "filled": np.zeros((B, T + 1, 1), np.int64)}
+    for b in range(B):
+        env.reset()
+        t, done = 0, False
+        while True:
+            om, em, gt = env.get_masks()
+            d["entities"][b, t] = np.stack(env.get_entities())
+            d["obs_mask"][b, t], d["entity_mask"][b, t], d["gt_mask"][b, t] = om, em, gt
+            d["avail_actions"][b, t] = np.array(env.get_avail_actions())
+            d["filled"][b, t] = 1
+            acts = rng.randint(0, 3, size=na)
+            d["actions"][b, t, :, 0] = acts
+            if done:
+                break
+            rew, done, info = env.step(acts)
+            d["reward"][b, t] = rew
+            d["terminated"][b, t] = int(done and not info.get("episode_limit", False))   # episode_runner.py:110
+            t += 1
+    return {k: th.from_numpy(v) for k, v in d.items()}, ed
+
+
+def run_gm_case(name, case, out_dir):
+    """cfg 1 of BASELINE.json: group_matching + refil_group_matching (FF agent, lin_flex_qmix, gt factors)."""
+    le_REGISTRY, mac_REGISTRY, EpisodeBatch, OneHot = import_reference()
+    data, ed = group_matching_rollouts(case)
+    case = dict(case, ne=case["na"], A=3, ed=ed, imagine=True, H=64, entity_last_action=False)
+    args = ref_args(case)
+    args.agent, args.mixer = "imagine_entity_attend_ff", "lin_flex_qmix"
+    args.gt_mask_avail, args.test_gt_factors, args.gt_obs_mask = True, True, False
+    B, T, na = case["B"], case["T"], case["na"]
+    scheme = {
+        "entities": {"vshape": ed, "group": "entities"},
+        "obs_mask": {"vshape": na, "group": "entities", "dtype": th.uint8},
+        "entity_mask": {"vshape": na, "dtype": th.uint8},
+        "gt_mask": {"vshape": na, "group": "agents", "dtype": th.uint8},
+        "actions": {"vshape": (1,), "group": "agents", "dtype": th.long},
+        "avail_actions": {"vshape": (3,), "group": "agents", "dtype": th.int},
+        "reward": {"vshape": (1,)},
+        "terminated": {"vshape": (1,), "dtype": th.uint8},
+    }
+    groups = {"agents": na, "entities": na}
+    batch = EpisodeBatch(scheme, groups, B, T + 1, preprocess={"actions": ("actions_onehot", [OneHot(out_dim=3)])}, device="cpu")
+    for k, v in data.items():
+        batch.data.transition_data[k] = v.clone()
+    batch.data.transition_data["actions_onehot"] = OneHot(3).transform(data["actions"])
+    th.manual_seed(case["seed"] + 1000)
+    mac = mac_REGISTRY[args.mac](batch.scheme, groups, args)
+    logger = _Logger()
+    learner = le_REGISTRY[args.learner](mac, batch.scheme, logger, args)
+    with th.no_grad():
+        for p in list(learner.target_mac.parameters()) + list(learner.target_mixer.parameters()):
+            p.add_(0.05 * th.randn_like(p))
+    rec = {"in." + k: v.numpy() for k, v in data.items()}
+    for pre, sd in (("agent0.", mac.agent.state_dict()), ("mixer0.", learner.mixer.state_dict()),
+                    ("tagent.", learner.target_mac.agent.state_dict()), ("tmixer.", learner.target_mixer.state_dict())):
+        for k, v in sd.items():
+            rec[pre + k] = v.numpy().copy()
+    cap = {"agent": [], "mixer": []}
+    mac.agent.register_forward_hook(lambda m, i, o: cap["agent"].append(o))
+    learner.mixer.register_forward_hook(lambda m, i, o: cap["mixer"].append((i, o)))
+    learner.target_mixer.register_forward_hook(lambda m, i, o: cap.__setitem__("tmixer", (i, o)))
+    draw_seed = case["seed"] + 7
+    th.manual_seed(draw_seed)
+    probs = th.rand(B, 1, 1).repeat(1, 1, na)
+    bits = th.bernoulli(probs).to(th.uint8).reshape(B, na)
+    th.manual_seed(draw_seed)
+    learner.train(batch, t_env=0, episode_num=0)
+    rec["group_bits"] = bits.numpy()
+    q_all = cap["agent"][0][0].detach()
+    rec["q"] = q_all.reshape(3, B, T + 1, na, 3).numpy()
+    rec["Wmask_noobs"] = cap["agent"][0][2][0][:, 0].numpy()
+    rec["Imask_noobs"] = cap["agent"][0][2][1][:, 0].numpy()
+    rec["q_gt"] = cap["agent"][1][0].detach().reshape(3, B, T + 1, na, 3).numpy()      # use_gt_factors=True pass (log step)
+    (i0, o0), (i1, o1), (i2, o2) = cap["mixer"][:3]
+    rec["chosen_q_real"], rec["q_tot"] = i0[0].detach().numpy(), o0.detach().numpy()
+    rec["chosen_q_imagine"], rec["q_tot_imagine"] = i1[0].detach().numpy(), o1[0].detach().numpy()
+    rec["chosen_q_imagine_gt"], rec["q_tot_imagine_gt"] = i2[0].detach().numpy(), o2[0].detach().numpy()
+    rec["target_max_q"] = cap["tmixer"][0][0].detach().numpy()
+    rec["target_q_tot"] = cap["tmixer"][1].detach().numpy()
+    for k, v in logger.stats.items():
+        rec["stat." + k] = np.float64(v)
+    gn = logger.stats["grad_norm"]
+    coef = min(1.0, args.grad_norm_clip / (gn + 1e-6))
+    rec["clip_coef"] = np.float64(coef)
+    for which, mod in (("agent", mac.agent), ("mixer", learner.mixer)):
+        for k, p in mod.named_parameters():
+            rec[f"grad.{which}.{k}"] = (p.grad.detach() / coef).numpy()
+            rec[f"post.{which}.{k}"] = p.detach().numpy().copy()
+            rec[f"sq.{which}.{k}"] = learner.optimiser.state[p]["square_avg"].numpy().copy()
+    case["kind"] = "gm"
+    rec["case"] = np.array(repr(case))
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print(f"{name}: loss={logger.stats['loss']:.6f} ingroup={logger.stats['ingroup_prop']:.4f} gt_ingroup={logger.stats['gt_ingroup_prop']:.4f} "
+          f"grad_norm={gn:.5f} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+GM_CASES = {
+    # BASELINE.json configs[0]: real group_matching episodes, refil_group_matching alg (scaled-down widths)
+    "gm_refil_ff_lin": dict(B=6, T=10, na=8, n_states=6, d=32, heads=4, h=32, M=32, seed=31),
+}
+
 CASES = {
     # tiny REFIL case: padded agents/enemies, deaths, softmax mixing weights
     "refil_tiny": dict(imagine=True, B=3, T=5, ne=6, na=3, A=5, ed=9, d=16, heads=4, H=64, h=16, M=32, seed=11),
@@ -196,6 +329,9 @@ CASES = {
 
 if __name__ == "__main__":
     out = os.path.join(REPO, "tests", "golden")
-    only = sys.argv[1:] or list(CASES)
+    only = sys.argv[1:] or (list(CASES) + list(GM_CASES))
     for nm in only:
-        run_case(nm, CASES[nm], out)
+        if nm in GM_CASES:
+            run_gm_case(nm, GM_CASES[nm], out)
+        else:
+            run_case(nm, CASES[nm], out)
