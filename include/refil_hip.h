@@ -288,6 +288,11 @@ typedef struct refil_profile_entry {
 int refil_profile_enable(int on);
 int refil_profile_collect(refil_profile_entry* out, int max_entries);
 
+/* Two-stream overlap of the agent chain with the hypernet chain inside refil_learner_forward_backward:
+ * 1 = on (default), 0 = serialise everything on the caller's stream (profiling one kernel at a time),
+ * -1 = follow the environment variable REFIL_NO_OVERLAP. */
+int refil_set_overlap(int on);
+
 const char* refil_last_error(void);
 int refil_version(void);
 

@@ -106,7 +106,7 @@ EXPORTS = [
     "refil_clip_rmsprop_step", "refil_agent_workspace_bytes", "refil_agent_forward",
     "refil_mixer_workspace_bytes", "refil_mixer_forward", "refil_gemm", "refil_attn_forward",
     "refil_attn_backward", "refil_gru_forward", "refil_gru_backward", "refil_last_error", "refil_version",
-    "refil_profile_enable", "refil_profile_collect",
+    "refil_profile_enable", "refil_profile_collect", "refil_set_overlap",
 ]
 
 _lib = None
@@ -145,6 +145,7 @@ def lib():
     L.refil_attn_backward.argtypes = [C.POINTER(AttnDesc), C.c_void_p]
     L.refil_gru_forward.argtypes = [C.POINTER(GruDesc), C.c_void_p]
     L.refil_gru_backward.argtypes = [C.POINTER(GruDesc), C.c_void_p]
+    L.refil_set_overlap.argtypes = [C.c_int]
     L.refil_profile_enable.argtypes = [C.c_int]
     L.refil_profile_collect.argtypes = [C.POINTER(ProfileEntry), C.c_int]
     _lib = L

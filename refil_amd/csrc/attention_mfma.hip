@@ -65,6 +65,38 @@ __device__ inline void stage(float* dst, const float* src, long row0, int rows, 
     }
 }
 
+// Two-phase staging with compile-time trip counts: ALL global loads of a head (Q, K, V [, dO]) are issued
+// back to back into registers and only then written to LDS -- the runtime-bound loop above costs one
+// dependent HBM round trip per iteration (10 per head at ne=32, hd=32).
+template <int ROWS_PAD, int C4MAX>
+struct Stage {
+    static constexpr int N = ROWS_PAD * C4MAX / 64;
+    float4 v[N];
+    __device__ inline void load(const float* src, long row0, int rows, int ld, int col0, int hd, int lane) {
+        const int c4n = hd >> 2;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int idx = lane + 64 * i, r = idx / C4MAX, c4 = idx % C4MAX;
+            const bool ok = r < rows && c4 < c4n;
+            const float* p = src + (row0 + (ok ? r : 0)) * (long)ld + col0 + (ok ? c4 : 0) * 4;
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            v[i] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __device__ inline void store(float* dst, int hd, int pd, int lane) const {
+        const int c4n = hd >> 2;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int idx = lane + 64 * i, r = idx / C4MAX, c4 = idx % C4MAX;
+            if (c4 < c4n) {
+                float2* d = reinterpret_cast<float2*>(dst + r * pd + c4 * 4);
+                d[0] = make_float2(v[i].x, v[i].y);
+                d[1] = make_float2(v[i].z, v[i].w);
+            }
+        }
+    }
+};
+
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // D[rowtile x coltile] = sum_c X[rowbase + (l&15)][c] * Y[colbase + (l&15)][c]   (both operands [rows][hd] in LDS)
@@ -201,9 +233,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
     const float scale = sqrtf((float)p.hd);
     (void)inv_scale;
     for (int head = wave; head < p.heads; head += 4) {
-        stage(Qs, p.Q, (long)r * p.na, p.na, NAT * 16, p.ldq, head * p.hd, p.hd, pd, lane);
-        stage(Ks, p.K, (long)r * p.ne, p.ne, NJT * 16, p.ldkv, head * p.hd, p.hd, pd, lane);
-        stage(Vs, p.V, (long)r * p.ne, p.ne, NJT * 16, p.ldkv, head * p.hd, p.hd, pd, lane);
+        {
+            Stage<NAT * 16, 4 * NCT> sq;
+            Stage<NJT * 16, 4 * NCT> sk, sv;
+            sq.load(p.Q, (long)r * p.na, p.na, p.ldq, head * p.hd, p.hd, lane);
+            sk.load(p.K, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane);
+            sv.load(p.V, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane);
+            sq.store(Qs, p.hd, pd, lane); sk.store(Ks, p.hd, pd, lane); sv.store(Vs, p.hd, pd, lane);
+        }
 #pragma unroll
         for (int at = 0; at < NAT; ++at) {
             const int agent = 16 * at + l15;
@@ -252,9 +289,14 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
     float* Ds = Vs + NJT * 16 * pd;          // dO of one (variant, agent tile): 16 rows
     const float scale = sqrtf((float)p.hd);
     for (int head = wave; head < p.heads; head += 4) {
-        stage(Qs, p.Q, (long)r * p.na, p.na, NAT * 16, p.ldq, head * p.hd, p.hd, pd, lane);
-        stage(Ks, p.K, (long)r * p.ne, p.ne, NJT * 16, p.ldkv, head * p.hd, p.hd, pd, lane);
-        stage(Vs, p.V, (long)r * p.ne, p.ne, NJT * 16, p.ldkv, head * p.hd, p.hd, pd, lane);
+        {
+            Stage<NAT * 16, 4 * NCT> sq;
+            Stage<NJT * 16, 4 * NCT> sk, sv;
+            sq.load(p.Q, (long)r * p.na, p.na, p.ldq, head * p.hd, p.hd, lane);
+            sk.load(p.K, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane);
+            sv.load(p.V, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane);
+            sq.store(Qs, p.hd, pd, lane); sk.store(Ks, p.hd, pd, lane); sv.store(Vs, p.hd, pd, lane);
+        }
         f32x4 dKt[NCT][NJT], dVt[NCT][NJT];     // [c 16ct+4q+reg][key 16jt+l15]
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
@@ -278,7 +320,11 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
             for (int ct = 0; ct < NCT; ++ct) dQt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int v = 0; v < p.nvar; ++v) {
                 const int na_t = min(16, p.na - 16 * at);
-                stage(Ds, p.dO + v * p.sO, (long)r * p.na + 16 * at, na_t, 16, p.ldo, head * p.hd, p.hd, pd, lane);
+                {
+                    Stage<16, 4 * NCT> sd;
+                    sd.load(p.dO + v * p.sO, (long)r * p.na + 16 * at, na_t, p.ldo, head * p.hd, p.hd, lane);
+                    sd.store(Ds, p.hd, pd, lane);
+                }
                 f32x4 pt[NJT], pn[NJT];
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt)

@@ -263,7 +263,9 @@ static int side_stream(SideStream*& out) {
     out = &sd;
     return 0;
 }
+static int g_overlap = -1;      // -1: follow the environment, 0/1: set by refil_set_overlap
 static bool overlap_enabled() {
+    if (g_overlap >= 0) return g_overlap != 0;
     const char* e = getenv("REFIL_NO_OVERLAP");
     return !(e && e[0] == '1');
 }
@@ -524,6 +526,7 @@ static int run_prep(const Ctx& c, int first_step_zero) {
 using namespace refil;
 
 extern "C" const char* refil_last_error(void) { return g_err; }
+extern "C" int refil_set_overlap(int on) { g_overlap = on < 0 ? -1 : (on != 0); return 0; }
 extern "C" int refil_version(void) { return 1; }
 
 extern "C" int refil_get_param_layout(const refil_dims* dims, refil_param_layout* out) {
