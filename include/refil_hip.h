@@ -53,6 +53,7 @@ typedef struct refil_dims {
     int32_t agent_ff;                /* 1: feed-forward agent fc1->relu(attn)->fc2 (entity_ff_agent.py:29-57),
                                         0: recurrent agent (entity_rnn_agent.py:31-64)                */
     int32_t mixer_lin;               /* 1: LinearFlexQMixer (flex_qmix.py:124-172), 0: FlexQMixer       */
+    int32_t mixer_vdn;               /* 1: VDNMixer (modules/mixers/vdn.py:9-10): q_tot = sum_i q_i, no hypernets / parameters */
     int32_t gt_factors;              /* 1: imagine groups = ground-truth factors batch.gt_mask
                                         (entity_ff_agent.py:93-95) instead of the random split       */
     int32_t gt_obs_mask;             /* 1: batch.gt_mask replaces obs_mask (entity_ff_agent.py:34-35)   */

@@ -54,6 +54,7 @@ class Cfg:
     imagine: bool = True           # 'imagine' in args.agent  (q_learner.py:86)
     agent_ff: bool = False         # entity_attend_ff agents (entity_ff_agent.py) instead of the recurrent ones
     mixer_lin: bool = False        # lin_flex_qmix (flex_qmix.py:124-172) instead of flex_qmix
+    mixer_vdn: bool = False        # VDNMixer (modules/mixers/vdn.py:9-10): q_tot = sum of the agents' Qs, no parameters
     gt_obs_mask: bool = False      # entity_ff_agent.py:34-35
     double_q: bool = True
     gamma: float = 0.99
@@ -98,6 +99,8 @@ def mixer_param_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
     """state_dict layout of FlexQMixer (flex_qmix.py:28-38,69-73)."""
     h, M, E = cfg.hypernet_embed, cfg.mixing_embed_dim, cfg.in_dim
     out = {}
+    if cfg.mixer_vdn:
+        return out
     for net in (LIN_HYPERNETS if cfg.mixer_lin else HYPERNETS):
         out[f"{net}.fc1.weight"] = (h, E)
         out[f"{net}.fc1.bias"] = (h,)
@@ -309,6 +312,9 @@ def mixer_forward(cfg: Cfg, p: Dict[str, Tensor], agent_qs: Tensor, xe: Tensor, 
     B, T, ne, E = xe.shape
     na, M = cfg.n_agents, cfg.mixing_embed_dim
     R = B * T
+    if cfg.mixer_vdn:                                                                      # vdn.py:9-10
+        q_tot = agent_qs.sum(dim=2, keepdim=True)
+        return q_tot if agent_qs_imagine is None else (q_tot, agent_qs_imagine.sum(dim=2, keepdim=True))
     xr = xe.reshape(R, ne, E)
     em = entity_mask.reshape(R, ne).bool()
     v = hypernet_x3(cfg, p, "V", xr, em)[0].mean(dim=(1, 2))                               # mode 'scalar' :55-56

@@ -23,7 +23,7 @@ MASK_OBS_GTW, MASK_OBS_GTI, MASK_GTW, MASK_GTI = 6, 7, 8, 9
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "B", "T1", "ne", "na", "ed", "A", "d", "heads", "H", "hyp", "M", "entity_last_action", "imagine",
-        "softmax_mixing_weights", "mixer_tanh", "double_q", "agent_ff", "mixer_lin", "gt_factors", "gt_obs_mask")] + [("gamma", C.c_float), ("lmbda", C.c_float)]
+        "softmax_mixing_weights", "mixer_tanh", "double_q", "agent_ff", "mixer_lin", "mixer_vdn", "gt_factors", "gt_obs_mask")] + [("gamma", C.c_float), ("lmbda", C.c_float)]
 
 
 class ParamLayout(C.Structure):

@@ -66,7 +66,7 @@ static void param_layout(const refil_dims& d, refil_param_layout& L) {
         L.ag_fc3_w = take(A * H); L.ag_fc3_b = take(A);
     }
     L.agent_total = o;
-    const long nn = d.mixer_lin ? 2 : 4;       // hypernets: (hyper_w_1, V) or (hyper_w_1, hyper_w_final, hyper_b_1, V)
+    const long nn = d.mixer_vdn ? 0 : (d.mixer_lin ? 2 : 4);       // hypernets: none (VDN), (hyper_w_1, V) or (hyper_w_1, hyper_w_final, hyper_b_1, V)
     L.mix_fc1_w_stride = h * E; L.mix_fc1_w = take(nn * h * E);
     L.mix_fc1_b_stride = h; L.mix_fc1_b = take(nn * h);
     L.mix_in_w_stride = 3 * h * h; L.mix_in_w = take(nn * 3 * h * h);
@@ -117,7 +117,7 @@ struct Sizes {
 static Sizes sizes_of(const refil_dims& d) {
     Sizes s;
     s.R = (long)d.B * d.T1; s.NE = s.R * d.ne; s.NA = s.R * d.na;
-    s.G = d.imagine ? 3 : 1; s.nv0 = s.G; s.nets = d.mixer_lin ? 2 : 4; s.NV = s.nv0 + s.nets - 1;
+    s.G = d.imagine ? 3 : 1; s.nv0 = s.G; s.nets = d.mixer_vdn ? 0 : (d.mixer_lin ? 2 : 4); s.NV = s.nets ? s.nv0 + s.nets - 1 : 0;
     s.E = in_dim(d); s.Ep = (int)rup(s.E, 4);
     return s;
 }
@@ -159,6 +159,7 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     if (mode == CARVE_MIXER_FWD) {
         carve_hyper(a, d, s, s.NV, w.lh);
         w.ingroup = a.take<float>(BT + d.B);
+        w.chosen = a.take<float>(3 * BT * d.na);          // de-interleaved agent Qs
         return;
     }
     carve_agent(a, d, s, s.G, true, w.la);
@@ -405,8 +406,10 @@ static MixArgs mix_args(const Ctx& c, const HyperBufs& b, int nv0, const float* 
     MixArgs m;
     memset(&m, 0, sizeof(m));
     m.x_w1 = b.x3; m.s_var = s.NA * d.M;
-    m.lin = d.mixer_lin;
-    if (d.mixer_lin) {                                  // hypernets (hyper_w_1, V)
+    m.lin = d.mixer_vdn ? 2 : d.mixer_lin;
+    if (d.mixer_vdn) {
+        // parameter-free sum: no hypernet outputs
+    } else if (d.mixer_lin) {                                  // hypernets (hyper_w_1, V)
         m.x_v = b.x3 + (long)(nv0 + 0) * s.NA * d.M;
     } else {                                            // (hyper_w_1, hyper_w_final, hyper_b_1, V)
         m.x_wf = b.x3 + (long)(nv0 + 0) * s.NA * d.M;
@@ -579,8 +582,10 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
         RUN(qselect_launch(q, ca.st));                                            // :91-96,115-128
     }
     if (overlap) REFIL_HIP(hipEventRecord(sd->ev[1], sd->s));
-    RUN(hyper_forward(c, params_live, w.lh, nv0));   // live mixer hypernets
-    RUN(hyper_forward(c, params_target, w.th, 1));                                // target mixer hypernets
+    if (!d.mixer_vdn) {
+        RUN(hyper_forward(c, params_live, w.lh, nv0));                            // live mixer hypernets
+        RUN(hyper_forward(c, params_target, w.th, 1));                            // target mixer hypernets
+    }
     if (overlap) REFIL_HIP(hipStreamWaitEvent(c.st, sd->ev[1], 0));               // join: mixing needs the agents' Q
     MixArgs ml = mix_args(c, w.lh, nv0, w.chosen, G, 0, T);
     ml.q_tot = w.q_tot; ml.q_tot_im = w.q_tot_im;
@@ -613,7 +618,9 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
     // ---------------- backward (q_learner.py:176, hand-scheduled) ----------------
     ml.gc_real = w.gc_real; ml.gc_im = w.gc_im;
     ml.dx_w1 = w.dx3h;
-    if (d.mixer_lin) {
+    if (d.mixer_vdn) {
+        // nothing flows to hypernets
+    } else if (d.mixer_lin) {
         ml.dx_v = w.dx3h + (long)(nv0 + 0) * s.NA * M;
     } else {
         ml.dx_wf = w.dx3h + (long)(nv0 + 0) * s.NA * M;
@@ -677,6 +684,7 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
         RUN(attn_block_backward(ca, k));
         RUN(gemm_launch(linear_dw(w.dx1a, dd, w.xe, s.Ep, grads + L.ag_fc1_w, s.E, grads + L.ag_fc1_b, s.NE, dd, s.E, ca.w.partial, 1), ca.st));
     }
+    if (!d.mixer_vdn) {
     // hypernet tails: fc2 (flex_qmix.py:49)
     for (int part = 0; part < 2; ++part) {
         const long rows = part == 0 ? nv0 * s.NA : s.NA;
@@ -710,6 +718,7 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
         refil_gemm_desc g = linear_dw(w.dx1h, s.nets * h, w.xe, s.Ep, grads + L.mix_fc1_w, s.E, grads + L.mix_fc1_b, s.NE, s.nets * h, s.E,
                                       w.partial, 1);
         RUN(gemm_launch(g, c.st));
+    }
     }
     if (overlap) {                                                                 // join
         REFIL_HIP(hipEventRecord(sd->ev[3], sd->s));
@@ -749,7 +758,7 @@ extern "C" int refil_mixer_forward(const refil_dims* dims, const refil_batch* ba
                                    size_t workspace_bytes_, void* stream) {
     Ctx c;
     if (int e = make_ctx(c, dims, batch, workspace, workspace_bytes_, CARVE_MIXER_FWD, stream)) return e;
-    REFIL_CHECK(params && agent_qs && q_tot, "refil_mixer_forward: null pointer");
+    REFIL_CHECK((params || dims->mixer_vdn) && agent_qs && q_tot, "refil_mixer_forward: null pointer");
     REFIL_CHECK(t0 >= 0 && T > 0 && t0 + T <= dims->T1, "refil_mixer_forward: step range [%d,%d) outside the batch", t0, t0 + T);
     const bool im = agent_qs_imagine != nullptr;
     REFIL_CHECK(!im || ((batch->group_bits || dims->gt_factors) && q_tot_imagine && dims->imagine),
@@ -757,10 +766,10 @@ extern "C" int refil_mixer_forward(const refil_dims* dims, const refil_batch* ba
     REFIL_CHECK(!dims->gt_factors || batch->gt_mask, "refil_mixer_forward: gt_factors needs batch.gt_mask");
     RUN(run_prep(c, 1));
     const int nv0 = im ? 3 : 1;
-    RUN(hyper_forward(c, params, c.w.lh, nv0));
+    if (!dims->mixer_vdn) RUN(hyper_forward(c, params, c.w.lh, nv0));
     // chosen-Q layout expected by the mix kernel: [G][B,T,na]; the ABI hands real [B,T,na] and
     // imagined [B,T,2na] = cat(W, I) (q_learner.py:96): de-interleave into scratch (reuse lh.q)
-    float* qs = c.w.lh.q;
+    float* qs = c.w.chosen;
     const long BTn = (long)dims->B * T * dims->na;
     REFIL_HIP(hipMemcpyAsync(qs, agent_qs, BTn * sizeof(float), hipMemcpyDeviceToDevice, c.st));
     if (im) {

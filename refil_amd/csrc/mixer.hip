@@ -405,7 +405,34 @@ __global__ __launch_bounds__(64) void mix_lin_bwd_kernel(MixArgs a) {
     }
 }
 
+// VDNMixer (modules/mixers/vdn.py:9-10): q_tot = sum of the agents' chosen Qs (2na of them for the imagined mix)
+__global__ void mix_vdn_fwd_kernel(MixArgs a) {
+    const int bt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bt >= a.B * a.T) return;
+    const long qb = (long)bt * a.na;
+    float s = 0.f;
+    for (int i = 0; i < a.na; ++i) s += a.qs[qb + i];
+    a.q_tot[bt] = s;
+    if (a.imagine) {
+        float si = 0.f;
+        for (int i = 0; i < a.na; ++i) si += a.qs[a.s_qs_g + qb + i];
+        for (int i = 0; i < a.na; ++i) si += a.qs[2 * a.s_qs_g + qb + i];
+        a.q_tot_im[bt] = si;
+    }
+}
+__global__ void mix_vdn_bwd_kernel(MixArgs a) {
+    const int bt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bt >= a.B * a.T) return;
+    const long qb = (long)bt * a.na, BTn = (long)a.B * a.T * a.na;
+    const float g_r = a.gc_real[bt], g_i = a.imagine ? a.gc_im[bt] : 0.f;
+    for (int i = 0; i < a.na; ++i) {
+        a.dqs[qb + i] = g_r;
+        if (a.imagine) { a.dqs[BTn + qb + i] = g_i; a.dqs[2 * BTn + qb + i] = g_i; }
+    }
+}
+
 static int mix_check(const MixArgs& a) {
+    if (a.lin == 2) { REFIL_CHECK(a.qs != nullptr, "refil mix: null input"); return 0; }
     REFIL_CHECK(a.M >= 1 && a.M <= 64, "refil mix: mixing_embed_dim %d must be in [1,64]", a.M);
     REFIL_CHECK(a.x_w1 && a.x_v && a.qs && (a.lin || (a.x_wf && a.x_b1)), "refil mix: null input");
     REFIL_CHECK(!a.lin || 2 * a.na <= 64, "refil mix: LinearFlexQMixer supports n_agents <= 32");
@@ -414,6 +441,12 @@ static int mix_check(const MixArgs& a) {
 int mix_forward_launch(const MixArgs& a, hipStream_t st) {
     if (int e = mix_check(a)) return e;
     if (a.B * a.T <= 0) return 0;
+    if (a.lin == 2) {
+        ProfScope prof("mix_vdn_fwd_kernel", 0.0, 0.0, st);
+        hipLaunchKernelGGL(mix_vdn_fwd_kernel, dim3(cdiv(a.B * a.T, 256)), dim3(256), 0, st, a);
+        REFIL_LAUNCH_CHECK();
+        return 0;
+    }
     ProfScope prof_mix_fwd_kernel(a.lin ? "mix_lin_fwd_kernel" : "mix_fwd_kernel", 0.0, 0.0, st);
     if (a.lin) hipLaunchKernelGGL(mix_lin_fwd_kernel, dim3(a.B * a.T), dim3(64), 0, st, a);
     else hipLaunchKernelGGL(mix_fwd_kernel, dim3(a.B * a.T), dim3(64), 0, st, a);
@@ -422,6 +455,12 @@ int mix_forward_launch(const MixArgs& a, hipStream_t st) {
 }
 int mix_backward_launch(const MixArgs& a, hipStream_t st) {
     if (int e = mix_check(a)) return e;
+    if (a.lin == 2) {
+        ProfScope prof("mix_vdn_bwd_kernel", 0.0, 0.0, st);
+        hipLaunchKernelGGL(mix_vdn_bwd_kernel, dim3(cdiv(a.B * a.T, 256)), dim3(256), 0, st, a);
+        REFIL_LAUNCH_CHECK();
+        return 0;
+    }
     ProfScope prof_mix_bwd_kernel(a.lin ? "mix_lin_bwd_kernel" : "mix_bwd_kernel", 0.0, 0.0, st);
     if (a.lin) hipLaunchKernelGGL(mix_lin_bwd_kernel, dim3(a.B * a.T1), dim3(64), 0, st, a);
     else hipLaunchKernelGGL(mix_bwd_kernel, dim3(a.B * a.T1), dim3(64), 0, st, a);

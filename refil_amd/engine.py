@@ -22,7 +22,7 @@ def dims_from_args(args, B: int, T1: int) -> Dims:
         imagine=int("imagine" in args.agent), softmax_mixing_weights=int(bool(args.softmax_mixing_weights)),
         mixer_tanh=int(getattr(args, "mixer_non_lin", "elu") == "tanh"), double_q=int(bool(args.double_q)),
         agent_ff=int(args.agent.endswith("_ff")), mixer_lin=int(getattr(args, "mixer", None) == "lin_flex_qmix"),
-        gt_factors=0, gt_obs_mask=int(bool(getattr(args, "gt_obs_mask", False))),
+        mixer_vdn=int(getattr(args, "mixer", None) == "vdn"), gt_factors=0, gt_obs_mask=int(bool(getattr(args, "gt_obs_mask", False))),
         gamma=float(args.gamma), lmbda=float(getattr(args, "lmbda", 0.0)))
 
 

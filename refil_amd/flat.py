@@ -63,7 +63,7 @@ def views(flat: torch.Tensor, dims: _lib.Dims) -> Tuple[Dict[str, torch.Tensor],
             n *= x
         o = getattr(L, fld)
         agent[key] = flat[o:o + n].view(*s)
-    for ni, net in enumerate(LIN_HYPERNETS if dims.mixer_lin else HYPERNETS):
+    for ni, net in enumerate(() if dims.mixer_vdn else (LIN_HYPERNETS if dims.mixer_lin else HYPERNETS)):
         for key, fld, shp in _MIXER:
             s = shp(c)
             n = 1

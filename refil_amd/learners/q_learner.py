@@ -10,6 +10,7 @@ import torch as th
 from .. import _lib, dp
 from ..engine import LearnerEngine, dims_from_args
 from ..modules.mixers.flex_qmix import FlexQMixer, LinearFlexQMixer
+from ..modules.mixers.vdn import VDNMixer
 
 
 class QLearner:
@@ -26,7 +27,9 @@ class QLearner:
             elif args.mixer == "lin_flex_qmix":
                 assert args.entity_scheme, "FlexQMixer only available with entity scheme"
                 self.mixer = LinearFlexQMixer(args)
-            elif args.mixer in ("vdn", "qmix"):
+            elif args.mixer == "vdn":
+                self.mixer = VDNMixer()
+            elif args.mixer == "qmix":
                 raise NotImplementedError(f"mixer {args.mixer} is outside the REFIL hot path built so far (SURVEY.md 8f4)")
             else:
                 raise ValueError("Mixer {} not recognised.".format(args.mixer))

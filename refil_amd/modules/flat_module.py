@@ -9,6 +9,10 @@ import torch
 import torch.nn as nn
 
 
+def th_zero():
+    return torch.zeros(0)
+
+
 class FlatParamModule(nn.Module):
     """Subclasses implement _fields() -> [(param name, offset in floats, shape)] and _flat_size()."""
 
@@ -60,6 +64,6 @@ class FlatParamModule(nn.Module):
     def flat(self) -> torch.Tensor:
         """The flat buffer holding all parameters (re-flattened after .cuda()/deepcopy broke the views)."""
         if not self._is_flat():
-            dev = next(self.parameters()).device
+            dev = next(self.parameters(), th_zero()).device
             self.adopt(torch.zeros(self._flat_size(), dtype=torch.float32, device=dev))
         return self._flat

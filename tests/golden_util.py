@@ -8,7 +8,7 @@ import torch
 from oracle import refil_oracle as orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["refil_tiny", "qmix_atten_tiny", "refil_abs_masked", "refil_odd", "refil_mid"]
+CASES = ["refil_tiny", "qmix_atten_tiny", "refil_abs_masked", "refil_odd", "refil_mid", "refil_vdn_tiny"]
 GM_CASES = ["gm_refil_ff_lin"]       # BASELINE.json configs[0]: group_matching + FF agent + lin_flex_qmix
 
 
@@ -24,7 +24,7 @@ def load(name):
         mixer_non_lin=case.get("mixer_non_lin", "elu"), imagine=case["imagine"],
         double_q=case.get("double_q", True), lmbda=case.get("lmbda", 0.5),
         grad_norm_clip=case.get("grad_norm_clip", 10),
-        agent_ff=case.get("kind") == "gm", mixer_lin=case.get("kind") == "gm",
+        agent_ff=case.get("kind") == "gm", mixer_lin=case.get("kind") == "gm", mixer_vdn=case.get("mixer") == "vdn",
     )
 
     def group(prefix):

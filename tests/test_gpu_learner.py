@@ -20,7 +20,7 @@ def _dims(cfg, B, T1):
                           d=cfg.attn_embed_dim, heads=cfg.attn_n_heads, H=cfg.rnn_hidden_dim, hyp=cfg.hypernet_embed,
                           M=cfg.mixing_embed_dim, entity_last_action=int(cfg.entity_last_action), imagine=int(cfg.imagine),
                           softmax_mixing_weights=int(cfg.softmax_mixing_weights), mixer_tanh=int(cfg.mixer_non_lin == "tanh"),
-                          double_q=int(cfg.double_q), agent_ff=int(cfg.agent_ff), mixer_lin=int(cfg.mixer_lin),
+                          double_q=int(cfg.double_q), agent_ff=int(cfg.agent_ff), mixer_lin=int(cfg.mixer_lin), mixer_vdn=int(cfg.mixer_vdn),
                           gt_factors=0, gt_obs_mask=int(cfg.gt_obs_mask), gamma=cfg.gamma, lmbda=cfg.lmbda)
 
 
@@ -221,3 +221,45 @@ def test_gt_factor_diagnostics_match_reference(name):
                                       torch.from_numpy(z["chosen_q_imagine"]).to(DEV).contiguous(), 0, T, want_ingroup=True)
     assert rel_err(qim2.cpu(), z["q_tot_imagine"][..., 0]) < TOL_FWD
     assert abs(ing2.item() / (B * T) - float(z["stat.ingroup_prop"])) < 1e-5
+
+
+@pytest.mark.parametrize("what", ["ff_lin_noimagine", "tanh_abs", "ne48_cfg5", "long_T150", "vdn_atten"])
+def test_config_matrix_matches_oracle(what):
+    """The remaining shipped alg/shape combinations (src/config/algs/*.yaml, BASELINE.json configs[3..4]):
+    qmix_atten_group_matching (FF agent + linear mixer, no imagination), tanh/abs mixing, the 48-entity MMM shape,
+    150-step episodes, vdn_atten."""
+    from refil_amd.synthetic import make_batch_fast, sc2_shape_law
+    kw = dict(B=3, T=6, ne=16, seed=9)
+    cfgkw = {}
+    if what == "ff_lin_noimagine":
+        cfgkw = dict(agent_ff=True, mixer_lin=True, imagine=False)
+    elif what == "tanh_abs":
+        cfgkw = dict(mixer_non_lin="tanh", softmax_mixing_weights=False)
+    elif what == "ne48_cfg5":
+        kw = dict(B=2, T=4, ne=48, seed=10)
+    elif what == "long_T150":
+        kw = dict(B=2, T=150, ne=16, seed=11)
+    elif what == "vdn_atten":
+        cfgkw = dict(mixer_vdn=True, imagine=False)
+    law = sc2_shape_law(kw["ne"])
+    cfg = orc.Cfg(n_agents=law["n_agents"], n_entities=kw["ne"], n_actions=law["n_actions"], entity_shape=law["entity_shape"],
+                  attn_embed_dim=64, attn_n_heads=4, hypernet_embed=64, **cfgkw)
+    batch = make_batch_fast(kw["B"], kw["T"], kw["ne"], seed=kw["seed"])
+    agent = orc.init_params(orc.agent_param_shapes(cfg), 21)
+    mixer = orc.init_params(orc.mixer_param_shapes(cfg), 22)
+    tagent = orc.init_params(orc.agent_param_shapes(cfg), 23)
+    tmixer = orc.init_params(orc.mixer_param_shapes(cfg), 24)
+    torch.manual_seed(kw["seed"])
+    bits = orc.draw_partition_bits(kw["B"], kw["ne"])
+    r = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer)
+    a2, m2 = dict(agent), dict(mixer)
+    out, grads, gnorm = orc.train_step(cfg, a2, m2, tagent, tmixer, batch, bits)
+    o, st = r["out"], r["stats"]
+    assert rel_err(o["chosen_q"], out.chosen_q.detach()) < TOL_FWD
+    assert rel_err(o["q_tot"], out.q_tot.detach()[..., 0]) < TOL_FWD
+    msum = st[0].item()
+    assert abs(st[1].item() / msum - out.q_loss.item()) < TOL_FWD * out.q_loss.item()
+    assert abs(r["grad_norm"] - gnorm) < TOL_GRAD * gnorm
+    gmax = max(v.abs().max().item() for v in grads.values())
+    for k, ref in grads.items():
+        assert (r["grads"][k] / msum - ref).abs().max().item() < TOL_GRAD * gmax, k

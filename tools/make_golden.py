@@ -54,7 +54,7 @@ class _Logger:
 def ref_args(case):
     a = types.SimpleNamespace(
         agent="imagine_entity_attend_rnn" if case["imagine"] else "entity_attend_rnn",
-        mac="entity_mac", learner="q_learner", mixer="flex_qmix", agent_output_type="q",
+        mac="entity_mac", learner="q_learner", mixer=case.get("mixer", "flex_qmix"), agent_output_type="q",
         action_selector="epsilon_greedy", epsilon_start=1.0, epsilon_finish=0.05, epsilon_anneal_time=500000,
         n_agents=case["na"], n_actions=case["A"], n_entities=case["ne"], entity_shape=case["ed"],
         entity_scheme=True, entity_last_action=case.get("entity_last_action", True), gt_mask_avail=False,
@@ -323,6 +323,8 @@ CASES = {
     "refil_odd": dict(imagine=True, B=2, T=3, ne=7, na=5, A=4, ed=10, d=24, heads=3, H=64, h=12, M=16, seed=14,
                       entity_last_action=False, double_q=False, lmbda=0.3),
     # mid-size, SC2 shape law (cfg-2-like entity sizes); weights stored, grads as per-tensor norms only
+    # refil_vdn.yaml: imagine agent + parameter-free VDN mixer
+    "refil_vdn_tiny": dict(imagine=True, B=3, T=4, ne=6, na=3, A=5, ed=9, d=16, heads=4, H=64, h=16, M=32, seed=16, mixer="vdn"),
     "refil_mid": dict(imagine=True, B=4, T=12, ne=16, na=8, A=14, ed=38, d=64, heads=4, H=64, h=64, M=32, seed=15,
                       store_grads=False, min_active=3, death_p=0.02),
 }
