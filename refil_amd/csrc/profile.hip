@@ -33,6 +33,7 @@ using namespace refil;
 
 extern "C" int refil_profile_enable(int on) {
     for (auto& r : g_recs) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    (void)hipGetLastError();      // never leave a sticky error behind for the next launch check
     g_recs.clear();
     g_on = on != 0;
     return 0;
@@ -44,7 +45,7 @@ extern "C" int refil_profile_collect(refil_profile_entry* out, int max_entries) 
     std::map<std::string, refil_profile_entry> agg;
     for (auto& r : g_recs) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { (void)hipGetLastError(); continue; }
         auto& e = agg[r.name];
         if (e.launches == 0) { memset(&e, 0, sizeof(e)); strncpy(e.name, r.name, sizeof(e.name) - 1); }
         e.launches += 1; e.total_ms += ms; e.flops += r.flops; e.bytes += r.bytes;

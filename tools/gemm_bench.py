@@ -11,7 +11,7 @@ import hip_ops
 from refil_amd._lib import GEMM_A_OUTC, GEMM_B_OUTC, GEMM_RELU
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-ABL = 0
+
 dev = "cuda"
 NE, NA = 82944, 41472
 
@@ -35,7 +35,7 @@ def nt(M, N, K, batch=1, relu=False, bias=True):
     W = torch.randn(batch, N, K, device=dev) / K ** 0.5
     b = torch.randn(batch, N, device=dev) if bias else None
     y = torch.empty(batch, M, N, device=dev)
-    fn = lambda: hip_ops.gemm(x, W, y, M, N, K, K * batch, K, N, flags=(GEMM_RELU if relu else 0) | ABL, bias=b, batch=batch, sA=K,
+    fn = lambda: hip_ops.gemm(x, W, y, M, N, K, K * batch, K, N, flags=(GEMM_RELU if relu else 0), bias=b, batch=batch, sA=K,
                               sB=N * K, sC=M * N, sBias=N)
     timeit(f"NT M={M} N={N} K={K} b={batch}", fn, 2.0 * M * N * K * batch)
 
@@ -44,7 +44,7 @@ def dx(M, N, K, batch=1):
     dy = torch.randn(batch, M, N, device=dev)
     W = torch.randn(batch, N, K, device=dev)
     o = torch.empty(M, K * batch, device=dev)
-    fn = lambda: hip_ops.gemm(dy, W, o, M, K, N, N, K, K * batch, flags=GEMM_B_OUTC | ABL, batch=batch, sA=M * N, sB=N * K, sC=K)
+    fn = lambda: hip_ops.gemm(dy, W, o, M, K, N, N, K, K * batch, flags=GEMM_B_OUTC, batch=batch, sA=M * N, sB=N * K, sC=K)
     timeit(f"dX M={M} N={N} K={K} b={batch}", fn, 2.0 * M * N * K * batch)
 
 
