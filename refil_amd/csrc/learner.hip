@@ -257,7 +257,8 @@ static int side_stream(SideStream*& out) {
     if (!sd.ok) {
         int lo = 0, hi = 0;
         REFIL_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        REFIL_HIP(hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, hi));   // latency-bound chain: high priority
+        const char* pe = getenv("REFIL_SIDE_PRIO");          // experiment knob: 0 = default priority
+        REFIL_HIP(hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, (pe && pe[0] == '0') ? 0 : hi));   // latency-bound chain: high priority
         for (auto& e : sd.ev) REFIL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         sd.ok = true;
     }
@@ -563,15 +564,24 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
 
     // ---------------- forward ----------------
     RUN(run_prep(c, 1));
-    Ctx ca = c;                       // agent chain context (side stream + its own split-K scratch)
+    // The hypernet chain is the longer one, so IT goes to the side stream and is enqueued first: whichever
+    // chain the host enqueues second starts several hundred microseconds late (the host needs that long to
+    // push the ~40 launches of the first chain), and the agent chain has that much slack.
+    Ctx ca = c;                       // agent chain: caller's stream
+    Ctx ch = c;                       // hypernet chain: side stream + its own split-K scratch
     SideStream* sd = nullptr;
     const bool overlap = overlap_enabled();
     if (overlap) {
         RUN(side_stream(sd));
-        ca.st = sd->s; ca.w.partial = w.partial2;
+        ch.st = sd->s; ch.w.partial = w.partial2;
         REFIL_HIP(hipEventRecord(sd->ev[0], c.st));
         REFIL_HIP(hipStreamWaitEvent(sd->s, sd->ev[0], 0));
     }
+    if (!d.mixer_vdn) {
+        RUN(hyper_forward(ch, params_live, w.lh, nv0));                           // live mixer hypernets
+        RUN(hyper_forward(ch, params_target, w.th, 1));                           // target mixer hypernets
+    }
+    if (overlap) REFIL_HIP(hipEventRecord(sd->ev[1], sd->s));
     RUN(agent_forward(ca, params_live, w.la, G, nullptr));                        // q_learner.py:86-89 / 107
     RUN(agent_forward(ca, params_target, w.ta, 1, nullptr));                      // :111-113
     {
@@ -581,12 +591,7 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
         q.chosen = w.chosen; q.tmax = w.tmax; q.G = G; q.B = d.B; q.T1 = d.T1; q.na = d.na; q.A = d.A; q.double_q = d.double_q;
         RUN(qselect_launch(q, ca.st));                                            // :91-96,115-128
     }
-    if (overlap) REFIL_HIP(hipEventRecord(sd->ev[1], sd->s));
-    if (!d.mixer_vdn) {
-        RUN(hyper_forward(c, params_live, w.lh, nv0));                            // live mixer hypernets
-        RUN(hyper_forward(c, params_target, w.th, 1));                            // target mixer hypernets
-    }
-    if (overlap) REFIL_HIP(hipStreamWaitEvent(c.st, sd->ev[1], 0));               // join: mixing needs the agents' Q
+    if (overlap) REFIL_HIP(hipStreamWaitEvent(c.st, sd->ev[1], 0));               // join: mixing needs the hypernet outputs
     MixArgs ml = mix_args(c, w.lh, nv0, w.chosen, G, 0, T);
     ml.q_tot = w.q_tot; ml.q_tot_im = w.q_tot_im;
     ml.ingroup_rows = (d.mixer_lin && d.imagine) ? w.ingroup : nullptr;
@@ -633,7 +638,43 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
         REFIL_HIP(hipEventRecord(sd->ev[2], c.st));
         REFIL_HIP(hipStreamWaitEvent(sd->s, sd->ev[2], 0));
     }
-    // (the agent chain is enqueued first: it is the latency-bound one and runs on the side stream)
+    // (the hypernet chain -- the critical path -- is enqueued first, on the side stream)
+    if (!d.mixer_vdn) {
+    // hypernet tails: fc2 (flex_qmix.py:49)
+    for (int part = 0; part < 2; ++part) {
+        const long rows = part == 0 ? nv0 * s.NA : s.NA;
+        const int batch = part == 0 ? 1 : s.nets - 1;
+        const long voff = part == 0 ? 0 : nv0;
+        const int net0 = part == 0 ? 0 : 1;
+        refil_gemm_desc gw = linear_dw(w.dx3h + voff * s.NA * M, M, w.lh.x2 + voff * s.NA * h, h,
+                                       grads + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h,
+                                       grads + L.mix_fc2_b + net0 * L.mix_fc2_b_stride, rows, M, h, ch.w.partial, batch);
+        gw.sA = s.NA * M; gw.sB = s.NA * h; gw.sC = L.mix_fc2_w_stride; gw.sColsum = L.mix_fc2_b_stride;
+        RUN(gemm_launch(gw, ch.st));
+        refil_gemm_desc gx = linear_dx(w.dx3h + voff * s.NA * M, M, params_live + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h,
+                                       w.dx2h + voff * s.NA * h, h, rows, M, h, 0);
+        gx.batch = batch; gx.sA = s.NA * M; gx.sB = L.mix_fc2_w_stride; gx.sC = s.NA * h;
+        gx.rowmask = w.amask; gx.rowmask_mod = (int)s.NA;
+        RUN(gemm_launch(gx, ch.st));
+    }
+    {
+        AttnBlockBwd k;
+        k.w = h; k.nets = s.nets; k.nv0 = nv0; k.P = params_live; k.Gr = grads;
+        k.in_w = L.mix_in_w; k.in_w_stride = L.mix_in_w_stride; k.out_w = L.mix_out_w; k.out_w_stride = L.mix_out_w_stride;
+        k.out_b = L.mix_out_b; k.out_b_stride = L.mix_out_b_stride;
+        k.x1 = w.lh.x1; k.kv = w.lh.kv; k.q = w.lh.q; k.ao = w.lh.ao; k.dx2 = w.dx2h;
+        k.dao = w.daoh; k.dq = w.dqh; k.dkv = w.dkvh; k.dx1 = w.dx1h;
+        k.var_first[0] = REFIL_MASK_ENTITY;
+        k.var_first[1] = d.gt_factors ? REFIL_MASK_GTW : REFIL_MASK_WITHIN;
+        k.var_first[2] = d.gt_factors ? REFIL_MASK_GTI : REFIL_MASK_INTERACT;
+        k.var_rest = REFIL_MASK_ENTITY;
+        RUN(attn_block_backward(ch, k));
+        // the four hypernet fc1 layers: dW = dx1^T xe (one [4h,E] GEMM), db = colsum(dx1)
+        refil_gemm_desc g = linear_dw(w.dx1h, s.nets * h, w.xe, s.Ep, grads + L.mix_fc1_w, s.E, grads + L.mix_fc1_b, s.NE, s.nets * h, s.E,
+                                      ch.w.partial, 1);
+        RUN(gemm_launch(g, ch.st));
+    }
+    }
     // agent: chosen-Q gather + inactive-agent fill, then fc3
     {
         QSelBwdArgs q;
@@ -683,42 +724,6 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
         k.var_rest = REFIL_MASK_OBS;
         RUN(attn_block_backward(ca, k));
         RUN(gemm_launch(linear_dw(w.dx1a, dd, w.xe, s.Ep, grads + L.ag_fc1_w, s.E, grads + L.ag_fc1_b, s.NE, dd, s.E, ca.w.partial, 1), ca.st));
-    }
-    if (!d.mixer_vdn) {
-    // hypernet tails: fc2 (flex_qmix.py:49)
-    for (int part = 0; part < 2; ++part) {
-        const long rows = part == 0 ? nv0 * s.NA : s.NA;
-        const int batch = part == 0 ? 1 : s.nets - 1;
-        const long voff = part == 0 ? 0 : nv0;
-        const int net0 = part == 0 ? 0 : 1;
-        refil_gemm_desc gw = linear_dw(w.dx3h + voff * s.NA * M, M, w.lh.x2 + voff * s.NA * h, h,
-                                       grads + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h,
-                                       grads + L.mix_fc2_b + net0 * L.mix_fc2_b_stride, rows, M, h, w.partial, batch);
-        gw.sA = s.NA * M; gw.sB = s.NA * h; gw.sC = L.mix_fc2_w_stride; gw.sColsum = L.mix_fc2_b_stride;
-        RUN(gemm_launch(gw, c.st));
-        refil_gemm_desc gx = linear_dx(w.dx3h + voff * s.NA * M, M, params_live + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h,
-                                       w.dx2h + voff * s.NA * h, h, rows, M, h, 0);
-        gx.batch = batch; gx.sA = s.NA * M; gx.sB = L.mix_fc2_w_stride; gx.sC = s.NA * h;
-        gx.rowmask = w.amask; gx.rowmask_mod = (int)s.NA;
-        RUN(gemm_launch(gx, c.st));
-    }
-    {
-        AttnBlockBwd k;
-        k.w = h; k.nets = s.nets; k.nv0 = nv0; k.P = params_live; k.Gr = grads;
-        k.in_w = L.mix_in_w; k.in_w_stride = L.mix_in_w_stride; k.out_w = L.mix_out_w; k.out_w_stride = L.mix_out_w_stride;
-        k.out_b = L.mix_out_b; k.out_b_stride = L.mix_out_b_stride;
-        k.x1 = w.lh.x1; k.kv = w.lh.kv; k.q = w.lh.q; k.ao = w.lh.ao; k.dx2 = w.dx2h;
-        k.dao = w.daoh; k.dq = w.dqh; k.dkv = w.dkvh; k.dx1 = w.dx1h;
-        k.var_first[0] = REFIL_MASK_ENTITY;
-        k.var_first[1] = d.gt_factors ? REFIL_MASK_GTW : REFIL_MASK_WITHIN;
-        k.var_first[2] = d.gt_factors ? REFIL_MASK_GTI : REFIL_MASK_INTERACT;
-        k.var_rest = REFIL_MASK_ENTITY;
-        RUN(attn_block_backward(c, k));
-        // the four hypernet fc1 layers: dW = dx1^T xe (one [4h,E] GEMM), db = colsum(dx1)
-        refil_gemm_desc g = linear_dw(w.dx1h, s.nets * h, w.xe, s.Ep, grads + L.mix_fc1_w, s.E, grads + L.mix_fc1_b, s.NE, s.nets * h, s.E,
-                                      w.partial, 1);
-        RUN(gemm_launch(g, c.st));
-    }
     }
     if (overlap) {                                                                 // join
         REFIL_HIP(hipEventRecord(sd->ev[3], sd->s));
