@@ -198,10 +198,16 @@ __device__ inline float nonlin_grad(float pre, float hid, int tanh_nl) {
     return tanh_nl ? 1.0f - hid * hid : (pre > 0.f ? 1.0f : expf(pre));
 }
 
-__device__ inline MixRow mix_row_forward(const MixArgs& a, long base, long qbase, long BTn, int m, bool act) {
-    MixRow o;
+// MIXW waves cooperate on one (b,t): wave w takes agents w, w+MIXW, ... (the per-agent softmax over the M
+// lanes is a chain of dependent cross-lane reductions -- 48 of them per row at na=16 with 3 mask variants --
+// so splitting the agents over 4 waves cuts the serial chain 4x; these kernels sit at the join point of the
+// two streams, i.e. directly on the critical path). Partial sums are combined through LDS.
+constexpr int MIXW = 4;
+
+__device__ inline MixRow mix_row_forward(const MixArgs& a, long base, long qbase, int m, bool act, int wave,
+                                         float (*red)[5][64]) {
     float acc_r = 0.f, acc_i = 0.f, b1 = 0.f, wfr = 0.f, vs = 0.f;
-    for (int i = 0; i < a.na; ++i) {
+    for (int i = wave; i < a.na; i += MIXW) {
         const long o_im = base + (long)i * a.M + m;
         const float x0 = act ? a.x_w1[o_im] : 0.f;
         acc_r = fmaf(a.qs[qbase + i], mix_weight(x0, act, a.softmax_w), acc_r);
@@ -213,6 +219,14 @@ __device__ inline MixRow mix_row_forward(const MixArgs& a, long base, long qbase
         }
         if (act) { b1 += a.x_b1[o_im]; wfr += a.x_wf[o_im]; vs += a.x_v[o_im]; }
     }
+    red[wave][0][m] = acc_r; red[wave][1][m] = acc_i; red[wave][2][m] = b1; red[wave][3][m] = wfr; red[wave][4][m] = vs;
+    __syncthreads();
+    acc_r = acc_i = b1 = wfr = vs = 0.f;
+#pragma unroll
+    for (int w = 0; w < MIXW; ++w) {
+        acc_r += red[w][0][m]; acc_i += red[w][1][m]; b1 += red[w][2][m]; wfr += red[w][3][m]; vs += red[w][4][m];
+    }
+    MixRow o;
     o.b1 = b1 / (float)a.na;
     o.wf_raw = wfr / (float)a.na;
     o.wf = mix_weight(o.wf_raw, act, a.softmax_w);
@@ -224,16 +238,17 @@ __device__ inline MixRow mix_row_forward(const MixArgs& a, long base, long qbase
     return o;
 }
 
-__global__ __launch_bounds__(64) void mix_fwd_kernel(MixArgs a) {
+__global__ __launch_bounds__(64 * MIXW) void mix_fwd_kernel(MixArgs a) {
+    __shared__ float red[MIXW][5][64];
     const int bt = blockIdx.x;
     const int b = bt / a.T, t = bt % a.T;
-    const int m = threadIdx.x;
+    const int m = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool act = m < a.M;
     const long rr = (long)b * a.T1 + t + a.t_off;
     const long base = rr * a.na * a.M;
     const long qbase = (long)bt * a.na;
-    const long BTn = (long)a.B * a.T * a.na;
-    const MixRow o = mix_row_forward(a, base, qbase, BTn, m, act);
+    const MixRow o = mix_row_forward(a, base, qbase, m, act, wave, red);
+    if (wave != 0) return;
     const float qt = wave_sum(act ? o.hid_r * o.wf : 0.f) + o.v;
     if (m == 0) a.q_tot[bt] = qt;
     if (a.imagine) {
@@ -244,18 +259,19 @@ __global__ __launch_bounds__(64) void mix_fwd_kernel(MixArgs a) {
 
 __device__ inline float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 
-__global__ __launch_bounds__(64) void mix_bwd_kernel(MixArgs a) {
+__global__ __launch_bounds__(64 * MIXW) void mix_bwd_kernel(MixArgs a) {
     // grid = B*T1 rows of the R space: rows outside [t_off, t_off+T) get zero gradients
+    __shared__ float red[MIXW][5][64];
     const int r = blockIdx.x;
     const int b = r / a.T1, tt = r % a.T1;
-    const int m = threadIdx.x;
+    const int m = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool act = m < a.M;
     const long base = (long)r * a.na * a.M;
     const int t = tt - a.t_off;
     const int nvar = a.imagine ? 3 : 1;
     if (t < 0 || t >= a.T) {
         if (act) {
-            for (int i = 0; i < a.na; ++i) {
+            for (int i = wave; i < a.na; i += MIXW) {
                 const long o = base + (long)i * a.M + m;
                 for (int v = 0; v < nvar; ++v) a.dx_w1[v * a.s_var + o] = 0.f;
                 a.dx_wf[o] = 0.f; a.dx_b1[o] = 0.f; a.dx_v[o] = 0.f;
@@ -266,7 +282,7 @@ __global__ __launch_bounds__(64) void mix_bwd_kernel(MixArgs a) {
     const int bt = b * a.T + t;
     const long qbase = (long)bt * a.na;
     const long BTn = (long)a.B * a.T * a.na;
-    const MixRow o = mix_row_forward(a, base, qbase, BTn, m, act);
+    const MixRow o = mix_row_forward(a, base, qbase, m, act, wave, red);
     const float g_r = a.gc_real[bt];
     const float g_i = a.imagine ? a.gc_im[bt] : 0.f;
     // q_tot = sum_m hid*wf + v
@@ -283,7 +299,7 @@ __global__ __launch_bounds__(64) void mix_bwd_kernel(MixArgs a) {
     const float dpre_r = g_r * o.wf * nonlin_grad(o.pre_r, o.hid_r, a.tanh_nl);
     const float dpre_i = g_i * o.wf * nonlin_grad(o.pre_i, o.hid_i, a.tanh_nl);
     const float db1 = (dpre_r + dpre_i) / (float)a.na;
-    for (int i = 0; i < a.na; ++i) {
+    for (int i = wave; i < a.na; i += MIXW) {
         const long oo = base + (long)i * a.M + m;
         const bool dead = a.amask[(long)r * a.na + i];
         for (int v = 0; v < nvar; ++v) {
@@ -291,16 +307,10 @@ __global__ __launch_bounds__(64) void mix_bwd_kernel(MixArgs a) {
             const float w = mix_weight(x, act, a.softmax_w);
             const float dpre = v == 0 ? dpre_r : dpre_i;
             const float q = a.qs[v * a.s_qs_g + qbase + i];
-            const float dq = wave_sum(act ? dpre * w : 0.f);
+            const float dq = wave_sum(act ? dpre * w : 0.f);          // = sum_m w dw / q : also the softmax-backward dot
             if (m == 0) a.dqs[(long)v * BTn + qbase + i] = dq;
             const float dw = q * dpre;
-            float dx;
-            if (a.softmax_w) {
-                const float dot = wave_sum(act ? w * dw : 0.f);
-                dx = w * (dw - dot);
-            } else {
-                dx = sgn(x) * dw;
-            }
+            const float dx = a.softmax_w ? w * (dw - q * dq) : sgn(x) * dw;
             if (act) a.dx_w1[v * a.s_var + oo] = dead ? 0.f : dx;
         }
         if (act) {
@@ -449,7 +459,7 @@ int mix_forward_launch(const MixArgs& a, hipStream_t st) {
     }
     ProfScope prof_mix_fwd_kernel(a.lin ? "mix_lin_fwd_kernel" : "mix_fwd_kernel", 0.0, 0.0, st);
     if (a.lin) hipLaunchKernelGGL(mix_lin_fwd_kernel, dim3(a.B * a.T), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(mix_fwd_kernel, dim3(a.B * a.T), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(mix_fwd_kernel, dim3(a.B * a.T), dim3(64 * MIXW), 0, st, a);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
@@ -463,7 +473,7 @@ int mix_backward_launch(const MixArgs& a, hipStream_t st) {
     }
     ProfScope prof_mix_bwd_kernel(a.lin ? "mix_lin_bwd_kernel" : "mix_bwd_kernel", 0.0, 0.0, st);
     if (a.lin) hipLaunchKernelGGL(mix_lin_bwd_kernel, dim3(a.B * a.T1), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL(mix_bwd_kernel, dim3(a.B * a.T1), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(mix_bwd_kernel, dim3(a.B * a.T1), dim3(64 * MIXW), 0, st, a);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
