@@ -1,0 +1,79 @@
+"""Data-parallel learner step on the GPU path: two processes (sharing the one GPU of the test box, gloo
+backend so that both ranks may use device 0) each train on half of the episodes through the plugin surface;
+after the all-reduce their parameters must equal a single process training on the whole batch
+(global-mean loss, q_learner.py:165). The driver's multi-GPU bench uses the same code with backend nccl."""
+import os
+import socket
+
+import pytest
+import torch as th
+import torch.distributed as dist
+import multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _train(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from golden_util import load
+    from plugin_util import RecLogger, make_args, make_episode_batch
+    from refil_amd import dp
+    from refil_amd.controllers import REGISTRY as mac_REGISTRY
+    from refil_amd.learners import REGISTRY as le_REGISTRY
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = load("refil_abs_masked")
+    cfg = g["cfg"]
+    args = make_args(cfg)
+    data, bits = g["batch"], g["bits"]
+    if world > 1:
+        data = {k: v.contiguous() for k, v in dp.shard_episodes(data, rank, world).items()}
+        bits = dp.shard_bits(bits, rank, world)
+    batch, groups = make_episode_batch(cfg, data)
+    mac = mac_REGISTRY[args.mac](batch.scheme, groups, args)
+    learner = le_REGISTRY[args.learner](mac, batch.scheme, RecLogger(), args)
+    learner.cuda()
+    batch.to("cuda")
+    z = g["z"]
+    mac.agent.load_state_dict({k[len("agent0."):]: th.from_numpy(z[k]) for k in z.files if k.startswith("agent0.")})
+    learner.mixer.load_state_dict({k[len("mixer0."):]: th.from_numpy(z[k]) for k in z.files if k.startswith("mixer0.")})
+    learner.target_mac.agent.load_state_dict({k[len("tagent."):]: th.from_numpy(z[k]) for k in z.files if k.startswith("tagent.")})
+    learner.target_mixer.load_state_dict({k[len("tmixer."):]: th.from_numpy(z[k]) for k in z.files if k.startswith("tmixer.")})
+    learner.train(batch, 0, 0, group_bits=bits)
+    th.cuda.synchronize()
+    q.put((rank, learner.flat_live.cpu().numpy(), dict(learner.logger.stats)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict((r, (f, s)) for r, f, s in (q.get(timeout=280) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return out
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_step_equals_single_process_step():
+    one = _run(1)[0]
+    two = _run(2)
+    assert (two[0][0] == two[1][0]).all(), "replicas diverged"
+    assert abs(two[0][0] - one[0]).max() < 2e-6
+    for k in ("loss", "grad_norm", "td_error_abs"):
+        assert abs(two[0][1][k] - one[1][k]) < 1e-4 * max(abs(one[1][k]), 1e-3), k
