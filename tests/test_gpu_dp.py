@@ -77,3 +77,23 @@ def test_two_rank_step_equals_single_process_step():
     assert abs(two[0][0] - one[0]).max() < 2e-6
     for k in ("loss", "grad_norm", "td_error_abs"):
         assert abs(two[0][1][k] - one[1][k]) < 1e-4 * max(abs(one[1][k]), 1e-3), k
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_control_flow():
+    """bench.py under torch.distributed.run with 2 ranks (sharing the one GPU over gloo): every pass that calls
+    train() must run on every rank (train all-reduces), and rank 0 prints one JSON line for the whole job."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, REFIL_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 64
+    assert out["roofline"]["frac"] > 0 and out["value"] > 0
