@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="serialise the two chains on one stream for the whole run "
+                    "(kernel-quality profiling: in-situ == isolated); the default overlaps them")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -188,6 +190,9 @@ def main():
     B, T = W["B"], W["T"]
     args, batch, learner, data = build(dims, B, T, seed=100 + rank, device=device)
 
+    if a.serial:
+        _lib.lib().refil_set_overlap(0)
+
     def step(i):
         learner.train(batch, t_env=0, episode_num=i)
 
@@ -205,19 +210,15 @@ def main():
     host_enqueue = time.perf_counter() - t0          # host time to enqueue K steps (no sync inside)
     barrier()
     elapsed = time.perf_counter() - t0
-    clocked = not a.no_profile       # every rank runs the extra passes (train() all-reduces); rank 0 reports
-    ents, ms_clocked = [], None
-    if clocked:
-        # the same K steps again with the device-clock kernel spans on (one atomic per workgroup, no host sync,
-        # both streams overlapping as in the timed region; costs ~2%, which is why it is not the timed region)
-        _lib.profile_enable(2)
-        t1 = time.perf_counter()
-        for i in range(a.steps):
+    profiled = not a.no_profile       # every rank runs the extra passes (train() all-reduces); rank 0 reports
+    ents, nprof = [], max(3, min(a.steps, 10))
+    if profiled:
+        # HIP events around every launch, both streams overlapping as in the timed region (in situ)
+        _lib.profile_enable(True)
+        for i in range(nprof):
             step(a.warmup + a.steps + i)
-        torch.cuda.synchronize()
-        ms_clocked = (time.perf_counter() - t1) / a.steps * 1e3
         ents = _lib.profile_collect()
-        _lib.profile_enable(0)
+        _lib.profile_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -229,32 +230,30 @@ def main():
     flops_step = algorithmic_flops(B, T, dims["ne"], dims["na"], E, dims["A"], dims["d"], dims["h"], dims["H"], dims["M"], 3)
     roofline = None
     kernels = None
-    if clocked:
-        ents = [e for e in ents if e["clock_launches"] > 0]
-        ents.sort(key=lambda e: -e["clock_ms"])
-        tot = sum(e["clock_ms"] for e in ents)
-        # second pass, streams serialised + HIP events around every launch: each kernel alone on the GPU
-        # (kernel quality; also times the small kernels that carry no device clock)
-        niso = max(3, min(a.steps, 10))
+    if profiled:
+        ents.sort(key=lambda e: -e["total_ms"])
+        tot = sum(e["total_ms"] for e in ents)
+        # second pass with the two streams serialised: every kernel alone on the GPU (kernel quality). These
+        # are the durations rocprofv3 --kernel-trace reports for the same steps (and for a whole `--serial` run)
         _lib.lib().refil_set_overlap(0)
-        _lib.profile_enable(1)
-        for i in range(niso):
-            step(a.warmup + 2 * a.steps + i)
+        _lib.profile_enable(True)
+        for i in range(nprof):
+            step(a.warmup + a.steps + nprof + i)
         iso = {e["name"]: e for e in _lib.profile_collect()}
-        _lib.profile_enable(0)
-        _lib.lib().refil_set_overlap(-1)
+        _lib.profile_enable(False)
+        _lib.lib().refil_set_overlap(0 if a.serial else -1)
         kernels = []
         for e in ents[:8]:
-            k = {"name": e["name"], "launches_per_step": e["launches"] // a.steps,
-                 "ms_per_step": round(e["clock_ms"] / a.steps, 4), "avg_us": round(1e3 * e["clock_ms"] / e["clock_launches"], 2),
-                 "tflops": round(e["flops"] / (e["clock_ms"] * 1e-3) / 1e12, 2) if e["flops"] > 0 else None}
+            k = {"name": e["name"], "launches_per_step": e["launches"] // nprof, "ms_per_step": round(e["total_ms"] / nprof, 4),
+                 "avg_us": round(1e3 * e["total_ms"] / e["launches"], 2),
+                 "tflops": round(e["flops"] / (e["total_ms"] * 1e-3) / 1e12, 2) if e["flops"] > 0 else None}
             x = iso.get(e["name"])
-            if x and x["event_launches"] > 0:
-                k["avg_us_isolated"] = round(1e3 * x["total_ms"] / x["event_launches"], 2)
+            if x:
+                k["avg_us_isolated"] = round(1e3 * x["total_ms"] / x["launches"], 2)
                 if x["flops"] > 0:
                     k["tflops_isolated"] = round(x["flops"] / (x["total_ms"] * 1e-3) / 1e12, 2)
             kernels.append(k)
-        iso_total = sum(x["total_ms"] for x in iso.values()) / niso
+        iso_total = sum(x["total_ms"] for x in iso.values()) / nprof
         dom = ents[0]
         traffic = None          # HBM bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 runs)
         try:
@@ -262,26 +261,28 @@ def main():
             traffic = pmc.get(dom["name"], {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-        ach = dom["flops"] / (dom["clock_ms"] * 1e-3) / 1e12
+        ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
         roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes/launch (PMC 2*FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.json)",
                     "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                     "achieved_isolated": kernels[0].get("tflops_isolated"),
                     "frac_isolated": round((kernels[0].get("tflops_isolated") or 0.0) / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "launches_per_step": dom["launches"] // a.steps,
-                    "avg_launch_us": round(1e3 * dom["clock_ms"] / dom["clock_launches"], 2),
+                    "launches_per_step": dom["launches"] // nprof,
+                    "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
+                    "avg_launch_us_isolated": kernels[0].get("avg_us_isolated"),
                     "flops_per_launch": dom["flops"] / dom["launches"],
-                    "share_of_clocked_kernel_time": round(dom["clock_ms"] / tot, 3),
-                    "clocked_kernel_ms_per_step": round(tot / a.steps, 3),
-                    "isolated_gpu_ms_per_step_all_kernels": round(iso_total, 3),
+                    "share_of_gpu_time": round(dom["total_ms"] / tot, 3),
+                    "gpu_ms_per_step_all_kernels": round(tot / nprof, 3),
+                    "gpu_ms_per_step_all_kernels_isolated": round(iso_total, 3),
                     "step_frac_of_mfma_roofline": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "ms_per_step_while_clocked": round(ms_clocked, 3),
-                    "measured": f"`achieved`/`avg_launch_us`: device-clock span of each launch (first workgroup start -> last "
-                                f"workgroup end, 100 MHz wall clock) over {a.steps} steps right after the timed region, agent and "
-                                "hypernet chains overlapping on two streams exactly as in the timed region (kernels share the "
-                                f"GPU); `*_isolated`: HIP events, {niso} more steps with the streams serialised (each kernel "
-                                "alone on the GPU; agrees with rocprofv3 --kernel-trace for those steps)"}
+                    "streams": "serialised (--serial)" if a.serial else "agent and hypernet chains overlap on two streams",
+                    "measured": f"HIP events on the launch streams, {nprof} steps right after the timed region. `achieved` / "
+                                "`avg_launch_us` are in situ: with the two chains overlapping a launch shares the GPU with the "
+                                "other stream's kernels (and the event markers themselves wait behind them), so this is a lower "
+                                f"bound on kernel quality. `*_isolated` repeats the {nprof} steps with the streams serialised: "
+                                "each kernel alone on the GPU, the duration rocprofv3 --kernel-trace reports for it "
+                                "(profiles/r01_rocprofv3_kernel_stats_serial.csv is the whole run under --serial)"}
     if world > 1:
         dist.barrier()
 

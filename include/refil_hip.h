@@ -275,27 +275,18 @@ typedef struct refil_gru_desc {
 int refil_gru_forward(const refil_gru_desc* desc, void* stream);
 int refil_gru_backward(const refil_gru_desc* desc, void* stream);
 
-/* Optional per-kernel timing, aggregated per kernel symbol; bench.py uses it for the roofline fraction.
- * mode 1: HIP events recorded on the launch stream around every kernel (exact when the stream has the GPU
- *         to itself; with the two-stream overlap they include the wait behind the other stream's kernels)
- *         + the device-clock spans of mode 2.
- * mode 2: device-clock spans only -- the GEMM, attention and GRU kernels write {first workgroup start, last
- *         workgroup end} on the 100 MHz wall clock: the kernel's own begin->end as rocprofv3 --kernel-trace
- *         reports it, cheap enough to stay on inside a timed region.
- * mode 0: off (default; one branch per launch).
+/* Optional per-kernel timing (HIP events recorded on the launch stream around every kernel the
+ * library launches, aggregated per kernel symbol). bench.py uses it for the roofline fraction.
  * refil_profile_collect synchronises the device and returns MINUS the number of entries written
- * (so 0 / positive values keep meaning "error code"). flops/bytes are ALGORITHMIC totals over `launches`. */
+ * (so 0 / positive values keep meaning "error code"). flops/bytes are ALGORITHMIC totals. */
 typedef struct refil_profile_entry {
     char name[96];          /* kernel symbol, e.g. "gemm_kernel<2,2,2,2,false,false>"             */
     int64_t launches;
-    double total_ms;        /* HIP-event time summed over event_launches                          */
+    double total_ms;
     double flops;
     double bytes;
-    int64_t event_launches;
-    double clock_ms;        /* device-clock span summed over clock_launches                       */
-    int64_t clock_launches;
 } refil_profile_entry;
-int refil_profile_enable(int mode);
+int refil_profile_enable(int on);
 int refil_profile_collect(refil_profile_entry* out, int max_entries);
 
 /* Two-stream overlap of the agent chain with the hypernet chain inside refil_learner_forward_backward:

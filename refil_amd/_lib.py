@@ -97,8 +97,7 @@ class GruDesc(C.Structure):
 
 class ProfileEntry(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
-                ("bytes", C.c_double), ("event_launches", C.c_int64), ("clock_ms", C.c_double),
-                ("clock_launches", C.c_int64)]
+                ("bytes", C.c_double)]
 
 
 # every symbol include/refil_hip.h declares (tests/test_abi.py checks the library exports them all)
@@ -153,20 +152,18 @@ def lib():
     return L
 
 
-def profile_enable(mode):
-    """0/False off, 1/True HIP events + device-clock spans, 2 device-clock spans only (include/refil_hip.h)."""
-    check(lib().refil_profile_enable(int(mode)), "refil_profile_enable")
+def profile_enable(on: bool):
+    check(lib().refil_profile_enable(int(on)), "refil_profile_enable")
 
 
 def profile_collect():
-    """[{name, launches, total_ms, flops, bytes, event_launches, clock_ms, clock_launches}] per kernel symbol."""
+    """[{name, launches, total_ms, flops, bytes}] aggregated per kernel symbol since profile_enable(True)."""
     buf = (ProfileEntry * 64)()
     n = lib().refil_profile_collect(buf, 64)
     if n > 0:
         check(n, "refil_profile_collect")
     return [dict(name=buf[i].name.decode(), launches=buf[i].launches, total_ms=buf[i].total_ms, flops=buf[i].flops,
-                 bytes=buf[i].bytes, event_launches=buf[i].event_launches, clock_ms=buf[i].clock_ms,
-                 clock_launches=buf[i].clock_launches) for i in range(-n)]
+                 bytes=buf[i].bytes) for i in range(-n)]
 
 
 def check(rc: int, what: str):

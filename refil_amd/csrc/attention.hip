@@ -333,7 +333,7 @@ int attn_forward_launch(const refil_attn_desc& d, hipStream_t st) {
     const double unit = (double)d.R * d.heads * d.na * d.ne * d.hd;
     ProfScope prof("attn_fwd_kernel", unit * (2.0 + 2.0 * d.nvar),
                    4.0 * d.R * d.heads * d.hd * (d.na * (1.0 + d.nvar) + 2.0 * d.ne), st);
-    REFIL_LAUNCH(attn_fwd_kernel, dim3(d.R, d.heads), dim3(ANT), smem, st, k);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(d.R, d.heads), dim3(ANT), smem, st, k);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
@@ -353,7 +353,7 @@ int attn_backward_launch(const refil_attn_desc& d, hipStream_t st) {
     const double unit = (double)d.R * d.heads * d.na * d.ne * d.hd;
     ProfScope prof("attn_bwd_kernel", unit * (2.0 + 8.0 * d.nvar),
                    4.0 * d.R * d.heads * d.hd * (d.na * (2.0 + d.nvar) + 4.0 * d.ne), st);
-    REFIL_LAUNCH(attn_bwd_kernel, dim3(d.R, d.heads), dim3(ANT), smem, st, k);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(d.R, d.heads), dim3(ANT), smem, st, k);
     REFIL_LAUNCH_CHECK();
     return 0;
 }

@@ -31,7 +31,6 @@ struct AttnM {
     const uint8_t* ent_mask; const uint8_t* ent_mask0; const uint8_t* group_bits;
     const uint8_t* gt_mask; long gt_sB, gt_sT;
     int wave_floats;   // LDS floats per wave region
-    unsigned long long* clk;   // profiler span slot or nullptr
 };
 
 struct MaskLds { const uint8_t *emt, *em0, *gb, *om, *gt; };
@@ -219,7 +218,6 @@ __device__ inline bool uses_obs_m(const AttnM& p) {
 // NJT/NAT/NCT: 16-tiles along keys / agents / head channels
 template <int NJT, int NAT, int NCT>
 __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
-    ClkScope clk_(p.clk);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
@@ -277,7 +275,6 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
 
 template <int NJT, int NAT, int NCT>
 __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
-    ClkScope clk_(p.clk);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
@@ -400,15 +397,13 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
 static inline int tiles16(int n) { return (n + 15) / 16; }
 
 template <int NJT, int NAT, int NCT>
-static int launch_pair(const AttnM& k0, bool bwd, size_t smem, hipStream_t st) {
-    AttnM k = k0;
-    k.clk = prof_clock_slot();
+static int launch_pair(const AttnM& k, bool bwd, size_t smem, hipStream_t st) {
     if (bwd) {
         if (smem > 64 * 1024) REFIL_HIP(hipFuncSetAttribute((const void*)attn_bwd_mfma<NJT, NAT, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        REFIL_LAUNCH((attn_bwd_mfma<NJT, NAT, NCT>), dim3(k.R), dim3(256), smem, st, k);
+        hipLaunchKernelGGL((attn_bwd_mfma<NJT, NAT, NCT>), dim3(k.R), dim3(256), smem, st, k);
     } else {
         if (smem > 64 * 1024) REFIL_HIP(hipFuncSetAttribute((const void*)attn_fwd_mfma<NJT, NAT, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        REFIL_LAUNCH((attn_fwd_mfma<NJT, NAT, NCT>), dim3(k.R), dim3(256), smem, st, k);
+        hipLaunchKernelGGL((attn_fwd_mfma<NJT, NAT, NCT>), dim3(k.R), dim3(256), smem, st, k);
     }
     REFIL_LAUNCH_CHECK();
     return 0;

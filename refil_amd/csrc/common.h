@@ -55,24 +55,4 @@ struct RowMap {
 
 __device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// Device-side kernel span for the profiler: first workgroup's start / last workgroup's end on the constant
-// 100 MHz wall clock (s_memrealtime). A slot is CLK_LINES cache lines of {min start, min ~end} so that the
-// one atomic per workgroup spreads over L2 channels (a single address caps at ~1 atomic/clk and would
-// stretch a 40k-workgroup launch by tens of us). clk == nullptr (always, unless refil_profile_enable)
-// costs one branch.
-constexpr int CLK_LINES = 16, CLK_LINE_U64 = 16;
-struct ClkScope {
-    unsigned long long* line;
-    __device__ explicit ClkScope(unsigned long long* clk) : line(nullptr) {
-        if (clk && threadIdx.x == 0) {
-            const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-            line = clk + (id % CLK_LINES) * CLK_LINE_U64;
-            if (id < 256) atomicMin(line, (unsigned long long)wall_clock64());   // dispatch is in order
-        }
-    }
-    __device__ ~ClkScope() {
-        if (line) atomicMin(line + 1, ~(unsigned long long)wall_clock64());
-    }
-};
-
 }  // namespace refil

@@ -33,7 +33,6 @@ struct GemmK {
     int rowmask_mod, batch, splits, flags;
     int vecA, vecB;   // 16-byte global loads legal for this operand
     int vecC;         // 16-byte stores (and aux / accumulate loads) legal for C
-    unsigned long long* clk;   // profiler span slot or nullptr
 };
 
 constexpr int BK = 32;
@@ -124,7 +123,6 @@ struct Tile {
 // VEC: both operands admit 16-byte global loads (compile-time so that the loads stay straight-line code).
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool A_OUTC, bool B_OUTC, int EPI, bool VEC>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N == 8 ? 4 : 3) void gemm_kernel(GemmK p) {
-    ClkScope clk_(p.clk);
     constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N, NT = 64 * WAVES_M * WAVES_N, NW = WAVES_M * WAVES_N;
     using TA = Tile<BM, A_OUTC, NT>;
     using TB = Tile<BN, B_OUTC, NT>;
@@ -291,7 +289,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N == 8 ? 4 
 // wave w adds splits w, w+16, ... (independent loads in flight), then a 16-way LDS reduction.
 constexpr int RED_WAVES = 16;
 __global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_kernel(GemmK p) {
-    ClkScope clk_(p.clk);
     __shared__ float red[RED_WAVES][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long MN = (long)p.M * p.N;
@@ -364,11 +361,9 @@ static const char* gemm_name(int wm, int tm, int tn, bool ao, bool bo) {
 }
 
 template <int WM, int WN, int TM, int TN, bool AO, bool BO, int EPI>
-static void launch_vec(const GemmK& k0, dim3 grid, hipStream_t st) {
-    GemmK k = k0;
-    k.clk = prof_clock_slot();
-    if (k.vecA && k.vecB) REFIL_LAUNCH((gemm_kernel<WM, WN, TM, TN, AO, BO, EPI, true>), grid, dim3(64 * WM * WN), 0, st, k);
-    else REFIL_LAUNCH((gemm_kernel<WM, WN, TM, TN, AO, BO, EPI, false>), grid, dim3(64 * WM * WN), 0, st, k);
+static void launch_vec(const GemmK& k, dim3 grid, hipStream_t st) {
+    if (k.vecA && k.vecB) hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, AO, BO, EPI, true>), grid, dim3(64 * WM * WN), 0, st, k);
+    else hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, AO, BO, EPI, false>), grid, dim3(64 * WM * WN), 0, st, k);
 }
 
 // Only the operand-layout x epilogue combinations the learner schedule uses are instantiated:
@@ -414,7 +409,6 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
         REFIL_CHECK(rows * (long)(d.splits > 1 ? d.N : d.ldc) < (1L << 32), "refil_gemm: C exceeds 2^32 elements per batch");
     }
     GemmK k;
-    k.clk = nullptr;
     k.A = d.A; k.B = d.B; k.C = d.C; k.bias = d.bias; k.aux = d.aux; k.rowmask = d.rowmask;
     k.colsum = d.colsum; k.partial = d.partial;
     k.M = d.M; k.N = d.N; k.K = d.K; k.lda = d.lda; k.ldb = d.ldb; k.ldc = d.ldc;
@@ -444,8 +438,7 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
         const long total = (long)d.batch * d.M * d.N;
         const int blocks = (int)min((long)2048, cdivl(total, 64) + cdivl((long)d.batch * d.M, 64));
         ProfScope prof("reduce_partials_kernel", 0.0, 4.0 * total * (d.splits + 1), st);
-        k.clk = prof_clock_slot();
-        REFIL_LAUNCH(reduce_partials_kernel, dim3(blocks), dim3(64 * RED_WAVES), 0, st, k);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(64 * RED_WAVES), 0, st, k);
         REFIL_LAUNCH_CHECK();
     }
     return 0;

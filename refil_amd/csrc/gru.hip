@@ -35,12 +35,10 @@ struct GruK {
     float* save_r; float* save_z; float* save_n; float* save_ghn;
     const float* dhs; float* dgi; float* dgh;
     int NR, T1, na;
-    unsigned long long* clk;   // profiler span slot or nullptr
 };
 
 template <bool SAVE>
 __global__ __launch_bounds__(256) void gru_fwd_kernel(GruK p) {
-    ClkScope clk_(p.clk);
     __shared__ float hbuf[2][GROWS * HP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, c16 = lane & 15;
@@ -127,7 +125,6 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruK p) {
 //   dr_pre = dr r (1-r);  dz_pre = dz z (1-z)
 //   dgi[t] = (dr_pre, dz_pre, dn_pre);  dgh[t] = (dr_pre, dz_pre, dgh_n);  carry' += dgh[t] W_hh
 __global__ __launch_bounds__(256) void gru_bwd_kernel(GruK p) {
-    ClkScope clk_(p.clk);
     __shared__ float gbuf[2][GROWS * GP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, c16 = lane & 15;
@@ -220,15 +217,14 @@ int gru_forward_launch(const refil_gru_desc& d, hipStream_t st) {
     REFIL_CHECK(d.H == GH, "refil_gru: rnn_hidden_dim must be %d (got %d)", GH, d.H);
     REFIL_CHECK(d.gi && d.hsx && d.w_hh && d.b_hh, "refil_gru_forward: null pointer");
     REFIL_CHECK(d.NR > 0 && d.T1 > 0 && d.na > 0, "refil_gru_forward: bad sizes");
-    GruK k{d.gi, d.hsx, d.w_hh, d.b_hh, d.save_r, d.save_z, d.save_n, d.save_ghn, d.dhs, d.dgi, d.dgh, d.NR, d.T1, d.na, nullptr};
+    GruK k{d.gi, d.hsx, d.w_hh, d.b_hh, d.save_r, d.save_z, d.save_n, d.save_ghn, d.dhs, d.dgi, d.dgh, d.NR, d.T1, d.na};
     const bool save = d.save_r != nullptr;
     REFIL_CHECK(!save || (d.save_z && d.save_n && d.save_ghn), "refil_gru_forward: all four save buffers or none");
     dim3 grid(cdiv(d.NR, GROWS));
     ProfScope prof(save ? "gru_fwd_kernel<true>" : "gru_fwd_kernel<false>", 2.0 * d.NR * d.T1 * GH * 3 * GH,
                    4.0 * d.NR * d.T1 * GH * (save ? 8.0 : 4.0), st);
-    k.clk = prof_clock_slot();
-    if (save) REFIL_LAUNCH(gru_fwd_kernel<true>, grid, dim3(256), 0, st, k);
-    else REFIL_LAUNCH(gru_fwd_kernel<false>, grid, dim3(256), 0, st, k);
+    if (save) hipLaunchKernelGGL(gru_fwd_kernel<true>, grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL(gru_fwd_kernel<false>, grid, dim3(256), 0, st, k);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
@@ -238,10 +234,9 @@ int gru_backward_launch(const refil_gru_desc& d, hipStream_t st) {
     REFIL_CHECK(d.hsx && d.w_hh && d.save_r && d.save_z && d.save_n && d.save_ghn && d.dhs && d.dgi && d.dgh,
                 "refil_gru_backward: null pointer");
     REFIL_CHECK(d.NR > 0 && d.T1 > 0 && d.na > 0, "refil_gru_backward: bad sizes");
-    GruK k{d.gi, d.hsx, d.w_hh, d.b_hh, d.save_r, d.save_z, d.save_n, d.save_ghn, d.dhs, d.dgi, d.dgh, d.NR, d.T1, d.na, nullptr};
+    GruK k{d.gi, d.hsx, d.w_hh, d.b_hh, d.save_r, d.save_z, d.save_n, d.save_ghn, d.dhs, d.dgi, d.dgh, d.NR, d.T1, d.na};
     ProfScope prof("gru_bwd_kernel", 2.0 * d.NR * d.T1 * GH * 3 * GH, 4.0 * d.NR * d.T1 * GH * 12.0, st);
-    k.clk = prof_clock_slot();
-    REFIL_LAUNCH(gru_bwd_kernel, dim3(cdiv(d.NR, GROWS)), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv(d.NR, GROWS)), dim3(256), 0, st, k);
     REFIL_LAUNCH_CHECK();
     return 0;
 }

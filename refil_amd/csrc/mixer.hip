@@ -62,7 +62,7 @@ int prep_launch(const PrepArgs& a, hipStream_t st) {
     const long total = (long)a.B * a.T1 * a.ne * a.Ep;
     const int blocks = (int)min((long)4096, cdivl(total, 256));
     ProfScope prof_prep_kernel("prep_kernel", 0.0, 0.0, st);
-    REFIL_LAUNCH(prep_kernel, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, st, a);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
@@ -77,7 +77,7 @@ __global__ void set_h0_kernel(float* hsx, const float* h0, int GB, int T1, int n
 int set_h0_launch(float* hsx, const float* h0, int GB, int T1, int na, int H, hipStream_t st) {
     const long total = (long)GB * na * H;
     ProfScope prof_set_h0_kernel("set_h0_kernel", 0.0, 0.0, st);
-    REFIL_LAUNCH(set_h0_kernel, dim3((int)min((long)1024, cdivl(total, 256))), dim3(256), 0, st, hsx, h0, GB, T1, na, H);
+    hipLaunchKernelGGL(set_h0_kernel, dim3((int)min((long)1024, cdivl(total, 256))), dim3(256), 0, st, hsx, h0, GB, T1, na, H);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
@@ -91,7 +91,7 @@ __global__ void get_hT_kernel(const float* hsx, float* h_out, int GB, int T1, in
 int get_hT_launch(const float* hsx, float* h_out, int GB, int T1, int na, int H, hipStream_t st) {
     const long total = (long)GB * na * H;
     ProfScope prof_get_hT_kernel("get_hT_kernel", 0.0, 0.0, st);
-    REFIL_LAUNCH(get_hT_kernel, dim3((int)min((long)1024, cdivl(total, 256))), dim3(256), 0, st, hsx, h_out, GB, T1, na, H);
+    hipLaunchKernelGGL(get_hT_kernel, dim3((int)min((long)1024, cdivl(total, 256))), dim3(256), 0, st, hsx, h_out, GB, T1, na, H);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
@@ -138,7 +138,7 @@ int qselect_launch(const QSelArgs& a, hipStream_t st) {
     const long total = (long)a.B * (a.T1 - 1) * a.na;
     if (total <= 0) return 0;
     ProfScope prof_qselect_kernel("qselect_kernel", 0.0, 0.0, st);
-    REFIL_LAUNCH(qselect_kernel, dim3((int)min((long)2048, cdivl(total, 256))), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(qselect_kernel, dim3((int)min((long)2048, cdivl(total, 256))), dim3(256), 0, st, a);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
@@ -169,7 +169,7 @@ __global__ void qselect_bwd_kernel(QSelBwdArgs a) {
 int qselect_bwd_launch(const QSelBwdArgs& a, hipStream_t st) {
     const long total = (long)a.G * a.B * a.T1 * a.na * a.A;
     ProfScope prof_qselect_bwd_kernel("qselect_bwd_kernel", 0.0, 0.0, st);
-    REFIL_LAUNCH(qselect_bwd_kernel, dim3((int)min((long)4096, cdivl(total, 256))), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(qselect_bwd_kernel, dim3((int)min((long)4096, cdivl(total, 256))), dim3(256), 0, st, a);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
@@ -453,13 +453,13 @@ int mix_forward_launch(const MixArgs& a, hipStream_t st) {
     if (a.B * a.T <= 0) return 0;
     if (a.lin == 2) {
         ProfScope prof("mix_vdn_fwd_kernel", 0.0, 0.0, st);
-        REFIL_LAUNCH(mix_vdn_fwd_kernel, dim3(cdiv(a.B * a.T, 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(mix_vdn_fwd_kernel, dim3(cdiv(a.B * a.T, 256)), dim3(256), 0, st, a);
         REFIL_LAUNCH_CHECK();
         return 0;
     }
     ProfScope prof_mix_fwd_kernel(a.lin ? "mix_lin_fwd_kernel" : "mix_fwd_kernel", 0.0, 0.0, st);
-    if (a.lin) REFIL_LAUNCH(mix_lin_fwd_kernel, dim3(a.B * a.T), dim3(64), 0, st, a);
-    else REFIL_LAUNCH(mix_fwd_kernel, dim3(a.B * a.T), dim3(64 * MIXW), 0, st, a);
+    if (a.lin) hipLaunchKernelGGL(mix_lin_fwd_kernel, dim3(a.B * a.T), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(mix_fwd_kernel, dim3(a.B * a.T), dim3(64 * MIXW), 0, st, a);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
@@ -467,13 +467,13 @@ int mix_backward_launch(const MixArgs& a, hipStream_t st) {
     if (int e = mix_check(a)) return e;
     if (a.lin == 2) {
         ProfScope prof("mix_vdn_bwd_kernel", 0.0, 0.0, st);
-        REFIL_LAUNCH(mix_vdn_bwd_kernel, dim3(cdiv(a.B * a.T, 256)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(mix_vdn_bwd_kernel, dim3(cdiv(a.B * a.T, 256)), dim3(256), 0, st, a);
         REFIL_LAUNCH_CHECK();
         return 0;
     }
     ProfScope prof_mix_bwd_kernel(a.lin ? "mix_lin_bwd_kernel" : "mix_bwd_kernel", 0.0, 0.0, st);
-    if (a.lin) REFIL_LAUNCH(mix_lin_bwd_kernel, dim3(a.B * a.T1), dim3(64), 0, st, a);
-    else REFIL_LAUNCH(mix_bwd_kernel, dim3(a.B * a.T1), dim3(64 * MIXW), 0, st, a);
+    if (a.lin) hipLaunchKernelGGL(mix_lin_bwd_kernel, dim3(a.B * a.T1), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(mix_bwd_kernel, dim3(a.B * a.T1), dim3(64 * MIXW), 0, st, a);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(1024) void td_loss_kernel(TdArgs a) {
 }
 int td_loss_launch(const TdArgs& a, hipStream_t st) {
     ProfScope prof_td_loss_kernel("td_loss_kernel", 0.0, 0.0, st);
-    REFIL_LAUNCH(td_loss_kernel, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(1024), 0, st, a);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void sum_kernel(const float* x, long n, float*
     if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
 }
 int sum_launch(const float* x, long n, float* out, hipStream_t st) {
-    REFIL_LAUNCH(sum_kernel, dim3(1), dim3(256), 0, st, x, n, out);
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, x, n, out);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
@@ -591,11 +591,11 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* p, const float* g, 
 int clip_rmsprop_launch(float* params, const float* grads, float* sq, long n, float lr, float alpha, float eps,
                         float wd, float clip, float* stats, float* scratch, hipStream_t st) {
     ProfScope prof_sumsq_kernel("sumsq_kernel", 0.0, 0.0, st);
-    REFIL_LAUNCH(sumsq_kernel, dim3(OPT_BLOCKS), dim3(256), 0, st, grads, n, scratch);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(OPT_BLOCKS), dim3(256), 0, st, grads, n, scratch);
     REFIL_LAUNCH_CHECK();
     const int blocks = (int)min((long)1024, cdivl(n, 256));
     ProfScope prof_rmsprop_kernel("rmsprop_kernel", 0.0, 0.0, st);
-    REFIL_LAUNCH(rmsprop_kernel, dim3(blocks), dim3(256), 0, st, params, grads, sq, n, lr, alpha, eps, wd, clip, stats, scratch);
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(blocks), dim3(256), 0, st, params, grads, sq, n, lr, alpha, eps, wd, clip, stats, scratch);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
