@@ -31,6 +31,7 @@ struct AttnM {
     const uint8_t* ent_mask; const uint8_t* ent_mask0; const uint8_t* group_bits;
     const uint8_t* gt_mask; long gt_sB, gt_sT;
     int wave_floats;   // LDS floats per wave region
+    int mask_floats;   // LDS floats of the mask byte region (the mask words follow it)
 };
 
 struct MaskLds { const uint8_t *emt, *em0, *gb, *om, *gt; };
@@ -126,17 +127,30 @@ __device__ inline float cross4_max(float v) {
     return v;
 }
 
-// masked softmax of transposed logits: st[jt][reg] = S^T[key 16jt+4q+reg][agent], in place -> P^T
+// Mask words: mw[v * NA_PAD + agent] is a 64-bit word whose bit `key` is set when logit (agent, key) of mask
+// variant v is masked; padded agents (>= na) are all ones and padded keys (>= ne) are set. Built once per
+// row by the whole workgroup (one ballot per (variant, agent)), shared by the 4 heads and both orientations.
+__device__ inline void build_mask_words(const AttnM& p, const MaskLds& m, unsigned long long* mw, int na_pad, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int idx = wave; idx < p.nvar * na_pad; idx += 4) {
+        const int v = idx / na_pad, i = idx % na_pad;
+        bool masked = true;
+        if (i < p.na && lane < p.ne) masked = premask_m(p.var[v], m, p.ne, i, lane);
+        const unsigned long long w = __ballot(masked);
+        if (lane == 0) mw[idx] = w;
+    }
+}
+
+// masked softmax of transposed logits: st[jt][reg] = S^T[key 16jt+4q+reg][agent] (already scaled), in place -> P^T
 template <int NJT>
-__device__ inline void softmax_T(f32x4 (&st)[NJT], int code, const MaskLds& m, int ne, int na, int agent, int q, float inv_scale) {
+__device__ inline void softmax_T(f32x4 (&st)[NJT], unsigned long long w, int q) {
     float mx = -INFINITY;
 #pragma unroll
     for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int key = 16 * jt + 4 * q + reg;
-            const bool masked = agent >= na || key >= ne || premask_m(code, m, ne, agent, key);
-            const float v = masked ? -INFINITY : st[jt][reg] * inv_scale;
+            const bool masked = (w >> (16 * jt + 4 * q + reg)) & 1ull;
+            const float v = masked ? -INFINITY : st[jt][reg];
             st[jt][reg] = v;
             mx = fmaxf(mx, v);
         }
@@ -146,31 +160,28 @@ __device__ inline void softmax_T(f32x4 (&st)[NJT], int code, const MaskLds& m, i
     for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const float e = st[jt][reg] == -INFINITY ? 0.f : expf(st[jt][reg] - mx);
+            const float e = st[jt][reg] == -INFINITY ? 0.f : __expf(st[jt][reg] - mx);
             st[jt][reg] = e;
             sum += e;
         }
     sum = cross4_sum(sum);
-    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    const float inv = sum > 0.f ? __builtin_amdgcn_rcpf(sum) : 0.f;     // fully masked row -> 0 (attention.py:60 NaN -> 0)
 #pragma unroll
     for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) st[jt][reg] = sum > 0.f ? st[jt][reg] / sum : 0.f;
-    (void)inv;
+        for (int reg = 0; reg < 4; ++reg) st[jt][reg] *= inv;
 }
 
 // masked softmax of non-transposed logits: sn[jt][reg] = S[agent 16at+4q+reg][key 16jt + l15] -> P
 template <int NJT>
-__device__ inline void softmax_N(f32x4 (&sn)[NJT], int code, const MaskLds& m, int ne, int na, int agent0, int l15, float inv_scale) {
+__device__ inline void softmax_N(f32x4 (&sn)[NJT], const unsigned long long (&w)[4], int l15) {
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-        const int agent = agent0 + reg;
         float mx = -INFINITY;
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
-            const int key = 16 * jt + l15;
-            const bool masked = agent >= na || key >= ne || premask_m(code, m, ne, agent, key);
-            const float v = masked ? -INFINITY : sn[jt][reg] * inv_scale;
+            const bool masked = (w[reg] >> (16 * jt + l15)) & 1ull;
+            const float v = masked ? -INFINITY : sn[jt][reg];
             sn[jt][reg] = v;
             mx = fmaxf(mx, v);
         }
@@ -178,13 +189,14 @@ __device__ inline void softmax_N(f32x4 (&sn)[NJT], int code, const MaskLds& m, i
         float sum = 0.f;
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
-            const float e = sn[jt][reg] == -INFINITY ? 0.f : expf(sn[jt][reg] - mx);
+            const float e = sn[jt][reg] == -INFINITY ? 0.f : __expf(sn[jt][reg] - mx);
             sn[jt][reg] = e;
             sum += e;
         }
         sum = group16_sum(sum);
+        const float inv = sum > 0.f ? __builtin_amdgcn_rcpf(sum) : 0.f;
 #pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) sn[jt][reg] = sum > 0.f ? sn[jt][reg] / sum : 0.f;
+        for (int jt = 0; jt < NJT; ++jt) sn[jt][reg] *= inv;
     }
 }
 
@@ -225,13 +237,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
     const int pd = p.hd + 2;
     MaskLds m;
     load_masks(p, reinterpret_cast<uint8_t*>(smem + 4 * p.wave_floats), m, r, tid, 256, uses_obs_m(p));
+    unsigned long long* mw = reinterpret_cast<unsigned long long*>(smem + 4 * p.wave_floats + p.mask_floats);
+    __syncthreads();
+    build_mask_words(p, m, mw, NAT * 16, tid);
     __syncthreads();
     float* Qs = smem + wave * p.wave_floats;
     float* Ks = Qs + NAT * 16 * pd;
     float* Vs = Ks + NJT * 16 * pd;
     const float inv_scale = 1.0f / sqrtf((float)p.hd);
-    const float scale = sqrtf((float)p.hd);
-    (void)inv_scale;
     for (int head = wave; head < p.heads; head += 4) {
         {
             Stage<NAT * 16, 4 * NCT> sq;
@@ -252,8 +265,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) pt[jt][reg] = st0[jt][reg] / scale;   // attention.py:54 divides
-                softmax_T<NJT>(pt, p.var[v], m, p.ne, p.na, agent, q, 1.0f);
+                    for (int reg = 0; reg < 4; ++reg) pt[jt][reg] = st0[jt][reg] * inv_scale;   // attention.py:54
+                softmax_T<NJT>(pt, mw[v * NAT * 16 + agent], q);
                 float* O = p.O + v * p.sO;
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
@@ -282,12 +295,15 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
     const int pd = p.hd + 2;
     MaskLds m;
     load_masks(p, reinterpret_cast<uint8_t*>(smem + 4 * p.wave_floats), m, r, tid, 256, uses_obs_m(p));
+    unsigned long long* mw = reinterpret_cast<unsigned long long*>(smem + 4 * p.wave_floats + p.mask_floats);
+    __syncthreads();
+    build_mask_words(p, m, mw, NAT * 16, tid);
     __syncthreads();
     float* Qs = smem + wave * p.wave_floats;
     float* Ks = Qs + NAT * 16 * pd;
     float* Vs = Ks + NJT * 16 * pd;
     float* Ds = Vs + NJT * 16 * pd;          // dO of one (variant, agent tile): 16 rows
-    const float scale = sqrtf((float)p.hd);
+    const float inv_scale = 1.0f / sqrtf((float)p.hd);
     for (int head = wave; head < p.heads; head += 4) {
         {
             Stage<NAT * 16, 4 * NCT> sq;
@@ -330,11 +346,13 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
                 for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        pt[jt][reg] = st0[jt][reg] / scale;
-                        pn[jt][reg] = sn0[jt][reg] / scale;
+                        pt[jt][reg] = st0[jt][reg] * inv_scale;
+                        pn[jt][reg] = sn0[jt][reg] * inv_scale;
                     }
-                softmax_T<NJT>(pt, p.var[v], m, p.ne, p.na, agentT, q, 1.0f);
-                softmax_N<NJT>(pn, p.var[v], m, p.ne, p.na, agentN0, l15, 1.0f);
+                const unsigned long long* mv = mw + v * NAT * 16;
+                const unsigned long long wn[4] = {mv[agentN0], mv[agentN0 + 1], mv[agentN0 + 2], mv[agentN0 + 3]};
+                softmax_T<NJT>(pt, mv[agentT], q);
+                softmax_N<NJT>(pn, wn, l15);
                 // dP^T[key][agent] = V dO^T ; dP[agent][key] = dO V^T ; dS = P (dP - sum_key P dP) / scale
                 f32x4 dst[NJT], dsn[NJT];
                 float rdT = 0.f, rdN[4] = {0.f, 0.f, 0.f, 0.f};
@@ -355,8 +373,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
                 for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        dst[jt][reg] = pt[jt][reg] * (dst[jt][reg] - rdT) / scale;
-                        dsn[jt][reg] = pn[jt][reg] * (dsn[jt][reg] - rdN[reg]) / scale;
+                        dst[jt][reg] = pt[jt][reg] * (dst[jt][reg] - rdT) * inv_scale;
+                        dsn[jt][reg] = pn[jt][reg] * (dsn[jt][reg] - rdN[reg]) * inv_scale;
                     }
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
@@ -423,7 +441,8 @@ int attn_mfma_launch(const refil_attn_desc& d, bool bwd, hipStream_t st) {
     const int pd = d.hd + 2;
     // +16 floats of slack: fragment reads of a partial channel tile (hd < 16*nct) run past the last row
     k.wave_floats = ((nat * 16 + 2 * njt * 16 + (bwd ? 16 : 0)) * pd + 16 + 3) & ~3;
-    const size_t smem = ((size_t)4 * k.wave_floats * 4 + 3 * (size_t)d.ne + 2 * (size_t)d.na * d.ne + 15) & ~(size_t)15;
+    k.mask_floats = (int)(((3 * (size_t)d.ne + 2 * (size_t)d.na * d.ne + 15) & ~(size_t)15) / 4);
+    const size_t smem = (size_t)4 * k.wave_floats * 4 + (size_t)k.mask_floats * 4 + (size_t)3 * nat * 16 * 8;
     if (smem > 160 * 1024) return -1;
     const double unit = (double)d.R * d.heads * d.na * d.ne * d.hd;
     ProfScope prof(bwd ? "attn_bwd_mfma" : "attn_fwd_mfma", unit * (bwd ? 2.0 + 8.0 * d.nvar : 2.0 + 2.0 * d.nvar),
