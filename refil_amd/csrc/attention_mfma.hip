@@ -303,6 +303,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
     float* Ks = Qs + NAT * 16 * pd;
     float* Vs = Ks + NJT * 16 * pd;
     float* Ds = Vs + NJT * 16 * pd;          // dO of one (variant, agent tile): 16 rows
+    constexpr int TP = NJT * 16 + 4;         // pitch of the dS transposition tile (16 agents x keys)
+    float* Ts = Qs + p.wave_floats - 16 * TP;
     const float inv_scale = 1.0f / sqrtf((float)p.hd);
     for (int head = wave; head < p.heads; head += 4) {
         {
@@ -323,14 +325,11 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
             }
 #pragma unroll
         for (int at = 0; at < NAT; ++at) {
-            const int agentT = 16 * at + l15;        // agent of this lane in the transposed orientation
+            const int agentT = 16 * at + l15;        // agent of this lane in the transposed orientation (dQ^T columns)
             const int agentN0 = 16 * at + 4 * q;     // first agent of this lane in the normal orientation
-            f32x4 st0[NJT], sn0[NJT];
+            f32x4 sn0[NJT];
 #pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) {
-                st0[jt] = dot_tile(Ks, 16 * jt, Qs, 16 * at, p.hd, pd, l15, q);   // S^T[key][agent]
-                sn0[jt] = dot_tile(Qs, 16 * at, Ks, 16 * jt, p.hd, pd, l15, q);   // S[agent][key]
-            }
+            for (int jt = 0; jt < NJT; ++jt) sn0[jt] = dot_tile(Qs, 16 * at, Ks, 16 * jt, p.hd, pd, l15, q);   // S[agent][key]
             f32x4 dQt[NCT];                           // [c][agent 16at+l15]
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) dQt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -341,41 +340,39 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
                     sd.load(p.dO + v * p.sO, (long)r * p.na + 16 * at, na_t, p.ldo, head * p.hd, p.hd, lane);
                     sd.store(Ds, p.hd, pd, lane);
                 }
-                f32x4 pt[NJT], pn[NJT];
+                f32x4 pn[NJT];
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        pt[jt][reg] = st0[jt][reg] * inv_scale;
-                        pn[jt][reg] = sn0[jt][reg] * inv_scale;
-                    }
+                    for (int reg = 0; reg < 4; ++reg) pn[jt][reg] = sn0[jt][reg] * inv_scale;
                 const unsigned long long* mv = mw + v * NAT * 16;
                 const unsigned long long wn[4] = {mv[agentN0], mv[agentN0 + 1], mv[agentN0 + 2], mv[agentN0 + 3]};
-                softmax_T<NJT>(pt, mv[agentT], q);
                 softmax_N<NJT>(pn, wn, l15);
-                // dP^T[key][agent] = V dO^T ; dP[agent][key] = dO V^T ; dS = P (dP - sum_key P dP) / scale
-                f32x4 dst[NJT], dsn[NJT];
-                float rdT = 0.f, rdN[4] = {0.f, 0.f, 0.f, 0.f};
+                // dP[agent][key] = dO V^T ; dS = P (dP - sum_key P dP) / scale
+                f32x4 dsn[NJT];
+                float rdN[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt) {
-                    dst[jt] = dot_tile(Vs, 16 * jt, Ds, 0, p.hd, pd, l15, q);
                     dsn[jt] = dot_tile(Ds, 0, Vs, 16 * jt, p.hd, pd, l15, q);
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        rdT += pt[jt][reg] * dst[jt][reg];
-                        rdN[reg] += pn[jt][reg] * dsn[jt][reg];
-                    }
+                    for (int reg = 0; reg < 4; ++reg) rdN[reg] += pn[jt][reg] * dsn[jt][reg];
                 }
-                rdT = cross4_sum(rdT);
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) rdN[reg] = group16_sum(rdN[reg]);
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        dst[jt][reg] = pt[jt][reg] * (dst[jt][reg] - rdT) * inv_scale;
                         dsn[jt][reg] = pn[jt][reg] * (dsn[jt][reg] - rdN[reg]) * inv_scale;
+                        Ts[(4 * q + reg) * TP + 16 * jt + l15] = dsn[jt][reg];
                     }
+                // the transposed copy dS^T[key 16jt+4q+reg][agent l15] (B operand of the contraction over keys)
+                // comes back through wave-private LDS (same-wave LDS operations execute in order)
+                __builtin_amdgcn_wave_barrier();
+                f32x4 dst[NJT];
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) dst[jt] = *reinterpret_cast<const f32x4*>(Ts + l15 * TP + 16 * jt + 4 * q);
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
 #pragma unroll
@@ -441,6 +438,7 @@ int attn_mfma_launch(const refil_attn_desc& d, bool bwd, hipStream_t st) {
     const int pd = d.hd + 2;
     // +16 floats of slack: fragment reads of a partial channel tile (hd < 16*nct) run past the last row
     k.wave_floats = ((nat * 16 + 2 * njt * 16 + (bwd ? 16 : 0)) * pd + 16 + 3) & ~3;
+    if (bwd) k.wave_floats += 16 * (njt * 16 + 4);     // dS transposition tile at the end of the wave region
     k.mask_floats = (int)(((3 * (size_t)d.ne + 2 * (size_t)d.na * d.ne + 15) & ~(size_t)15) / 4);
     const size_t smem = (size_t)4 * k.wave_floats * 4 + (size_t)k.mask_floats * 4 + (size_t)3 * nat * 16 * 8;
     if (smem > 160 * 1024) return -1;
