@@ -327,6 +327,12 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
         for (int at = 0; at < NAT; ++at) {
             const int agentT = 16 * at + l15;        // agent of this lane in the transposed orientation (dQ^T columns)
             const int agentN0 = 16 * at + 4 * q;     // first agent of this lane in the normal orientation
+            // dO of variant v+1 is fetched into registers while variant v is being processed: one exposed HBM
+            // round trip per agent tile instead of one per variant (LDS operations of a wave execute in order,
+            // so overwriting Ds at the top of the next iteration is safe)
+            const int na_t = min(16, p.na - 16 * at);
+            Stage<16, 4 * NCT> sd;
+            sd.load(p.dO, (long)r * p.na + 16 * at, na_t, p.ldo, head * p.hd, p.hd, lane);
             f32x4 sn0[NJT];
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt) sn0[jt] = dot_tile(Qs, 16 * at, Ks, 16 * jt, p.hd, pd, l15, q);   // S[agent][key]
@@ -334,12 +340,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) dQt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int v = 0; v < p.nvar; ++v) {
-                const int na_t = min(16, p.na - 16 * at);
-                {
-                    Stage<16, 4 * NCT> sd;
-                    sd.load(p.dO + v * p.sO, (long)r * p.na + 16 * at, na_t, p.ldo, head * p.hd, p.hd, lane);
-                    sd.store(Ds, p.hd, pd, lane);
-                }
+                sd.store(Ds, p.hd, pd, lane);
+                if (v + 1 < p.nvar) sd.load(p.dO + (v + 1) * p.sO, (long)r * p.na + 16 * at, na_t, p.ldo, head * p.hd, p.hd, lane);
                 f32x4 pn[NJT];
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt)
