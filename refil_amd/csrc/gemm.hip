@@ -18,6 +18,9 @@
 // Replaces the implicit aten::mm / addmm calls of the reference.
 #include <stdlib.h>
 
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 #include "profile.h"
 #include "../../include/refil_hip.h"
@@ -391,6 +394,9 @@ static int launch_cfg(const GemmK& k, hipStream_t st) {
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
+    static const bool log_shapes = [] { const char* e = getenv("REFIL_GEMM_LOG"); return e && e[0] == '1'; }();
+    if (log_shapes)   // debugging aid: one line per launch, in launch order (pair with a rocprofv3 kernel trace)
+        fprintf(stderr, "refil_gemm M=%d N=%d K=%d batch=%d splits=%d flags=0x%x\n", d.M, d.N, d.K, d.batch, d.splits, d.flags);
     REFIL_CHECK(d.A && d.B && d.C, "refil_gemm: null operand");
     REFIL_CHECK(d.M > 0 && d.N > 0 && d.K > 0, "refil_gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
     REFIL_CHECK(d.batch >= 1 && d.splits >= 1, "refil_gemm: batch/splits must be >= 1");
