@@ -434,7 +434,9 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
     static const bool big_tile = []() { const char* e = getenv("REFIL_GEMM_BIG"); return !(e && e[0] == '0'); }();
     // 8 waves, 256x128 tile: wins when the reduction is long enough to amortise the bigger prologue (measured: K>=128
     // shapes +20 %, K=84 shapes -10 %)
-    if (d.N > 64 && d.M >= 8192 && d.K >= 96 && big_tile) rc = launch_cfg<4, 2, 2, 2>(k, st);
+    static const long big_min_blocks = []() { const char* e = getenv("REFIL_GEMM_BIG_MINBLK"); return e ? atol(e) : 200L; }();   // fewer big tiles than this leave CUs idle: use 128x128
+    const long big_blocks = (long)cdiv(d.M, 256) * cdiv(d.N, 128) * d.batch * d.splits;
+    if (d.N > 64 && d.M >= 8192 && d.K >= 96 && big_tile && big_blocks >= big_min_blocks) rc = launch_cfg<4, 2, 2, 2>(k, st);
     else if (d.N > 64) rc = launch_cfg<2, 2, 2, 2>(k, st);
     else if (d.N > 32) rc = launch_cfg<4, 1, 1, 2>(k, st);
     else rc = launch_cfg<4, 1, 1, 1>(k, st);

@@ -14,6 +14,8 @@ import os
 import sys
 import types
 
+sys.dont_write_bytecode = True     # importing the reference must not write __pycache__ into /root/reference
+
 import numpy as np
 import torch as th
 
