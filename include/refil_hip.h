@@ -55,7 +55,8 @@ typedef struct refil_dims {
     int32_t mixer_lin;               /* 1: LinearFlexQMixer (flex_qmix.py:124-172), 0: FlexQMixer       */
     int32_t mixer_vdn;               /* 1: VDNMixer (modules/mixers/vdn.py:9-10): q_tot = sum_i q_i, no hypernets / parameters */
     int32_t gt_factors;              /* 1: imagine groups = ground-truth factors batch.gt_mask
-                                        (entity_ff_agent.py:93-95) instead of the random split       */
+                                        (entity_ff_agent.py:93-95) instead of the random split;
+                                        2: random split OR-ed with them (use_rand_gt_factors, :111-114) */
     int32_t gt_obs_mask;             /* 1: batch.gt_mask replaces obs_mask (entity_ff_agent.py:34-35)   */
     float gamma;
     float lmbda;
@@ -231,6 +232,11 @@ enum {
     REFIL_MASK_OBS_GTI,        /* !gt | obs_mask                                                        */
     REFIL_MASK_GTW,            /*  gt | inactive0_i | inactive0_j                                       */
     REFIL_MASK_GTI,            /* !gt | inactive0_i | inactive0_j                                       */
+    /* randomised ground-truth factors (entity_ff_agent.py:111-121): within = !same | gt, interact = !within */
+    REFIL_MASK_OBS_RGTW,       /*  !same | gt | obs_mask                                                */
+    REFIL_MASK_OBS_RGTI,       /* (same & !gt) | obs_mask                                               */
+    REFIL_MASK_RGTW,           /*  !same | gt                                                           */
+    REFIL_MASK_RGTI,           /* (same & !gt) | inactive0_i | inactive0_j                              */
     REFIL_MASK_COUNT
 };
 

@@ -56,6 +56,8 @@ class Cfg:
     mixer_lin: bool = False        # lin_flex_qmix (flex_qmix.py:124-172) instead of flex_qmix
     mixer_vdn: bool = False        # VDNMixer (modules/mixers/vdn.py:9-10): q_tot = sum of the agents' Qs, no parameters
     gt_obs_mask: bool = False      # entity_ff_agent.py:34-35
+    train_gt_factors: bool = False       # q_learner.py:88: imagined groups = ground-truth factors (batch["gt_mask"])
+    train_rand_gt_factors: bool = False  # q_learner.py:89: random split OR-ed with the ground-truth factors
     double_q: bool = True
     gamma: float = 0.99
     lmbda: float = 0.5
@@ -166,14 +168,19 @@ def imagine_masks(group_bits: Tensor, entity_mask0: Tensor) -> Tuple[Tensor, Ten
 
 
 def group_masks(cfg: "Cfg", entity_mask: Tensor, group_bits: Optional[Tensor] = None,
-                gt_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+                gt_mask: Optional[Tensor] = None, rand_gt: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
     """(within, interact, active) bool [B,Tg,na,ne] for the query rows (agents):
     random split (Tg = 1; entity_rnn_agent.py:97-108 == entity_ff_agent.py:98-109): within = not same,
     interact = same; ground-truth factors (Tg = T1; entity_ff_agent.py:93-95): within = gt_mask,
-    interact = not gt_mask. active[i,j] = inactive0_i | inactive0_j (":91 activeattnmask")."""
+    interact = not gt_mask; randomised ground-truth factors (rand_gt, Tg = T1; entity_ff_agent.py:111-114):
+    within = (not same) | gt_mask, interact = not within. active[i,j] = inactive0_i | inactive0_j (":91 activeattnmask")."""
     na = cfg.n_agents
     inact = entity_mask[:, 0].bool()
     active = (inact[:, :na, None] | inact[:, None, :])[:, None]
+    if rand_gt:
+        Wm, _ = imagine_masks(group_bits, entity_mask[:, 0])
+        W = Wm[:, None, :na, :] | gt_mask.bool()
+        return W, ~W, active
     if gt_mask is not None:
         W = gt_mask.bool()
         return W, ~W, active
@@ -226,7 +233,7 @@ def gru_cell(x: Tensor, h: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih: Tensor, b_h
 
 def agent_forward(cfg: Cfg, p: Dict[str, Tensor], xe: Tensor, obs_mask: Tensor, entity_mask: Tensor,
                   h0: Optional[Tensor] = None, group_bits: Optional[Tensor] = None,
-                  gt_mask: Optional[Tensor] = None, use_gt_factors: bool = False):
+                  gt_mask: Optional[Tensor] = None, use_gt_factors: bool = False, use_rand_gt_factors: bool = False):
     """Returns (q [G,B,T1,na,A], hs, groups) where G = 3 when imagining (group_bits or use_gt_factors) else 1.
 
     Copy 0 = real obs mask, copy 1 = within-group, copy 2 = between-group (entity_rnn_agent.py:116-124,
@@ -240,7 +247,9 @@ def agent_forward(cfg: Cfg, p: Dict[str, Tensor], xe: Tensor, obs_mask: Tensor, 
     pre = [om]
     groups = None
     if group_bits is not None or use_gt_factors:
-        W, I, active = group_masks(cfg, entity_mask, group_bits, gt_mask if use_gt_factors else None)
+        assert not (use_gt_factors and use_rand_gt_factors)                                # entity_ff_agent.py:112
+        W, I, active = group_masks(cfg, entity_mask, group_bits, gt_mask if (use_gt_factors or use_rand_gt_factors) else None,
+                                   rand_gt=use_rand_gt_factors)
         groups = (W | active, I | active)
         pre.append(W | om)
         pre.append(I | om)
@@ -383,7 +392,9 @@ def learner_forward(cfg: Cfg, agent_p, mixer_p, tgt_agent_p, tgt_mixer_p, batch:
 
     gt = batch.get("gt_mask")
     q, _, groups = agent_forward(cfg, agent_p, xe, batch["obs_mask"], batch["entity_mask"],
-                                 group_bits=group_bits if cfg.imagine else None, gt_mask=gt)
+                                 group_bits=group_bits if cfg.imagine else None, gt_mask=gt,
+                                 use_gt_factors=cfg.imagine and cfg.train_gt_factors,
+                                 use_rand_gt_factors=cfg.imagine and cfg.train_rand_gt_factors)          # q_learner.py:87-89
     G = q.shape[0]
     chosen = torch.gather(q[:, :, :-1], 4, actions[None].expand(G, -1, -1, -1, -1)).squeeze(4)   # :91,109
     with torch.no_grad():

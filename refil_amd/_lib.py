@@ -18,6 +18,7 @@ STAT_MASK_SUM, STAT_TD_SQ, STAT_IM_TD_SQ, STAT_TD_ABS, STAT_QTOT_SUM, STAT_TARGE
 GEMM_RELU, GEMM_RELU_BWD, GEMM_ACCUM, GEMM_A_OUTC, GEMM_B_OUTC, GEMM_COLSUM_A = 1, 2, 4, 8, 16, 32
 MASK_OBS, MASK_OBS_WITHIN, MASK_OBS_INTERACT, MASK_ENTITY, MASK_WITHIN, MASK_INTERACT = range(6)
 MASK_OBS_GTW, MASK_OBS_GTI, MASK_GTW, MASK_GTI = 6, 7, 8, 9
+MASK_OBS_RGTW, MASK_OBS_RGTI, MASK_RGTW, MASK_RGTI = 10, 11, 12, 13
 
 
 class Dims(C.Structure):

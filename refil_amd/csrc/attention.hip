@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "kernels.h"
 #include "profile.h"
 #include "../../include/refil_hip.h"
 
@@ -94,7 +95,11 @@ __device__ inline bool premask(int code, const AttnSmem& s, int ne, int i, int j
         case REFIL_MASK_OBS_GTW: return s.gt[i * ne + j] || s.om[i * ne + j];
         case REFIL_MASK_OBS_GTI: return !s.gt[i * ne + j] || s.om[i * ne + j];
         case REFIL_MASK_GTW: return s.gt[i * ne + j] || in0;
-        default: return !s.gt[i * ne + j] || in0;  // REFIL_MASK_GTI
+        case REFIL_MASK_GTI: return !s.gt[i * ne + j] || in0;
+        case REFIL_MASK_OBS_RGTW: return !same || s.gt[i * ne + j] || s.om[i * ne + j];
+        case REFIL_MASK_OBS_RGTI: return (same && !s.gt[i * ne + j]) || s.om[i * ne + j];
+        case REFIL_MASK_RGTW: return !same || s.gt[i * ne + j];
+        default: return (same && !s.gt[i * ne + j]) || in0;   // REFIL_MASK_RGTI
     }
 }
 
@@ -150,7 +155,7 @@ __device__ inline void compute_logits(const AttnK& p, const AttnSmem& s, int tid
 __device__ inline bool uses_obs(const AttnK& p) {
     bool u = false;
     for (int v = 0; v < p.nvar; ++v)
-        u |= (p.var[v] <= REFIL_MASK_OBS_INTERACT) || p.var[v] == REFIL_MASK_OBS_GTW || p.var[v] == REFIL_MASK_OBS_GTI;
+        u |= mask_uses_obs(p.var[v]);
     return u;
 }
 
@@ -288,11 +293,10 @@ static int fill(const refil_attn_desc& d, AttnK& k, bool bwd) {
     bool need_obs = false, need_grp = false, need_emt = false, need_gt = false, need_e0 = false;
     for (int v = 0; v < d.nvar; ++v) {
         REFIL_CHECK(d.var[v] >= 0 && d.var[v] < REFIL_MASK_COUNT, "refil_attn: bad mask code %d", d.var[v]);
-        const bool gtv = d.var[v] >= REFIL_MASK_OBS_GTW;
-        need_gt |= gtv;
-        need_obs |= d.var[v] <= REFIL_MASK_OBS_INTERACT || d.var[v] == REFIL_MASK_OBS_GTW || d.var[v] == REFIL_MASK_OBS_GTI;
-        need_grp |= !gtv && d.var[v] != REFIL_MASK_OBS && d.var[v] != REFIL_MASK_ENTITY;
-        need_e0 |= d.var[v] == REFIL_MASK_GTW || d.var[v] == REFIL_MASK_GTI;
+        need_gt |= mask_uses_gt(d.var[v]);
+        need_obs |= mask_uses_obs(d.var[v]);
+        need_grp |= mask_uses_groups(d.var[v]);
+        need_e0 |= mask_uses_inactive0(d.var[v]);
         need_emt |= d.var[v] == REFIL_MASK_ENTITY;
     }
     REFIL_CHECK(!need_gt || d.gt_mask, "refil_attn: gt_mask required by a ground-truth-factor mask variant");

@@ -17,6 +17,7 @@
 // recomputed in the other orientation S[agent,key] too -- MFMA work is free here, the kernel is
 // bound by its HBM traffic.
 #include "common.h"
+#include "kernels.h"
 #include "profile.h"
 #include "../../include/refil_hip.h"
 
@@ -49,7 +50,11 @@ __device__ inline bool premask_m(int code, const MaskLds& s, int ne, int i, int 
         case REFIL_MASK_OBS_GTW: return s.gt[i * ne + j] || s.om[i * ne + j];
         case REFIL_MASK_OBS_GTI: return !s.gt[i * ne + j] || s.om[i * ne + j];
         case REFIL_MASK_GTW: return s.gt[i * ne + j] || in0;
-        default: return !s.gt[i * ne + j] || in0;
+        case REFIL_MASK_GTI: return !s.gt[i * ne + j] || in0;
+        case REFIL_MASK_OBS_RGTW: return !same || s.gt[i * ne + j] || s.om[i * ne + j];
+        case REFIL_MASK_OBS_RGTI: return (same && !s.gt[i * ne + j]) || s.om[i * ne + j];
+        case REFIL_MASK_RGTW: return !same || s.gt[i * ne + j];
+        default: return (same && !s.gt[i * ne + j]) || in0;   // REFIL_MASK_RGTI
     }
 }
 
@@ -223,7 +228,7 @@ __device__ inline void load_masks(const AttnM& p, uint8_t* base, MaskLds& m, int
 __device__ inline bool uses_obs_m(const AttnM& p) {
     bool u = false;
     for (int v = 0; v < p.nvar; ++v)
-        u |= (p.var[v] <= REFIL_MASK_OBS_INTERACT) || p.var[v] == REFIL_MASK_OBS_GTW || p.var[v] == REFIL_MASK_OBS_GTI;
+        u |= mask_uses_obs(p.var[v]);
     return u;
 }
 

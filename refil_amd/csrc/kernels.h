@@ -5,6 +5,16 @@
 
 namespace refil {
 
+// which per-row inputs a pre-softmax mask variant reads (include/refil_hip.h: REFIL_MASK_*)
+__host__ __device__ inline bool mask_uses_obs(int c) {
+    return c <= REFIL_MASK_OBS_INTERACT || c == REFIL_MASK_OBS_GTW || c == REFIL_MASK_OBS_GTI || c == REFIL_MASK_OBS_RGTW || c == REFIL_MASK_OBS_RGTI;
+}
+__host__ __device__ inline bool mask_uses_gt(int c) { return c >= REFIL_MASK_OBS_GTW; }
+__host__ __device__ inline bool mask_uses_groups(int c) {   // same(i,j): group bits + inactive-at-t0
+    return c == REFIL_MASK_OBS_WITHIN || c == REFIL_MASK_OBS_INTERACT || c == REFIL_MASK_WITHIN || c == REFIL_MASK_INTERACT || c >= REFIL_MASK_OBS_RGTW;
+}
+__host__ __device__ inline bool mask_uses_inactive0(int c) { return mask_uses_groups(c) || c == REFIL_MASK_GTW || c == REFIL_MASK_GTI; }
+
 int gemm_launch(const refil_gemm_desc& d, hipStream_t st);
 int attn_forward_launch(const refil_attn_desc& d, hipStream_t st);
 int attn_backward_launch(const refil_attn_desc& d, hipStream_t st);

@@ -243,6 +243,16 @@ static refil_gemm_desc linear_dw(const float* dy, int lddy, const float* x, int 
 
 #define RUN(x) do { if (int e_ = (x)) return e_; } while (0)
 
+// mask code of the within-group (which = 0) / between-group (which = 1) imagined copy: random split,
+// ground-truth factors or their combination (dims.gt_factors), with or without the observability mask
+static int group_code(const refil_dims& d, int which, bool with_obs) {
+    static const int T[3][2][2] = {
+        {{REFIL_MASK_WITHIN, REFIL_MASK_INTERACT}, {REFIL_MASK_OBS_WITHIN, REFIL_MASK_OBS_INTERACT}},
+        {{REFIL_MASK_GTW, REFIL_MASK_GTI}, {REFIL_MASK_OBS_GTW, REFIL_MASK_OBS_GTI}},
+        {{REFIL_MASK_RGTW, REFIL_MASK_RGTI}, {REFIL_MASK_OBS_RGTW, REFIL_MASK_OBS_RGTI}}};
+    return T[d.gt_factors][with_obs ? 1 : 0][which];
+}
+
 // The step has two independent chains between its join points: the agent chain (3-variant live agent,
 // target agent, GRUs -- latency-bound, few workgroups) and the hypernet chain (throughput-bound GEMMs).
 // They run on two HIP streams (fork/join with events, graph-capturable) so that the persistent GRU's 96
@@ -310,8 +320,8 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
         refil_attn_desc a = attn_base(c, dd);
         a.Q = b.q; a.K = b.kv; a.V = b.kv + dd; a.O = b.ao; a.sO = s.NA * dd;
         a.nvar = G; a.var[0] = REFIL_MASK_OBS;
-        a.var[1] = d.gt_factors ? REFIL_MASK_OBS_GTW : REFIL_MASK_OBS_WITHIN;
-        a.var[2] = d.gt_factors ? REFIL_MASK_OBS_GTI : REFIL_MASK_OBS_INTERACT;
+        a.var[1] = group_code(d, 0, true);
+        a.var[2] = group_code(d, 1, true);
         RUN(attn_forward_launch(a, c.st));
     }
     if (d.agent_ff) {
@@ -378,8 +388,8 @@ static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int n
         a.O = b.ao + (long)(n == 0 ? 0 : nv0 + n - 1) * s.NA * h; a.sO = s.NA * h;
         a.nvar = n == 0 ? nv0 : 1;
         a.var[0] = REFIL_MASK_ENTITY;
-        a.var[1] = d.gt_factors ? REFIL_MASK_GTW : REFIL_MASK_WITHIN;
-        a.var[2] = d.gt_factors ? REFIL_MASK_GTI : REFIL_MASK_INTERACT;
+        a.var[1] = group_code(d, 0, false);
+        a.var[2] = group_code(d, 1, false);
         RUN(attn_forward_launch(a, c.st));
     }
     // out_trans and fc2, both with inactive agents zeroed (attention.py:65-67, flex_qmix.py:49-50)
@@ -554,7 +564,8 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
     REFIL_CHECK(dims->T1 >= 2, "refil_learner_forward_backward: need at least one transition (T1 >= 2)");
     REFIL_CHECK(batch->obs_mask && batch->actions && batch->avail_actions && batch->reward && batch->terminated && batch->filled,
                 "refil_learner_forward_backward: incomplete batch");
-    REFIL_CHECK(!dims->imagine || batch->group_bits || dims->gt_factors, "refil_learner_forward_backward: group_bits required when imagine=1");
+    REFIL_CHECK(dims->gt_factors >= 0 && dims->gt_factors <= 2, "refil: gt_factors must be 0, 1 or 2");
+    REFIL_CHECK(!dims->imagine || batch->group_bits || dims->gt_factors == 1, "refil_learner_forward_backward: group_bits required when imagine=1");
     REFIL_CHECK(!(dims->gt_factors || dims->gt_obs_mask) || batch->gt_mask, "refil_learner_forward_backward: gt_mask required by gt_factors / gt_obs_mask");
     const refil_dims& d = c.d; const Sizes& s = c.s; const refil_param_layout& L = c.L; Work& w = c.w;
     const int T = d.T1 - 1, G = s.G, nv0 = s.nv0, H = d.H, h = d.hyp, M = d.M, dd = d.d;
@@ -665,8 +676,8 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
         k.x1 = w.lh.x1; k.kv = w.lh.kv; k.q = w.lh.q; k.ao = w.lh.ao; k.dx2 = w.dx2h;
         k.dao = w.daoh; k.dq = w.dqh; k.dkv = w.dkvh; k.dx1 = w.dx1h;
         k.var_first[0] = REFIL_MASK_ENTITY;
-        k.var_first[1] = d.gt_factors ? REFIL_MASK_GTW : REFIL_MASK_WITHIN;
-        k.var_first[2] = d.gt_factors ? REFIL_MASK_GTI : REFIL_MASK_INTERACT;
+        k.var_first[1] = group_code(d, 0, false);
+        k.var_first[2] = group_code(d, 1, false);
         k.var_rest = REFIL_MASK_ENTITY;
         RUN(attn_block_backward(ch, k));
         // the four hypernet fc1 layers: dW = dx1^T xe (one [4h,E] GEMM), db = colsum(dx1)
@@ -719,8 +730,8 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
         k.x1 = w.la.x1; k.kv = w.la.kv; k.q = w.la.q; k.ao = w.la.ao; k.dx2 = w.dx2a;
         k.dao = w.daoa; k.dq = w.dqa; k.dkv = w.dkva; k.dx1 = w.dx1a;
         k.var_first[0] = REFIL_MASK_OBS;
-        k.var_first[1] = d.gt_factors ? REFIL_MASK_OBS_GTW : REFIL_MASK_OBS_WITHIN;
-        k.var_first[2] = d.gt_factors ? REFIL_MASK_OBS_GTI : REFIL_MASK_OBS_INTERACT;
+        k.var_first[1] = group_code(d, 0, true);
+        k.var_first[2] = group_code(d, 1, true);
         k.var_rest = REFIL_MASK_OBS;
         RUN(attn_block_backward(ca, k));
         RUN(gemm_launch(linear_dw(w.dx1a, dd, w.xe, s.Ep, grads + L.ag_fc1_w, s.E, grads + L.ag_fc1_b, s.NE, dd, s.E, ca.w.partial, 1), ca.st));
@@ -739,7 +750,8 @@ extern "C" int refil_agent_forward(const refil_dims* dims, const refil_batch* ba
     if (int e = make_ctx(c, dims, batch, workspace, workspace_bytes_, CARVE_AGENT_FWD, stream)) return e;
     REFIL_CHECK(params && q_out, "refil_agent_forward: null params / q_out");
     REFIL_CHECK(batch->obs_mask, "refil_agent_forward: obs_mask missing");
-    REFIL_CHECK(!dims->imagine || batch->group_bits || dims->gt_factors, "refil_agent_forward: group_bits required when imagine=1");
+    REFIL_CHECK(dims->gt_factors >= 0 && dims->gt_factors <= 2, "refil: gt_factors must be 0, 1 or 2");
+    REFIL_CHECK(!dims->imagine || batch->group_bits || dims->gt_factors == 1, "refil_agent_forward: group_bits required when imagine=1");
     REFIL_CHECK(!(dims->gt_factors || dims->gt_obs_mask) || batch->gt_mask, "refil_agent_forward: gt_mask required by gt_factors / gt_obs_mask");
     RUN(run_prep(c, first_step_zero));
     RUN(agent_forward(c, params, c.w.la, c.s.G, h0));
@@ -766,7 +778,8 @@ extern "C" int refil_mixer_forward(const refil_dims* dims, const refil_batch* ba
     REFIL_CHECK((params || dims->mixer_vdn) && agent_qs && q_tot, "refil_mixer_forward: null pointer");
     REFIL_CHECK(t0 >= 0 && T > 0 && t0 + T <= dims->T1, "refil_mixer_forward: step range [%d,%d) outside the batch", t0, t0 + T);
     const bool im = agent_qs_imagine != nullptr;
-    REFIL_CHECK(!im || ((batch->group_bits || dims->gt_factors) && q_tot_imagine && dims->imagine),
+    REFIL_CHECK(dims->gt_factors >= 0 && dims->gt_factors <= 2, "refil: gt_factors must be 0, 1 or 2");
+    REFIL_CHECK(!im || ((batch->group_bits || dims->gt_factors == 1) && q_tot_imagine && dims->imagine),
                 "refil_mixer_forward: imagined mix needs imagine=1, group_bits (or gt_factors) and q_tot_imagine");
     REFIL_CHECK(!dims->gt_factors || batch->gt_mask, "refil_mixer_forward: gt_factors needs batch.gt_mask");
     RUN(run_prep(c, 1));

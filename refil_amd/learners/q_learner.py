@@ -112,9 +112,9 @@ class QLearner:
         args = self.args
         B, T1 = batch.batch_size, batch.max_seq_length
         dims = dims_from_args(args, B, T1)
-        if getattr(args, "train_rand_gt_factors", False):
-            raise NotImplementedError("train_rand_gt_factors is not built (entity_ff_agent.py:111-114)")
-        dims.gt_factors = int(bool(getattr(args, "train_gt_factors", False)))       # q_learner.py:88
+        tgt, trgt = bool(getattr(args, "train_gt_factors", False)), bool(getattr(args, "train_rand_gt_factors", False))
+        assert not (tgt and trgt), "Can only select one of use_rand_gt_factors and use_gt_factors"   # entity_ff_agent.py:112
+        dims.gt_factors = 2 if trgt else int(tgt)                                   # q_learner.py:88-89
         fields = self._fields(batch)
         dev = self.flat_live.device
         will_log = t_env - self.log_stats_t >= args.learner_log_interval
@@ -122,7 +122,7 @@ class QLearner:
         if will_log and dims.imagine and getattr(args, "test_gt_factors", False):
             gt_ingroup = self._gt_ingroup_prop(dims, fields, B, T1)                     # with the pre-update weights
         bits = None
-        if dims.imagine:
+        if dims.imagine:        # (drawn even when train_gt_factors ignores it: the reference consumes the RNG too, :86)
             bits = group_bits.to(dev).to(th.uint8).contiguous() if group_bits is not None else \
                 self._draw_partition(B, args.n_entities, dev)
         self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads)

@@ -49,9 +49,8 @@ class ImagineEntityAttentionFFAgent(EntityAttentionFFAgent):
                 group_bits=None, **kwargs):
         if not imagine:
             return super().forward(inputs, hidden_state)
-        if use_rand_gt_factors:
-            raise NotImplementedError("use_rand_gt_factors (entity_ff_agent.py:111-114) is not built yet")
-        q, _, gb = self._run(inputs, None, imagine=True, group_bits=group_bits, use_gt_factors=use_gt_factors)
+        q, _, gb = self._run(inputs, None, imagine=True, group_bits=group_bits, use_gt_factors=use_gt_factors,
+                             use_rand_gt_factors=use_rand_gt_factors)
         G, bs, ts, na, A = q.shape
         ne = self.args.n_entities
         if isinstance(inputs, EntityInputs):
@@ -67,5 +66,9 @@ class ImagineEntityAttentionFFAgent(EntityAttentionFFAgent):
             g = gb.bool()
             same = (~inact)[:, :na, None] & (~inact)[:, None, :] & (g[:, :na, None] == g[:, None, :])
             W = (~same)[:, None]
-            groups = ImagineGroups((W | active).to(th.uint8).repeat(1, ts, 1, 1), (~W | active).to(th.uint8).repeat(1, ts, 1, 1), bits=gb)
+            if use_rand_gt_factors:                                                        # :111-114 (time-dependent, :131-135)
+                W = W | gt_mask.bool()
+                groups = ImagineGroups((W | active).to(th.uint8), (~W | active).to(th.uint8), bits=gb, gt_mask=gt_mask)
+            else:
+                groups = ImagineGroups((W | active).to(th.uint8).repeat(1, ts, 1, 1), (~W | active).to(th.uint8).repeat(1, ts, 1, 1), bits=gb)
         return q.reshape(G * bs, ts, na, A), hidden_state, groups

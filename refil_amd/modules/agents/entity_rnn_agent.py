@@ -91,7 +91,7 @@ class EntityAttentionRNNAgent(FlatParamModule):
             object.__setattr__(self, "_engine", LearnerEngine(self.fc1.weight.device))
         return self._engine
 
-    def _run(self, inputs, hidden_state, imagine, group_bits=None, use_gt_factors=False):
+    def _run(self, inputs, hidden_state, imagine, group_bits=None, use_gt_factors=False, use_rand_gt_factors=False):
         na, H = self.args.n_agents, self.args.rnn_hidden_dim
         gt_mask = None
         if isinstance(inputs, EntityInputs):
@@ -109,7 +109,8 @@ class EntityAttentionRNNAgent(FlatParamModule):
             dims = self._dims(ents.shape[0], ents.shape[1], ed=ents.shape[3], last_action=False)
             fsz = True
         dims.imagine = int(imagine)
-        dims.gt_factors = int(bool(use_gt_factors))
+        assert not (use_gt_factors and use_rand_gt_factors), "Can only select one of use_rand_gt_factors and use_gt_factors"
+        dims.gt_factors = 2 if use_rand_gt_factors else int(bool(use_gt_factors))
         if dims.gt_factors or dims.gt_obs_mask:
             assert gt_mask is not None, "gt_mask needed (env must provide it: gt_mask_avail)"
             fields["gt_mask"] = gt_mask

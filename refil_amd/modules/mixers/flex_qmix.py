@@ -93,7 +93,8 @@ class FlexQMixer(FlatParamModule):
                 if imagine_groups.gt_mask is not None:
                     gt = imagine_groups.gt_mask
                     fields["gt_mask"] = (gt[:, :T] if gt.shape[1] != T else gt).contiguous()
-                    dims.gt_factors = 1
+                    gb = imagine_groups.bits                 # bits AND gt mask: randomised ground-truth factors
+                    dims.gt_factors = 2 if gb is not None else 1
                 else:
                     gb = imagine_groups.bits
             elif isinstance(imagine_groups, (tuple, list)):

@@ -159,3 +159,28 @@ def test_cfg1_group_matching_ff_agent_linear_mixer():
     mac2.init_hidden(batch2.batch_size)
     acts = mac2.select_actions(batch2, t_ep=0, t_env=0, test_mode=True)
     assert acts.shape == (batch2.batch_size, g["cfg"].n_agents)
+
+
+@pytest.mark.parametrize("name,flag", [("gm_refil_train_gt", "train_gt_factors"), ("gm_refil_train_randgt", "train_rand_gt_factors")])
+def test_cfg1_training_with_ground_truth_factor_options(name, flag):
+    """default.yaml:52-53 / q_learner.py:87-89: the imagined groups of the TRAINING pass are the ground-truth
+    factors, or the random split OR-ed with them (entity_ff_agent.py:93-95,111-114) -- against the reference's run."""
+    g, args, batch, mac, learner, logger = _build(name, gt_mask_avail=True, test_gt_factors=True, **{flag: True})
+    z, case = g["z"], g["case"]
+    th.manual_seed(case["seed"] + 7)
+    learner.train(batch, t_env=0, episode_num=0)
+    th.cuda.synchronize()
+    for k in ("loss", "im_loss", "grad_norm", "td_error_abs", "q_taken_mean", "target_mean", "ingroup_prop", "gt_ingroup_prop"):
+        ref = float(z["stat." + k])
+        assert abs(logger.stats[k] - ref) < 2e-4 * max(abs(ref), 1e-3), (k, logger.stats[k], ref)
+    sd = {**{"agent." + k: v for k, v in mac.agent.state_dict().items()},
+          **{"mixer." + k: v for k, v in learner.mixer.state_dict().items()}}
+    for k in z.files:
+        if k.startswith("post."):
+            assert (sd[k[5:]].cpu() - th.from_numpy(z[k])).abs().max().item() < 5e-6, k
+    # the groups the agent hands to the mixer are the reference's time-dependent masks
+    g2, args2, batch2, mac2, _, _ = _build(name, gt_mask_avail=True)
+    mac2.init_hidden(batch2.batch_size)
+    _, groups = mac2.forward(batch2, t=None, imagine=True, group_bits=g["bits"].cuda(), **{flag.replace("train_", "use_"): True})
+    assert th.equal(groups[0].cpu(), th.from_numpy(z["Wmask_noobs_t"]))
+    assert th.equal(groups[1].cpu(), th.from_numpy(z["Imask_noobs_t"]))

@@ -5,12 +5,12 @@ import pytest
 import torch
 
 from oracle import refil_oracle as orc
-from golden_util import CASES, GM_CASES, load, rel_err
+from golden_util import CASES, GM_CASES, GM_TRAIN_CASES, load, rel_err
 
 TOL = 2e-5   # fp32, different op order than the reference (shared fc1/K/V, fused masks)
 
 
-@pytest.mark.parametrize("name", CASES + GM_CASES)
+@pytest.mark.parametrize("name", CASES + GM_CASES + GM_TRAIN_CASES)
 def test_oracle_matches_reference(name):
     g = load(name)
     z, cfg, case = g["z"], g["cfg"], g["case"]
@@ -29,13 +29,20 @@ def test_oracle_matches_reference(name):
         assert rel_err(caq_im, z["chosen_q_imagine"]) < TOL
         assert rel_err(out.q_tot_imagine.detach(), z["q_tot_imagine"]) < TOL
         assert abs(out.im_loss.item() - float(z["stat.im_loss"])) < TOL * abs(float(z["stat.im_loss"]))
-        if z["Wmask_noobs"].shape[-2] == cfg.n_entities:          # recurrent agent: full [ne,ne] masks
+        if "Wmask_noobs_t" in z.files:                            # (randomised) ground-truth factors: time-dependent groups
+            W, I, act = orc.group_masks(cfg, g["batch"]["entity_mask"], g["bits"], g["batch"]["gt_mask"],
+                                        rand_gt=cfg.train_rand_gt_factors)
+            assert np.array_equal((W | act).numpy().astype(np.uint8), z["Wmask_noobs_t"])
+            assert np.array_equal((I | act).numpy().astype(np.uint8), z["Imask_noobs_t"])
+            W = None
+        elif z["Wmask_noobs"].shape[-2] == cfg.n_entities:        # recurrent agent: full [ne,ne] masks
             Wm, Im = orc.imagine_masks(g["bits"], g["batch"]["entity_mask"][:, 0])
             assert np.array_equal(Wm.numpy().astype(np.uint8), z["Wmask_noobs"])
             assert np.array_equal(Im.numpy().astype(np.uint8), z["Imask_noobs"])
-        W, I, act = orc.group_masks(cfg, g["batch"]["entity_mask"], g["bits"])
-        assert np.array_equal((W | act)[:, 0].numpy().astype(np.uint8), z["Wmask_noobs"][:, :cfg.n_agents])
-        assert np.array_equal((I | act)[:, 0].numpy().astype(np.uint8), z["Imask_noobs"][:, :cfg.n_agents])
+        if "Wmask_noobs" in z.files:
+            W, I, act = orc.group_masks(cfg, g["batch"]["entity_mask"], g["bits"])
+            assert np.array_equal((W | act)[:, 0].numpy().astype(np.uint8), z["Wmask_noobs"][:, :cfg.n_agents])
+            assert np.array_equal((I | act)[:, 0].numpy().astype(np.uint8), z["Imask_noobs"][:, :cfg.n_agents])
     assert abs(gnorm - float(z["stat.grad_norm"])) < 1e-4 * float(z["stat.grad_norm"])
     for k in ("td_error_abs", "q_taken_mean", "target_mean"):
         assert abs(out.stats[k] - float(z["stat." + k])) < 1e-4 * max(abs(float(z["stat." + k])), 1e-3)

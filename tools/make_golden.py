@@ -240,6 +240,8 @@ def run_gm_case(name, case, out_dir):
     args = ref_args(case)
     args.agent, args.mixer = "imagine_entity_attend_ff", "lin_flex_qmix"
     args.gt_mask_avail, args.test_gt_factors, args.gt_obs_mask = True, True, False
+    args.train_gt_factors = bool(case.get("train_gt_factors", False))
+    args.train_rand_gt_factors = bool(case.get("train_rand_gt_factors", False))
     B, T, na = case["B"], case["T"], case["na"]
     scheme = {
         "entities": {"vshape": ed, "group": "entities"},
@@ -281,8 +283,12 @@ def run_gm_case(name, case, out_dir):
     rec["group_bits"] = bits.numpy()
     q_all = cap["agent"][0][0].detach()
     rec["q"] = q_all.reshape(3, B, T + 1, na, 3).numpy()
-    rec["Wmask_noobs"] = cap["agent"][0][2][0][:, 0].numpy()
-    rec["Imask_noobs"] = cap["agent"][0][2][1][:, 0].numpy()
+    if args.train_gt_factors or args.train_rand_gt_factors:    # time-dependent groups (rep_t = 1, entity_ff_agent.py:131-135)
+        rec["Wmask_noobs_t"] = cap["agent"][0][2][0].numpy()
+        rec["Imask_noobs_t"] = cap["agent"][0][2][1].numpy()
+    else:
+        rec["Wmask_noobs"] = cap["agent"][0][2][0][:, 0].numpy()
+        rec["Imask_noobs"] = cap["agent"][0][2][1][:, 0].numpy()
     rec["q_gt"] = cap["agent"][1][0].detach().reshape(3, B, T + 1, na, 3).numpy()      # use_gt_factors=True pass (log step)
     (i0, o0), (i1, o1), (i2, o2) = cap["mixer"][:3]
     rec["chosen_q_real"], rec["q_tot"] = i0[0].detach().numpy(), o0.detach().numpy()
@@ -311,6 +317,9 @@ def run_gm_case(name, case, out_dir):
 GM_CASES = {
     # BASELINE.json configs[0]: real group_matching episodes, refil_group_matching alg (scaled-down widths)
     "gm_refil_ff_lin": dict(B=6, T=10, na=8, n_states=6, d=32, heads=4, h=32, M=32, seed=31),
+    # the two training-time factor options of the same alg (default.yaml:52-53, q_learner.py:87-89)
+    "gm_refil_train_gt": dict(B=4, T=8, na=8, n_states=6, d=32, heads=4, h=32, M=32, seed=32, train_gt_factors=True),
+    "gm_refil_train_randgt": dict(B=4, T=8, na=8, n_states=6, d=32, heads=4, h=32, M=32, seed=33, train_rand_gt_factors=True),
 }
 
 CASES = {
