@@ -23,7 +23,7 @@
 
 #include "common.h"
 #include "profile.h"
-#include "../../include/refil_hip.h"
+#include "kernels.h"
 
 namespace refil {
 
@@ -414,6 +414,8 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
         const long rows = d.c_map.grp ? ((long)(d.M - 1) / d.c_map.grp) * d.c_map.gstride + d.c_map.grp + d.c_map.off : d.M;
         REFIL_CHECK(rows * (long)(d.splits > 1 ? d.N : d.ldc) < (1L << 32), "refil_gemm: C exceeds 2^32 elements per batch");
     }
+    static const bool wres = []() { const char* e = getenv("REFIL_GEMM_WRES"); return !(e && e[0] == '0'); }();
+    if (wres && gemm_wres_eligible(d)) return gemm_wres_launch(d, st);
     GemmK k;
     k.A = d.A; k.B = d.B; k.C = d.C; k.bias = d.bias; k.aux = d.aux; k.rowmask = d.rowmask;
     k.colsum = d.colsum; k.partial = d.partial;

@@ -16,6 +16,9 @@ __host__ __device__ inline bool mask_uses_groups(int c) {   // same(i,j): group 
 __host__ __device__ inline bool mask_uses_inactive0(int c) { return mask_uses_groups(c) || c == REFIL_MASK_GTW || c == REFIL_MASK_GTI; }
 
 int gemm_launch(const refil_gemm_desc& d, hipStream_t st);
+// weight-resident kernel for short-reduction forward projections (gemm_wres.hip); gemm_launch dispatches to it
+bool gemm_wres_eligible(const refil_gemm_desc& d);
+int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st);
 int attn_forward_launch(const refil_attn_desc& d, hipStream_t st);
 int attn_backward_launch(const refil_attn_desc& d, hipStream_t st);
 int gru_forward_launch(const refil_gru_desc& d, hipStream_t st);

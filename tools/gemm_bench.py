@@ -1,5 +1,5 @@
 """Micro-benchmark of the GEMM shapes of the cfg-T learner step through the C ABI (for rocprofv3 / PMC runs).
-usage: python tools/gemm_bench.py [reps]"""
+usage: python tools/gemm_bench.py [reps] [kv]"""
 import os
 import sys
 
@@ -58,6 +58,10 @@ def dw(R, N, K, batch=1, splits=256):
     timeit(f"dW R={R} N={N} K={K} b={batch} s={splits}", fn, 2.0 * R * N * K * batch)
 
 
+only = sys.argv[2] if len(sys.argv) > 2 else ""      # e.g. "kv": just the dominant shape (for PMC runs)
+if only == "kv":
+    nt(NE, 256, 128, batch=4, bias=False)
+    sys.exit(0)
 nt(NE, 128, 84, relu=True)
 nt(NE, 512, 84, relu=True)
 nt(NE, 256, 128, bias=False)
