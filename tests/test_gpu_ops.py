@@ -112,6 +112,72 @@ def test_gemm_dw_bmap_hprev():
     _close(dW, ref, tol=5e-5, what="dW_hh")
 
 
+# ---- weight-resident kernel (gemm_wres.hip): taken for M >= 2048, M % 32 == 0, N % 32 == 0, short reductions ----
+@pytest.mark.parametrize("M,N,K,batch", [(4096, 128, 128, 1), (2048 + 64, 256, 128, 2), (6400, 512, 84, 1), (4096, 192, 64, 1),
+                                         (2560, 64, 128, 1), (3200, 32, 128, 3), (2048, 128, 16, 1), (4096, 96, 40, 1)])
+def test_gemm_wres_forward(M, N, K, batch):
+    import hip_ops
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, batch * K)
+    W = torch.randn(batch, N, K) / math.sqrt(K)
+    b = torch.randn(batch, N)
+    mask = (torch.rand(48) < 0.3).to(torch.uint8)
+    ref = torch.stack([torch.relu(x[:, n * K:(n + 1) * K] @ W[n].t() + b[n]) for n in range(batch)])
+    ref[:, mask[torch.arange(M) % 48].bool()] = 0
+    y = torch.full((batch, M, N), float("nan"), device=DEV)
+    hip_ops.gemm(x.to(DEV), W.to(DEV), y, M, N, K, batch * K, K, N, flags=GEMM_RELU, bias=b.to(DEV), rowmask=mask.to(DEV),
+                 rowmask_mod=48, batch=batch, sA=K, sB=N * K, sC=M * N, sBias=N)
+    _close(y, ref, what="wres forward")
+    # no bias / no mask / no relu, agent-row gather on the input and scatter on the output
+    na, ne = 4, 8
+    R = M // na
+    xe = torch.randn(R * ne, K)
+    ref2 = xe.view(R, ne, K)[:, :na].reshape(R * na, K) @ W[0].t()
+    y2 = torch.zeros(R * ne, N, device=DEV)
+    hip_ops.gemm(xe.to(DEV), W[0].contiguous().to(DEV), y2, R * na, N, K, K, K, N, a_map=(na, ne, 0), c_map=(na, ne, 0))
+    _close(y2.view(R, ne, N)[:, :na].reshape(R * na, N), ref2, what="wres forward (row maps)")
+    assert y2.view(R, ne, N)[:, na:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 128, 128), (2304, 128, 32), (4096, 128, 64), (2560, 64, 96), (4096, 256, 128)])
+def test_gemm_wres_dx(M, N, K):
+    """dx[M,N] = dy[M,K] W[K,N]  (N = layer input width, K = layer output width = the reduction)."""
+    import hip_ops
+    torch.manual_seed(M + N + K + 1)
+    dy = torch.randn(M, K)
+    W = torch.randn(K, N) / math.sqrt(K)
+    mask = (torch.rand(40) < 0.3).to(torch.uint8)
+    ref = dy @ W
+    ref[mask[torch.arange(M) % 40].bool()] = 0
+    dx = torch.full((M, N), float("nan"), device=DEV)
+    hip_ops.gemm(dy.to(DEV), W.to(DEV), dx, M, N, K, K, N, N, flags=GEMM_B_OUTC, rowmask=mask.to(DEV), rowmask_mod=40)
+    _close(dx, ref, what="wres dx")
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 128, 256), (2048, 64, 192), (4096, 128, 128), (2560, 128, 64), (2048, 64, 52)])
+def test_gemm_wres_dx_relu_bwd_accum(M, N, K):
+    import hip_ops
+    torch.manual_seed(M + N + K + 2)
+    na, ne = 4, 8
+    R = M // ne
+    dy = torch.randn(M, K)
+    W = torch.randn(K, N) / math.sqrt(K)
+    x1 = torch.randn(M, N)
+    dq = torch.randn(R * na, K)
+    Wq = torch.randn(K, N) / math.sqrt(K)
+    ref = (dy @ W) * (x1 > 0)
+    ref.view(R, ne, N)[:, :na] += (dq @ Wq).view(R, na, N) * (x1.view(R, ne, N)[:, :na] > 0)
+    dx = torch.full((M, N), float("nan"), device=DEV)
+    x1d = x1.to(DEV)
+    hip_ops.gemm(dy.to(DEV), W.to(DEV), dx, M, N, K, K, N, N, flags=GEMM_B_OUTC | GEMM_RELU_BWD, aux=x1d)
+    if R * na >= 2048:
+        hip_ops.gemm(dq.to(DEV), Wq.to(DEV), dx, R * na, N, K, K, N, N, flags=GEMM_B_OUTC | GEMM_RELU_BWD | GEMM_ACCUM, aux=x1d,
+                     c_map=(na, ne, 0))
+        _close(dx, ref, what="wres dx relu-bwd + accumulate")
+    else:
+        _close(dx, (dy @ W) * (x1 > 0), what="wres dx relu-bwd")
+
+
 # ------------------------------------------------------------------------------------------------
 # attention core
 # ------------------------------------------------------------------------------------------------
