@@ -354,6 +354,8 @@ static const char* gemm_name(int wm, int tm, int tn, bool ao, bool bo) {
         {"gemm_kernel<2,2,2,2,false,false>", "gemm_kernel<2,2,2,2,false,true>", "gemm_kernel<2,2,2,2,true,false>", "gemm_kernel<2,2,2,2,true,true>"},
         {"gemm_kernel<4,1,1,2,false,false>", "gemm_kernel<4,1,1,2,false,true>", "gemm_kernel<4,1,1,2,true,false>", "gemm_kernel<4,1,1,2,true,true>"},
         {"gemm_kernel<4,1,1,1,false,false>", "gemm_kernel<4,1,1,1,false,true>", "gemm_kernel<4,1,1,1,true,false>", "gemm_kernel<4,1,1,1,true,true>"}};
+    if (wm == 1) return "gemm_kernel<1,4,1,1,true,true>";
+    if (wm == 2 && tm == 1) return "gemm_kernel<2,2,1,2,true,true>";
     if (wm == 4 && tm == 2) {
         static const char* big[4] = {"gemm_kernel<4,2,2,2,false,false>", "gemm_kernel<4,2,2,2,false,true>",
                                      "gemm_kernel<4,2,2,2,true,false>", "gemm_kernel<4,2,2,2,true,true>"};
@@ -388,6 +390,18 @@ static int launch_cfg(const GemmK& k, hipStream_t st) {
         set_error("refil_gemm: unsupported combination (A_OUTC=%d, B_OUTC=%d, epilogue=%d)", (int)ao, (int)bo, epi);
         return 1;
     }
+    return 0;
+}
+
+// narrow-M tiles for the weight gradients of thin layers (dW[N_out <= 64, K]): only the (OUTC, OUTC) combinations
+template <int WM, int WN, int TM, int TN>
+static int launch_cfg_dw(const GemmK& k, hipStream_t st) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    dim3 grid(cdiv(k.N, BN), cdiv(k.M, BM), k.batch * k.splits);
+    ProfScope prof(gemm_name(WM, TM, TN, true, true), 2.0 * k.M * k.N * k.K * k.batch,
+                   4.0 * k.batch * ((double)k.M * k.K + (double)k.N * k.K + (double)k.M * k.N), st);
+    if (k.splits > 1) launch_vec<WM, WN, TM, TN, true, true, 2>(k, grid, st);
+    else launch_vec<WM, WN, TM, TN, true, true, 0>(k, grid, st);
     return 0;
 }
 
@@ -438,7 +452,10 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
     // shapes +20 %, K=84 shapes -10 %)
     static const long big_min_blocks = []() { const char* e = getenv("REFIL_GEMM_BIG_MINBLK"); return e ? atol(e) : 200L; }();   // fewer big tiles than this leave CUs idle: use 128x128
     const long big_blocks = (long)cdiv(d.M, 256) * cdiv(d.N, 128) * d.batch * d.splits;
-    if (d.N > 64 && d.M >= 8192 && d.K >= 96 && big_tile && big_blocks >= big_min_blocks) rc = launch_cfg<4, 2, 2, 2>(k, st);
+    const bool dw = (d.flags & REFIL_GEMM_A_OUTC) && (d.flags & REFIL_GEMM_B_OUTC) && !(d.flags & (REFIL_GEMM_RELU | REFIL_GEMM_RELU_BWD));
+    if (dw && d.M <= 32 && d.N > 64) rc = launch_cfg_dw<1, 4, 1, 1>(k, st);
+    else if (dw && d.M <= 64 && d.N > 64) rc = launch_cfg_dw<2, 2, 1, 2>(k, st);
+    else if (d.N > 64 && d.M >= 8192 && d.K >= 96 && big_tile && big_blocks >= big_min_blocks) rc = launch_cfg<4, 2, 2, 2>(k, st);
     else if (d.N > 64) rc = launch_cfg<2, 2, 2, 2>(k, st);
     else if (d.N > 32) rc = launch_cfg<4, 1, 1, 2>(k, st);
     else rc = launch_cfg<4, 1, 1, 1>(k, st);
