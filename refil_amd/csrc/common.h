@@ -54,5 +54,10 @@ struct RowMap {
 };
 
 __device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// hardware-rate versions for the per-step GRU gate math (v_exp_f32 + v_rcp_f32, ~1 ulp each; both saturate
+// correctly: exp2 -> inf gives 0 resp. +-1). expf / tanhf / IEEE division cost ~10x the instructions, and the
+// persistent GRU runs one wave per SIMD, so gate-math instructions are directly on the per-step critical path.
+__device__ inline float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
+__device__ inline float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)); }
 
 }  // namespace refil

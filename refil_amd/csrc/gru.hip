@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruK p) {
         hold[reg] = valid[reg] ? p.hsx[hs_base[reg] * GH + c] : 0.f;
         hbuf[0][(4 * q + reg) * HP + c] = hold[reg];
     }
-    float gcur[4][3], gnext[4][3];
+    float gcur[4][3], gnext[4][3] = {};
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
@@ -94,27 +94,37 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruK p) {
             az = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[1][s], az, 0, 0, 0);
             an = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[2][s], an, 0, 0, 0);
         }
+        float rgv[4], zgv[4], ngv[4], ghv[4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const float rg = sigmoidf_(gcur[reg][0] + ar[reg] + bhr);
-            const float zg = sigmoidf_(gcur[reg][1] + az[reg] + bhz);
-            const float ghn = an[reg] + bhn;
-            const float ng = tanhf(gcur[reg][2] + rg * ghn);
-            const float hnew = (1.0f - zg) * ng + zg * hold[reg];
+            rgv[reg] = fast_sigmoid(gcur[reg][0] + ar[reg] + bhr);
+            zgv[reg] = fast_sigmoid(gcur[reg][1] + az[reg] + bhz);
+            ghv[reg] = an[reg] + bhn;
+            ngv[reg] = fast_tanh(gcur[reg][2] + rgv[reg] * ghv[reg]);
+            const float hnew = (1.0f - zgv[reg]) * ngv[reg] + zgv[reg] * hold[reg];
             hold[reg] = hnew;
             hn[(4 * q + reg) * HP + c] = hnew;
-            if (valid[reg]) {
-                p.hsx[(hs_base[reg] + (long)(t + 1) * p.na) * GH + c] = hnew;
-                if (SAVE) {
-                    const long o = (gi_base[reg] + (long)t * p.na) * GH + c;
-                    p.save_r[o] = rg; p.save_z[o] = zg; p.save_n[o] = ng; p.save_ghn[o] = ghn;
-                }
-            }
         }
+        // gfx9 counts loads and stores in one counter (vmcnt): awaiting the prefetched gi AFTER this step's stores
+        // would stall every step on the store acknowledgements. So the prefetch is collected first (it had the whole
+        // step to arrive) and the stores are issued last; they drain during the next step.
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
-            for (int g = 0; g < 3; ++g) gcur[reg][g] = gnext[reg][g];
+            for (int g = 0; g < 3; ++g) {
+                asm volatile("" : "+v"(gnext[reg][g]));
+                gcur[reg][g] = gnext[reg][g];
+            }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            if (valid[reg]) {
+                p.hsx[(hs_base[reg] + (long)(t + 1) * p.na) * GH + c] = hold[reg];
+                if (SAVE) {
+                    const long o = (gi_base[reg] + (long)t * p.na) * GH + c;
+                    p.save_r[o] = rgv[reg]; p.save_z[o] = zgv[reg]; p.save_n[o] = ngv[reg]; p.save_ghn[o] = ghv[reg];
+                }
+            }
+        }
         __syncthreads();
     }
 }
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruK p) {
         carry[reg] = 0.f;
     }
     // per-step inputs: 0 dhs, 1 r, 2 z, 3 n, 4 ghn, 5 h_{t-1}
-    float cur[4][6], nxt[4][6];
+    float cur[4][6], nxt[4][6] = {};
     auto fetch = [&](float (&dst)[4][6], int t) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruK p) {
     for (int t = p.T1 - 1; t >= 0; --t, ++it) {
         float* gb_w = gbuf[it & 1];
         if (t > 0) fetch(nxt, t - 1);
-        float dhz[4];
+        float dhz[4], sv[4][4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const float dh = carry[reg] + cur[reg][0];
@@ -187,11 +197,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruK p) {
             const float dz_pre = dz * zg * (1.0f - zg);
             float* row = gb_w + (4 * q + reg) * GP;
             row[c] = dr_pre; row[GH + c] = dz_pre; row[2 * GH + c] = dghn;
-            if (valid[reg]) {
-                const long o = (gi_base[reg] + (long)t * p.na) * (3 * GH) + c;
-                p.dgi[o] = dr_pre; p.dgi[o + GH] = dz_pre; p.dgi[o + 2 * GH] = dn_pre;
-                p.dgh[o] = dr_pre; p.dgh[o + GH] = dz_pre; p.dgh[o + 2 * GH] = dghn;
-            }
+            sv[reg][0] = dr_pre; sv[reg][1] = dz_pre; sv[reg][2] = dn_pre; sv[reg][3] = dghn;
         }
         __syncthreads();
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
@@ -204,11 +210,23 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruK p) {
             a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, bw[s + 1], a1, 0, 0, 0);
             a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x2, bw[s + 2], a2, 0, 0, 0);
         }
+        // (same ordering rule as the forward kernel: collect the prefetch, then issue this step's stores)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             carry[reg] = dhz[reg] + (a0[reg] + a1[reg] + a2[reg]);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) cur[reg][k] = nxt[reg][k];
+            for (int k = 0; k < 6; ++k) {
+                asm volatile("" : "+v"(nxt[reg][k]));
+                cur[reg][k] = nxt[reg][k];
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            if (valid[reg]) {
+                const long o = (gi_base[reg] + (long)t * p.na) * (3 * GH) + c;
+                p.dgi[o] = sv[reg][0]; p.dgi[o + GH] = sv[reg][1]; p.dgi[o + 2 * GH] = sv[reg][2];
+                p.dgh[o] = sv[reg][0]; p.dgh[o + GH] = sv[reg][1]; p.dgh[o + 2 * GH] = sv[reg][3];
+            }
         }
     }
 }
