@@ -452,8 +452,10 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
     // shapes +20 %, K=84 shapes -10 %)
     static const long big_min_blocks = []() { const char* e = getenv("REFIL_GEMM_BIG_MINBLK"); return e ? atol(e) : 200L; }();   // fewer big tiles than this leave CUs idle: use 128x128
     const long big_blocks = (long)cdiv(d.M, 256) * cdiv(d.N, 128) * d.batch * d.splits;
+    static const bool dw_stream = []() { const char* e = getenv("REFIL_GEMM_DWSTREAM"); return !(e && e[0] == '0'); }();
     const bool dw = (d.flags & REFIL_GEMM_A_OUTC) && (d.flags & REFIL_GEMM_B_OUTC) && !(d.flags & (REFIL_GEMM_RELU | REFIL_GEMM_RELU_BWD));
-    if (dw && d.M <= 32 && d.N > 64) rc = launch_cfg_dw<1, 4, 1, 1>(k, st);
+    if (dw_stream && gemm_dw_stream_eligible(d)) rc = gemm_dw_stream_launch(d, st);
+    else if (dw && d.M <= 32 && d.N > 64) rc = launch_cfg_dw<1, 4, 1, 1>(k, st);
     else if (dw && d.M <= 64 && d.N > 64) rc = launch_cfg_dw<2, 2, 1, 2>(k, st);
     else if (d.N > 64 && d.M >= 8192 && d.K >= 96 && big_tile && big_blocks >= big_min_blocks) rc = launch_cfg<4, 2, 2, 2>(k, st);
     else if (d.N > 64) rc = launch_cfg<2, 2, 2, 2>(k, st);

@@ -27,8 +27,8 @@ namespace refil {
 
 constexpr int GH = 64;        // hidden size (rnn_hidden_dim of every shipped config)
 constexpr int GROWS = 16;     // rows per workgroup
-constexpr int HP = GH + 2;    // LDS pitch of the h tile
-constexpr int GP = 3 * GH + 2;  // LDS pitch of the dgh tile
+constexpr int HP = GH + 4;    // LDS pitch of the h tile (HP/4 odd: conflict-free 16-byte fragment reads)
+constexpr int GP = 3 * GH + 4;  // LDS pitch of the dgh tile (GP/4 odd)
 
 struct GruK {
     const float* gi; float* hsx; const float* w_hh; const float* b_hh;
@@ -39,18 +39,20 @@ struct GruK {
 
 template <bool SAVE>
 __global__ __launch_bounds__(256) void gru_fwd_kernel(GruK p) {
-    __shared__ float hbuf[2][GROWS * HP];
+    __shared__ __attribute__((aligned(16))) float hbuf[2][GROWS * HP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, c16 = lane & 15;
     const int c = wave * 16 + c16;           // hidden column owned by this lane
     const int r0 = blockIdx.x * GROWS;
 
-    // W_hh fragments: bw[g][s] = W_hh[g*64 + c][4s + q]
+    // W_hh fragments: bw[g][s] = W_hh[g*64 + c][16q + s]. (The MFMA k order is a free permutation as long as both
+    // operands agree: giving lane group q the CONTIGUOUS k range [16q, 16q+16) turns the 16 scalar LDS reads of the
+    // h fragment into 4 ds_read_b128.)
     float bw[3][16];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) bw[g][s] = p.w_hh[(long)(g * GH + c) * GH + 4 * s + q];
+        for (int s = 0; s < 16; ++s) bw[g][s] = p.w_hh[(long)(g * GH + c) * GH + 16 * q + s];
     const float bhr = p.b_hh[c], bhz = p.b_hh[GH + c], bhn = p.b_hh[2 * GH + c];
 
     long gi_base[4], hs_base[4];
@@ -86,7 +88,10 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruK p) {
         }
         float a[16];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) a[s] = hb[c16 * HP + 4 * s + q];
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float4 v = *reinterpret_cast<const float4*>(hb + c16 * HP + 16 * q + 4 * s4);
+            a[4 * s4] = v.x; a[4 * s4 + 1] = v.y; a[4 * s4 + 2] = v.z; a[4 * s4 + 3] = v.w;
+        }
         f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -135,16 +140,16 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruK p) {
 //   dr_pre = dr r (1-r);  dz_pre = dz z (1-z)
 //   dgi[t] = (dr_pre, dz_pre, dn_pre);  dgh[t] = (dr_pre, dz_pre, dgh_n);  carry' += dgh[t] W_hh
 __global__ __launch_bounds__(256) void gru_bwd_kernel(GruK p) {
-    __shared__ float gbuf[2][GROWS * GP];
+    __shared__ __attribute__((aligned(16))) float gbuf[2][GROWS * GP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, c16 = lane & 15;
     const int c = wave * 16 + c16;
     const int r0 = blockIdx.x * GROWS;
 
-    // W_hh^T fragments: carry[row][c] += sum_k dgh[row][k] W_hh[k][c];  bw[s] = W_hh[4s+q][c]
+    // W_hh^T fragments: carry[row][c] += sum_k dgh[row][k] W_hh[k][c];  bw[s] = W_hh[48q+s][c]  (contiguous k range per lane group, see the forward kernel)
     float bw[48];
 #pragma unroll
-    for (int s = 0; s < 48; ++s) bw[s] = p.w_hh[(long)(4 * s + q) * GH + c];
+    for (int s = 0; s < 48; ++s) bw[s] = p.w_hh[(long)(48 * q + s) * GH + c];
 
     long gi_base[4], hs_base[4];
     bool valid[4];
@@ -202,13 +207,22 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruK p) {
         __syncthreads();
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
 #pragma unroll
-        for (int s = 0; s < 48; s += 3) {
-            const float x0 = gb_w[c16 * GP + 4 * s + q];
-            const float x1 = gb_w[c16 * GP + 4 * (s + 1) + q];
-            const float x2 = gb_w[c16 * GP + 4 * (s + 2) + q];
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, bw[s], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, bw[s + 1], a1, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x2, bw[s + 2], a2, 0, 0, 0);
+        for (int s = 0; s < 48; s += 12) {
+            const float4 v0 = *reinterpret_cast<const float4*>(gb_w + c16 * GP + 48 * q + s);
+            const float4 v1 = *reinterpret_cast<const float4*>(gb_w + c16 * GP + 48 * q + s + 4);
+            const float4 v2 = *reinterpret_cast<const float4*>(gb_w + c16 * GP + 48 * q + s + 8);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0.x, bw[s], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0.y, bw[s + 1], a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0.z, bw[s + 2], a2, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0.w, bw[s + 3], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1.x, bw[s + 4], a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1.y, bw[s + 5], a2, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1.z, bw[s + 6], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v1.w, bw[s + 7], a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(v2.x, bw[s + 8], a2, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v2.y, bw[s + 9], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v2.z, bw[s + 10], a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(v2.w, bw[s + 11], a2, 0, 0, 0);
         }
         // (same ordering rule as the forward kernel: collect the prefetch, then issue this step's stores)
 #pragma unroll

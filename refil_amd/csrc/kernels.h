@@ -18,6 +18,9 @@ __host__ __device__ inline bool mask_uses_inactive0(int c) { return mask_uses_gr
 int gemm_launch(const refil_gemm_desc& d, hipStream_t st);
 // weight-resident kernel for short-reduction forward projections (gemm_wres.hip); gemm_launch dispatches to it
 bool gemm_wres_eligible(const refil_gemm_desc& d);
+// streaming weight-gradient kernel (gemm_dw.hip): writes the split partials, gemm_launch runs the reduction
+bool gemm_dw_stream_eligible(const refil_gemm_desc& d);
+int gemm_dw_stream_launch(const refil_gemm_desc& d, hipStream_t st);
 int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st);
 int attn_forward_launch(const refil_attn_desc& d, hipStream_t st);
 int attn_backward_launch(const refil_attn_desc& d, hipStream_t st);

@@ -233,7 +233,8 @@ static refil_gemm_desc linear_dw(const float* dy, int lddy, const float* x, int 
     g.colsum = db; g.partial = partial; g.batch = batch;
     const int bn = K > 64 ? 128 : (K > 32 ? 64 : 32);
     const long tiles = (long)cdiv(N, 128) * cdiv(K, bn) * batch;
-    long splits = 1024 / tiles;
+    static const long target = [] { const char* e = getenv("REFIL_DW_TARGET"); return e ? atol(e) : 1024L; }();
+    long splits = target / tiles;
     splits = min(splits, cdivl(R, N <= 64 ? 128 : 256));      // thin layers run narrow tiles: more, shorter splits
     splits = max(splits, 1L);
     while (splits > 1 && (long)batch * splits * ((long)N * K + N) > PARTIAL_FLOATS) --splits;

@@ -112,6 +112,27 @@ def test_gemm_dw_bmap_hprev():
     _close(dW, ref, tol=5e-5, what="dW_hh")
 
 
+@pytest.mark.parametrize("N,K,splits", [(192, 64, 9), (128, 128, 5), (256, 128, 16), (512, 84, 7), (100, 52, 3)])
+def test_gemm_dw_stream_rowmaps(N, K, splits):
+    """The streaming weight-gradient kernel (gemm_dw.hip; long reductions, N_out >= 96): row maps on both operands
+    (agent rows of a [R, ne] buffer; h_{t-1} rows of the [gb, T1+1, na] buffer), bias gradient, odd row counts."""
+    import hip_ops
+    torch.manual_seed(N + K + splits)
+    na, ne, R = 3, 5, 1499
+    dyb = torch.randn(R * ne, N)                 # only the first na of every ne rows are used
+    xb = torch.randn(R * ne, K)
+    dy = dyb.view(R, ne, N)[:, :na].reshape(R * na, N)
+    x = xb.view(R, ne, K)[:, :na].reshape(R * na, K)
+    ref_w, ref_b = dy.t() @ x, dy.sum(0)
+    dW = torch.full((N, K), float("nan"), device=DEV)
+    db = torch.full((N,), float("nan"), device=DEV)
+    partial = torch.empty(splits * (N * K + N) + 16, device=DEV)
+    hip_ops.gemm(dyb.to(DEV), xb.to(DEV), dW, N, K, R * na, N, K, K, flags=GEMM_A_OUTC | GEMM_B_OUTC | GEMM_COLSUM_A, colsum=db,
+                 partial=partial, splits=splits, a_map=(na, ne, 0), b_map=(na, ne, 0))
+    _close(dW, ref_w, tol=5e-5, what="dW (stream, row maps)")
+    _close(db, ref_b, tol=5e-5, what="db (stream)")
+
+
 # ---- weight-resident kernel (gemm_wres.hip): taken for M >= 2048, M % 32 == 0, N % 32 == 0, short reductions ----
 @pytest.mark.parametrize("M,N,K,batch", [(4096, 128, 128, 1), (2048 + 64, 256, 128, 2), (6400, 512, 84, 1), (4096, 192, 64, 1),
                                          (2560, 64, 128, 1), (3200, 32, 128, 3), (2048, 128, 16, 1), (4096, 96, 40, 1)])
