@@ -169,10 +169,16 @@ int gemm_dw_stream_launch(const refil_gemm_desc& d, hipStream_t st) {
     auto mk = [](const refil_rowmap& m) { return m.grp ? RowMap{m.grp, m.gstride, m.off} : RowMap{1 << 30, 0, 0}; };
     k.amap = mk(d.a_map); k.bmap = mk(d.b_map);
     k.splits = d.splits; k.batch = d.batch; k.colsum = (d.flags & REFIL_GEMM_COLSUM_A) ? 1 : 0;
-    const bool wide = d.N > 64;
-    ProfScope prof(wide ? "gemm_dw_stream_kernel<2,2>" : "gemm_dw_stream_kernel<4,1>", 2.0 * d.M * d.N * d.K * d.batch,
+    const bool wide = d.N > 64, tall = d.M >= 256;
+    // wide + tall: 8 waves cover 256 x 128 of the output so that x (the B operand) is read once per workgroup -- two
+    // 128-row workgroups would land on different XCDs and each fetch its own copy from HBM
+    const char* nm = wide ? (tall ? "gemm_dw_stream_kernel<4,2,16>" : "gemm_dw_stream_kernel<2,2,16>") : "gemm_dw_stream_kernel<4,1,16>";
+    ProfScope prof(nm, 2.0 * d.M * d.N * d.K * d.batch,
                    4.0 * d.batch * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N), st);
-    if (wide) {
+    if (wide && tall) {
+        dim3 grid(cdiv(d.N, 128), cdiv(d.M, 256), d.batch * d.splits);
+        hipLaunchKernelGGL((gemm_dw_stream_kernel<4, 2, 16>), grid, dim3(512), 0, st, k);
+    } else if (wide) {
         dim3 grid(cdiv(d.N, 128), cdiv(d.M, 128), d.batch * d.splits);
         hipLaunchKernelGGL((gemm_dw_stream_kernel<2, 2, 16>), grid, dim3(256), 0, st, k);
     } else {

@@ -23,6 +23,8 @@
 // The loop is straight-line code (compile-time chunk counts, whole tiles only, no predicated memory operation):
 // gfx9 counts loads and stores in ONE counter (vmcnt) and the compiler has to assume they complete out of order, so
 // every place where a load is awaited while a store is in flight degenerates to vmcnt(0) -- see the loop tail.
+#include <string.h>
+
 #include "common.h"
 #include "kernels.h"
 #include "profile.h"
@@ -313,9 +315,23 @@ int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st) {
     }();
     const int gx = min(cdiv(k.ntiles, WR_WAVES), max(1, n_cu / (gy * gz)));
     dim3 grid(gx, gy, gz);
-    static const char* names[2][3] = {{"gemm_wres_kernel<1,fwd>", "gemm_wres_kernel<2,fwd>", "gemm_wres_kernel<4,fwd>"},
-                                      {"gemm_wres_kernel<1,bwd>", "gemm_wres_kernel<2,bwd>", "gemm_wres_kernel<4,bwd>"}};
-    ProfScope prof(names[bt ? 1 : 0][tn == 1 ? 0 : (tn == 2 ? 1 : 2)], 2.0 * d.M * d.N * d.K * d.batch,
+    // profiler name = the kernel symbol as rocprofv3 prints it (template arguments TN,NC,NPASS,BT,EPI,ACC,RMASK)
+    const int nc8 = cdiv(d.K, 8);
+    int ncp, npass = 1;
+    if (rb) { if (nc8 <= 8) ncp = 8; else if (nc8 <= 16) ncp = 16; else if (nc8 <= 24) { ncp = 12; npass = 2; } else { ncp = 16; npass = 2; } }
+    else if (bt) ncp = nc8 <= 4 ? 4 : (nc8 <= 8 ? 8 : 16);
+    else ncp = nc8 <= 4 ? 4 : (nc8 <= 8 ? 8 : (nc8 <= 11 ? 11 : 16));
+    static thread_local char names[64][64];
+    static thread_local int n_names = 0;
+    char nm[64];
+    snprintf(nm, sizeof(nm), "gemm_wres_kernel<%d,%d,%d,%d,%d,%d,%d>", tn, ncp, npass, bt ? 1 : 0, rb ? 1 : 0,
+             (d.flags & REFIL_GEMM_ACCUM) ? 1 : 0, d.rowmask ? 1 : 0);
+    const char* pname = nullptr;
+    for (int i = 0; i < n_names; ++i)
+        if (!strcmp(names[i], nm)) pname = names[i];
+    if (!pname && n_names < 64) { strcpy(names[n_names], nm); pname = names[n_names++]; }
+    if (!pname) pname = "gemm_wres_kernel";
+    ProfScope prof(pname, 2.0 * d.M * d.N * d.K * d.batch,
                    4.0 * d.batch * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N * (rb ? ((d.flags & REFIL_GEMM_ACCUM) ? 3.0 : 2.0) : 1.0)), st);
     int rc;
     if (rb) rc = wres_launch_rbwd(k, (d.flags & REFIL_GEMM_ACCUM) != 0, grid, st);
