@@ -114,13 +114,19 @@ __device__ inline f32x4 dot_tile(const float* X, int rowbase, const float* Y, in
     return acc;
 }
 
-__device__ inline float group16_sum(float v) {   // sum over the 16 lanes sharing l>>4
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+// all-reduce over the 16 lanes of a DPP row (lanes sharing l>>4) with 4 DPP-modified VALU ops instead of 4
+// ds_bpermute round trips: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror (quad 0 <-> quad 1 of each
+// half; every lane of a quad already holds the quad's value), row_mirror (half 0 <-> half 1)
+template <int CTRL>
+__device__ inline float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ inline float group16_sum(float v) {
+    v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v);
     return v;
 }
 __device__ inline float group16_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
-    v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
+    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
     return v;
 }
 __device__ inline float cross4_sum(float v) {    // sum over the 4 lanes sharing l&15
