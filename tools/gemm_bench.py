@@ -59,6 +59,10 @@ def dw(R, N, K, batch=1, splits=256):
 
 
 only = sys.argv[2] if len(sys.argv) > 2 else ""      # e.g. "kv": just the dominant shape (for PMC runs)
+if only == "dw":
+    dw(NE, 256, 128, batch=4, splits=128)
+    dw(3 * NA, 128, 128, splits=486)
+    sys.exit(0)
 if only == "kv":
     nt(NE, 256, 128, batch=4, bias=False)
     sys.exit(0)
