@@ -56,6 +56,7 @@ class Cfg:
     mixer_lin: bool = False        # lin_flex_qmix (flex_qmix.py:124-172) instead of flex_qmix
     mixer_vdn: bool = False        # VDNMixer (modules/mixers/vdn.py:9-10): q_tot = sum of the agents' Qs, no parameters
     gt_obs_mask: bool = False      # entity_ff_agent.py:34-35
+    pooling_type: Optional[str] = None   # 'mean' / 'max': EntityPoolingLayer instead of attention (default.yaml:43)
     train_gt_factors: bool = False       # q_learner.py:88: imagined groups = ground-truth factors (batch["gt_mask"])
     train_rand_gt_factors: bool = False  # q_learner.py:89: random split OR-ed with the ground-truth factors
     double_q: bool = True
@@ -79,16 +80,23 @@ LIN_HYPERNETS = ("hyper_w_1", "V")                           # flex_qmix.py:133-
 # --------------------------------------------------------------------------------------
 # parameters
 # --------------------------------------------------------------------------------------
+def _in_trans_shapes(cfg: Cfg, prefix: str, w: int) -> Dict[str, Tuple[int, ...]]:
+    """EntityAttentionLayer: in_trans [3w,w] without bias (attention.py:21); EntityPoolingLayer: [w,w] + bias (:93)."""
+    if cfg.pooling_type is None:
+        return {prefix + "attn.in_trans.weight": (3 * w, w)}
+    return {prefix + "attn.in_trans.weight": (w, w), prefix + "attn.in_trans.bias": (w,)}
+
+
 def agent_param_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
     """state_dict layout of EntityAttentionRNNAgent (entity_rnn_agent.py:8-25)."""
     d, H, A, E = cfg.attn_embed_dim, cfg.rnn_hidden_dim, cfg.n_actions, cfg.in_dim
     if cfg.agent_ff:                                  # EntityAttentionFFAgent (entity_ff_agent.py:8-23)
-        return {"fc1.weight": (d, E), "fc1.bias": (d,), "attn.in_trans.weight": (3 * d, d),
+        return {"fc1.weight": (d, E), "fc1.bias": (d,), **_in_trans_shapes(cfg, "", d),
                 "attn.out_trans.weight": (d, d), "attn.out_trans.bias": (d,),
                 "fc2.weight": (A, d), "fc2.bias": (A,)}
     return {
         "fc1.weight": (d, E), "fc1.bias": (d,),
-        "attn.in_trans.weight": (3 * d, d),
+        **_in_trans_shapes(cfg, "", d),
         "attn.out_trans.weight": (d, d), "attn.out_trans.bias": (d,),
         "fc2.weight": (H, d), "fc2.bias": (H,),
         "rnn.weight_ih": (3 * H, H), "rnn.weight_hh": (3 * H, H),
@@ -106,7 +114,7 @@ def mixer_param_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
     for net in (LIN_HYPERNETS if cfg.mixer_lin else HYPERNETS):
         out[f"{net}.fc1.weight"] = (h, E)
         out[f"{net}.fc1.bias"] = (h,)
-        out[f"{net}.attn.in_trans.weight"] = (3 * h, h)
+        out.update(_in_trans_shapes(cfg, net + ".", h))
         out[f"{net}.attn.out_trans.weight"] = (h, h)
         out[f"{net}.attn.out_trans.bias"] = (h,)
         out[f"{net}.fc2.weight"] = (M, h)
@@ -191,6 +199,34 @@ def group_masks(cfg: "Cfg", entity_mask: Tensor, group_bits: Optional[Tensor] = 
 
 
 # --------------------------------------------------------------------------------------
+# EntityPoolingLayer (attention.py:82-132) with several pre-masks sharing the in_trans projection
+# --------------------------------------------------------------------------------------
+def pooling_variants(x1: Tensor, w_in: Tensor, b_in: Tensor, w_out: Tensor, b_out: Tensor, pooling_type: str,
+                     pre_masks: List[Tensor], post_mask: Tensor) -> List[Tensor]:
+    """x1 [R,ne,w]; pre_masks: bool [R,na,ne]; post_mask bool [R,na]. Masked entities enter the pool as ZEROS (:117-118)
+    and the mean divides by ne, masked or not (:122-123)."""
+    ents = x1 @ w_in.t() + b_in                                              # :110
+    outs = []
+    for pm in pre_masks:
+        rep = ents[:, None, :, :].expand(-1, pm.shape[1], -1, -1).masked_fill(pm[:, :, :, None], 0.0)   # :114-118
+        pooled = rep.max(dim=2)[0] if pooling_type == "max" else rep.mean(dim=2)                      # :120-123
+        o = pooled @ w_out.t() + b_out                                       # :125
+        outs.append(o.masked_fill(post_mask[:, :, None], 0.0))               # :127-128
+    return outs
+
+
+def entity_layer(cfg: "Cfg", p: Dict[str, Tensor], prefix: str, x1: Tensor, n_heads: int, pre_masks: List[Tensor],
+                 post_mask: Tensor) -> List[Tensor]:
+    """The `attn` sub-module of agents and hypernets: attention, or pooling when cfg.pooling_type is set."""
+    if cfg.pooling_type is None:
+        return attention_variants(x1, p[prefix + "attn.in_trans.weight"], p[prefix + "attn.out_trans.weight"],
+                                  p[prefix + "attn.out_trans.bias"], n_heads, pre_masks, post_mask)
+    return pooling_variants(x1, p[prefix + "attn.in_trans.weight"], p[prefix + "attn.in_trans.bias"],
+                            p[prefix + "attn.out_trans.weight"], p[prefix + "attn.out_trans.bias"], cfg.pooling_type,
+                            pre_masks, post_mask)
+
+
+# --------------------------------------------------------------------------------------
 # EntityAttentionLayer (attention.py:24-79) with several pre-masks sharing Q/K/V
 # --------------------------------------------------------------------------------------
 def attention_variants(x1: Tensor, w_in: Tensor, w_out: Tensor, b_out: Tensor, n_heads: int,
@@ -255,9 +291,8 @@ def agent_forward(cfg: Cfg, p: Dict[str, Tensor], xe: Tensor, obs_mask: Tensor, 
         pre.append(I | om)
     agent_mask = entity_mask.bool()[:, :, :na]
     x1 = torch.relu(xe.reshape(R, ne, E) @ p["fc1.weight"].t() + p["fc1.bias"])           # :38
-    x2s = attention_variants(x1, p["attn.in_trans.weight"], p["attn.out_trans.weight"],
-                             p["attn.out_trans.bias"], cfg.attn_n_heads,
-                             [m.expand(B, T1, na, ne).reshape(R, na, ne) for m in pre], agent_mask.reshape(R, na))
+    x2s = entity_layer(cfg, p, "", x1, cfg.attn_n_heads,
+                       [m.expand(B, T1, na, ne).reshape(R, na, ne) for m in pre], agent_mask.reshape(R, na))
     G = len(x2s)
     x2 = torch.stack(x2s, 0)                                                               # [G,R,na,d]
     if cfg.agent_ff:
@@ -293,8 +328,7 @@ def hypernet_x3(cfg: Cfg, p: Dict[str, Tensor], net: str, xe: Tensor, entity_mas
     else:
         pre = [m[:, :na, :] for m in attn_masks]   # [R,na,ne] (or [R,ne,ne]: only the query rows are used)
     x1 = torch.relu(xe @ p[f"{net}.fc1.weight"].t() + p[f"{net}.fc1.bias"])
-    x2s = attention_variants(x1, p[f"{net}.attn.in_trans.weight"], p[f"{net}.attn.out_trans.weight"],
-                             p[f"{net}.attn.out_trans.bias"], cfg.attn_n_heads, pre, am)
+    x2s = entity_layer(cfg, p, net + ".", x1, cfg.attn_n_heads, pre, am)
     outs = []
     for x2 in x2s:
         x3 = x2 @ p[f"{net}.fc2.weight"].t() + p[f"{net}.fc2.bias"]

@@ -5,12 +5,12 @@ import pytest
 import torch
 
 from oracle import refil_oracle as orc
-from golden_util import CASES, GM_CASES, GM_TRAIN_CASES, load, rel_err
+from golden_util import CASES, GM_CASES, GM_TRAIN_CASES, POOL_CASES, load, rel_err
 
 TOL = 2e-5   # fp32, different op order than the reference (shared fc1/K/V, fused masks)
 
 
-@pytest.mark.parametrize("name", CASES + GM_CASES + GM_TRAIN_CASES)
+@pytest.mark.parametrize("name", CASES + GM_CASES + GM_TRAIN_CASES + POOL_CASES)
 def test_oracle_matches_reference(name):
     g = load(name)
     z, cfg, case = g["z"], g["cfg"], g["case"]

@@ -62,7 +62,7 @@ def ref_args(case):
         entity_scheme=True, entity_last_action=case.get("entity_last_action", True), gt_mask_avail=False,
         attn_embed_dim=case["d"], attn_n_heads=case["heads"], rnn_hidden_dim=case["H"],
         hypernet_embed=case["h"], mixing_embed_dim=case["M"],
-        softmax_mixing_weights=case.get("softmax_mixing_weights", True), pooling_type=None,
+        softmax_mixing_weights=case.get("softmax_mixing_weights", True), pooling_type=case.get("pooling_type"),
         double_q=case.get("double_q", True), gamma=0.99, lmbda=case.get("lmbda", 0.5), lr=0.0005, optim_alpha=0.99,
         optim_eps=0.00001, weight_decay=0, grad_norm_clip=case.get("grad_norm_clip", 10),
         target_update_interval=200, learner_log_interval=1,
@@ -336,6 +336,11 @@ CASES = {
     # mid-size, SC2 shape law (cfg-2-like entity sizes); weights stored, grads as per-tensor norms only
     # refil_vdn.yaml: imagine agent + parameter-free VDN mixer
     "refil_vdn_tiny": dict(imagine=True, B=3, T=4, ne=6, na=3, A=5, ed=9, d=16, heads=4, H=64, h=16, M=32, seed=16, mixer="vdn"),
+    # EntityPoolingLayer instead of attention in agents and hypernets (default.yaml:43, attention.py:82-132)
+    "refil_pool_mean": dict(imagine=True, B=3, T=5, ne=6, na=3, A=5, ed=9, d=16, heads=4, H=64, h=16, M=32, seed=17,
+                            pooling_type="mean"),
+    "refil_pool_max": dict(imagine=True, B=3, T=5, ne=6, na=3, A=5, ed=9, d=16, heads=4, H=64, h=16, M=32, seed=18,
+                           pooling_type="max", death_p=0.2),
     "refil_mid": dict(imagine=True, B=4, T=12, ne=16, na=8, A=14, ed=38, d=64, heads=4, H=64, h=64, M=32, seed=15,
                       store_grads=False, min_active=3, death_p=0.02),
 }
