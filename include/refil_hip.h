@@ -58,6 +58,9 @@ typedef struct refil_dims {
                                         (entity_ff_agent.py:93-95) instead of the random split;
                                         2: random split OR-ed with them (use_rand_gt_factors, :111-114) */
     int32_t gt_obs_mask;             /* 1: batch.gt_mask replaces obs_mask (entity_ff_agent.py:34-35)   */
+    int32_t pooling;                 /* 0: EntityAttentionLayer; 1 / 2: EntityPoolingLayer 'mean' / 'max'
+                                        (attention.py:82-132, pooling_type of default.yaml:43). The in_trans slot of
+                                        the parameter layout then holds W[w,w] followed by its bias[w].      */
     float gamma;
     float lmbda;
 } refil_dims;
@@ -261,6 +264,14 @@ typedef struct refil_attn_desc {
 
 int refil_attn_forward(const refil_attn_desc* desc, void* stream);
 int refil_attn_backward(const refil_attn_desc* desc, void* stream);
+
+/* Masked entity pooling core of EntityPoolingLayer (attention.py:114-123) under the same mask variants:
+ *   O[v][r*na+i][c] = pool_j ( masked_v(i,j) ? 0 : K[r*ne+j][c] ),  pool = mean over ALL ne entities (mode 1) or
+ *   max (mode 2; masked entities enter as zeros). K = the in_trans output [R*ne, w] (ldkv), w = heads*hd.
+ * Backward: dK[r*ne+j][c] = sum over variants and agents of the routed dO (mean: dO/ne to every unmasked j;
+ * max: to the FIRST j attaining the maximum, nothing if that j is a masked zero). Q/V/dQ/dV are ignored. */
+int refil_pool_forward(const refil_attn_desc* desc, int32_t mode, void* stream);
+int refil_pool_backward(const refil_attn_desc* desc, int32_t mode, void* stream);
 
 /* nn.GRUCell unrolled over T1 steps (entity_rnn_agent.py:49-55) as ONE persistent kernel per
  * 16-row tile, W_hh fragments resident in registers. Logical row r in [0,NR) = (gb, i) with

@@ -24,7 +24,7 @@ MASK_OBS_RGTW, MASK_OBS_RGTI, MASK_RGTW, MASK_RGTI = 10, 11, 12, 13
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "B", "T1", "ne", "na", "ed", "A", "d", "heads", "H", "hyp", "M", "entity_last_action", "imagine",
-        "softmax_mixing_weights", "mixer_tanh", "double_q", "agent_ff", "mixer_lin", "mixer_vdn", "gt_factors", "gt_obs_mask")] + [("gamma", C.c_float), ("lmbda", C.c_float)]
+        "softmax_mixing_weights", "mixer_tanh", "double_q", "agent_ff", "mixer_lin", "mixer_vdn", "gt_factors", "gt_obs_mask", "pooling")] + [("gamma", C.c_float), ("lmbda", C.c_float)]
 
 
 class ParamLayout(C.Structure):
@@ -106,7 +106,7 @@ EXPORTS = [
     "refil_get_param_layout", "refil_learner_workspace_bytes", "refil_learner_forward_backward",
     "refil_clip_rmsprop_step", "refil_agent_workspace_bytes", "refil_agent_forward",
     "refil_mixer_workspace_bytes", "refil_mixer_forward", "refil_gemm", "refil_attn_forward",
-    "refil_attn_backward", "refil_gru_forward", "refil_gru_backward", "refil_last_error", "refil_version",
+    "refil_attn_backward", "refil_pool_forward", "refil_pool_backward", "refil_gru_forward", "refil_gru_backward", "refil_last_error", "refil_version",
     "refil_profile_enable", "refil_profile_collect", "refil_set_overlap",
 ]
 
@@ -144,6 +144,8 @@ def lib():
     L.refil_gemm.argtypes = [C.POINTER(GemmDesc), C.c_void_p]
     L.refil_attn_forward.argtypes = [C.POINTER(AttnDesc), C.c_void_p]
     L.refil_attn_backward.argtypes = [C.POINTER(AttnDesc), C.c_void_p]
+    L.refil_pool_forward.argtypes = [C.POINTER(AttnDesc), C.c_int32, C.c_void_p]
+    L.refil_pool_backward.argtypes = [C.POINTER(AttnDesc), C.c_int32, C.c_void_p]
     L.refil_gru_forward.argtypes = [C.POINTER(GruDesc), C.c_void_p]
     L.refil_gru_backward.argtypes = [C.POINTER(GruDesc), C.c_void_p]
     L.refil_set_overlap.argtypes = [C.c_int]

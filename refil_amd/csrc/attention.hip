@@ -372,3 +372,12 @@ extern "C" int refil_attn_backward(const refil_attn_desc* desc, void* stream) {
     REFIL_CHECK(desc, "refil_attn_backward: null desc");
     return refil::attn_backward_launch(*desc, (hipStream_t)stream);
 }
+
+extern "C" int refil_pool_forward(const refil_attn_desc* desc, int32_t mode, void* stream) {
+    REFIL_CHECK(desc, "refil_pool_forward: null desc");
+    return refil::pool_launch(*desc, mode, false, (hipStream_t)stream);
+}
+extern "C" int refil_pool_backward(const refil_attn_desc* desc, int32_t mode, void* stream) {
+    REFIL_CHECK(desc, "refil_pool_backward: null desc");
+    return refil::pool_launch(*desc, mode, true, (hipStream_t)stream);
+}

@@ -16,6 +16,8 @@
 // Backward needs products contracted over agents as well (dV, dK), for which the logits are
 // recomputed in the other orientation S[agent,key] too -- MFMA work is free here, the kernel is
 // bound by its HBM traffic.
+#include <string.h>
+
 #include "common.h"
 #include "kernels.h"
 #include "profile.h"
@@ -420,6 +422,140 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
                 }
             }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// EntityPoolingLayer core (attention.py:114-123): masked mean / max over the entities, same mask variants.
+// One workgroup per row (b,t); the row's in_trans outputs E[ne][w] sit in LDS; the mask words are the
+// attention kernels' (one ballot per (variant, agent)).
+// ------------------------------------------------------------------------------------------------
+struct PoolK {
+    AttnM a;
+    int mode;      // 1 mean, 2 max
+    int w;         // channels = heads * hd
+    int na_pad;
+};
+
+__device__ inline void pool_stage(const PoolK& k, float* E, int r, int tid) {
+    const AttnM& p = k.a;
+    const int w4 = k.w >> 2;
+    for (int idx = tid; idx < p.ne * w4; idx += 256) {
+        const int j = idx / w4, c4 = idx - j * w4;
+        *reinterpret_cast<float4*>(E + j * k.w + 4 * c4) = *reinterpret_cast<const float4*>(p.K + ((long)r * p.ne + j) * p.ldkv + 4 * c4);
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_fwd_kernel(PoolK k) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const AttnM& p = k.a;
+    const int tid = threadIdx.x, r = blockIdx.x;
+    float* E = smem;
+    uint8_t* mb = reinterpret_cast<uint8_t*>(smem + p.ne * k.w);
+    unsigned long long* mw = reinterpret_cast<unsigned long long*>(mb + 4 * p.mask_floats);
+    MaskLds m;
+    load_masks(p, mb, m, r, tid, 256, uses_obs_m(p));
+    pool_stage(k, E, r, tid);
+    __syncthreads();
+    build_mask_words(p, m, mw, k.na_pad, tid);
+    __syncthreads();
+    const float inv_ne = 1.0f / (float)p.ne;
+    for (int idx = tid; idx < p.nvar * p.na * k.w; idx += 256) {
+        const int c = idx % k.w, vi = idx / k.w, i = vi % p.na, v = vi / p.na;
+        const unsigned long long word = mw[v * k.na_pad + i];
+        float acc = k.mode == 2 ? -INFINITY : 0.f;
+        for (int j = 0; j < p.ne; ++j) {
+            const float x = ((word >> j) & 1ull) ? 0.f : E[j * k.w + c];
+            acc = k.mode == 2 ? fmaxf(acc, x) : acc + x;
+        }
+        p.O[v * p.sO + ((long)r * p.na + i) * p.ldo + c] = k.mode == 2 ? acc : acc * inv_ne;
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_kernel(PoolK k) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const AttnM& p = k.a;
+    const int tid = threadIdx.x, r = blockIdx.x;
+    float* E = smem;                                   // [ne][w] forward values (max mode)
+    float* G = smem + p.ne * k.w;                      // [ne][w] gradient accumulator
+    uint8_t* mb = reinterpret_cast<uint8_t*>(G + p.ne * k.w);
+    unsigned long long* mw = reinterpret_cast<unsigned long long*>(mb + 4 * p.mask_floats);
+    MaskLds m;
+    load_masks(p, mb, m, r, tid, 256, uses_obs_m(p));
+    if (k.mode == 2) pool_stage(k, E, r, tid);
+    for (int idx = tid; idx < p.ne * k.w; idx += 256) G[idx] = 0.f;
+    __syncthreads();
+    build_mask_words(p, m, mw, k.na_pad, tid);
+    __syncthreads();
+    const float inv_ne = 1.0f / (float)p.ne;
+    // a thread owns channel(s) c: every (variant, agent) of that channel is routed by the same thread, so the LDS
+    // accumulator column needs no atomics
+    for (int c = tid; c < k.w; c += 256) {
+        for (int v = 0; v < p.nvar; ++v)
+            for (int i = 0; i < p.na; ++i) {
+                const unsigned long long word = mw[v * k.na_pad + i];
+                const float g = p.dO[v * p.sO + ((long)r * p.na + i) * p.ldo + c];
+                if (k.mode == 2) {
+                    float best = -INFINITY; int jb = 0;
+                    for (int j = 0; j < p.ne; ++j) {
+                        const float x = ((word >> j) & 1ull) ? 0.f : E[j * k.w + c];
+                        if (x > best) { best = x; jb = j; }       // strict: the FIRST maximum wins (torch.max)
+                    }
+                    if (!((word >> jb) & 1ull)) G[jb * k.w + c] += g;      // masked_fill blocks the gradient
+                } else {
+                    const float gs = g * inv_ne;
+                    for (int j = 0; j < p.ne; ++j)
+                        if (!((word >> j) & 1ull)) G[j * k.w + c] += gs;
+                }
+            }
+    }
+    __syncthreads();
+    const int w4 = k.w >> 2;
+    for (int idx = tid; idx < p.ne * w4; idx += 256) {
+        const int j = idx / w4, c4 = idx - j * w4;
+        *reinterpret_cast<float4*>(p.dK + ((long)r * p.ne + j) * p.ldkv + 4 * c4) = *reinterpret_cast<const float4*>(G + j * k.w + 4 * c4);
+    }
+}
+
+int pool_launch(const refil_attn_desc& d, int mode, bool bwd, hipStream_t st) {
+    REFIL_CHECK(mode == 1 || mode == 2, "refil_pool: mode must be 1 (mean) or 2 (max)");
+    REFIL_CHECK(d.K && (bwd ? (d.dO && d.dK) : (d.O != nullptr)), "refil_pool: null pointer");
+    REFIL_CHECK(d.ne >= 1 && d.ne <= 64 && d.na >= 1 && d.na <= d.ne, "refil_pool: n_entities must be <= 64");
+    REFIL_CHECK(d.nvar >= 1 && d.nvar <= 3 && d.R > 0 && d.T1 > 0, "refil_pool: bad nvar / R / T1");
+    const int w = d.heads * d.hd;
+    REFIL_CHECK(w % 4 == 0 && d.ldkv % 4 == 0, "refil_pool: width and ldkv must be multiples of 4");
+    for (int v = 0; v < d.nvar; ++v) {
+        REFIL_CHECK(d.var[v] >= 0 && d.var[v] < REFIL_MASK_COUNT, "refil_pool: bad mask code %d", d.var[v]);
+        REFIL_CHECK(!mask_uses_obs(d.var[v]) || d.obs_mask, "refil_pool: obs_mask required by a mask variant");
+        REFIL_CHECK(!mask_uses_gt(d.var[v]) || d.gt_mask, "refil_pool: gt_mask required by a mask variant");
+        REFIL_CHECK(!mask_uses_groups(d.var[v]) || (d.ent_mask0 && d.group_bits), "refil_pool: ent_mask0/group_bits required by a mask variant");
+        REFIL_CHECK(!mask_uses_inactive0(d.var[v]) || d.ent_mask0, "refil_pool: ent_mask0 required by a mask variant");
+        REFIL_CHECK(d.var[v] != REFIL_MASK_ENTITY || d.ent_mask, "refil_pool: ent_mask required by a mask variant");
+    }
+    PoolK k;
+    AttnM& a = k.a;
+    memset(&a, 0, sizeof(a));
+    a.K = d.K; a.O = d.O; a.dO = d.dO; a.dK = d.dK; a.ldkv = d.ldkv; a.ldo = d.ldo; a.sO = d.sO;
+    a.R = d.R; a.T1 = d.T1; a.ne = d.ne; a.na = d.na; a.heads = d.heads; a.hd = d.hd; a.nvar = d.nvar;
+    for (int v = 0; v < 3; ++v) a.var[v] = d.var[v];
+    a.obs_mask = d.obs_mask; a.om_sB = d.om_sB; a.om_sT = d.om_sT;
+    a.ent_mask = d.ent_mask; a.ent_mask0 = d.ent_mask0; a.group_bits = d.group_bits;
+    a.gt_mask = d.gt_mask; a.gt_sB = d.gt_sB; a.gt_sT = d.gt_sT;
+    a.mask_floats = (int)(((3 * (size_t)d.ne + 2 * (size_t)d.na * d.ne + 15) & ~(size_t)15) / 4);
+    k.mode = mode; k.w = w; k.na_pad = d.na;
+    const size_t smem = ((size_t)(bwd ? 2 : 1) * d.ne * w + a.mask_floats) * sizeof(float) + (size_t)3 * d.na * 8 + 16;
+    REFIL_CHECK(smem <= 160 * 1024, "refil_pool: row tile does not fit LDS");
+    ProfScope prof(bwd ? "pool_bwd_kernel" : "pool_fwd_kernel", 0.0, 4.0 * d.R * w * (d.ne + (double)d.nvar * d.na), st);
+    if (bwd) {
+        static bool raised = false;
+        if (smem > 64 * 1024 && !raised) { REFIL_HIP(hipFuncSetAttribute((const void*)pool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); raised = true; }
+        hipLaunchKernelGGL(pool_bwd_kernel, dim3(d.R), dim3(256), smem, st, k);
+    } else {
+        static bool raised = false;
+        if (smem > 64 * 1024 && !raised) { REFIL_HIP(hipFuncSetAttribute((const void*)pool_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); raised = true; }
+        hipLaunchKernelGGL(pool_fwd_kernel, dim3(d.R), dim3(256), smem, st, k);
+    }
+    REFIL_LAUNCH_CHECK();
+    return 0;
 }
 
 static inline int tiles16(int n) { return (n + 15) / 16; }

@@ -24,6 +24,7 @@ int gemm_dw_stream_launch(const refil_gemm_desc& d, hipStream_t st);
 int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st);
 int attn_forward_launch(const refil_attn_desc& d, hipStream_t st);
 int attn_backward_launch(const refil_attn_desc& d, hipStream_t st);
+int pool_launch(const refil_attn_desc& d, int mode, bool bwd, hipStream_t st);
 int gru_forward_launch(const refil_gru_desc& d, hipStream_t st);
 int gru_backward_launch(const refil_gru_desc& d, hipStream_t st);
 

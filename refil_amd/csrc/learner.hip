@@ -41,6 +41,7 @@ static int check_dims(const refil_dims& d) {
     REFIL_CHECK(d.agent_ff || d.H == 64, "refil: rnn_hidden_dim must be 64 (got %d)", d.H);
     REFIL_CHECK(!d.mixer_lin || 2 * d.na <= 64, "refil: LinearFlexQMixer supports n_agents <= 32");
     REFIL_CHECK(d.M >= 1 && d.M <= 64, "refil: mixing_embed_dim must be in [1,64]");
+    REFIL_CHECK(d.pooling >= 0 && d.pooling <= 2, "refil: pooling must be 0 (attention), 1 (mean) or 2 (max)");
     return 0;
 }
 
@@ -310,6 +311,16 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
     const int dd = d.d, H = d.H;
     // x1 = relu(fc1(entities))                                       :38
     RUN(gemm_launch(linear(c.w.xe, s.Ep, P + L.ag_fc1_w, s.E, P + L.ag_fc1_b, b.x1, dd, s.NE, dd, s.E, REFIL_GEMM_RELU), c.st));
+    if (d.pooling) {
+        // EntityPoolingLayer: in_trans (with bias) on all entities, masked mean / max pool       attention.py:110-123
+        RUN(gemm_launch(linear(b.x1, dd, P + L.ag_in_w, dd, P + L.ag_in_w + (long)dd * dd, b.kv, 2 * dd, s.NE, dd, dd, 0), c.st));
+        refil_attn_desc a = attn_base(c, dd);
+        a.K = b.kv; a.O = b.ao; a.sO = s.NA * dd;
+        a.nvar = G; a.var[0] = REFIL_MASK_OBS;
+        a.var[1] = group_code(d, 0, true);
+        a.var[2] = group_code(d, 1, true);
+        RUN(pool_launch(a, d.pooling, false, c.st));
+    } else {
     // K,V for all entities; Q for the agents only                    attention.py:46-48
     RUN(gemm_launch(linear(b.x1, dd, P + L.ag_in_w + (long)dd * dd, dd, nullptr, b.kv, 2 * dd, s.NE, 2 * dd, dd, 0), c.st));
     {
@@ -324,6 +335,7 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
         a.var[1] = group_code(d, 0, true);
         a.var[2] = group_code(d, 1, true);
         RUN(attn_forward_launch(a, c.st));
+    }
     }
     if (d.agent_ff) {
         // feed-forward agent (entity_ff_agent.py:40-52): x2 = relu(out_trans(attn)) (inactive agents zeroed), q = fc2(x2)
@@ -372,16 +384,18 @@ static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int n
     const refil_dims& d = c.d; const Sizes& s = c.s; const refil_param_layout& L = c.L;
     const int h = d.hyp, M = d.M, nets = s.nets;
     RUN(gemm_launch(linear(c.w.xe, s.Ep, P + L.mix_fc1_w, s.E, P + L.mix_fc1_b, b.x1, nets * h, s.NE, nets * h, s.E, REFIL_GEMM_RELU), c.st));
-    {
+    if (d.pooling) {
+        refil_gemm_desc g = linear(b.x1, nets * h, P + L.mix_in_w, h, P + L.mix_in_w + (long)h * h, b.kv, 2 * h, s.NE, h, h, 0);
+        g.batch = nets; g.sA = h; g.sB = L.mix_in_w_stride; g.sBias = L.mix_in_w_stride; g.sC = s.NE * 2 * h;
+        RUN(gemm_launch(g, c.st));
+    } else {
         refil_gemm_desc g = linear(b.x1, nets * h, P + L.mix_in_w + (long)h * h, h, nullptr, b.kv, 2 * h, s.NE, 2 * h, h, 0);
         g.batch = nets; g.sA = h; g.sB = L.mix_in_w_stride; g.sC = s.NE * 2 * h;
         RUN(gemm_launch(g, c.st));
-    }
-    {
-        refil_gemm_desc g = linear(b.x1, nets * h, P + L.mix_in_w, h, nullptr, b.q, h, s.NA, h, h, 0);
-        g.a_map = agent_rows(c);
-        g.batch = nets; g.sA = h; g.sB = L.mix_in_w_stride; g.sC = s.NA * h;
-        RUN(gemm_launch(g, c.st));
+        refil_gemm_desc q = linear(b.x1, nets * h, P + L.mix_in_w, h, nullptr, b.q, h, s.NA, h, h, 0);
+        q.a_map = agent_rows(c);
+        q.batch = nets; q.sA = h; q.sB = L.mix_in_w_stride; q.sC = s.NA * h;
+        RUN(gemm_launch(q, c.st));
     }
     for (int n = 0; n < nets; ++n) {
         refil_attn_desc a = attn_base(c, h);
@@ -391,7 +405,8 @@ static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int n
         a.var[0] = REFIL_MASK_ENTITY;
         a.var[1] = group_code(d, 0, false);
         a.var[2] = group_code(d, 1, false);
-        RUN(attn_forward_launch(a, c.st));
+        if (d.pooling) RUN(pool_launch(a, d.pooling, false, c.st));
+        else RUN(attn_forward_launch(a, c.st));
     }
     // out_trans and fc2, both with inactive agents zeroed (attention.py:65-67, flex_qmix.py:49-50)
     for (int part = 0; part < 2; ++part) {
@@ -482,7 +497,19 @@ static int attn_block_backward(const Ctx& c, const AttnBlockBwd& k) {
         a.nvar = n == 0 ? k.nv0 : 1;
         if (n == 0) { a.var[0] = k.var_first[0]; a.var[1] = k.var_first[1]; a.var[2] = k.var_first[2]; }
         else a.var[0] = k.var_rest;
-        RUN(attn_backward_launch(a, c.st));
+        if (d.pooling) RUN(pool_launch(a, d.pooling, true, c.st));       // d(in_trans output) -> dkv (first w columns)
+        else RUN(attn_backward_launch(a, c.st));
+    }
+    if (d.pooling) {
+        // EntityPoolingLayer: dW_in = dE^T x1, db_in = colsum(dE);  dx1 = relu'(x1) * (dE W_in)
+        refil_gemm_desc g = linear_dw(k.dkv, 2 * w, k.x1, (int)ldx1, k.Gr + k.in_w, w, k.Gr + k.in_w + (long)w * w, s.NE, w, w,
+                                      c.w.partial, k.nets);
+        g.sA = s.NE * 2 * w; g.sB = w; g.sC = k.in_w_stride; g.sColsum = k.in_w_stride;
+        RUN(gemm_launch(g, c.st));
+        refil_gemm_desc x = linear_dx(k.dkv, 2 * w, k.P + k.in_w, w, k.dx1, (int)ldx1, s.NE, w, w, REFIL_GEMM_RELU_BWD);
+        x.aux = k.x1; x.batch = k.nets; x.sA = s.NE * 2 * w; x.sB = k.in_w_stride; x.sC = w;
+        RUN(gemm_launch(x, c.st));
+        return 0;
     }
     // dW_in rows [w,3w) = dKV^T x1 ; rows [0,w) = dQ^T x1[agent rows]
     {

@@ -56,21 +56,26 @@ def views(flat: torch.Tensor, dims: _lib.Dims) -> Tuple[Dict[str, torch.Tensor],
     c = _consts(dims)
     assert flat.numel() >= L.total and flat.is_contiguous()
     agent, mixer = {}, {}
-    for key, fld, shp in (_AGENT_FF if dims.agent_ff else _AGENT):
-        s = shp(c)
+    def put(dst, key, o, s):
         n = 1
         for x in s:
             n *= x
-        o = getattr(L, fld)
-        agent[key] = flat[o:o + n].view(*s)
+        dst[key] = flat[o:o + n].view(*s)
+
+    for key, fld, shp in (_AGENT_FF if dims.agent_ff else _AGENT):
+        if key == "attn.in_trans.weight" and dims.pooling:        # EntityPoolingLayer: W [d,d] then bias [d] in the same slot
+            put(agent, key, L.ag_in_w, (c["d"], c["d"]))
+            put(agent, "attn.in_trans.bias", L.ag_in_w + c["d"] * c["d"], (c["d"],))
+            continue
+        put(agent, key, getattr(L, fld), shp(c))
     for ni, net in enumerate(() if dims.mixer_vdn else (LIN_HYPERNETS if dims.mixer_lin else HYPERNETS)):
         for key, fld, shp in _MIXER:
-            s = shp(c)
-            n = 1
-            for x in s:
-                n *= x
             o = getattr(L, fld) + ni * getattr(L, fld + "_stride")
-            mixer[f"{net}.{key}"] = flat[o:o + n].view(*s)
+            if key == "attn.in_trans.weight" and dims.pooling:
+                put(mixer, f"{net}.{key}", o, (c["h"], c["h"]))
+                put(mixer, f"{net}.attn.in_trans.bias", o + c["h"] * c["h"], (c["h"],))
+                continue
+            put(mixer, f"{net}.{key}", o, shp(c))
     return agent, mixer
 
 

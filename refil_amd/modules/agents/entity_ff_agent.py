@@ -7,7 +7,7 @@ import torch as th
 import torch.nn as nn
 
 from ... import _lib
-from .entity_rnn_agent import EntityAttentionRNNAgent, EntityInputs, ImagineGroups, _InTrans
+from .entity_rnn_agent import EntityAttentionRNNAgent, EntityInputs, ImagineGroups, _InTrans, in_trans_fields
 from ..flat_module import FlatParamModule
 
 
@@ -18,14 +18,14 @@ class EntityAttentionFFAgent(EntityAttentionRNNAgent):
     def __init__(self, input_shape, args):
         FlatParamModule.__init__(self)
         self.args = args
-        assert getattr(args, "pooling_type", None) is None, "EntityPoolingLayer is out of scope"
         assert args.agent.endswith("_ff")
         d = args.attn_embed_dim
         assert d % args.attn_n_heads == 0, "Embed dim must be divisible by n_heads"
         self.fc1 = nn.Linear(input_shape, d)                 # same construction order as the reference => same init
-        self.attn = _InTrans(d)
+        self.attn = _InTrans(d, getattr(args, "pooling_type", None))
         self.fc2 = nn.Linear(d, args.n_actions)
-        self.attn.register_buffer("scale_factor", th.scalar_tensor(d // args.attn_n_heads).sqrt())
+        if getattr(args, "pooling_type", None) is None:
+            self.attn.register_buffer("scale_factor", th.scalar_tensor(d // args.attn_n_heads).sqrt())
         self.input_shape = input_shape
         self._engine = None
 
@@ -34,7 +34,7 @@ class EntityAttentionFFAgent(EntityAttentionRNNAgent):
         a = self.args
         d, A, E = a.attn_embed_dim, a.n_actions, self.input_shape
         return [("fc1.weight", L.ag_fc1_w, (d, E)), ("fc1.bias", L.ag_fc1_b, (d,)),
-                ("attn.in_trans.weight", L.ag_in_w, (3 * d, d)),
+                *in_trans_fields("", L.ag_in_w, d, getattr(a, "pooling_type", None)),
                 ("attn.out_trans.weight", L.ag_out_w, (d, d)), ("attn.out_trans.bias", L.ag_out_b, (d,)),
                 ("fc2.weight", L.ag_fc2_w, (A, d)), ("fc2.bias", L.ag_fc2_b, (A,))]
 

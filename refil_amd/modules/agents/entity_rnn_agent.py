@@ -31,28 +31,40 @@ class ImagineGroups(tuple):
 
 
 class _InTrans(nn.Module):
-    """Parameter holder with the reference's attribute names (attention.py:21-22)."""
+    """Parameter holder with the reference's attribute names: EntityAttentionLayer (attention.py:21-22; in_trans
+    [3w,w] without bias) or, when pooling_type is set, EntityPoolingLayer (attention.py:93-94; in_trans [w,w] + bias)."""
 
-    def __init__(self, dim):
+    def __init__(self, dim, pooling_type=None):
         super().__init__()
-        self.in_trans = nn.Linear(dim, dim * 3, bias=False)
+        if pooling_type is None:
+            self.in_trans = nn.Linear(dim, dim * 3, bias=False)
+        else:
+            assert pooling_type in ("mean", "max"), "pooling_type must be None, 'mean' or 'max'"
+            self.in_trans = nn.Linear(dim, dim)
         self.out_trans = nn.Linear(dim, dim)
+
+
+def in_trans_fields(prefix, off, w, pooling_type):
+    """_fields() entries of the in_trans slot of the flat layout (include/refil_hip.h: refil_dims.pooling)."""
+    if pooling_type is None:
+        return [(prefix + "attn.in_trans.weight", off, (3 * w, w))]
+    return [(prefix + "attn.in_trans.weight", off, (w, w)), (prefix + "attn.in_trans.bias", off + w * w, (w,))]
 
 
 class EntityAttentionRNNAgent(FlatParamModule):
     def __init__(self, input_shape, args):
         super().__init__()
         self.args = args
-        assert getattr(args, "pooling_type", None) is None, "EntityPoolingLayer is out of scope (SURVEY.md section 2)"
         d, H = args.attn_embed_dim, args.rnn_hidden_dim
         assert d % args.attn_n_heads == 0, "Embed dim must be divisible by n_heads"     # attention.py:16
         # same construction order as the reference => identical default init under the same seed
         self.fc1 = nn.Linear(input_shape, d)
-        self.attn = _InTrans(d)
+        self.attn = _InTrans(d, getattr(args, "pooling_type", None))
         self.fc2 = nn.Linear(d, H)
         self.rnn = nn.GRUCell(H, H)
         self.fc3 = nn.Linear(H, args.n_actions)
-        self.attn.register_buffer("scale_factor", th.scalar_tensor(d // args.attn_n_heads).sqrt())   # checkpoint key parity
+        if getattr(args, "pooling_type", None) is None:
+            self.attn.register_buffer("scale_factor", th.scalar_tensor(d // args.attn_n_heads).sqrt())   # checkpoint key parity
         self.input_shape = input_shape
         self._engine = None
 
@@ -72,7 +84,7 @@ class EntityAttentionRNNAgent(FlatParamModule):
         a = self.args
         d, H, A, E = a.attn_embed_dim, a.rnn_hidden_dim, a.n_actions, self.input_shape
         return [("fc1.weight", L.ag_fc1_w, (d, E)), ("fc1.bias", L.ag_fc1_b, (d,)),
-                ("attn.in_trans.weight", L.ag_in_w, (3 * d, d)),
+                *in_trans_fields("", L.ag_in_w, d, getattr(a, "pooling_type", None)),
                 ("attn.out_trans.weight", L.ag_out_w, (d, d)), ("attn.out_trans.bias", L.ag_out_b, (d,)),
                 ("fc2.weight", L.ag_fc2_w, (H, d)), ("fc2.bias", L.ag_fc2_b, (H,)),
                 ("rnn.weight_ih", L.ag_w_ih, (3 * H, H)), ("rnn.weight_hh", L.ag_w_hh, (3 * H, H)),

@@ -7,7 +7,7 @@ import torch.nn as nn
 
 from ... import _lib
 from ...engine import LearnerEngine, dims_from_args
-from ..agents.entity_rnn_agent import _InTrans
+from ..agents.entity_rnn_agent import _InTrans, in_trans_fields
 from ..flat_module import FlatParamModule
 
 HYPERNETS = ("hyper_w_1", "hyper_w_final", "hyper_b_1", "V")
@@ -21,10 +21,10 @@ class AttentionHyperNet(nn.Module):
         self.mode = mode
         E = args.entity_shape + (args.n_actions if args.entity_last_action else 0)
         h = args.hypernet_embed
-        assert getattr(args, "pooling_type", None) is None, "EntityPoolingLayer is out of scope"
         self.fc1 = nn.Linear(E, h)
-        self.attn = _InTrans(h)
-        self.attn.register_buffer("scale_factor", th.scalar_tensor(h // args.attn_n_heads).sqrt())
+        self.attn = _InTrans(h, getattr(args, "pooling_type", None))
+        if getattr(args, "pooling_type", None) is None:
+            self.attn.register_buffer("scale_factor", th.scalar_tensor(h // args.attn_n_heads).sqrt())
         self.fc2 = nn.Linear(h, args.mixing_embed_dim)
 
 
@@ -59,7 +59,7 @@ class FlexQMixer(FlatParamModule):
         for n, net in enumerate(self._nets()):
             out += [(f"{net}.fc1.weight", L.mix_fc1_w + n * L.mix_fc1_w_stride - base, (h, E)),
                     (f"{net}.fc1.bias", L.mix_fc1_b + n * L.mix_fc1_b_stride - base, (h,)),
-                    (f"{net}.attn.in_trans.weight", L.mix_in_w + n * L.mix_in_w_stride - base, (3 * h, h)),
+                    *in_trans_fields(net + ".", L.mix_in_w + n * L.mix_in_w_stride - base, h, getattr(a, "pooling_type", None)),
                     (f"{net}.attn.out_trans.weight", L.mix_out_w + n * L.mix_out_w_stride - base, (h, h)),
                     (f"{net}.attn.out_trans.bias", L.mix_out_b + n * L.mix_out_b_stride - base, (h,)),
                     (f"{net}.fc2.weight", L.mix_fc2_w + n * L.mix_fc2_w_stride - base, (M, h)),

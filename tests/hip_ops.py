@@ -57,6 +57,18 @@ def attn_backward(d: AttnDesc, dO, ldo, sO, dQ, dK, dV):
     check(lib().refil_attn_backward(C.byref(d), _stream()), "refil_attn_backward")
 
 
+def pool_forward(d: AttnDesc, mode, O, ldo, sO):
+    d.O, d.ldo, d.sO = O.data_ptr(), ldo, sO
+    check(lib().refil_pool_forward(C.byref(d), mode, _stream()), "refil_pool_forward")
+
+
+def pool_backward(d: AttnDesc, mode, dO, ldo, sO, dK):
+    d._keep.append(dO)
+    d.dO, d.ldo, d.sO = dO.data_ptr(), ldo, sO
+    d.dK = dK.data_ptr()
+    check(lib().refil_pool_backward(C.byref(d), mode, _stream()), "refil_pool_backward")
+
+
 def gru_desc(gi, hsx, w_hh, b_hh, NR, T1, na, H=64, saves=None, dhs=None, dgi=None, dgh=None):
     d = GruDesc()
     d.gi = gi.data_ptr() if gi is not None else None

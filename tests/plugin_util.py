@@ -27,7 +27,7 @@ def make_args(cfg, imagine=None, **over):
         entity_scheme=True, entity_last_action=cfg.entity_last_action, gt_mask_avail=False,
         attn_embed_dim=cfg.attn_embed_dim, attn_n_heads=cfg.attn_n_heads, rnn_hidden_dim=cfg.rnn_hidden_dim,
         hypernet_embed=cfg.hypernet_embed, mixing_embed_dim=cfg.mixing_embed_dim,
-        softmax_mixing_weights=cfg.softmax_mixing_weights, pooling_type=None, double_q=cfg.double_q, gamma=cfg.gamma,
+        softmax_mixing_weights=cfg.softmax_mixing_weights, pooling_type=cfg.pooling_type, double_q=cfg.double_q, gamma=cfg.gamma,
         lmbda=cfg.lmbda, lr=cfg.lr, optim_alpha=cfg.optim_alpha, optim_eps=cfg.optim_eps, weight_decay=cfg.weight_decay,
         grad_norm_clip=cfg.grad_norm_clip, target_update_interval=200, learner_log_interval=1, device="cuda",
         use_cuda=True)

@@ -6,7 +6,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from golden_util import CASES, GM_CASES, GM_TRAIN_CASES, load, rel_err
+from golden_util import CASES, GM_CASES, GM_TRAIN_CASES, POOL_CASES, load, rel_err
 from oracle import refil_oracle as orc
 
 DEV = "cuda"
@@ -22,7 +22,7 @@ def _dims(cfg, B, T1):
                           softmax_mixing_weights=int(cfg.softmax_mixing_weights), mixer_tanh=int(cfg.mixer_non_lin == "tanh"),
                           double_q=int(cfg.double_q), agent_ff=int(cfg.agent_ff), mixer_lin=int(cfg.mixer_lin), mixer_vdn=int(cfg.mixer_vdn),
                           gt_factors=2 if cfg.train_rand_gt_factors else int(cfg.train_gt_factors), gt_obs_mask=int(cfg.gt_obs_mask),
-                          gamma=cfg.gamma, lmbda=cfg.lmbda)
+                          pooling={None: 0, "mean": 1, "max": 2}[cfg.pooling_type], gamma=cfg.gamma, lmbda=cfg.lmbda)
 
 
 def run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, debug=True, step=True):
@@ -54,7 +54,7 @@ def run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, debug=True, ste
     return res
 
 
-@pytest.mark.parametrize("name", CASES + GM_CASES + GM_TRAIN_CASES)
+@pytest.mark.parametrize("name", CASES + GM_CASES + GM_TRAIN_CASES + POOL_CASES)
 def test_learner_step_matches_reference_golden(name):
     g = load(name)
     z, cfg, case = g["z"], g["cfg"], g["case"]

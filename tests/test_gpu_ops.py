@@ -280,6 +280,43 @@ def test_attention_forward_backward(ne, na, heads, hd, variants, force_valu, mon
     assert torch.isfinite(O).all() and torch.isfinite(dQ).all() and torch.isfinite(dKV).all()
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("B,T1,ne,na,w,codes", [(3, 4, 6, 3, 16, (MASK_OBS, MASK_OBS_WITHIN, MASK_OBS_INTERACT)),
+                                                (2, 3, 32, 16, 128, (MASK_ENTITY, MASK_WITHIN, MASK_INTERACT)),
+                                                (2, 5, 7, 5, 24, (MASK_ENTITY,))])
+def test_pool_forward_backward(mode, B, T1, ne, na, w, codes):
+    """EntityPoolingLayer core (attention.py:114-123): masked entities enter as zeros, mean over ALL entities, max with
+    torch's first-maximum gradient routing -- against autograd."""
+    import hip_ops
+    torch.manual_seed(B * 100 + ne + w + mode)
+    R = B * T1
+    E = torch.randn(R * ne, 2 * w)                       # in_trans output lives in the first w columns of a [.., 2w] buffer
+    if mode == 2:
+        E[:, :w] -= 0.7                                   # many all-negative columns: the masked zeros win the max
+    obs = (torch.rand(B, T1, ne, ne) < 0.4).to(torch.uint8)
+    em = (torch.rand(B, T1, ne) < 0.3).to(torch.uint8)
+    em0 = em[:, 0].contiguous()
+    gb = (torch.rand(B, ne) < 0.5).to(torch.uint8)
+    Er = E[:, :w].clone().view(R, ne, w).requires_grad_(True)
+    outs = []
+    for c in codes:
+        pm = _masks(c, obs, em, em0, gb, na).reshape(R, na, ne)
+        rep = Er[:, None].expand(-1, na, -1, -1).masked_fill(pm[..., None], 0.0)
+        outs.append(rep.max(dim=2)[0] if mode == 2 else rep.mean(dim=2))
+    ref = torch.stack(outs)                               # [nvar, R, na, w]
+    dO = torch.randn_like(ref)
+    ref.backward(dO)
+    Ed = E.to(DEV)
+    d = hip_ops.attn_desc(Ed, Ed, Ed, 2 * w, 2 * w, R, T1, ne, na, 1, w, list(codes), obs_mask=obs.to(DEV), ent_mask=em.view(R, ne).to(DEV),
+                          ent_mask0=em0.to(DEV), group_bits=gb.to(DEV))
+    O = torch.full((len(codes), R * na, w), float("nan"), device=DEV)
+    hip_ops.pool_forward(d, mode, O, w, R * na * w)
+    _close(O.view_as(ref), ref.detach(), what="pool fwd")
+    dE = torch.full((R * ne, 2 * w), float("nan"), device=DEV)
+    hip_ops.pool_backward(d, mode, dO.reshape(len(codes), R * na, w).to(DEV), w, R * na * w, dE)
+    _close(dE[:, :w], Er.grad.reshape(R * ne, w), what="pool bwd")
+
+
 # ------------------------------------------------------------------------------------------------
 # persistent GRU
 # ------------------------------------------------------------------------------------------------

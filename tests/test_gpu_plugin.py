@@ -32,7 +32,8 @@ def _build(name, **over):
     return g, args, batch, mac, learner, logger
 
 
-@pytest.mark.parametrize("name", ["refil_tiny", "qmix_atten_tiny", "refil_abs_masked", "refil_odd", "refil_vdn_tiny"])
+@pytest.mark.parametrize("name", ["refil_tiny", "qmix_atten_tiny", "refil_abs_masked", "refil_odd", "refil_vdn_tiny",
+                                  "refil_pool_mean", "refil_pool_max"])
 def test_qlearner_train_matches_reference(name):
     g, args, batch, mac, learner, logger = _build(name)
     z, case = g["z"], g["case"]
