@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--batch", type=int, default=0, help="episodes per GPU instead of the north-star 32 (e.g. 64 = BASELINE.json "
+                    "configs[2]); the default line always uses 32")
     ap.add_argument("--serial", action="store_true", help="serialise the two chains on one stream for the whole run "
                     "(kernel-quality profiling: in-situ == isolated); the default overlaps them")
     a = ap.parse_args()
@@ -183,7 +185,7 @@ def main():
 
     from refil_amd import _lib
     from refil_amd.synthetic import sc2_shape_law
-    W = WORKLOAD
+    W = dict(WORKLOAD, B=a.batch) if a.batch > 0 else WORKLOAD
     law = sc2_shape_law(W["ne"])
     dims = dict(ne=W["ne"], na=law["n_agents"], A=law["n_actions"], ed=law["entity_shape"], d=W["d"], h=W["h"],
                 heads=W["heads"], H=W["H"], M=W["M"])

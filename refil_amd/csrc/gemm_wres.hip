@@ -313,7 +313,11 @@ int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = 256; }
         return n;
     }();
-    const int gx = min(cdiv(k.ntiles, WR_WAVES), max(1, n_cu / (gy * gz)));
+    int gx = min(cdiv(k.ntiles, WR_WAVES), max(1, n_cu / (gy * gz)));
+    // XCD-aware: workgroups are dealt round-robin to the 8 XCDs by linear id = x + gx (y + gy z). With gx a multiple
+    // of 8 the column blocks y = 0, 1, .. that re-read the SAME rows of x (N > 128) land on the same XCD, so the
+    // second read is an L2 hit instead of a second trip to HBM.
+    if (gy > 1 && gx >= 8) gx &= ~7;
     dim3 grid(gx, gy, gz);
     // profiler name = the kernel symbol as rocprofv3 prints it (template arguments TN,NC,NPASS,BT,EPI,ACC,RMASK)
     const int nc8 = cdiv(d.K, 8);
