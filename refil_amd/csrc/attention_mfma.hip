@@ -35,6 +35,11 @@ struct AttnM {
     const uint8_t* gt_mask; long gt_sB, gt_sT;
     int wave_floats;   // LDS floats per wave region
     int mask_floats;   // LDS floats of the mask byte region (the mask words follow it)
+    // hypernets in 'vector' / 'scalar' mode only use the SUM of their per-agent outputs (flex_qmix.py:51-56), and every
+    // layer between the attention core and that sum is linear, so the sum can be taken right here:
+    int sum_agents;    // forward (nvar = 1): O[r][:] = sum over agents of the attention output (row r of a [R, w] matrix)
+    float* nact;       // forward: nact[r] = number of active agents of row r (weight of the bias terms downstream) or NULL
+    int bcast_do;      // backward: dO is one row per r ([R, w]) shared by all agents of the row
 };
 
 struct MaskLds { const uint8_t *emt, *em0, *gb, *om, *gt; };
@@ -254,6 +259,11 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
     __syncthreads();
     build_mask_words(p, m, mw, NAT * 16, tid);
     __syncthreads();
+    if (p.nact && tid == 0) {
+        int n = 0;
+        for (int i = 0; i < p.na; ++i) n += m.emt[i] ? 0 : 1;
+        p.nact[r] = (float)n;
+    }
     float* Qs = smem + wave * p.wave_floats;
     float* Ks = Qs + NAT * 16 * pd;
     float* Vs = Ks + NJT * 16 * pd;
@@ -267,6 +277,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
             sv.load(p.V, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane);
             sq.store(Qs, p.hd, pd, lane); sk.store(Ks, p.hd, pd, lane); sv.store(Vs, p.hd, pd, lane);
         }
+        f32x4 osum[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) osum[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int at = 0; at < NAT; ++at) {
             const int agent = 16 * at + l15;
@@ -291,9 +304,20 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
                         for (int reg = 0; reg < 4; ++reg)
                             o = MFMA16(Vs[(16 * jt + 4 * q + reg) * pd + 16 * ct + l15], pt[jt][reg], o);
                     const int c = 16 * ct + 4 * q;
-                    if (agent < p.na && c < p.hd)
+                    if (p.sum_agents) {          // padded / inactive agents have P = 0, hence o = 0: plain sum over the 16 lanes
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) osum[ct][e] += group16_sum(o[e]);
+                    } else if (agent < p.na && c < p.hd)
                         *reinterpret_cast<float4*>(O + ((long)r * p.na + agent) * p.ldo + head * p.hd + c) = make_float4(o[0], o[1], o[2], o[3]);
                 }
+            }
+        }
+        if (p.sum_agents && l15 == 0) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int c = 16 * ct + 4 * q;
+                if (c < p.hd)
+                    *reinterpret_cast<float4*>(p.O + (long)r * p.ldo + head * p.hd + c) = make_float4(osum[ct][0], osum[ct][1], osum[ct][2], osum[ct][3]);
             }
         }
     }
@@ -345,7 +369,11 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
             // so overwriting Ds at the top of the next iteration is safe)
             const int na_t = min(16, p.na - 16 * at);
             Stage<16, 4 * NCT> sd;
-            sd.load(p.dO, (long)r * p.na + 16 * at, na_t, p.ldo, head * p.hd, p.hd, lane);
+            // (bcast_do: one dO row per (b,t), shared by its agents -- leading dimension 0 re-reads the same row)
+            const float* dO0 = p.bcast_do ? p.dO + (long)r * p.ldo : p.dO;
+            const long drow0 = p.bcast_do ? 0 : (long)r * p.na + 16 * at;
+            const int dld = p.bcast_do ? 0 : p.ldo;
+            sd.load(dO0, drow0, na_t, dld, head * p.hd, p.hd, lane);
             f32x4 sn0[NJT];
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt) sn0[jt] = dot_tile(Qs, 16 * at, Ks, 16 * jt, p.hd, pd, l15, q);   // S[agent][key]
@@ -354,7 +382,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
             for (int ct = 0; ct < NCT; ++ct) dQt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int v = 0; v < p.nvar; ++v) {
                 sd.store(Ds, p.hd, pd, lane);
-                if (v + 1 < p.nvar) sd.load(p.dO + (v + 1) * p.sO, (long)r * p.na + 16 * at, na_t, p.ldo, head * p.hd, p.hd, lane);
+                if (v + 1 < p.nvar) sd.load(dO0 + (v + 1) * p.sO, drow0, na_t, dld, head * p.hd, p.hd, lane);
                 f32x4 pn[NJT];
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt)
@@ -573,8 +601,16 @@ static int launch_pair(const AttnM& k, bool bwd, size_t smem, hipStream_t st) {
     return 0;
 }
 
+bool attn_mfma_supported(int ne, int na, int hd) {
+    const int j = tiles16(ne), a = tiles16(na), c = tiles16(hd);
+    return (j == 1 && a == 1 && c <= 2) || (j == 2 && a == 1 && c <= 2) || (a == 2 && c == 2 && j >= 2 && j <= 4);
+}
+
+int attn_mfma_launch_ex(const refil_attn_desc& d, bool bwd, hipStream_t st, int sum_agents, float* nact, int bcast_do);
+int attn_mfma_launch(const refil_attn_desc& d, bool bwd, hipStream_t st) { return attn_mfma_launch_ex(d, bwd, st, 0, nullptr, 0); }
+
 // returns -1 when the tile shape is not instantiated (caller falls back to the VALU kernel)
-int attn_mfma_launch(const refil_attn_desc& d, bool bwd, hipStream_t st) {
+int attn_mfma_launch_ex(const refil_attn_desc& d, bool bwd, hipStream_t st, int sum_agents, float* nact, int bcast_do) {
     const int njt = tiles16(d.ne), nat = tiles16(d.na), nct = tiles16(d.hd);
     AttnM k;
     k.Q = d.Q; k.K = d.K; k.V = d.V; k.O = d.O; k.dO = d.dO; k.dQ = d.dQ; k.dK = d.dK; k.dV = d.dV;
@@ -584,6 +620,8 @@ int attn_mfma_launch(const refil_attn_desc& d, bool bwd, hipStream_t st) {
     k.obs_mask = d.obs_mask; k.om_sB = d.om_sB; k.om_sT = d.om_sT;
     k.ent_mask = d.ent_mask; k.ent_mask0 = d.ent_mask0; k.group_bits = d.group_bits;
     k.gt_mask = d.gt_mask; k.gt_sB = d.gt_sB; k.gt_sT = d.gt_sT;
+    k.sum_agents = sum_agents; k.nact = nact; k.bcast_do = bcast_do;
+    REFIL_CHECK(!sum_agents || (!bwd && d.nvar == 1), "refil_attn: the agent-sum output is a forward, single-variant option");
     const int pd = d.hd + 2;
     // +16 floats of slack: fragment reads of a partial channel tile (hd < 16*nct) run past the last row
     k.wave_floats = ((nat * 16 + 2 * njt * 16 + (bwd ? 16 : 0)) * pd + 16 + 3) & ~3;

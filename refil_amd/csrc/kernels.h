@@ -75,6 +75,8 @@ struct MixArgs {
     int B, T1, T, t_off, na, M, imagine, softmax_w, tanh_nl;
     int lin;                          // LinearFlexQMixer (flex_qmix.py:136-172): x_wf/x_b1 unused
     float* ingroup_rows;              // lin + imagine: per-(b,t) in-group weight mass sum_{i<na} w1[i] (or NULL)
+    int presum;                       // x_wf / x_b1 / x_v (and their gradients) are ONE row per (b,t): the sum over the
+                                      // active agents of the hypernet output, [R, M] instead of [R*na, M]
 };
 int mix_forward_launch(const MixArgs& a, hipStream_t st);
 int mix_backward_launch(const MixArgs& a, hipStream_t st);
@@ -91,6 +93,12 @@ struct TdArgs {
 int td_loss_launch(const TdArgs& a, hipStream_t st);
 
 int sum_launch(const float* x, long n, float* out, hipStream_t st);   // out[0] = sum(x)
+
+// agent-summed hypernet tails: y[b][r][:] += nact[r] * bias[b][:]
+int rowscale_bias_launch(float* y, int ld, long sY, const float* nact, const float* bias, long sBias, long R, int N, int batch, hipStream_t st);
+// attention_mfma.hip: matrix-core attention with the agent-sum / broadcast-dO options; -1 = tile shape not instantiated
+bool attn_mfma_supported(int ne, int na, int hd);
+int attn_mfma_launch_ex(const refil_attn_desc& d, bool bwd, hipStream_t st, int sum_agents, float* nact, int bcast_do);
 
 int clip_rmsprop_launch(float* params, const float* grads, float* sq, long n, float lr, float alpha, float eps,
                         float wd, float clip, float* stats, float* scratch, hipStream_t st);

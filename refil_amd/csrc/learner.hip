@@ -105,6 +105,7 @@ struct Work {
     AgentBufs la, ta;
     HyperBufs lh, th;
     float *chosen, *tmax, *q_tot, *q_tot_im, *tq_tot, *gc_real, *gc_im, *targets, *ingroup;
+    float* nact;       // [R] active agents per (b,t): weight of the bias terms of the agent-summed hypernet tails
     // backward
     float *dx3h, *dchosen, *dx2h, *daoh, *dqh, *dkvh, *dx1h;
     float *dqva, *dhs, *dgi, *dgh, *dx3a, *dx2a, *daoa, *dqa, *dkva, *dx1a;
@@ -156,6 +157,7 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     memset(&w, 0, sizeof(w));
     w.xe = a.take<float>(s.NE * s.Ep);
     w.emc = a.take<uint8_t>(s.NE); w.amask = a.take<uint8_t>(s.NA); w.em0 = a.take<uint8_t>((long)d.B * d.ne);
+    w.nact = a.take<float>(s.R);
     if (mode == CARVE_AGENT_FWD) { carve_agent(a, d, s, s.G, false, w.la); return; }
     if (mode == CARVE_MIXER_FWD) {
         carve_hyper(a, d, s, s.NV, w.lh);
@@ -286,6 +288,11 @@ static bool overlap_enabled() {
 
 struct Ctx {
     refil_dims d; Sizes s; refil_batch b; refil_param_layout L; Work w; hipStream_t st;
+    // FlexQMixer's hyper_w_final / hyper_b_1 / V are consumed only through their MEAN over the agents
+    // (flex_qmix.py:51-56) and out_trans / fc2 are linear, so these three nets are evaluated on the agent-SUM of the
+    // attention output: [R, h] rows instead of [R*na, h] through out_trans, fc2 and their backward (16x fewer rows):
+    //   S2 = W_o (sum_i a_i) + n_act b_o ,  S3 = W_2 S2 + n_act b_2 ,  mean_i x3_i = S3 / na .
+    bool presum;
 };
 
 static refil_rowmap agent_rows(const Ctx& c) { return refil_rowmap{c.d.na, c.d.ne, 0}; }
@@ -406,7 +413,11 @@ static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int n
         a.var[1] = group_code(d, 0, false);
         a.var[2] = group_code(d, 1, false);
         if (d.pooling) RUN(pool_launch(a, d.pooling, false, c.st));
-        else RUN(attn_forward_launch(a, c.st));
+        else if (c.presum && n > 0) {
+            const int rc = attn_mfma_launch_ex(a, false, c.st, 1, c.w.nact, 0);      // O = sum over agents, [R, h]
+            REFIL_CHECK(rc >= 0, "refil: agent-sum attention shape not instantiated");
+            if (rc) return rc;
+        } else RUN(attn_forward_launch(a, c.st));
     }
     // out_trans and fc2, both with inactive agents zeroed (attention.py:65-67, flex_qmix.py:49-50)
     for (int part = 0; part < 2; ++part) {
@@ -414,6 +425,22 @@ static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int n
         const int batch = part == 0 ? 1 : nets - 1;
         const long voff = part == 0 ? 0 : nv0;
         const int net0 = part == 0 ? 0 : 1;
+        if (part == 1 && c.presum) {
+            // agent-summed tails on R rows: S2 = W_o S + n_act b_o ; S3 = W_2 S2 + n_act b_2
+            refil_gemm_desc g = linear(b.ao + voff * s.NA * h, h, P + L.mix_out_w + net0 * L.mix_out_w_stride, h, nullptr,
+                                       b.x2 + voff * s.NA * h, h, s.R, h, h, 0);
+            g.batch = batch; g.sA = s.NA * h; g.sB = L.mix_out_w_stride; g.sC = s.NA * h;
+            RUN(gemm_launch(g, c.st));
+            RUN(rowscale_bias_launch(b.x2 + voff * s.NA * h, h, s.NA * h, c.w.nact, P + L.mix_out_b + net0 * L.mix_out_b_stride,
+                                     L.mix_out_b_stride, s.R, h, batch, c.st));
+            refil_gemm_desc f = linear(b.x2 + voff * s.NA * h, h, P + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h, nullptr,
+                                       b.x3 + voff * s.NA * M, M, s.R, M, h, 0);
+            f.batch = batch; f.sA = s.NA * h; f.sB = L.mix_fc2_w_stride; f.sC = s.NA * M;
+            RUN(gemm_launch(f, c.st));
+            RUN(rowscale_bias_launch(b.x3 + voff * s.NA * M, M, s.NA * M, c.w.nact, P + L.mix_fc2_b + net0 * L.mix_fc2_b_stride,
+                                     L.mix_fc2_b_stride, s.R, M, batch, c.st));
+            continue;
+        }
         refil_gemm_desc g = linear(b.ao + voff * s.NA * h, h, P + L.mix_out_w + net0 * L.mix_out_w_stride, h,
                                    P + L.mix_out_b + net0 * L.mix_out_b_stride, b.x2 + voff * s.NA * h, h, M_rows, h, h, 0);
         g.batch = batch; g.sA = s.NA * h; g.sB = L.mix_out_w_stride; g.sBias = L.mix_out_b_stride; g.sC = s.NA * h;
@@ -448,6 +475,7 @@ static MixArgs mix_args(const Ctx& c, const HyperBufs& b, int nv0, const float* 
     m.B = d.B; m.T1 = d.T1; m.T = T; m.t_off = t_off; m.na = d.na; m.M = d.M;
     m.imagine = (nv0 == 3 && G_qs == 3) ? 1 : 0;
     m.softmax_w = d.softmax_mixing_weights; m.tanh_nl = d.mixer_tanh;
+    m.presum = c.presum ? 1 : 0;
     return m;
 }
 
@@ -466,6 +494,7 @@ struct AttnBlockBwd {
     float *dao, *dq, *dkv, *dx1;         // scratch / outputs
     int var_first[3];                    // mask codes of net 0's variants
     int var_rest;                        // mask code of nets 1..3
+    bool presum;                         // nets 1..3 run on agent-summed rows (Ctx::presum)
 };
 
 static int attn_block_backward(const Ctx& c, const AttnBlockBwd& k) {
@@ -477,6 +506,22 @@ static int attn_block_backward(const Ctx& c, const AttnBlockBwd& k) {
         const int batch = part == 0 ? 1 : k.nets - 1;
         const long voff = part == 0 ? 0 : k.nv0;
         const int net0 = part == 0 ? 0 : 1;
+        if (part == 1 && k.presum) {
+            // agent-summed tail: dW_o = g2^T S ; db_o = sum_r n_act[r] g2[r] ; d(attn out of every agent of row r) = g2 W_o
+            refil_gemm_desc gw = linear_dw(k.dx2 + voff * s.NA * w, w, k.ao + voff * s.NA * w, w,
+                                           k.Gr + k.out_w + net0 * k.out_w_stride, w, nullptr, s.R, w, w, c.w.partial, batch);
+            gw.sA = s.NA * w; gw.sB = s.NA * w; gw.sC = k.out_w_stride;
+            RUN(gemm_launch(gw, c.st));
+            refil_gemm_desc gb = linear_dw(k.dx2 + voff * s.NA * w, w, c.w.nact, 1, k.Gr + k.out_b + net0 * k.out_b_stride, 1, nullptr,
+                                           s.R, w, 1, c.w.partial, batch);
+            gb.sA = s.NA * w; gb.sB = 0; gb.sC = k.out_b_stride;
+            RUN(gemm_launch(gb, c.st));
+            refil_gemm_desc gx = linear_dx(k.dx2 + voff * s.NA * w, w, k.P + k.out_w + net0 * k.out_w_stride, w,
+                                           k.dao + voff * s.NA * w, w, s.R, w, w, 0);
+            gx.batch = batch; gx.sA = s.NA * w; gx.sB = k.out_w_stride; gx.sC = s.NA * w;
+            RUN(gemm_launch(gx, c.st));
+            continue;
+        }
         // dW_out = dx2^T ao ; db_out = colsum(dx2)
         refil_gemm_desc gw = linear_dw(k.dx2 + voff * s.NA * w, w, k.ao + voff * s.NA * w, w,
                                        k.Gr + k.out_w + net0 * k.out_w_stride, w, k.Gr + k.out_b + net0 * k.out_b_stride,
@@ -498,7 +543,11 @@ static int attn_block_backward(const Ctx& c, const AttnBlockBwd& k) {
         if (n == 0) { a.var[0] = k.var_first[0]; a.var[1] = k.var_first[1]; a.var[2] = k.var_first[2]; }
         else a.var[0] = k.var_rest;
         if (d.pooling) RUN(pool_launch(a, d.pooling, true, c.st));       // d(in_trans output) -> dkv (first w columns)
-        else RUN(attn_backward_launch(a, c.st));
+        else if (k.presum && n > 0) {
+            const int rc = attn_mfma_launch_ex(a, true, c.st, 0, nullptr, 1);       // dO: one row per (b,t) for all its agents
+            REFIL_CHECK(rc >= 0, "refil: broadcast-dO attention shape not instantiated");
+            if (rc) return rc;
+        } else RUN(attn_backward_launch(a, c.st));
     }
     if (d.pooling) {
         // EntityPoolingLayer: dW_in = dE^T x1, db_in = colsum(dE);  dx1 = relu'(x1) * (dE W_in)
@@ -546,6 +595,9 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
     if (int e = check_dims(*dims)) return e;
     c.d = *dims; c.s = sizes_of(*dims); c.b = *batch; c.st = (hipStream_t)stream;
     param_layout(c.d, c.L);
+    static const bool presum_on = [] { const char* e = getenv("REFIL_PRESUM"); return !(e && e[0] == '0'); }();
+    c.presum = presum_on && !dims->mixer_lin && !dims->mixer_vdn && !dims->pooling &&
+               attn_mfma_supported(dims->ne, dims->na, dims->hyp / dims->heads);
     REFIL_CHECK(batch->entities && batch->entity_mask, "refil: batch.entities / entity_mask missing");
     REFIL_CHECK(!dims->entity_last_action || batch->actions, "refil: batch.actions missing");
     REFIL_CHECK((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "refil: workspace must be 256-byte aligned");
@@ -685,6 +737,22 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
         const int batch = part == 0 ? 1 : s.nets - 1;
         const long voff = part == 0 ? 0 : nv0;
         const int net0 = part == 0 ? 0 : 1;
+        if (part == 1 && c.presum) {
+            // agent-summed tail (one row per (b,t)): dW_2 = g3^T S2 ; db_2 = sum_r n_act[r] g3[r] ; g2 = g3 W_2
+            refil_gemm_desc gw = linear_dw(w.dx3h + voff * s.NA * M, M, w.lh.x2 + voff * s.NA * h, h,
+                                           grads + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h, nullptr, s.R, M, h, ch.w.partial, batch);
+            gw.sA = s.NA * M; gw.sB = s.NA * h; gw.sC = L.mix_fc2_w_stride;
+            RUN(gemm_launch(gw, ch.st));
+            refil_gemm_desc gb = linear_dw(w.dx3h + voff * s.NA * M, M, w.nact, 1, grads + L.mix_fc2_b + net0 * L.mix_fc2_b_stride, 1,
+                                           nullptr, s.R, M, 1, ch.w.partial, batch);
+            gb.sA = s.NA * M; gb.sB = 0; gb.sC = L.mix_fc2_b_stride;
+            RUN(gemm_launch(gb, ch.st));
+            refil_gemm_desc gx = linear_dx(w.dx3h + voff * s.NA * M, M, params_live + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h,
+                                           w.dx2h + voff * s.NA * h, h, s.R, M, h, 0);
+            gx.batch = batch; gx.sA = s.NA * M; gx.sB = L.mix_fc2_w_stride; gx.sC = s.NA * h;
+            RUN(gemm_launch(gx, ch.st));
+            continue;
+        }
         refil_gemm_desc gw = linear_dw(w.dx3h + voff * s.NA * M, M, w.lh.x2 + voff * s.NA * h, h,
                                        grads + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h,
                                        grads + L.mix_fc2_b + net0 * L.mix_fc2_b_stride, rows, M, h, ch.w.partial, batch);
@@ -698,7 +766,7 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
     }
     {
         AttnBlockBwd k;
-        k.w = h; k.nets = s.nets; k.nv0 = nv0; k.P = params_live; k.Gr = grads;
+        k.w = h; k.nets = s.nets; k.nv0 = nv0; k.P = params_live; k.Gr = grads; k.presum = c.presum;
         k.in_w = L.mix_in_w; k.in_w_stride = L.mix_in_w_stride; k.out_w = L.mix_out_w; k.out_w_stride = L.mix_out_w_stride;
         k.out_b = L.mix_out_b; k.out_b_stride = L.mix_out_b_stride;
         k.x1 = w.lh.x1; k.kv = w.lh.kv; k.q = w.lh.q; k.ao = w.lh.ao; k.dx2 = w.dx2h;
@@ -753,7 +821,7 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
             RUN(gemm_launch(gx2, ca.st));
         }
         AttnBlockBwd k;
-        k.w = dd; k.nets = 1; k.nv0 = G; k.P = params_live; k.Gr = grads;
+        k.w = dd; k.nets = 1; k.nv0 = G; k.P = params_live; k.Gr = grads; k.presum = false;
         k.in_w = L.ag_in_w; k.in_w_stride = 0; k.out_w = L.ag_out_w; k.out_w_stride = 0; k.out_b = L.ag_out_b; k.out_b_stride = 0;
         k.x1 = w.la.x1; k.kv = w.la.kv; k.q = w.la.q; k.ao = w.la.ao; k.dx2 = w.dx2a;
         k.dao = w.daoa; k.dq = w.dqa; k.dkv = w.dkva; k.dx1 = w.dx1a;

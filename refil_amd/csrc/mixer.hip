@@ -217,7 +217,11 @@ __device__ inline MixRow mix_row_forward(const MixArgs& a, long base, long qbase
             acc_i = fmaf(a.qs[a.s_qs_g + qbase + i], mix_weight(xw, act, a.softmax_w), acc_i);
             acc_i = fmaf(a.qs[2 * a.s_qs_g + qbase + i], mix_weight(xi, act, a.softmax_w), acc_i);
         }
-        if (act) { b1 += a.x_b1[o_im]; wfr += a.x_wf[o_im]; vs += a.x_v[o_im]; }
+        if (act && !a.presum) { b1 += a.x_b1[o_im]; wfr += a.x_wf[o_im]; vs += a.x_v[o_im]; }
+    }
+    if (a.presum && act && wave == 0) {          // already summed over the active agents: row rr of [R, M]
+        const long o_m = base / a.na + m;
+        b1 = a.x_b1[o_m]; wfr = a.x_wf[o_m]; vs = a.x_v[o_m];
     }
     red[wave][0][m] = acc_r; red[wave][1][m] = acc_i; red[wave][2][m] = b1; red[wave][3][m] = wfr; red[wave][4][m] = vs;
     __syncthreads();
@@ -274,8 +278,9 @@ __global__ __launch_bounds__(64 * MIXW) void mix_bwd_kernel(MixArgs a) {
             for (int i = wave; i < a.na; i += MIXW) {
                 const long o = base + (long)i * a.M + m;
                 for (int v = 0; v < nvar; ++v) a.dx_w1[v * a.s_var + o] = 0.f;
-                a.dx_wf[o] = 0.f; a.dx_b1[o] = 0.f; a.dx_v[o] = 0.f;
+                if (!a.presum) { a.dx_wf[o] = 0.f; a.dx_b1[o] = 0.f; a.dx_v[o] = 0.f; }
             }
+            if (a.presum && wave == 0) { const long o = (long)r * a.M + m; a.dx_wf[o] = 0.f; a.dx_b1[o] = 0.f; a.dx_v[o] = 0.f; }
         }
         return;
     }
@@ -313,11 +318,15 @@ __global__ __launch_bounds__(64 * MIXW) void mix_bwd_kernel(MixArgs a) {
             const float dx = a.softmax_w ? w * (dw - q * dq) : sgn(x) * dw;
             if (act) a.dx_w1[v * a.s_var + oo] = dead ? 0.f : dx;
         }
-        if (act) {
+        if (act && !a.presum) {
             a.dx_wf[oo] = dead ? 0.f : dwf_raw;
             a.dx_b1[oo] = dead ? 0.f : db1;
             a.dx_v[oo] = dead ? 0.f : dv;
         }
+    }
+    if (a.presum && act && wave == 0) {          // gradient w.r.t. the agent-summed outputs: one row per (b,t)
+        const long o = (long)r * a.M + m;
+        a.dx_wf[o] = dwf_raw; a.dx_b1[o] = db1; a.dx_v[o] = dv;
     }
 }
 
@@ -539,6 +548,22 @@ __global__ __launch_bounds__(256) void sum_kernel(const float* x, long n, float*
     __syncthreads();
     if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
 }
+// ---- agent-summed hypernet tails (see MixArgs::presum) ------------------------------------------------
+__global__ void rowscale_bias_kernel(float* y, int ld, long sY, const float* nact, const float* bias, long sBias, long R, int N, int batch) {
+    const long total = (long)batch * R * N;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int n = idx % N; const long br = idx / N; const long r = br % R; const int b = br / R;
+        y[b * sY + r * ld + n] += nact[r] * bias[b * sBias + n];
+    }
+}
+int rowscale_bias_launch(float* y, int ld, long sY, const float* nact, const float* bias, long sBias, long R, int N, int batch, hipStream_t st) {
+    const long total = (long)batch * R * N;
+    ProfScope prof("rowscale_bias_kernel", 0.0, 8.0 * total, st);
+    hipLaunchKernelGGL(rowscale_bias_kernel, dim3((int)min((long)1024, cdivl(total, 256))), dim3(256), 0, st, y, ld, sY, nact, bias, sBias, R, N, batch);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
 int sum_launch(const float* x, long n, float* out, hipStream_t st) {
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, x, n, out);
     REFIL_LAUNCH_CHECK();
