@@ -96,6 +96,18 @@ int sum_launch(const float* x, long n, float* out, hipStream_t st);   // out[0] 
 
 // agent-summed hypernet tails: y[b][r][:] += nact[r] * bias[b][:]
 int rowscale_bias_launch(float* y, int ld, long sY, const float* nact, const float* bias, long sBias, long R, int N, int batch, hipStream_t st);
+// out_trans followed by fc2 is ONE linear map per hypernet (no non-linearity in between, flex_qmix.py:47-50):
+//   W_c = W_2 W_o [M,h],  b_c = W_2 b_o + b_2.   compose: build (W_c, b_c) of `nets` hypernets;
+//   decompose: turn (dL/dW_c, dL/db_c) into dW_2 = G W_o^T + g b_o^T, dW_o = W_2^T G, db_o = W_2^T g, db_2 = g (stored, not added)
+struct ComposeArgs {
+    const float* W2; long sW2; const float* b2; long sb2; const float* Wo; long sWo; const float* bo; long sbo;   // parameters
+    float* Wc; float* bc;                    // [nets][M][h], [nets][M]
+    const float* Gc; const float* gc;        // backward inputs, same layouts
+    float* dW2; float* db2; float* dWo; float* dbo;   // gradient outputs (parameter strides)
+    int nets, M, h;
+};
+int compose_forward_launch(const ComposeArgs& a, hipStream_t st);
+int compose_backward_launch(const ComposeArgs& a, hipStream_t st);
 // attention_mfma.hip: matrix-core attention with the agent-sum / broadcast-dO options; -1 = tile shape not instantiated
 bool attn_mfma_supported(int ne, int na, int hd);
 int attn_mfma_launch_ex(const refil_attn_desc& d, bool bwd, hipStream_t st, int sum_agents, float* nact, int bcast_do);

@@ -99,6 +99,7 @@ struct AgentBufs {     // one entity-attention recurrent agent evaluation (G mas
 };
 struct HyperBufs {     // the four attention hypernets (NV variant evaluations in total)
     float *x1, *kv, *q, *ao, *x2, *x3;
+    float *wc, *bc;    // composed out_trans o fc2 maps [nets][M][h], [nets][M] (Ctx::presum)
 };
 struct Work {
     float* xe; uint8_t *emc, *amask, *em0;
@@ -108,6 +109,7 @@ struct Work {
     float* nact;       // [R] active agents per (b,t): weight of the bias terms of the agent-summed hypernet tails
     // backward
     float *dx3h, *dchosen, *dx2h, *daoh, *dqh, *dkvh, *dx1h;
+    float *gwc, *gbc;  // gradients of the composed maps [nets][M][h], [nets][M]
     float *dqva, *dhs, *dgi, *dgh, *dx3a, *dx2a, *daoa, *dqa, *dkva, *dx1a;
     float* partial;
     float* partial2;   // split-K scratch of the side (agent-chain) stream
@@ -147,6 +149,8 @@ static void carve_hyper(Arena& a, const refil_dims& d, const Sizes& s, int NV, H
     b.ao = a.take<float>((long)NV * s.NA * d.hyp);
     b.x2 = a.take<float>((long)NV * s.NA * d.hyp);
     b.x3 = a.take<float>((long)NV * s.NA * d.M);
+    b.wc = a.take<float>((long)s.nets * d.M * d.hyp);
+    b.bc = a.take<float>((long)s.nets * d.M);
 }
 
 enum CarveMode { CARVE_LEARNER, CARVE_AGENT_FWD, CARVE_MIXER_FWD };
@@ -180,6 +184,8 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     w.dqh = a.take<float>(s.nets * s.NA * d.hyp);
     w.dkvh = a.take<float>(s.nets * s.NE * 2 * d.hyp);
     w.dx1h = a.take<float>(s.NE * s.nets * d.hyp);
+    w.gwc = a.take<float>((long)s.nets * d.M * d.hyp);
+    w.gbc = a.take<float>((long)s.nets * d.M);
     w.dqva = a.take<float>((long)s.G * s.NA * d.A);
     w.dhs = a.take<float>((long)s.G * s.NA * d.H);
     w.dgi = a.take<float>((long)s.G * s.NA * 3 * d.H);
@@ -419,28 +425,30 @@ static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int n
             if (rc) return rc;
         } else RUN(attn_forward_launch(a, c.st));
     }
+    if (c.presum) {
+        // out_trans o fc2 is one linear map per hypernet: x3 = mask(a W_c^T + b_c), W_c = W_2 W_o (kernels.h: ComposeArgs).
+        // x2 is never formed. hyper_w_1 (matrix mode) per agent row; the other nets on the agent-summed rows.
+        ComposeArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.W2 = P + L.mix_fc2_w; ca.sW2 = L.mix_fc2_w_stride; ca.b2 = P + L.mix_fc2_b; ca.sb2 = L.mix_fc2_b_stride;
+        ca.Wo = P + L.mix_out_w; ca.sWo = L.mix_out_w_stride; ca.bo = P + L.mix_out_b; ca.sbo = L.mix_out_b_stride;
+        ca.Wc = b.wc; ca.bc = b.bc; ca.nets = nets; ca.M = M; ca.h = h;
+        RUN(compose_forward_launch(ca, c.st));
+        refil_gemm_desc g = linear(b.ao, h, b.wc, h, b.bc, b.x3, M, (long)nv0 * s.NA, M, h, 0);
+        g.rowmask = c.w.amask; g.rowmask_mod = (int)s.NA;
+        RUN(gemm_launch(g, c.st));
+        refil_gemm_desc f = linear(b.ao + (long)nv0 * s.NA * h, h, b.wc + (long)M * h, h, nullptr, b.x3 + (long)nv0 * s.NA * M, M, s.R, M, h, 0);
+        f.batch = nets - 1; f.sA = s.NA * h; f.sB = (long)M * h; f.sC = s.NA * M;
+        RUN(gemm_launch(f, c.st));
+        RUN(rowscale_bias_launch(b.x3 + (long)nv0 * s.NA * M, M, s.NA * M, c.w.nact, b.bc + M, M, s.R, M, nets - 1, c.st));
+        return 0;
+    }
     // out_trans and fc2, both with inactive agents zeroed (attention.py:65-67, flex_qmix.py:49-50)
     for (int part = 0; part < 2; ++part) {
         const long M_rows = part == 0 ? nv0 * s.NA : s.NA;
         const int batch = part == 0 ? 1 : nets - 1;
         const long voff = part == 0 ? 0 : nv0;
         const int net0 = part == 0 ? 0 : 1;
-        if (part == 1 && c.presum) {
-            // agent-summed tails on R rows: S2 = W_o S + n_act b_o ; S3 = W_2 S2 + n_act b_2
-            refil_gemm_desc g = linear(b.ao + voff * s.NA * h, h, P + L.mix_out_w + net0 * L.mix_out_w_stride, h, nullptr,
-                                       b.x2 + voff * s.NA * h, h, s.R, h, h, 0);
-            g.batch = batch; g.sA = s.NA * h; g.sB = L.mix_out_w_stride; g.sC = s.NA * h;
-            RUN(gemm_launch(g, c.st));
-            RUN(rowscale_bias_launch(b.x2 + voff * s.NA * h, h, s.NA * h, c.w.nact, P + L.mix_out_b + net0 * L.mix_out_b_stride,
-                                     L.mix_out_b_stride, s.R, h, batch, c.st));
-            refil_gemm_desc f = linear(b.x2 + voff * s.NA * h, h, P + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h, nullptr,
-                                       b.x3 + voff * s.NA * M, M, s.R, M, h, 0);
-            f.batch = batch; f.sA = s.NA * h; f.sB = L.mix_fc2_w_stride; f.sC = s.NA * M;
-            RUN(gemm_launch(f, c.st));
-            RUN(rowscale_bias_launch(b.x3 + voff * s.NA * M, M, s.NA * M, c.w.nact, P + L.mix_fc2_b + net0 * L.mix_fc2_b_stride,
-                                     L.mix_fc2_b_stride, s.R, M, batch, c.st));
-            continue;
-        }
         refil_gemm_desc g = linear(b.ao + voff * s.NA * h, h, P + L.mix_out_w + net0 * L.mix_out_w_stride, h,
                                    P + L.mix_out_b + net0 * L.mix_out_b_stride, b.x2 + voff * s.NA * h, h, M_rows, h, h, 0);
         g.batch = batch; g.sA = s.NA * h; g.sB = L.mix_out_w_stride; g.sBias = L.mix_out_b_stride; g.sC = s.NA * h;
@@ -501,27 +509,11 @@ static int attn_block_backward(const Ctx& c, const AttnBlockBwd& k) {
     const Sizes& s = c.s; const refil_dims& d = c.d;
     const int w = k.w;
     const long ldx1 = (long)k.nets * w;
-    for (int part = 0; part < (k.nets > 1 ? 2 : 1); ++part) {
+    for (int part = 0; part < (k.presum ? 0 : (k.nets > 1 ? 2 : 1)); ++part) {     // (presum: d(attn out) already in k.dao)
         const long rows = part == 0 ? k.nv0 * s.NA : s.NA;
         const int batch = part == 0 ? 1 : k.nets - 1;
         const long voff = part == 0 ? 0 : k.nv0;
         const int net0 = part == 0 ? 0 : 1;
-        if (part == 1 && k.presum) {
-            // agent-summed tail: dW_o = g2^T S ; db_o = sum_r n_act[r] g2[r] ; d(attn out of every agent of row r) = g2 W_o
-            refil_gemm_desc gw = linear_dw(k.dx2 + voff * s.NA * w, w, k.ao + voff * s.NA * w, w,
-                                           k.Gr + k.out_w + net0 * k.out_w_stride, w, nullptr, s.R, w, w, c.w.partial, batch);
-            gw.sA = s.NA * w; gw.sB = s.NA * w; gw.sC = k.out_w_stride;
-            RUN(gemm_launch(gw, c.st));
-            refil_gemm_desc gb = linear_dw(k.dx2 + voff * s.NA * w, w, c.w.nact, 1, k.Gr + k.out_b + net0 * k.out_b_stride, 1, nullptr,
-                                           s.R, w, 1, c.w.partial, batch);
-            gb.sA = s.NA * w; gb.sB = 0; gb.sC = k.out_b_stride;
-            RUN(gemm_launch(gb, c.st));
-            refil_gemm_desc gx = linear_dx(k.dx2 + voff * s.NA * w, w, k.P + k.out_w + net0 * k.out_w_stride, w,
-                                           k.dao + voff * s.NA * w, w, s.R, w, w, 0);
-            gx.batch = batch; gx.sA = s.NA * w; gx.sB = k.out_w_stride; gx.sC = s.NA * w;
-            RUN(gemm_launch(gx, c.st));
-            continue;
-        }
         // dW_out = dx2^T ao ; db_out = colsum(dx2)
         refil_gemm_desc gw = linear_dw(k.dx2 + voff * s.NA * w, w, k.ao + voff * s.NA * w, w,
                                        k.Gr + k.out_w + net0 * k.out_w_stride, w, k.Gr + k.out_b + net0 * k.out_b_stride,
@@ -731,28 +723,38 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
     }
     // (the hypernet chain -- the critical path -- is enqueued first, on the side stream)
     if (!d.mixer_vdn) {
+    if (c.presum) {
+        // composed tails (x3 = mask(a W_c^T + b_c)): G_c = g3^T a, g_c = colsum(g3) (weighted by n_act on the summed rows),
+        // d(attention output) = g3 W_c straight into daoh; compose_backward turns (G_c, g_c) into the four parameter gradients
+        refil_gemm_desc gw = linear_dw(w.dx3h, M, w.lh.ao, h, w.gwc, h, w.gbc, (long)nv0 * s.NA, M, h, ch.w.partial, 1);
+        RUN(gemm_launch(gw, ch.st));
+        refil_gemm_desc gx = linear_dx(w.dx3h, M, w.lh.wc, h, w.daoh, h, (long)nv0 * s.NA, M, h, 0);
+        RUN(gemm_launch(gx, ch.st));
+        const long o3 = (long)nv0 * s.NA * M, oh = (long)nv0 * s.NA * h;
+        refil_gemm_desc gw1 = linear_dw(w.dx3h + o3, M, w.lh.ao + oh, h, w.gwc + (long)M * h, h, nullptr, s.R, M, h, ch.w.partial, s.nets - 1);
+        gw1.sA = s.NA * M; gw1.sB = s.NA * h; gw1.sC = (long)M * h;
+        RUN(gemm_launch(gw1, ch.st));
+        refil_gemm_desc gb1 = linear_dw(w.dx3h + o3, M, w.nact, 1, w.gbc + M, 1, nullptr, s.R, M, 1, ch.w.partial, s.nets - 1);
+        gb1.sA = s.NA * M; gb1.sB = 0; gb1.sC = M;
+        RUN(gemm_launch(gb1, ch.st));
+        refil_gemm_desc gx1 = linear_dx(w.dx3h + o3, M, w.lh.wc + (long)M * h, h, w.daoh + oh, h, s.R, M, h, 0);
+        gx1.batch = s.nets - 1; gx1.sA = s.NA * M; gx1.sB = (long)M * h; gx1.sC = s.NA * h;
+        RUN(gemm_launch(gx1, ch.st));
+        ComposeArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.W2 = params_live + L.mix_fc2_w; ca.sW2 = L.mix_fc2_w_stride; ca.b2 = params_live + L.mix_fc2_b; ca.sb2 = L.mix_fc2_b_stride;
+        ca.Wo = params_live + L.mix_out_w; ca.sWo = L.mix_out_w_stride; ca.bo = params_live + L.mix_out_b; ca.sbo = L.mix_out_b_stride;
+        ca.Gc = w.gwc; ca.gc = w.gbc;
+        ca.dW2 = grads + L.mix_fc2_w; ca.db2 = grads + L.mix_fc2_b; ca.dWo = grads + L.mix_out_w; ca.dbo = grads + L.mix_out_b;
+        ca.nets = s.nets; ca.M = M; ca.h = h;
+        RUN(compose_backward_launch(ca, ch.st));
+    } else {
     // hypernet tails: fc2 (flex_qmix.py:49)
     for (int part = 0; part < 2; ++part) {
         const long rows = part == 0 ? nv0 * s.NA : s.NA;
         const int batch = part == 0 ? 1 : s.nets - 1;
         const long voff = part == 0 ? 0 : nv0;
         const int net0 = part == 0 ? 0 : 1;
-        if (part == 1 && c.presum) {
-            // agent-summed tail (one row per (b,t)): dW_2 = g3^T S2 ; db_2 = sum_r n_act[r] g3[r] ; g2 = g3 W_2
-            refil_gemm_desc gw = linear_dw(w.dx3h + voff * s.NA * M, M, w.lh.x2 + voff * s.NA * h, h,
-                                           grads + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h, nullptr, s.R, M, h, ch.w.partial, batch);
-            gw.sA = s.NA * M; gw.sB = s.NA * h; gw.sC = L.mix_fc2_w_stride;
-            RUN(gemm_launch(gw, ch.st));
-            refil_gemm_desc gb = linear_dw(w.dx3h + voff * s.NA * M, M, w.nact, 1, grads + L.mix_fc2_b + net0 * L.mix_fc2_b_stride, 1,
-                                           nullptr, s.R, M, 1, ch.w.partial, batch);
-            gb.sA = s.NA * M; gb.sB = 0; gb.sC = L.mix_fc2_b_stride;
-            RUN(gemm_launch(gb, ch.st));
-            refil_gemm_desc gx = linear_dx(w.dx3h + voff * s.NA * M, M, params_live + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h,
-                                           w.dx2h + voff * s.NA * h, h, s.R, M, h, 0);
-            gx.batch = batch; gx.sA = s.NA * M; gx.sB = L.mix_fc2_w_stride; gx.sC = s.NA * h;
-            RUN(gemm_launch(gx, ch.st));
-            continue;
-        }
         refil_gemm_desc gw = linear_dw(w.dx3h + voff * s.NA * M, M, w.lh.x2 + voff * s.NA * h, h,
                                        grads + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h,
                                        grads + L.mix_fc2_b + net0 * L.mix_fc2_b_stride, rows, M, h, ch.w.partial, batch);
@@ -763,6 +765,7 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
         gx.batch = batch; gx.sA = s.NA * M; gx.sB = L.mix_fc2_w_stride; gx.sC = s.NA * h;
         gx.rowmask = w.amask; gx.rowmask_mod = (int)s.NA;
         RUN(gemm_launch(gx, ch.st));
+    }
     }
     {
         AttnBlockBwd k;

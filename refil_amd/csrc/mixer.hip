@@ -564,6 +564,74 @@ int rowscale_bias_launch(float* y, int ld, long sY, const float* nact, const flo
     return 0;
 }
 
+// ---- out_trans o fc2 composition (ComposeArgs in kernels.h). Tiny matrices (M x h, h x h): one workgroup per output
+// row so that every inner product is a short, fully pipelined loop (a single workgroup per net made them 2048 dependent
+// iterations long: 60+ us on the critical hypernet chain).
+__global__ void compose_fwd_kernel(ComposeArgs a) {      // grid (M, nets): W_c[m][:] and b_c[m]
+    const int n = blockIdx.y, m = blockIdx.x, M = a.M, h = a.h;
+    const float* W2 = a.W2 + n * a.sW2 + (long)m * h; const float* Wo = a.Wo + n * a.sWo;
+    for (int k = threadIdx.x; k < h; k += blockDim.x) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < h; ++j) s = fmaf(W2[j], Wo[j * h + k], s);
+        a.Wc[((long)n * M + m) * h + k] = s;
+    }
+    if (threadIdx.x == 0) {
+        float s = a.b2[n * a.sb2 + m];
+        for (int j = 0; j < h; ++j) s = fmaf(W2[j], a.bo[n * a.sbo + j], s);
+        a.bc[(long)n * M + m] = s;
+    }
+}
+__global__ void compose_bwd_w2_kernel(ComposeArgs a) {   // grid (M, nets): dW_2[m][j] = sum_k G[m][k] W_o[j][k] + g[m] b_o[j]; db_2[m] = g[m]
+    extern __shared__ float Gs[];
+    const int n = blockIdx.y, m = blockIdx.x, M = a.M, h = a.h;
+    const float* Wo = a.Wo + n * a.sWo; const float* bo = a.bo + n * a.sbo;
+    const float* G = a.Gc + ((long)n * M + m) * h;
+    const float gm = a.gc[(long)n * M + m];
+    for (int k = threadIdx.x; k < h; k += blockDim.x) Gs[k] = G[k];
+    __syncthreads();
+    for (int j = threadIdx.x; j < h; j += blockDim.x) {
+        float s = gm * bo[j];
+        const float* wr = Wo + (long)j * h;
+#pragma unroll 8
+        for (int k = 0; k < h; ++k) s = fmaf(Gs[k], wr[k], s);
+        a.dW2[n * a.sW2 + (long)m * h + j] = s;
+    }
+    if (threadIdx.x == 0) a.db2[n * a.sb2 + m] = gm;
+}
+__global__ void compose_bwd_wo_kernel(ComposeArgs a) {   // grid (h, nets): dW_o[j][k] = sum_m W_2[m][j] G[m][k]; db_o[j] = sum_m W_2[m][j] g[m]
+    const int n = blockIdx.y, j = blockIdx.x, M = a.M, h = a.h;
+    const float* W2 = a.W2 + n * a.sW2; const float* G = a.Gc + (long)n * M * h; const float* g = a.gc + (long)n * M;
+    for (int k = threadIdx.x; k < h; k += blockDim.x) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int m = 0; m < M; ++m) s = fmaf(W2[m * h + j], G[m * h + k], s);
+        a.dWo[n * a.sWo + (long)j * h + k] = s;
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int m = 0; m < M; ++m) s = fmaf(W2[m * h + j], g[m], s);
+        a.dbo[n * a.sbo + j] = s;
+    }
+}
+int compose_forward_launch(const ComposeArgs& a, hipStream_t st) {
+    ProfScope prof("compose_fwd_kernel", 2.0 * a.nets * a.M * a.h * a.h, 0.0, st);
+    hipLaunchKernelGGL(compose_fwd_kernel, dim3(a.M, a.nets), dim3(128), 0, st, a);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+int compose_backward_launch(const ComposeArgs& a, hipStream_t st) {
+    {
+        ProfScope prof("compose_bwd_w2_kernel", 2.0 * a.nets * a.M * a.h * a.h, 0.0, st);
+        hipLaunchKernelGGL(compose_bwd_w2_kernel, dim3(a.M, a.nets), dim3(128), a.h * sizeof(float), st, a);
+        REFIL_LAUNCH_CHECK();
+    }
+    ProfScope prof("compose_bwd_wo_kernel", 2.0 * a.nets * a.M * a.h * a.h, 0.0, st);
+    hipLaunchKernelGGL(compose_bwd_wo_kernel, dim3(a.h, a.nets), dim3(128), 0, st, a);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
 int sum_launch(const float* x, long n, float* out, hipStream_t st) {
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, st, x, n, out);
     REFIL_LAUNCH_CHECK();
