@@ -218,6 +218,9 @@ typedef struct refil_gemm_desc {
     refil_rowmap a_map, b_map, c_map;     /* applied to the MEMORY row index of A / B / C          */
     int32_t rowmask_mod;
     int32_t batch, splits, flags;
+    /* optional second bias scaled per row (plain x W^T products only): C[r][:] += rowscale[r % rowscale_mod] * bias2[:]
+     * (per-batch stride of bias2 = sBias). Used for bias terms that apply to a subset / a multiplicity of the rows. */
+    const float* bias2; const float* rowscale; int32_t rowscale_mod;
 } refil_gemm_desc;
 
 int refil_gemm(const refil_gemm_desc* desc, void* stream);

@@ -70,6 +70,7 @@ class GemmDesc(C.Structure):
         ("sA", C.c_int64), ("sB", C.c_int64), ("sC", C.c_int64), ("sBias", C.c_int64), ("sColsum", C.c_int64),
         ("a_map", RowMap), ("b_map", RowMap), ("c_map", RowMap),
         ("rowmask_mod", C.c_int32), ("batch", C.c_int32), ("splits", C.c_int32), ("flags", C.c_int32),
+        ("bias2", C.c_void_p), ("rowscale", C.c_void_p), ("rowscale_mod", C.c_int32),
     ]
 
 

@@ -40,6 +40,7 @@ struct AttnM {
     int sum_agents;    // forward (nvar = 1): O[r][:] = sum over agents of the attention output (row r of a [R, w] matrix)
     float* nact;       // forward: nact[r] = number of active agents of row r (weight of the bias terms downstream) or NULL
     int bcast_do;      // backward: dO is one row per r ([R, w]) shared by all agents of the row
+    int zero_dead;     // forward: write zeros for inactive agents (the layer's post_mask, attention.py:66-67, applied early)
 };
 
 struct MaskLds { const uint8_t *emt, *em0, *gb, *om, *gt; };
@@ -307,8 +308,10 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
                     if (p.sum_agents) {          // padded / inactive agents have P = 0, hence o = 0: plain sum over the 16 lanes
 #pragma unroll
                         for (int e = 0; e < 4; ++e) osum[ct][e] += group16_sum(o[e]);
-                    } else if (agent < p.na && c < p.hd)
+                    } else if (agent < p.na && c < p.hd) {
+                        if (p.zero_dead && m.emt[agent]) o = f32x4{0.f, 0.f, 0.f, 0.f};
                         *reinterpret_cast<float4*>(O + ((long)r * p.na + agent) * p.ldo + head * p.hd + c) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
                 }
             }
         }
@@ -606,11 +609,11 @@ bool attn_mfma_supported(int ne, int na, int hd) {
     return (j == 1 && a == 1 && c <= 2) || (j == 2 && a == 1 && c <= 2) || (a == 2 && c == 2 && j >= 2 && j <= 4);
 }
 
-int attn_mfma_launch_ex(const refil_attn_desc& d, bool bwd, hipStream_t st, int sum_agents, float* nact, int bcast_do);
-int attn_mfma_launch(const refil_attn_desc& d, bool bwd, hipStream_t st) { return attn_mfma_launch_ex(d, bwd, st, 0, nullptr, 0); }
+int attn_mfma_launch_ex(const refil_attn_desc& d, bool bwd, hipStream_t st, int sum_agents, float* nact, int bcast_do, int zero_dead);
+int attn_mfma_launch(const refil_attn_desc& d, bool bwd, hipStream_t st) { return attn_mfma_launch_ex(d, bwd, st, 0, nullptr, 0, 0); }
 
 // returns -1 when the tile shape is not instantiated (caller falls back to the VALU kernel)
-int attn_mfma_launch_ex(const refil_attn_desc& d, bool bwd, hipStream_t st, int sum_agents, float* nact, int bcast_do) {
+int attn_mfma_launch_ex(const refil_attn_desc& d, bool bwd, hipStream_t st, int sum_agents, float* nact, int bcast_do, int zero_dead) {
     const int njt = tiles16(d.ne), nat = tiles16(d.na), nct = tiles16(d.hd);
     AttnM k;
     k.Q = d.Q; k.K = d.K; k.V = d.V; k.O = d.O; k.dO = d.dO; k.dQ = d.dQ; k.dK = d.dK; k.dV = d.dV;
@@ -620,7 +623,8 @@ int attn_mfma_launch_ex(const refil_attn_desc& d, bool bwd, hipStream_t st, int 
     k.obs_mask = d.obs_mask; k.om_sB = d.om_sB; k.om_sT = d.om_sT;
     k.ent_mask = d.ent_mask; k.ent_mask0 = d.ent_mask0; k.group_bits = d.group_bits;
     k.gt_mask = d.gt_mask; k.gt_sB = d.gt_sB; k.gt_sT = d.gt_sT;
-    k.sum_agents = sum_agents; k.nact = nact; k.bcast_do = bcast_do;
+    k.sum_agents = sum_agents; k.nact = nact; k.bcast_do = bcast_do; k.zero_dead = zero_dead;
+    REFIL_CHECK(!zero_dead || d.ent_mask, "refil_attn: zeroing inactive agents needs ent_mask");
     REFIL_CHECK(!sum_agents || (!bwd && d.nvar == 1), "refil_attn: the agent-sum output is a forward, single-variant option");
     const int pd = d.hd + 2;
     // +16 floats of slack: fragment reads of a partial channel tile (hd < 16*nct) run past the last row

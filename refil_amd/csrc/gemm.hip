@@ -36,6 +36,7 @@ struct GemmK {
     int rowmask_mod, batch, splits, flags;
     int vecA, vecB;   // 16-byte global loads legal for this operand
     int vecC;         // 16-byte stores (and aux / accumulate loads) legal for C
+    const float* bias2; const float* rowscale; int rowscale_mod;   // EPI 0: + rowscale[r % mod] * bias2
 };
 
 constexpr int BK = 32;
@@ -236,6 +237,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N == 8 ? 4 
         bias4.z = ncol + 2 < p.N ? bp[ncol + 2] : 0.f;
         bias4.w = ncol + 3 < p.N ? bp[ncol + 3] : 0.f;
     }
+    float4 bias24 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == 0 && p.bias2) {
+        const float* bp = p.bias2 + bz * p.sBias;
+        bias24.x = ncol < p.N ? bp[ncol] : 0.f;
+        bias24.y = ncol + 1 < p.N ? bp[ncol + 1] : 0.f;
+        bias24.z = ncol + 2 < p.N ? bp[ncol + 2] : 0.f;
+        bias24.w = ncol + 3 < p.N ? bp[ncol + 3] : 0.f;
+    }
     const bool vecc = p.vecC;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -255,6 +264,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N == 8 ? 4 
             const long off = (EPI == 2 ? (long)(rok ? m : 0) : p.cmap(rok ? m : 0)) * ldc + ncol;
             if (EPI == 0) {
                 v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                if (p.bias2) {
+                    const float rs = p.rowscale[(rok ? m : 0) % p.rowscale_mod];
+                    v.x = fmaf(rs, bias24.x, v.x); v.y = fmaf(rs, bias24.y, v.y); v.z = fmaf(rs, bias24.z, v.z); v.w = fmaf(rs, bias24.w, v.w);
+                }
                 if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (p.rowmask) {
                     const bool dead = rok && p.rowmask[m % p.rowmask_mod] != 0;
@@ -423,6 +436,8 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
     REFIL_CHECK(!(d.flags & REFIL_GEMM_RELU_BWD) || (!d.bias && !d.rowmask && !(d.flags & REFIL_GEMM_RELU)),
                 "refil_gemm: RELU_BWD excludes bias / rowmask / RELU");
     REFIL_CHECK(!(d.flags & REFIL_GEMM_COLSUM_A) || d.colsum, "refil_gemm: COLSUM_A needs colsum");
+    REFIL_CHECK(!d.bias2 || (d.rowscale && d.rowscale_mod > 0 && d.splits == 1 && !(d.flags & (REFIL_GEMM_RELU_BWD | REFIL_GEMM_A_OUTC | REFIL_GEMM_B_OUTC))),
+                "refil_gemm: bias2 needs rowscale / rowscale_mod and a plain x W^T product");
     REFIL_CHECK(!d.rowmask || d.rowmask_mod > 0, "refil_gemm: rowmask_mod must be > 0");
     {
         const long rows = d.c_map.grp ? ((long)(d.M - 1) / d.c_map.grp) * d.c_map.gstride + d.c_map.grp + d.c_map.off : d.M;
@@ -438,6 +453,7 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
     auto mk = [](const refil_rowmap& m) { return m.grp ? RowMap{m.grp, m.gstride, m.off} : RowMap{1 << 30, 0, 0}; };
     k.amap = mk(d.a_map); k.bmap = mk(d.b_map); k.cmap = mk(d.c_map);
     k.rowmask_mod = d.rowmask_mod; k.batch = d.batch; k.splits = d.splits; k.flags = d.flags;
+    k.bias2 = d.bias2; k.rowscale = d.rowscale; k.rowscale_mod = d.rowscale_mod > 0 ? d.rowscale_mod : 1;
     // 16-byte loads: aligned base/strides and the contiguous extent (K for reduction-contiguous operands,
     // M resp. N for output-contiguous ones) a multiple of 4, so a float4 is never partially valid
     const int extA = (d.flags & REFIL_GEMM_A_OUTC) ? d.M : d.K, extB = (d.flags & REFIL_GEMM_B_OUTC) ? d.N : d.K;

@@ -37,6 +37,7 @@ struct WresK {
     long sA, sW, sC, sBias;
     RowMap amap, cmap;
     int rowmask_mod, relu, ntiles;
+    const float* bias2; const float* rowscale; int rowscale_mod;   // EPI 0: + rowscale[r % mod] * bias2
 };
 
 constexpr int WR_WAVES = 8;
@@ -113,6 +114,13 @@ __global__ __launch_bounds__(64 * WR_WAVES, 2) void gemm_wres_kernel(WresK p) {
         bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (EPI == 0 && p.bias) bias4[j] = *reinterpret_cast<const float4*>(p.bias + bz * p.sBias + n0 + 32 * j + 4 * c4);
     }
+    const bool has_b2 = EPI == 0 && p.bias2 != nullptr;
+    float4 bias24[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        bias24[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_b2) bias24[j] = *reinterpret_cast<const float4*>(p.bias2 + bz * p.sBias + n0 + 32 * j + 4 * c4);
+    }
     const float* wb = Ws + lane31 * KP + 4 * hf;       // + 32 j KP + 8 c
     const bool relu = p.relu != 0;
 
@@ -139,6 +147,7 @@ __global__ __launch_bounds__(64 * WR_WAVES, 2) void gemm_wres_kernel(WresK p) {
         const int m0 = tile * 32;
         long coff[4];
         uint8_t dead[4];
+        float rsc[4];
         float4 ax[EPI == 1 ? TN : 1][4], cx[ACC ? TN : 1][4];
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
@@ -146,6 +155,8 @@ __global__ __launch_bounds__(64 * WR_WAVES, 2) void gemm_wres_kernel(WresK p) {
             coff[ps] = p.cmap(m) * (long)p.ldc + n0 + 4 * c4;
             dead[ps] = 0;
             if (RMASK) dead[ps] = p.rowmask[m % p.rowmask_mod];
+            rsc[ps] = 0.f;
+            if (has_b2) rsc[ps] = p.rowscale[m % p.rowscale_mod];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if (EPI == 1) ax[j][ps] = *reinterpret_cast<const float4*>(AUX + coff[ps] + 32 * j);
@@ -204,6 +215,10 @@ __global__ __launch_bounds__(64 * WR_WAVES, 2) void gemm_wres_kernel(WresK p) {
                 float4 v = *reinterpret_cast<const float4*>(slab + (ps * 8 + rsub) * WR_SLAB_P + 4 * c4);
                 if (EPI == 0) {
                     v.x += bias4[j].x; v.y += bias4[j].y; v.z += bias4[j].z; v.w += bias4[j].w;
+                    if (has_b2) {
+                        v.x = fmaf(rsc[ps], bias24[j].x, v.x); v.y = fmaf(rsc[ps], bias24[j].y, v.y);
+                        v.z = fmaf(rsc[ps], bias24[j].z, v.z); v.w = fmaf(rsc[ps], bias24[j].w, v.w);
+                    }
                     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     if (RMASK) v = keep_if(dead[ps] == 0, v);
                 } else {
@@ -243,6 +258,7 @@ bool gemm_wres_eligible(const refil_gemm_desc& d) {
     if (d.M < 2048 || (d.M % 32) != 0 || (d.N % 32) != 0) return false;    // whole 32 x 32 tiles only; tiny calls: tiled kernel
     if (!al16(d.C) || (d.ldc % 4) || (d.sC % 4)) return false;
     if (d.bias && (!al16(d.bias) || (d.sBias % 4))) return false;
+    if (d.bias2 && (!al16(d.bias2) || (d.sBias % 4))) return false;
     if (rb && !al16(d.aux)) return false;
     return true;
 }
@@ -303,6 +319,7 @@ int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st) {
     auto mk = [](const refil_rowmap& m) { return m.grp ? RowMap{m.grp, m.gstride, m.off} : RowMap{1 << 30, 0, 0}; };
     k.amap = mk(d.a_map); k.cmap = mk(d.c_map);
     k.rowmask_mod = d.rowmask_mod; k.relu = (d.flags & REFIL_GEMM_RELU) ? 1 : 0;
+    k.bias2 = d.bias2; k.rowscale = d.rowscale; k.rowscale_mod = d.rowscale_mod > 0 ? d.rowscale_mod : 1;
     k.ntiles = d.M / 32;
     const bool bt = d.flags & REFIL_GEMM_B_OUTC, rb = d.flags & REFIL_GEMM_RELU_BWD;
     int tn = (d.N % 128 == 0) ? 4 : ((d.N % 64 == 0) ? 2 : 1);

@@ -33,6 +33,7 @@ struct PrepArgs {
     refil_batch b;
     int B, T1, ne, na, ed, A, Ep, last_action, first_step_zero;
     float* xe; uint8_t* emc; uint8_t* amask; uint8_t* em0;
+    float* actf;   // [R*na] 1.0 for active agents, 0.0 for inactive ones (row weights of bias terms)
 };
 int prep_launch(const PrepArgs& a, hipStream_t st);
 
@@ -102,6 +103,8 @@ int rowscale_bias_launch(float* y, int ld, long sY, const float* nact, const flo
 struct ComposeArgs {
     const float* W2; long sW2; const float* b2; long sb2; const float* Wo; long sWo; const float* bo; long sbo;   // parameters
     float* Wc; float* bc;                    // [nets][M][h], [nets][M]
+    float* bd;                               // optional [nets][M]: W_2 b_o alone (b_c - b_2)
+    const float* gc_b2;                      // optional: the vector that becomes db_2 when it differs from gc
     const float* Gc; const float* gc;        // backward inputs, same layouts
     float* dW2; float* db2; float* dWo; float* dbo;   // gradient outputs (parameter strides)
     int nets, M, h;
@@ -110,7 +113,7 @@ int compose_forward_launch(const ComposeArgs& a, hipStream_t st);
 int compose_backward_launch(const ComposeArgs& a, hipStream_t st);
 // attention_mfma.hip: matrix-core attention with the agent-sum / broadcast-dO options; -1 = tile shape not instantiated
 bool attn_mfma_supported(int ne, int na, int hd);
-int attn_mfma_launch_ex(const refil_attn_desc& d, bool bwd, hipStream_t st, int sum_agents, float* nact, int bcast_do);
+int attn_mfma_launch_ex(const refil_attn_desc& d, bool bwd, hipStream_t st, int sum_agents, float* nact, int bcast_do, int zero_dead);
 
 int clip_rmsprop_launch(float* params, const float* grads, float* sq, long n, float lr, float alpha, float eps,
                         float wd, float clip, float* stats, float* scratch, hipStream_t st);

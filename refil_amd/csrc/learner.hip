@@ -96,6 +96,7 @@ constexpr long PARTIAL_FLOATS = 40L << 20;   // split-K scratch (160 MiB)
 
 struct AgentBufs {     // one entity-attention recurrent agent evaluation (G mask variants)
     float *x1, *kv, *q, *ao, *x2, *x3, *gi, *hsx, *sr, *sz, *sn, *sg, *qv;
+    float *wc, *bc, *bd;   // composed out_trans o fc2 of the recurrent agent: W_2 W_o [H,d], W_2 b_o + b_2, W_2 b_o (Ctx::compose_agent)
 };
 struct HyperBufs {     // the four attention hypernets (NV variant evaluations in total)
     float *x1, *kv, *q, *ao, *x2, *x3;
@@ -106,10 +107,12 @@ struct Work {
     AgentBufs la, ta;
     HyperBufs lh, th;
     float *chosen, *tmax, *q_tot, *q_tot_im, *tq_tot, *gc_real, *gc_im, *targets, *ingroup;
+    float* actf;       // [R*na] 1 / 0 for active / inactive agents
     float* nact;       // [R] active agents per (b,t): weight of the bias terms of the agent-summed hypernet tails
     // backward
     float *dx3h, *dchosen, *dx2h, *daoh, *dqh, *dkvh, *dx1h;
     float *gwc, *gbc;  // gradients of the composed maps [nets][M][h], [nets][M]
+    float *gwca, *gbca, *gbact;   // agent: dL/dW_c [H,d], colsum(dx3) over all rows [H], over active rows [H]
     float *dqva, *dhs, *dgi, *dgh, *dx3a, *dx2a, *daoa, *dqa, *dkva, *dx1a;
     float* partial;
     float* partial2;   // split-K scratch of the side (agent-chain) stream
@@ -141,6 +144,7 @@ static void carve_agent(Arena& a, const refil_dims& d, const Sizes& s, int G, bo
         b.sn = a.take<float>((long)G * s.NA * d.H); b.sg = a.take<float>((long)G * s.NA * d.H);
     }
     b.qv = a.take<float>((long)G * s.NA * d.A);
+    b.wc = a.take<float>((long)d.H * d.d); b.bc = a.take<float>(d.H); b.bd = a.take<float>(d.H);
 }
 static void carve_hyper(Arena& a, const refil_dims& d, const Sizes& s, int NV, HyperBufs& b) {
     b.x1 = a.take<float>(s.NE * s.nets * d.hyp);
@@ -162,6 +166,7 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     w.xe = a.take<float>(s.NE * s.Ep);
     w.emc = a.take<uint8_t>(s.NE); w.amask = a.take<uint8_t>(s.NA); w.em0 = a.take<uint8_t>((long)d.B * d.ne);
     w.nact = a.take<float>(s.R);
+    w.actf = a.take<float>(s.NA);
     if (mode == CARVE_AGENT_FWD) { carve_agent(a, d, s, s.G, false, w.la); return; }
     if (mode == CARVE_MIXER_FWD) {
         carve_hyper(a, d, s, s.NV, w.lh);
@@ -186,6 +191,7 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     w.dx1h = a.take<float>(s.NE * s.nets * d.hyp);
     w.gwc = a.take<float>((long)s.nets * d.M * d.hyp);
     w.gbc = a.take<float>((long)s.nets * d.M);
+    w.gwca = a.take<float>((long)d.H * d.d); w.gbca = a.take<float>(d.H); w.gbact = a.take<float>(d.H);
     w.dqva = a.take<float>((long)s.G * s.NA * d.A);
     w.dhs = a.take<float>((long)s.G * s.NA * d.H);
     w.dgi = a.take<float>((long)s.G * s.NA * 3 * d.H);
@@ -299,6 +305,9 @@ struct Ctx {
     // attention output: [R, h] rows instead of [R*na, h] through out_trans, fc2 and their backward (16x fewer rows):
     //   S2 = W_o (sum_i a_i) + n_act b_o ,  S3 = W_2 S2 + n_act b_2 ,  mean_i x3_i = S3 / na .
     bool presum;
+    // recurrent agent: x3 = relu(fc2(mask(out_trans(a)))) = relu(a W_c^T + b_2 + active * W_2 b_o) with a = 0 for inactive
+    // agents (the attention kernel applies the post-mask): out_trans and its backward GEMMs disappear
+    bool compose_agent;
 };
 
 static refil_rowmap agent_rows(const Ctx& c) { return refil_rowmap{c.d.na, c.d.ne, 0}; }
@@ -347,7 +356,11 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
         a.nvar = G; a.var[0] = REFIL_MASK_OBS;
         a.var[1] = group_code(d, 0, true);
         a.var[2] = group_code(d, 1, true);
-        RUN(attn_forward_launch(a, c.st));
+        if (c.compose_agent) {
+            const int rc = attn_mfma_launch_ex(a, false, c.st, 0, nullptr, 0, 1);      // inactive agents -> exact zeros
+            REFIL_CHECK(rc >= 0, "refil: agent attention shape not instantiated");
+            if (rc) return rc;
+        } else RUN(attn_forward_launch(a, c.st));
     }
     }
     if (d.agent_ff) {
@@ -360,6 +373,17 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
         RUN(gemm_launch(f, c.st));
         return 0;
     }
+    if (c.compose_agent) {
+        // x3 = relu(fc2(mask(out_trans(a)))) = relu(a W_c^T + b_2 + active * (W_2 b_o)),  a = 0 for inactive agents
+        ComposeArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.W2 = P + L.ag_fc2_w; ca.b2 = P + L.ag_fc2_b; ca.Wo = P + L.ag_out_w; ca.bo = P + L.ag_out_b;
+        ca.Wc = b.wc; ca.bc = b.bc; ca.bd = b.bd; ca.nets = 1; ca.M = H; ca.h = dd;
+        RUN(compose_forward_launch(ca, c.st));
+        refil_gemm_desc g = linear(b.ao, dd, b.wc, dd, P + L.ag_fc2_b, b.x3, H, (long)G * s.NA, H, dd, REFIL_GEMM_RELU);
+        g.bias2 = b.bd; g.rowscale = c.w.actf; g.rowscale_mod = (int)s.NA;
+        RUN(gemm_launch(g, c.st));
+    } else {
     // x2 = out_trans(attn) with inactive agents zeroed                attention.py:65-67
     {
         refil_gemm_desc g = linear(b.ao, dd, P + L.ag_out_w, dd, P + L.ag_out_b, b.x2, dd, (long)G * s.NA, dd, dd, 0);
@@ -368,6 +392,7 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
     }
     // x3 = relu(fc2(x2))                                              :46
     RUN(gemm_launch(linear(b.x2, dd, P + L.ag_fc2_w, dd, P + L.ag_fc2_b, b.x3, H, (long)G * s.NA, H, dd, REFIL_GEMM_RELU), c.st));
+    }
     // gi = x3 W_ih^T + b_ih for all steps, then the persistent recurrence   :49-55
     RUN(gemm_launch(linear(b.x3, H, P + L.ag_w_ih, H, P + L.ag_b_ih, b.gi, 3 * H, (long)G * s.NA, 3 * H, H, 0), c.st));
     RUN(set_h0_launch(b.hsx, h0, G * d.B, d.T1, d.na, H, c.st));
@@ -420,7 +445,7 @@ static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int n
         a.var[2] = group_code(d, 1, false);
         if (d.pooling) RUN(pool_launch(a, d.pooling, false, c.st));
         else if (c.presum && n > 0) {
-            const int rc = attn_mfma_launch_ex(a, false, c.st, 1, c.w.nact, 0);      // O = sum over agents, [R, h]
+            const int rc = attn_mfma_launch_ex(a, false, c.st, 1, c.w.nact, 0, 0);      // O = sum over agents, [R, h]
             REFIL_CHECK(rc >= 0, "refil: agent-sum attention shape not instantiated");
             if (rc) return rc;
         } else RUN(attn_forward_launch(a, c.st));
@@ -439,8 +464,8 @@ static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int n
         RUN(gemm_launch(g, c.st));
         refil_gemm_desc f = linear(b.ao + (long)nv0 * s.NA * h, h, b.wc + (long)M * h, h, nullptr, b.x3 + (long)nv0 * s.NA * M, M, s.R, M, h, 0);
         f.batch = nets - 1; f.sA = s.NA * h; f.sB = (long)M * h; f.sC = s.NA * M;
+        f.bias2 = b.bc + M; f.sBias = M; f.rowscale = c.w.nact; f.rowscale_mod = (int)s.R;      // + n_act[r] * b_c
         RUN(gemm_launch(f, c.st));
-        RUN(rowscale_bias_launch(b.x3 + (long)nv0 * s.NA * M, M, s.NA * M, c.w.nact, b.bc + M, M, s.R, M, nets - 1, c.st));
         return 0;
     }
     // out_trans and fc2, both with inactive agents zeroed (attention.py:65-67, flex_qmix.py:49-50)
@@ -536,7 +561,7 @@ static int attn_block_backward(const Ctx& c, const AttnBlockBwd& k) {
         else a.var[0] = k.var_rest;
         if (d.pooling) RUN(pool_launch(a, d.pooling, true, c.st));       // d(in_trans output) -> dkv (first w columns)
         else if (k.presum && n > 0) {
-            const int rc = attn_mfma_launch_ex(a, true, c.st, 0, nullptr, 1);       // dO: one row per (b,t) for all its agents
+            const int rc = attn_mfma_launch_ex(a, true, c.st, 0, nullptr, 1, 0);       // dO: one row per (b,t) for all its agents
             REFIL_CHECK(rc >= 0, "refil: broadcast-dO attention shape not instantiated");
             if (rc) return rc;
         } else RUN(attn_backward_launch(a, c.st));
@@ -590,6 +615,7 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
     static const bool presum_on = [] { const char* e = getenv("REFIL_PRESUM"); return !(e && e[0] == '0'); }();
     c.presum = presum_on && !dims->mixer_lin && !dims->mixer_vdn && !dims->pooling &&
                attn_mfma_supported(dims->ne, dims->na, dims->hyp / dims->heads);
+    c.compose_agent = presum_on && !dims->agent_ff && !dims->pooling && attn_mfma_supported(dims->ne, dims->na, dims->d / dims->heads);
     REFIL_CHECK(batch->entities && batch->entity_mask, "refil: batch.entities / entity_mask missing");
     REFIL_CHECK(!dims->entity_last_action || batch->actions, "refil: batch.actions missing");
     REFIL_CHECK((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "refil: workspace must be 256-byte aligned");
@@ -603,7 +629,7 @@ static int run_prep(const Ctx& c, int first_step_zero) {
     PrepArgs p;
     p.b = c.b; p.B = c.d.B; p.T1 = c.d.T1; p.ne = c.d.ne; p.na = c.d.na; p.ed = c.d.ed; p.A = c.d.A; p.Ep = c.s.Ep;
     p.last_action = c.d.entity_last_action; p.first_step_zero = first_step_zero;
-    p.xe = c.w.xe; p.emc = c.w.emc; p.amask = c.w.amask; p.em0 = c.w.em0;
+    p.xe = c.w.xe; p.emc = c.w.emc; p.amask = c.w.amask; p.actf = c.w.actf; p.em0 = c.w.em0;
     return prep_launch(p, c.st);
 }
 
@@ -817,14 +843,33 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
             refil_gemm_desc gx3 = linear_dx(w.dgi, 3 * H, params_live + L.ag_w_ih, H, w.dx3a, H, rows, 3 * H, H, REFIL_GEMM_RELU_BWD);
             gx3.aux = w.la.x3;
             RUN(gemm_launch(gx3, ca.st));
+            if (c.compose_agent) {
+                // composed fc2 o out_trans: G_c = dx3^T a (a = 0 on inactive rows), colsum over all rows -> db_2, over the
+                // active rows -> the b_o terms; d(attention out) = dx3 W_c on the active rows
+                RUN(gemm_launch(linear_dw(w.dx3a, H, w.la.ao, dd, w.gwca, dd, w.gbca, rows, H, dd, ca.w.partial, 1), ca.st));
+                refil_gemm_desc gb = linear_dw(w.dx3a, H, w.actf, 1, w.gbact, 1, nullptr, rows, H, 1, ca.w.partial, 1);
+                gb.b_map = refil_rowmap{(int)s.NA, 0, 0};          // the G mask copies share the [NA] activity vector
+                RUN(gemm_launch(gb, ca.st));
+                refil_gemm_desc gx2 = linear_dx(w.dx3a, H, w.la.wc, dd, w.daoa, dd, rows, H, dd, 0);
+                gx2.rowmask = w.amask; gx2.rowmask_mod = (int)s.NA;
+                RUN(gemm_launch(gx2, ca.st));
+                ComposeArgs cb;
+                memset(&cb, 0, sizeof(cb));
+                cb.W2 = params_live + L.ag_fc2_w; cb.b2 = params_live + L.ag_fc2_b; cb.Wo = params_live + L.ag_out_w; cb.bo = params_live + L.ag_out_b;
+                cb.Gc = w.gwca; cb.gc = w.gbact; cb.gc_b2 = w.gbca;
+                cb.dW2 = grads + L.ag_fc2_w; cb.db2 = grads + L.ag_fc2_b; cb.dWo = grads + L.ag_out_w; cb.dbo = grads + L.ag_out_b;
+                cb.nets = 1; cb.M = H; cb.h = dd;
+                RUN(compose_backward_launch(cb, ca.st));
+            } else {
             // fc2
             RUN(gemm_launch(linear_dw(w.dx3a, H, w.la.x2, dd, grads + L.ag_fc2_w, dd, grads + L.ag_fc2_b, rows, H, dd, ca.w.partial, 1), ca.st));
             refil_gemm_desc gx2 = linear_dx(w.dx3a, H, params_live + L.ag_fc2_w, dd, w.dx2a, dd, rows, H, dd, 0);
             gx2.rowmask = w.amask; gx2.rowmask_mod = (int)s.NA;
             RUN(gemm_launch(gx2, ca.st));
+            }
         }
         AttnBlockBwd k;
-        k.w = dd; k.nets = 1; k.nv0 = G; k.P = params_live; k.Gr = grads; k.presum = false;
+        k.w = dd; k.nets = 1; k.nv0 = G; k.P = params_live; k.Gr = grads; k.presum = c.compose_agent;   // (d(attn out) already in daoa)
         k.in_w = L.ag_in_w; k.in_w_stride = 0; k.out_w = L.ag_out_w; k.out_w_stride = 0; k.out_b = L.ag_out_b; k.out_b_stride = 0;
         k.x1 = w.la.x1; k.kv = w.la.kv; k.q = w.la.q; k.ao = w.la.ao; k.dx2 = w.dx2a;
         k.dao = w.daoa; k.dq = w.dqa; k.dkv = w.dkva; k.dx1 = w.dx1a;

@@ -53,7 +53,7 @@ __global__ void prep_kernel(PrepArgs a) {
         const int b = r / a.T1, t = r % a.T1;
         const uint8_t m = a.b.entity_mask[b * a.b.em_sB + t * a.b.em_sT + e];
         a.emc[idx] = m;
-        if (e < a.na) a.amask[r * a.na + e] = m;
+        if (e < a.na) { a.amask[r * a.na + e] = m; a.actf[r * a.na + e] = m ? 0.f : 1.f; }
         if (t == 0) a.em0[(long)b * a.ne + e] = m;
     }
 }
@@ -577,9 +577,10 @@ __global__ void compose_fwd_kernel(ComposeArgs a) {      // grid (M, nets): W_c[
         a.Wc[((long)n * M + m) * h + k] = s;
     }
     if (threadIdx.x == 0) {
-        float s = a.b2[n * a.sb2 + m];
+        float s = 0.f;
         for (int j = 0; j < h; ++j) s = fmaf(W2[j], a.bo[n * a.sbo + j], s);
-        a.bc[(long)n * M + m] = s;
+        if (a.bd) a.bd[(long)n * M + m] = s;
+        a.bc[(long)n * M + m] = s + a.b2[n * a.sb2 + m];
     }
 }
 __global__ void compose_bwd_w2_kernel(ComposeArgs a) {   // grid (M, nets): dW_2[m][j] = sum_k G[m][k] W_o[j][k] + g[m] b_o[j]; db_2[m] = g[m]
@@ -597,7 +598,7 @@ __global__ void compose_bwd_w2_kernel(ComposeArgs a) {   // grid (M, nets): dW_2
         for (int k = 0; k < h; ++k) s = fmaf(Gs[k], wr[k], s);
         a.dW2[n * a.sW2 + (long)m * h + j] = s;
     }
-    if (threadIdx.x == 0) a.db2[n * a.sb2 + m] = gm;
+    if (threadIdx.x == 0) a.db2[n * a.sb2 + m] = a.gc_b2 ? a.gc_b2[(long)n * M + m] : gm;
 }
 __global__ void compose_bwd_wo_kernel(ComposeArgs a) {   // grid (h, nets): dW_o[j][k] = sum_m W_2[m][j] G[m][k]; db_o[j] = sum_m W_2[m][j] g[m]
     const int n = blockIdx.y, j = blockIdx.x, M = a.M, h = a.h;
