@@ -54,7 +54,8 @@ constexpr int vmcnt_only(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >
 // TN: 32-column tiles per workgroup. NC x NPASS: 8-wide k chunks of the reduction (K <= 8 NC NPASS, zero padded);
 // NPASS = 2 walks a row in two halves through the same NC register chunks. BT: W is [reduction][out] in memory
 // (backward product) and is transposed while staging. EPI 0: + bias, ReLU, row mask; EPI 1: * relu'(aux) (+ C if ACC).
-template <int TN, int NC, int NPASS, bool BT, int EPI, bool ACC, bool RMASK>
+// B2: the row-scaled second bias of EPI 0 (only instantiated for TN <= 2: it costs registers the 128-wide tile needs).
+template <int TN, int NC, int NPASS, bool BT, int EPI, bool ACC, bool RMASK, bool B2>
 __global__ __launch_bounds__(64 * WR_WAVES, 2) void gemm_wres_kernel(WresK p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -114,10 +115,10 @@ __global__ __launch_bounds__(64 * WR_WAVES, 2) void gemm_wres_kernel(WresK p) {
         bias4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (EPI == 0 && p.bias) bias4[j] = *reinterpret_cast<const float4*>(p.bias + bz * p.sBias + n0 + 32 * j + 4 * c4);
     }
-    const bool has_b2 = EPI == 0 && p.bias2 != nullptr;
-    float4 bias24[TN];
+    constexpr bool has_b2 = EPI == 0 && B2;
+    float4 bias24[B2 ? TN : 1];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
+    for (int j = 0; j < (B2 ? TN : 1); ++j) {
         bias24[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (has_b2) bias24[j] = *reinterpret_cast<const float4*>(p.bias2 + bz * p.sBias + n0 + 32 * j + 4 * c4);
     }
@@ -216,8 +217,9 @@ __global__ __launch_bounds__(64 * WR_WAVES, 2) void gemm_wres_kernel(WresK p) {
                 if (EPI == 0) {
                     v.x += bias4[j].x; v.y += bias4[j].y; v.z += bias4[j].z; v.w += bias4[j].w;
                     if (has_b2) {
-                        v.x = fmaf(rsc[ps], bias24[j].x, v.x); v.y = fmaf(rsc[ps], bias24[j].y, v.y);
-                        v.z = fmaf(rsc[ps], bias24[j].z, v.z); v.w = fmaf(rsc[ps], bias24[j].w, v.w);
+                        const float4 b2 = bias24[B2 ? j : 0];
+                        v.x = fmaf(rsc[ps], b2.x, v.x); v.y = fmaf(rsc[ps], b2.y, v.y);
+                        v.z = fmaf(rsc[ps], b2.z, v.z); v.w = fmaf(rsc[ps], b2.w, v.w);
                     }
                     if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     if (RMASK) v = keep_if(dead[ps] == 0, v);
@@ -258,22 +260,22 @@ bool gemm_wres_eligible(const refil_gemm_desc& d) {
     if (d.M < 2048 || (d.M % 32) != 0 || (d.N % 32) != 0) return false;    // whole 32 x 32 tiles only; tiny calls: tiled kernel
     if (!al16(d.C) || (d.ldc % 4) || (d.sC % 4)) return false;
     if (d.bias && (!al16(d.bias) || (d.sBias % 4))) return false;
-    if (d.bias2 && (!al16(d.bias2) || (d.sBias % 4))) return false;
+    if (d.bias2 && (!al16(d.bias2) || (d.sBias % 4) || (d.N % 128) == 0)) return false;     // (no B2 instantiation of the 128-wide tile)
     if (rb && !al16(d.aux)) return false;
     return true;
 }
 
-template <int TN, int NC, int NPASS, bool BT, int EPI, bool ACC, bool RMASK>
+template <int TN, int NC, int NPASS, bool BT, int EPI, bool ACC, bool RMASK, bool B2 = false>
 static int wres_launch_i(const WresK& k, dim3 grid, hipStream_t st) {
     constexpr size_t smem = ((size_t)32 * TN * (8 * NC * NPASS + 4) + (size_t)WR_WAVES * 32 * WR_SLAB_P) * sizeof(float);
     static_assert(smem <= 160 * 1024, "W slice + slabs must fit the 160 KB LDS of a CU");
     static bool raised = false;                        // raise the dynamic-LDS cap of this instantiation once
     if (smem > 64 * 1024 && !raised) {
-        REFIL_HIP(hipFuncSetAttribute((const void*)gemm_wres_kernel<TN, NC, NPASS, BT, EPI, ACC, RMASK>,
+        REFIL_HIP(hipFuncSetAttribute((const void*)gemm_wres_kernel<TN, NC, NPASS, BT, EPI, ACC, RMASK, B2>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         raised = true;
     }
-    hipLaunchKernelGGL((gemm_wres_kernel<TN, NC, NPASS, BT, EPI, ACC, RMASK>), grid, dim3(64 * WR_WAVES), smem, st, k);
+    hipLaunchKernelGGL((gemm_wres_kernel<TN, NC, NPASS, BT, EPI, ACC, RMASK, B2>), grid, dim3(64 * WR_WAVES), smem, st, k);
     return 0;
 }
 
@@ -282,7 +284,13 @@ template <int TN>
 static int wres_launch_fwd(const WresK& k, dim3 grid, hipStream_t st) {
     const int nc = cdiv(k.K, 8);
     const bool rm = k.rowmask != nullptr;
-#define FWD(NC) return rm ? wres_launch_i<TN, NC, 1, false, 0, false, true>(k, grid, st) : wres_launch_i<TN, NC, 1, false, 0, false, false>(k, grid, st)
+#define FWD(NC)                                                                                                     \
+    do {                                                                                                            \
+        if (TN <= 2 && k.bias2)                                                                                     \
+            return rm ? wres_launch_i<(TN <= 2 ? TN : 1), NC, 1, false, 0, false, true, true>(k, grid, st)          \
+                      : wres_launch_i<(TN <= 2 ? TN : 1), NC, 1, false, 0, false, false, true>(k, grid, st);        \
+        return rm ? wres_launch_i<TN, NC, 1, false, 0, false, true>(k, grid, st) : wres_launch_i<TN, NC, 1, false, 0, false, false>(k, grid, st); \
+    } while (0)
     if (nc <= 4) FWD(4);
     if (nc <= 8) FWD(8);
     if (nc <= 11) FWD(11);      // K = 84: the fc1 layers at the SC2 shape law
@@ -345,8 +353,8 @@ int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st) {
     static thread_local char names[64][64];
     static thread_local int n_names = 0;
     char nm[64];
-    snprintf(nm, sizeof(nm), "gemm_wres_kernel<%d,%d,%d,%d,%d,%d,%d>", tn, ncp, npass, bt ? 1 : 0, rb ? 1 : 0,
-             (d.flags & REFIL_GEMM_ACCUM) ? 1 : 0, d.rowmask ? 1 : 0);
+    snprintf(nm, sizeof(nm), "gemm_wres_kernel<%d,%d,%d,%d,%d,%d,%d,%d>", tn, ncp, npass, bt ? 1 : 0, rb ? 1 : 0,
+             (d.flags & REFIL_GEMM_ACCUM) ? 1 : 0, d.rowmask ? 1 : 0, d.bias2 ? 1 : 0);
     const char* pname = nullptr;
     for (int i = 0; i < n_names; ++i)
         if (!strcmp(names[i], nm)) pname = names[i];
