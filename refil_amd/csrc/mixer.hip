@@ -568,19 +568,32 @@ int rowscale_bias_launch(float* y, int ld, long sY, const float* nact, const flo
 // row so that every inner product is a short, fully pipelined loop (a single workgroup per net made them 2048 dependent
 // iterations long: 60+ us on the critical hypernet chain).
 __global__ void compose_fwd_kernel(ComposeArgs a) {      // grid (M, nets): W_c[m][:] and b_c[m]
+    extern __shared__ float w2s[];
     const int n = blockIdx.y, m = blockIdx.x, M = a.M, h = a.h;
     const float* W2 = a.W2 + n * a.sW2 + (long)m * h; const float* Wo = a.Wo + n * a.sWo;
+    for (int j = threadIdx.x; j < h; j += blockDim.x) w2s[j] = W2[j];
+    __syncthreads();
     for (int k = threadIdx.x; k < h; k += blockDim.x) {
-        float s = 0.f;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;       // 4 independent chains, loads 32 deep
+        int j = 0;
 #pragma unroll 8
-        for (int j = 0; j < h; ++j) s = fmaf(W2[j], Wo[j * h + k], s);
-        a.Wc[((long)n * M + m) * h + k] = s;
+        for (; j + 3 < h; j += 4) {
+            s0 = fmaf(w2s[j], Wo[(long)j * h + k], s0);
+            s1 = fmaf(w2s[j + 1], Wo[(long)(j + 1) * h + k], s1);
+            s2 = fmaf(w2s[j + 2], Wo[(long)(j + 2) * h + k], s2);
+            s3 = fmaf(w2s[j + 3], Wo[(long)(j + 3) * h + k], s3);
+        }
+        for (; j < h; ++j) s0 = fmaf(w2s[j], Wo[(long)j * h + k], s0);
+        a.Wc[((long)n * M + m) * h + k] = (s0 + s1) + (s2 + s3);
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {                                   // b_c[m] = W_2[m] . b_o + b_2[m]: one wave
         float s = 0.f;
-        for (int j = 0; j < h; ++j) s = fmaf(W2[j], a.bo[n * a.sbo + j], s);
-        if (a.bd) a.bd[(long)n * M + m] = s;
-        a.bc[(long)n * M + m] = s + a.b2[n * a.sb2 + m];
+        for (int j = threadIdx.x; j < h; j += 64) s = fmaf(w2s[j], a.bo[n * a.sbo + j], s);
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (threadIdx.x == 0) {
+            if (a.bd) a.bd[(long)n * M + m] = s;
+            a.bc[(long)n * M + m] = s + a.b2[n * a.sb2 + m];
+        }
     }
 }
 __global__ void compose_bwd_w2_kernel(ComposeArgs a) {   // grid (M, nets): dW_2[m][j] = sum_k G[m][k] W_o[j][k] + g[m] b_o[j]; db_2[m] = g[m]
@@ -594,7 +607,7 @@ __global__ void compose_bwd_w2_kernel(ComposeArgs a) {   // grid (M, nets): dW_2
     for (int j = threadIdx.x; j < h; j += blockDim.x) {
         float s = gm * bo[j];
         const float* wr = Wo + (long)j * h;
-#pragma unroll 8
+#pragma unroll 32
         for (int k = 0; k < h; ++k) s = fmaf(Gs[k], wr[k], s);
         a.dW2[n * a.sW2 + (long)m * h + j] = s;
     }
@@ -605,7 +618,7 @@ __global__ void compose_bwd_wo_kernel(ComposeArgs a) {   // grid (h, nets): dW_o
     const float* W2 = a.W2 + n * a.sW2; const float* G = a.Gc + (long)n * M * h; const float* g = a.gc + (long)n * M;
     for (int k = threadIdx.x; k < h; k += blockDim.x) {
         float s = 0.f;
-#pragma unroll 8
+#pragma unroll 32
         for (int m = 0; m < M; ++m) s = fmaf(W2[m * h + j], G[m * h + k], s);
         a.dWo[n * a.sWo + (long)j * h + k] = s;
     }
@@ -617,7 +630,7 @@ __global__ void compose_bwd_wo_kernel(ComposeArgs a) {   // grid (h, nets): dW_o
 }
 int compose_forward_launch(const ComposeArgs& a, hipStream_t st) {
     ProfScope prof("compose_fwd_kernel", 2.0 * a.nets * a.M * a.h * a.h, 0.0, st);
-    hipLaunchKernelGGL(compose_fwd_kernel, dim3(a.M, a.nets), dim3(128), 0, st, a);
+    hipLaunchKernelGGL(compose_fwd_kernel, dim3(a.M, a.nets), dim3(128), a.h * sizeof(float), st, a);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
