@@ -612,7 +612,8 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
     if (int e = check_dims(*dims)) return e;
     c.d = *dims; c.s = sizes_of(*dims); c.b = *batch; c.st = (hipStream_t)stream;
     param_layout(c.d, c.L);
-    static const bool presum_on = [] { const char* e = getenv("REFIL_PRESUM"); return !(e && e[0] == '0'); }();
+    const char* pe = getenv("REFIL_PRESUM");          // read per call: tests compare both paths in one process
+    const bool presum_on = !(pe && pe[0] == '0');
     c.presum = presum_on && !dims->mixer_lin && !dims->mixer_vdn && !dims->pooling &&
                attn_mfma_supported(dims->ne, dims->na, dims->hyp / dims->heads);
     c.compose_agent = presum_on && !dims->agent_ff && !dims->pooling && attn_mfma_supported(dims->ne, dims->na, dims->d / dims->heads);

@@ -264,3 +264,26 @@ def test_config_matrix_matches_oracle(what):
     gmax = max(v.abs().max().item() for v in grads.values())
     for k, ref in grads.items():
         assert (r["grads"][k] / msum - ref).abs().max().item() < TOL_GRAD * gmax, k
+
+
+def test_algebraic_restructuring_equals_plain_path_at_mid_size():
+    """agent-summed hypernets and composed out_trans o fc2 (REFIL_PRESUM=1, default) against the
+    layer-by-layer schedule (REFIL_PRESUM=0) on a batch large enough to take the weight-resident / streaming GEMM
+    kernels: same forward values, same gradients, same post-step parameters up to fp32 re-association."""
+    import os
+    cfg, batch, bits, agent, mixer, tagent, tmixer = _oracle_case(8, 20, 32, seed=5, d=128, h=128)
+    res = {}
+    for flag in ("1", "0"):
+        os.environ["REFIL_PRESUM"] = flag
+        try:
+            res[flag] = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer)
+        finally:
+            os.environ.pop("REFIL_PRESUM", None)
+    a, b = res["1"], res["0"]
+    for k in ("chosen_q", "q_tot", "q_tot_imagine", "target_q_tot"):
+        assert rel_err(a["out"][k], b["out"][k]) < 2e-5, k
+    assert abs(a["grad_norm"] - b["grad_norm"]) < 2e-5 * b["grad_norm"]
+    gmax = max(v.abs().max().item() for v in b["grads"].values())
+    for k, gv in b["grads"].items():
+        assert (a["grads"][k] - gv).abs().max().item() < 5e-5 * gmax, k
+        assert (a["post"][k] - b["post"][k]).abs().max().item() < 2e-6, k
