@@ -95,8 +95,6 @@ int td_loss_launch(const TdArgs& a, hipStream_t st);
 
 int sum_launch(const float* x, long n, float* out, hipStream_t st);   // out[0] = sum(x)
 
-// agent-summed hypernet tails: y[b][r][:] += nact[r] * bias[b][:]
-int rowscale_bias_launch(float* y, int ld, long sY, const float* nact, const float* bias, long sBias, long R, int N, int batch, hipStream_t st);
 // out_trans followed by fc2 is ONE linear map per hypernet (no non-linearity in between, flex_qmix.py:47-50):
 //   W_c = W_2 W_o [M,h],  b_c = W_2 b_o + b_2.   compose: build (W_c, b_c) of `nets` hypernets;
 //   decompose: turn (dL/dW_c, dL/db_c) into dW_2 = G W_o^T + g b_o^T, dW_o = W_2^T G, db_o = W_2^T g, db_2 = g (stored, not added)

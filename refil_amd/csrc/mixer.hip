@@ -548,22 +548,6 @@ __global__ __launch_bounds__(256) void sum_kernel(const float* x, long n, float*
     __syncthreads();
     if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
 }
-// ---- agent-summed hypernet tails (see MixArgs::presum) ------------------------------------------------
-__global__ void rowscale_bias_kernel(float* y, int ld, long sY, const float* nact, const float* bias, long sBias, long R, int N, int batch) {
-    const long total = (long)batch * R * N;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int n = idx % N; const long br = idx / N; const long r = br % R; const int b = br / R;
-        y[b * sY + r * ld + n] += nact[r] * bias[b * sBias + n];
-    }
-}
-int rowscale_bias_launch(float* y, int ld, long sY, const float* nact, const float* bias, long sBias, long R, int N, int batch, hipStream_t st) {
-    const long total = (long)batch * R * N;
-    ProfScope prof("rowscale_bias_kernel", 0.0, 8.0 * total, st);
-    hipLaunchKernelGGL(rowscale_bias_kernel, dim3((int)min((long)1024, cdivl(total, 256))), dim3(256), 0, st, y, ld, sY, nact, bias, sBias, R, N, batch);
-    REFIL_LAUNCH_CHECK();
-    return 0;
-}
-
 // ---- out_trans o fc2 composition (ComposeArgs in kernels.h). Tiny matrices (M x h, h x h): one workgroup per output
 // row so that every inner product is a short, fully pipelined loop (a single workgroup per net made them 2048 dependent
 // iterations long: 60+ us on the critical hypernet chain).
