@@ -1,0 +1,28 @@
+"""Soak test on the GPU: a few hundred QLearner.train steps on one synthetic batch (bench shapes, smaller B/T). Checks
+that parameters and statistics stay finite and that the loss goes down (usage: python tools/soak_test.py [steps])."""
+import sys, os, math
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import torch
+import bench
+from refil_amd.synthetic import sc2_shape_law
+W = bench.WORKLOAD
+law = sc2_shape_law(W["ne"])
+dims = dict(ne=W["ne"], na=law["n_agents"], A=law["n_actions"], ed=law["entity_shape"], d=W["d"], h=W["h"], heads=W["heads"], H=W["H"], M=W["M"])
+args, batch, learner, data = bench.build(dims, 16, 40, seed=3, device=torch.device("cuda", 0))
+from plugin_util import RecLogger
+learner.logger = RecLogger()
+learner.args.learner_log_interval = 1
+learner.args.target_update_interval = 50
+losses = []
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+for i in range(N):
+    learner.train(batch, t_env=i, episode_num=i)
+    if i % 50 == 0 or i == N - 1:
+        torch.cuda.synchronize()
+        st = learner.logger.stats
+        print(i, {k: round(v, 5) for k, v in st.items() if k in ("loss", "grad_norm", "td_error_abs", "q_taken_mean")})
+        losses.append(st.get("loss"))
+flat = learner.flat_live
+assert torch.isfinite(flat).all(), "non-finite parameters"
+assert all(l is not None and math.isfinite(l) for l in losses)
+print("finite OK; loss first/last", losses[0], losses[-1])
