@@ -314,6 +314,10 @@ int refil_profile_collect(refil_profile_entry* out, int max_entries);
  * -1 = follow the environment variable REFIL_NO_OVERLAP. */
 int refil_set_overlap(int on);
 
+/* Destroys the calling thread's internal side streams / events (all devices). They are re-created lazily by
+ * the next refil_learner_forward_backward; call before tearing the HIP context down. */
+int refil_release_streams(void);
+
 const char* refil_last_error(void);
 int refil_version(void);
 

@@ -108,7 +108,7 @@ EXPORTS = [
     "refil_clip_rmsprop_step", "refil_agent_workspace_bytes", "refil_agent_forward",
     "refil_mixer_workspace_bytes", "refil_mixer_forward", "refil_gemm", "refil_attn_forward",
     "refil_attn_backward", "refil_pool_forward", "refil_pool_backward", "refil_gru_forward", "refil_gru_backward", "refil_last_error", "refil_version",
-    "refil_profile_enable", "refil_profile_collect", "refil_set_overlap",
+    "refil_profile_enable", "refil_profile_collect", "refil_set_overlap", "refil_release_streams",
 ]
 
 _lib = None
@@ -198,15 +198,53 @@ def param_layout(dims: Dims) -> ParamLayout:
     return out
 
 
-def make_batch(fields: dict, group_bits=None) -> Batch:
-    """fields: name -> tensor [B,T1,...] (any batch/time strides, inner dims contiguous)."""
+_FIELD_DTYPES = None
+
+
+def _field_dtypes():
+    """Element types the kernels read (include/refil_hip.h, refil_batch): the reference's scheme dtypes
+    (src/run.py:178-192, episode_buffer.py:51-54)."""
+    global _FIELD_DTYPES
+    if _FIELD_DTYPES is None:
+        import torch
+        _FIELD_DTYPES = {"entities": torch.float32, "obs_mask": torch.uint8, "entity_mask": torch.uint8,
+                         "actions": torch.int64, "avail_actions": torch.int32, "reward": torch.float32,
+                         "terminated": torch.uint8, "filled": torch.int64, "gt_mask": torch.uint8}
+    return _FIELD_DTYPES
+
+
+def make_batch(fields: dict, group_bits=None, device=None) -> Batch:
+    """fields: name -> DEVICE tensor [B,T1,...] (any batch/time strides, inner dims contiguous).
+
+    The kernels reinterpret raw pointers, so every field is checked here: a host tensor is an error (the library has no
+    CPU path), a scheme dtype other than the kernel's (th.bool masks, int64 avail_actions, float terminated from a
+    custom env -- all of which the reference's torch ops accept) is converted (bool -> uint8 is a zero-copy view).
+    Converted tensors are kept alive on the returned struct until it is dropped."""
+    import torch
     b = Batch()
+    keep = []
     names = {"entities": "ent", "obs_mask": "om", "entity_mask": "em", "actions": "ac", "avail_actions": "av",
              "reward": "rw", "terminated": "tm", "filled": "fl", "gt_mask": "gt"}
+    want = _field_dtypes()
     for name, short in names.items():
         t = fields.get(name)
         if t is None:
             continue
+        if not t.is_cuda:
+            raise ValueError(f"batch field {name} lives on {t.device}: move the batch to the GPU first "
+                             "(EpisodeBatch.to(device)); refil_amd has no host path")
+        if device is not None and t.device != torch.device(device):
+            raise ValueError(f"batch field {name} is on {t.device}, the learner on {device}")
+        if t.dim() < 2:
+            raise ValueError(f"batch field {name}: expected [B, T1, ...], got shape {tuple(t.shape)}")
+        if t.dtype != want[name]:
+            if t.dtype == torch.bool and want[name] == torch.uint8:
+                t = t.view(torch.uint8)
+            elif want[name].is_floating_point or not t.dtype.is_floating_point or name in ("terminated", "filled"):
+                t = t.to(want[name])
+            else:
+                raise TypeError(f"batch field {name}: dtype {t.dtype} cannot stand in for {want[name]}")
+            keep.append(t)
         inner = t[0, 0]
         if not inner.is_contiguous():
             raise ValueError(f"batch field {name}: inner dims must be contiguous")
@@ -214,5 +252,11 @@ def make_batch(fields: dict, group_bits=None) -> Batch:
         setattr(b, short + "_sB", t.stride(0))
         setattr(b, short + "_sT", t.stride(1))
     if group_bits is not None:
+        if not group_bits.is_cuda:
+            raise ValueError("group_bits must be a device tensor [B, n_entities]")
+        if group_bits.dtype != torch.uint8 or not group_bits.is_contiguous():
+            group_bits = group_bits.to(torch.uint8).contiguous()
+        keep.append(group_bits)
         b.group_bits = group_bits.data_ptr()
+    b._keep = keep
     return b

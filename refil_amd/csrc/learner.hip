@@ -278,8 +278,13 @@ struct SideStream {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ok = false;
 };
+constexpr int MAX_DEVICES = 16;
+static thread_local SideStream g_side[MAX_DEVICES];       // one per device: a stream is bound to the device it was created on
 static int side_stream(SideStream*& out) {
-    static thread_local SideStream sd;
+    int dev = 0;
+    REFIL_HIP(hipGetDevice(&dev));
+    REFIL_CHECK(dev >= 0 && dev < MAX_DEVICES, "refil: device ordinal %d out of range", dev);
+    SideStream& sd = g_side[dev];
     if (!sd.ok) {
         int lo = 0, hi = 0;
         REFIL_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -292,6 +297,12 @@ static int side_stream(SideStream*& out) {
     }
     out = &sd;
     return 0;
+}
+// error path: whatever was enqueued on the side stream after a fork must still be ordered before the caller's next work
+static void side_stream_rejoin(SideStream* sd, hipStream_t main) {
+    if (!sd || !sd->ok) return;
+    if (hipEventRecord(sd->ev[3], sd->s) == hipSuccess) (void)hipStreamWaitEvent(main, sd->ev[3], 0);
+    (void)hipGetLastError();
 }
 static int g_overlap = -1;      // -1: follow the environment, 0/1: set by refil_set_overlap
 static bool overlap_enabled() {
@@ -656,9 +667,9 @@ extern "C" size_t refil_learner_workspace_bytes(const refil_dims* dims) {
     return workspace_bytes(*dims, CARVE_LEARNER);
 }
 
-extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refil_batch* batch, const float* params_live,
-                                              const float* params_target, float* grads, void* workspace,
-                                              size_t workspace_bytes_, const refil_debug_out* debug, void* stream) {
+static int learner_forward_backward(const refil_dims* dims, const refil_batch* batch, const float* params_live,
+                                    const float* params_target, float* grads, void* workspace,
+                                    size_t workspace_bytes_, const refil_debug_out* debug, void* stream, SideStream*& sd) {
     Ctx c;
     if (int e = make_ctx(c, dims, batch, workspace, workspace_bytes_, CARVE_LEARNER, stream)) return e;
     REFIL_CHECK(params_live && params_target && grads, "refil_learner_forward_backward: null parameter/grad buffer");
@@ -681,7 +692,6 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
     // push the ~40 launches of the first chain), and the agent chain has that much slack.
     Ctx ca = c;                       // agent chain: caller's stream
     Ctx ch = c;                       // hypernet chain: side stream + its own split-K scratch
-    SideStream* sd = nullptr;
     const bool overlap = overlap_enabled();
     if (overlap) {
         RUN(side_stream(sd));
@@ -887,6 +897,34 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
         REFIL_HIP(hipEventRecord(sd->ev[3], sd->s));
         REFIL_HIP(hipStreamWaitEvent(c.st, sd->ev[3], 0));
     }
+    return 0;
+}
+
+extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refil_batch* batch, const float* params_live,
+                                              const float* params_target, float* grads, void* workspace,
+                                              size_t workspace_bytes_, const refil_debug_out* debug, void* stream) {
+    SideStream* sd = nullptr;
+    const int rc = learner_forward_backward(dims, batch, params_live, params_target, grads, workspace, workspace_bytes_, debug, stream, sd);
+    if (rc) side_stream_rejoin(sd, (hipStream_t)stream);       // a launch failed after the fork: join before reporting
+    return rc;
+}
+
+// Destroys this thread's side streams and events (all devices). Safe to call at any time: they are re-created lazily.
+extern "C" int refil_release_streams(void) {
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    for (int dev = 0; dev < MAX_DEVICES; ++dev) {
+        SideStream& sd = g_side[dev];
+        if (!sd.ok) continue;
+        if (hipSetDevice(dev) == hipSuccess) {
+            (void)hipStreamSynchronize(sd.s);
+            for (auto& e : sd.ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+            (void)hipStreamDestroy(sd.s);
+        }
+        sd.s = nullptr; sd.ok = false;
+    }
+    (void)hipSetDevice(cur);
+    (void)hipGetLastError();
     return 0;
 }
 

@@ -32,6 +32,17 @@ def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
+def mean_scalar(x) -> float:
+    """Mean over ranks of a per-shard scalar diagnostic (log steps only; equal shard sizes)."""
+    if world() == 1:
+        return float(x)
+    t = x.detach().reshape(1).clone() if isinstance(x, torch.Tensor) else torch.tensor([float(x)])
+    if dist.get_backend() == "nccl" and not t.is_cuda:
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.item() / world()
+
+
 def shard_episodes(fields: Dict[str, torch.Tensor], r: int, n: int) -> Dict[str, torch.Tensor]:
     """Rank r of n takes episodes [r*B/n, (r+1)*B/n) of the sampled minibatch (views, no copies)."""
     B = next(iter(fields.values())).shape[0]

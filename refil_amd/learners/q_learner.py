@@ -84,15 +84,28 @@ class QLearner:
             if getattr(mod, "_flat", None) is None or mod._flat.data_ptr() != st.data_ptr() or not mod._is_flat():
                 mod.adopt(st)
 
-    def _draw_partition(self, B, ne, device):
+    def _draw_partition(self, B, ne, device, bernoulli=True):
         """entity_rnn_agent.py:94-96: p = rand(B,1,1); groupA = bernoulli(p.repeat(1,1,ne)) -- drawn with the
-        CPU generator (same two calls, same stream as the reference's CPU run) and shipped to the device."""
+        CPU generator (same two calls, same stream as the reference's CPU run) and shipped to the device.
+        With use_gt_factors the FF agent consumes only the rand() call (entity_ff_agent.py:91-95): bernoulli=False.
+
+        train() never synchronises the host, so the async H2D copy of step k may still be queued when step k+1
+        draws: the pinned staging buffers form a ring, and a slot is rewritten only after the event recorded
+        behind its last copy has completed."""
         p = th.rand(B, 1, 1, generator=self.generator).repeat(1, 1, ne)
+        if not bernoulli:
+            return None
         bits = th.bernoulli(p, generator=self.generator).to(th.uint8).reshape(B, ne)
-        if self._bits_host is None or self._bits_host.shape != bits.shape:
-            self._bits_host = th.empty_like(bits).pin_memory()
-        self._bits_host.copy_(bits)
-        return self._bits_host.to(device, non_blocking=True)
+        if self._bits_host is None or self._bits_host[0][0].shape != bits.shape:
+            self._bits_host = [(th.empty_like(bits).pin_memory(), th.cuda.Event()) for _ in range(4)]
+            self._bits_slot = 0
+        host, ev = self._bits_host[self._bits_slot]
+        self._bits_slot = (self._bits_slot + 1) % len(self._bits_host)
+        ev.synchronize()                       # no-op unless the copy issued 4 steps ago is still pending
+        host.copy_(bits)
+        dev = host.to(device, non_blocking=True)
+        ev.record()
+        return dev
 
     def _fields(self, batch):
         names = ["entities", "obs_mask", "entity_mask", "actions", "avail_actions", "reward", "terminated", "filled"]
@@ -113,6 +126,8 @@ class QLearner:
         B, T1 = batch.batch_size, batch.max_seq_length
         dims = dims_from_args(args, B, T1)
         tgt, trgt = bool(getattr(args, "train_gt_factors", False)), bool(getattr(args, "train_rand_gt_factors", False))
+        if not dims.agent_ff:       # ImagineEntityAttentionRNNAgent.forward swallows both flags (**kwargs, entity_rnn_agent.py:87)
+            tgt = trgt = False
         assert not (tgt and trgt), "Can only select one of use_rand_gt_factors and use_gt_factors"   # entity_ff_agent.py:112
         dims.gt_factors = 2 if trgt else int(tgt)                                   # q_learner.py:88-89
         fields = self._fields(batch)
@@ -122,9 +137,9 @@ class QLearner:
         if will_log and dims.imagine and getattr(args, "test_gt_factors", False):
             gt_ingroup = self._gt_ingroup_prop(dims, fields, B, T1)                     # with the pre-update weights
         bits = None
-        if dims.imagine:        # (drawn even when train_gt_factors ignores it: the reference consumes the RNG too, :86)
+        if dims.imagine:        # (rand() is drawn even when train_gt_factors ignores it: the reference consumes the RNG too)
             bits = group_bits.to(dev).to(th.uint8).contiguous() if group_bits is not None else \
-                self._draw_partition(B, args.n_entities, dev)
+                self._draw_partition(B, args.n_entities, dev, bernoulli=dims.gt_factors != 1)
         self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads)
         # data parallel over episodes: ONE all-reduce(SUM) of [grads | stat sums]; the global
         # sum(mask) normaliser is applied afterwards by the optimiser kernel (q_learner.py:165)
@@ -148,8 +163,9 @@ class QLearner:
             else:
                 self.logger.log_stat("loss", q_loss, t_env)
             if getattr(args, "test_gt_factors", False) and dims.imagine:                # q_learner.py:188-190
-                self.logger.log_stat("ingroup_prop", st[_lib.STAT_INGROUP_SUM] / (B * (T1 - 1)), t_env)
-                self.logger.log_stat("gt_ingroup_prop", float(gt_ingroup), t_env)
+                # (the stat sums are all-reduced over the data-parallel ranks; B is the per-rank shard)
+                self.logger.log_stat("ingroup_prop", st[_lib.STAT_INGROUP_SUM] / (dp.world() * B * (T1 - 1)), t_env)
+                self.logger.log_stat("gt_ingroup_prop", float(dp.mean_scalar(gt_ingroup)), t_env)
             self.logger.log_stat("grad_norm", st[_lib.STAT_GRAD_NORM], t_env)
             self.logger.log_stat("td_error_abs", st[_lib.STAT_TD_ABS] / msum, t_env)
             self.logger.log_stat("q_taken_mean", st[_lib.STAT_QTOT_SUM] / (msum * args.n_agents), t_env)    # :194 quirk kept

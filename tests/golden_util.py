@@ -8,16 +8,16 @@ import torch
 from oracle import refil_oracle as orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["refil_tiny", "qmix_atten_tiny", "refil_abs_masked", "refil_odd", "refil_mid", "refil_vdn_tiny"]
+CASES = ["refil_tiny", "qmix_atten_tiny", "refil_abs_masked", "refil_odd", "refil_mid", "refil_vdn_tiny",
+         "refil_tanh", "refil_tanh_abs", "refil_d128"]
+TRAJ_CASES = ["refil_traj5"]      # consecutive train() calls: RMSprop state, weight decay, target syncs, checkpoint
 POOL_CASES = ["refil_pool_mean", "refil_pool_max"]     # pooling_type = mean / max (EntityPoolingLayer)
 GM_CASES = ["gm_refil_ff_lin"]       # BASELINE.json configs[0]: group_matching + FF agent + lin_flex_qmix
 GM_TRAIN_CASES = ["gm_refil_train_gt", "gm_refil_train_randgt"]   # same alg with train_gt_factors / train_rand_gt_factors
 
 
-def load(name):
-    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
-    case = ast.literal_eval(str(z["case"]))
-    cfg = orc.Cfg(
+def cfg_of(case):
+    return orc.Cfg(
         n_agents=case["na"], n_entities=case["ne"], n_actions=case["A"], entity_shape=case["ed"],
         attn_embed_dim=case["d"], attn_n_heads=case["heads"], rnn_hidden_dim=case["H"],
         hypernet_embed=case["h"], mixing_embed_dim=case["M"],
@@ -30,7 +30,14 @@ def load(name):
         pooling_type=case.get("pooling_type"),
         train_gt_factors=bool(case.get("train_gt_factors", False)),
         train_rand_gt_factors=bool(case.get("train_rand_gt_factors", False)),
+        weight_decay=case.get("weight_decay", 0.0),
     )
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    case = ast.literal_eval(str(z["case"]))
+    cfg = cfg_of(case)
 
     def group(prefix):
         return {k[len(prefix):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(prefix)}
@@ -44,6 +51,27 @@ def load(name):
         "tmixer": {k: v for k, v in group("tmixer.").items() if "scale_factor" not in k},
         "bits": torch.from_numpy(z["group_bits"].copy()),
     }
+
+
+def load_traj(name):
+    """Trajectory fixture (tools/make_golden.py:run_traj_case): state s0 before the first train() call, s{k} after
+    call k-1; per call its batch `in{k}.*`, partition bits `bits{k}` and logged stats `stat{k}.*`."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    case = ast.literal_eval(str(z["case"]))
+
+    def group(prefix):
+        return {k[len(prefix):]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith(prefix)}
+
+    def state(k):
+        return {"agent": group(f"s{k}.agent."), "mixer": group(f"s{k}.mixer."), "tagent": group(f"s{k}.tagent."),
+                "tmixer": group(f"s{k}.tmixer."), "sq": group(f"s{k}.sq.")}
+
+    n = case["n_steps"]
+    return {"z": z, "case": case, "cfg": cfg_of(case), "n_steps": n,
+            "states": [state(k) for k in range(n + 1)],
+            "batches": [group(f"in{k}.") for k in range(n)],
+            "bits": [torch.from_numpy(z[f"bits{k}"].copy()) for k in range(n)],
+            "stats": [{kk[len(f"stat{k}."):]: float(z[kk]) for kk in z.files if kk.startswith(f"stat{k}.")} for k in range(n)]}
 
 
 def rel_err(a, b):

@@ -6,7 +6,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from golden_util import CASES, GM_CASES, GM_TRAIN_CASES, POOL_CASES, load, rel_err
+from golden_util import CASES, GM_CASES, GM_TRAIN_CASES, POOL_CASES, TRAJ_CASES, load, load_traj, rel_err
 from oracle import refil_oracle as orc
 
 DEV = "cuda"
@@ -25,12 +25,14 @@ def _dims(cfg, B, T1):
                           pooling={None: 0, "mean": 1, "max": 2}[cfg.pooling_type], gamma=cfg.gamma, lmbda=cfg.lmbda)
 
 
-def run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, debug=True, step=True):
+def run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, debug=True, step=True, profile=False):
     from refil_amd import _lib, flat
     from refil_amd.engine import LearnerEngine
     B, T1 = batch["entities"].shape[:2]
     dims = _dims(cfg, B, T1)
     eng = LearnerEngine(DEV)
+    if profile:
+        _lib.profile_enable(True)
     live = flat.pack(dims, agent, mixer, DEV)
     targ = flat.pack(dims, tagent, tmixer, DEV)
     n = flat.total(dims)
@@ -38,9 +40,13 @@ def run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, debug=True, ste
     fields = {k: v.to(DEV) for k, v in batch.items()}
     out = eng.forward_backward(dims, fields, bits.to(DEV) if bits is not None else None, live, targ, grads, debug=debug)
     torch.cuda.synchronize()
+    kernels = None
+    if profile:
+        kernels = {e["name"]: e["launches"] for e in _lib.profile_collect()}
+        _lib.profile_enable(False)
     stats = grads[n:].cpu().double()
     g_agent, g_mixer = flat.views(grads[:n].clone(), dims)
-    res = {"dims": dims, "out": {k: v.cpu() for k, v in out.items()}, "stats": stats, "n": n,
+    res = {"dims": dims, "kernels": kernels, "out": {k: v.cpu() for k, v in out.items()}, "stats": stats, "n": n,
            "grads": {**{"agent." + k: v.cpu() for k, v in g_agent.items()}, **{"mixer." + k: v.cpu() for k, v in g_mixer.items()}}}
     if step:
         sq = torch.zeros(n, device=DEV)
@@ -93,6 +99,8 @@ def test_learner_step_matches_reference_golden(name):
         else:
             refn = float(z["gradnorm." + k])
             assert abs(gv.double().norm().item() - refn) < TOL_GRAD * max(refn, 1e-6), k
+            post = r["post"][k].double()
+            assert abs(post.sum().item() - float(z["postsum." + k])) < 5e-6 * post.numel() ** 0.5 + 1e-6, k
 
 
 def _oracle_case(B, T, ne, seed, imagine=True, d=64, h=64, heads=4):
@@ -134,6 +142,100 @@ def test_learner_step_matches_oracle(B, T, ne, imagine, d):
         assert (r["post"]["agent." + k] - a2[k]).abs().max().item() < 5e-6, k
     for k in m2:
         assert (r["post"]["mixer." + k] - m2[k]).abs().max().item() < 5e-6, k
+
+
+# BASELINE.json configs at their FULL sizes (SURVEY.md section 8d "Configs restated"): the kernel routes bench.py times
+# (weight-resident GEMM, streaming dW, MFMA attention, persistent GRU, agent-summed / composed tails as scheduled by
+# learner.hip) against the CPU oracle -- every output, all gradients, the post-step parameters.
+PRODUCTION = {
+    "cfgT_quarter": dict(B=8, T=20, ne=32, d=128, imagine=True),
+    "cfgT": dict(B=32, T=80, ne=32, d=128, imagine=True),                 # north-star shape (the bench line)
+    "cfg2": dict(B=32, T=80, ne=16, d=64, imagine=True),                  # configs[1]
+    "cfg3": dict(B=64, T=80, ne=32, d=128, imagine=True),                 # configs[2], "roofline run"
+    "cfg4_shape": dict(B=32, T=150, ne=16, d=128, imagine=False),         # configs[3]: qmix_atten on the 3-8sz shape
+    "cfg5_ne48": dict(B=32, T=80, ne=48, d=128, imagine=True),            # configs[4] scaled to 48 entities
+}
+
+
+@pytest.mark.parametrize("which", list(PRODUCTION))
+def test_production_size_step_matches_oracle(which):
+    kw = PRODUCTION[which]
+    cfg, batch, bits, agent, mixer, tagent, tmixer = _oracle_case(kw["B"], kw["T"], kw["ne"], seed=40 + kw["B"], imagine=kw["imagine"],
+                                                                  d=kw["d"], h=kw["d"])
+    r = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, profile=True)
+    names = " ".join(r["kernels"])
+    for sym in ("gemm_wres_kernel", "gemm_dw_stream_kernel", "attn_fwd_mfma", "attn_bwd_mfma", "gru_fwd_kernel", "gru_bwd_kernel"):
+        assert sym in names, f"{which}: {sym} did not run (kernels: {sorted(r['kernels'])})"
+    assert "attn_fwd_kernel" not in r["kernels"] and "attn_bwd_kernel" not in r["kernels"], "VALU attention fallback taken"
+    a2, m2 = dict(agent), dict(mixer)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    out, grads, gnorm = orc.train_step(cfg, a2, m2, tagent, tmixer, batch, bits)
+    o, st = r["out"], r["stats"]
+    assert rel_err(o["q"], out.q.detach()) < TOL_FWD
+    assert rel_err(o["chosen_q"], out.chosen_q.detach()) < TOL_FWD
+    assert rel_err(o["target_max_q"], out.target_max_q) < TOL_FWD
+    assert rel_err(o["q_tot"], out.q_tot.detach()[..., 0]) < TOL_FWD
+    assert rel_err(o["target_q_tot"], out.target_q_tot[..., 0]) < TOL_FWD
+    assert rel_err(o["targets"], out.targets[..., 0]) < TOL_FWD
+    msum = st[0].item()
+    assert abs(msum - out.mask.sum().item()) < 1e-6 * msum
+    assert abs(st[1].item() / msum - out.q_loss.item()) < TOL_FWD * out.q_loss.item()
+    if kw["imagine"]:
+        assert rel_err(o["q_tot_imagine"], out.q_tot_imagine.detach()[..., 0]) < TOL_FWD
+        assert abs(st[2].item() / msum - out.im_loss.item()) < TOL_FWD * out.im_loss.item()
+    assert abs(r["grad_norm"] - gnorm) < TOL_GRAD * gnorm
+    gmax = max(v.abs().max().item() for v in grads.values())
+    assert len(grads) == 41
+    for k, ref in grads.items():
+        assert (r["grads"][k] / msum - ref).abs().max().item() < TOL_GRAD * gmax, k
+    for k in a2:
+        assert (r["post"]["agent." + k] - a2[k]).abs().max().item() < 5e-6, k
+    for k in m2:
+        assert (r["post"]["mixer." + k] - m2[k]).abs().max().item() < 5e-6, k
+
+
+@pytest.mark.parametrize("name", TRAJ_CASES)
+def test_trajectory_matches_reference_golden(name):
+    """Five consecutive reference train() calls: carried RMSprop square_avg, weight decay, target syncs -- through the
+    C ABI (refil_learner_forward_backward + refil_clip_rmsprop_step on persistent flat buffers)."""
+    from refil_amd import _lib, flat
+    from refil_amd.engine import LearnerEngine
+    g = load_traj(name)
+    cfg, case, B, T = g["cfg"], g["case"], g["case"]["B"], g["case"]["T"]
+    dims = _dims(cfg, B, T + 1)
+    eng = LearnerEngine(DEV)
+    s0 = g["states"][0]
+    live = flat.pack(dims, s0["agent"], s0["mixer"], DEV)
+    targ = flat.pack(dims, s0["tagent"], s0["tmixer"], DEV)
+    n = flat.total(dims)
+    sq = torch.zeros(n, device=DEV)
+    grads = torch.zeros(n + _lib.REFIL_NSTAT, device=DEV)
+    last_sync = 0
+    for s in range(g["n_steps"]):
+        fields = {k: v.to(DEV) for k, v in g["batches"][s].items()}
+        eng.forward_backward(dims, fields, g["bits"][s].to(DEV), live, targ, grads)
+        eng.clip_rmsprop(live, grads, sq, n, cfg.lr, cfg.optim_alpha, cfg.optim_eps, cfg.weight_decay, cfg.grad_norm_clip)
+        if (s - last_sync) / case["target_update_interval"] >= 1.0:
+            targ.copy_(live)
+            last_sync = s
+        torch.cuda.synchronize()
+        st = grads[n:].cpu().double()
+        msum = st[0].item()
+        loss = (1 - cfg.lmbda) * st[1].item() / msum + cfg.lmbda * st[2].item() / msum
+        ref = g["stats"][s]
+        assert abs(loss - ref["loss"]) < TOL_FWD * abs(ref["loss"]), s
+        assert abs(st[_lib.STAT_GRAD_NORM].item() - ref["grad_norm"]) < TOL_GRAD * ref["grad_norm"], s
+        nxt = g["states"][s + 1]
+        pa, pm = flat.views(live, dims)
+        ta, tm = flat.views(targ, dims)
+        sa, sm = flat.views(sq, dims)
+        for which, cur in (("agent", pa), ("mixer", pm), ("tagent", ta), ("tmixer", tm)):
+            for k, v in cur.items():
+                assert (v.cpu() - nxt[which][k]).abs().max().item() < 5e-6 * (s + 1), (s, which, k)
+        for which, cur in (("agent", sa), ("mixer", sm)):
+            for k, v in cur.items():
+                ref_sq = nxt["sq"][which + "." + k]
+                assert rel_err(v.cpu(), ref_sq) < 2e-3 or ref_sq.abs().max() < 1e-12, (s, which, k)
 
 
 def test_time_truncated_strided_batch_equals_contiguous():

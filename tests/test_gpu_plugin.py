@@ -7,7 +7,7 @@ import torch as th
 
 pytestmark = pytest.mark.gpu
 
-from golden_util import load, rel_err
+from golden_util import load, load_traj, rel_err
 from oracle import refil_oracle as orc
 from plugin_util import RecLogger, make_args, make_episode_batch
 
@@ -114,14 +114,109 @@ def test_checkpoint_roundtrip_in_reference_format(tmp_path):
     assert len(opt["state"]) == 41 and set(opt["state"][0]) == {"step", "square_avg"}
     g2, args2, batch2, mac2, learner2, logger2 = _build("refil_tiny")
     learner2.load_models(str(tmp_path))
+    th.cuda.synchronize()
+    # what a reload defines: live agent + mixer + RMSprop state; the target agent is loaded from agent.th as well and the
+    # target mixer is not checkpointed (q_learner.py:222-229)
+    for (k, a), (_, b) in zip(mac.agent.state_dict().items(), mac2.agent.state_dict().items()):
+        assert th.equal(a, b), k
+    for (k, a), (_, b) in zip(learner.mixer.state_dict().items(), learner2.mixer.state_dict().items()):
+        assert th.equal(a, b), k
+    for (k, a), (_, b) in zip(mac2.agent.state_dict().items(), learner2.target_mac.agent.state_dict().items()):
+        assert th.equal(a, b), k
+    assert th.equal(learner.square_avg, learner2.square_avg) and learner.square_avg.abs().max().item() > 0
+    # ... and the next step of the reloaded learner equals the next step of the one that kept running (same targets)
+    learner._update_targets(); learner2._update_targets()
     th.manual_seed(4); learner.train(batch, 1, 1)
     th.manual_seed(4); learner2.train(batch2, 1, 1)
     th.cuda.synchronize()
-    # the target nets are not checkpointed (reference behaviour), so only compare what a reload defines
-    for (k, a), (_, b) in zip(mac.agent.state_dict().items(), mac2.agent.state_dict().items()):
-        if "fc3" in k or "rnn" in k:
-            continue
-    assert set(mac2.agent.state_dict()) == set(mac.agent.state_dict())
+    assert th.equal(learner.flat_live, learner2.flat_live)
+    assert th.equal(learner.square_avg, learner2.square_avg)
+    assert abs(logger.stats["loss"] - logger2.stats["loss"]) == 0.0
+
+
+def _build_traj(name, state, **over):
+    from refil_amd.controllers import REGISTRY as mac_REGISTRY
+    from refil_amd.learners import REGISTRY as le_REGISTRY
+    g = load_traj(name)
+    cfg, case = g["cfg"], g["case"]
+    args = make_args(cfg, target_update_interval=case["target_update_interval"], **over)
+    batches = [make_episode_batch(cfg, b, device="cuda")[0] for b in g["batches"]]
+    groups = {"agents": cfg.n_agents, "entities": cfg.n_entities}
+    mac = mac_REGISTRY[args.mac](batches[0].scheme, groups, args)
+    logger = RecLogger()
+    learner = le_REGISTRY[args.learner](mac, batches[0].scheme, logger, args)
+    learner.cuda()
+    if state is not None:
+        st = g["states"][state]
+        mac.agent.load_state_dict(st["agent"], strict=False)
+        learner.mixer.load_state_dict(st["mixer"], strict=False)
+        learner.target_mac.agent.load_state_dict(st["tagent"], strict=False)
+        learner.target_mixer.load_state_dict(st["tmixer"], strict=False)
+    return g, args, batches, mac, learner, logger
+
+
+def _assert_state(g, k, mac, learner, tol):
+    nxt = g["states"][k]
+    for which, sd in (("agent", mac.agent.state_dict()), ("mixer", learner.mixer.state_dict()),
+                      ("tagent", learner.target_mac.agent.state_dict()), ("tmixer", learner.target_mixer.state_dict())):
+        for name, ref in nxt[which].items():
+            assert (sd[name].cpu() - ref).abs().max().item() < tol, (k, which, name)
+    opt = learner._opt_state_dict()
+    names = ["agent." + n for n, _ in mac.agent.named_parameters()] + ["mixer." + n for n, _ in learner.mixer.named_parameters()]
+    for i, name in enumerate(names):
+        ref = nxt["sq"][name]
+        assert rel_err(opt["state"][i]["square_avg"].cpu(), ref) < 2e-3 or ref.abs().max() < 1e-12, (k, name)
+
+
+def test_qlearner_trajectory_matches_reference():
+    """Five consecutive QLearner.train calls through the plugin surface against the reference's own run: non-zero RMSprop
+    state, weight_decay = 1e-4, target syncs after episode 2 and 4 (q_learner.py:175-182,203-207)."""
+    g, args, batches, mac, learner, logger = _build_traj("refil_traj5", 0)
+    assert args.weight_decay == 1e-4
+    for s in range(g["n_steps"]):
+        th.manual_seed(g["case"]["seed"] + 7 + s)
+        learner.train(batches[s], t_env=s, episode_num=s)
+        th.cuda.synchronize()
+        for k in ("loss", "im_loss", "grad_norm", "td_error_abs", "q_taken_mean", "target_mean"):
+            ref = g["stats"][s][k]
+            assert abs(logger.stats[k] - ref) < 2e-4 * max(abs(ref), 1e-3), (s, k, logger.stats[k], ref)
+        _assert_state(g, s + 1, mac, learner, 5e-6 * (s + 1))
+    assert sum("Updated target network" in str(i) for i in logger.infos) == 2
+
+
+def test_reference_written_checkpoint_loads_and_continues(tmp_path):
+    """f3: agent.th / mixer.th / opt.th laid out exactly as the REFERENCE writes them (state_dict names incl. the
+    attn.scale_factor buffers, torch.optim.RMSprop.state_dict() layout; q_learner.py:216-220, basic_controller.py:87-88),
+    filled with the reference's own values after four train() calls, load into a fresh learner; its next train() call
+    reproduces the reference's fifth call."""
+    g = load_traj("refil_traj5")
+    cfg, ck = g["cfg"], g["case"]["checkpoint_after"]
+    st = g["states"][ck]
+    hd_a, hd_m = cfg.attn_embed_dim // cfg.attn_n_heads, cfg.hypernet_embed // cfg.attn_n_heads
+    agent_sd = dict(st["agent"]); agent_sd["attn.scale_factor"] = th.sqrt(th.scalar_tensor(hd_a))       # attention.py:18-19
+    mixer_sd = dict(st["mixer"])
+    for net in ("hyper_w_1", "hyper_w_final", "hyper_b_1", "V"):
+        mixer_sd[net + ".attn.scale_factor"] = th.sqrt(th.scalar_tensor(hd_m))
+    g0, args, batches, mac, learner, logger = _build_traj("refil_traj5", None)          # fresh, randomly initialised
+    names = ["agent." + n for n, _ in mac.agent.named_parameters()] + ["mixer." + n for n, _ in learner.mixer.named_parameters()]
+    opt_sd = {"state": {i: {"step": ck, "square_avg": st["sq"][n].clone()} for i, n in enumerate(names)},
+              "param_groups": [{"lr": cfg.lr, "momentum": 0, "alpha": cfg.optim_alpha, "eps": cfg.optim_eps, "centered": False,
+                                "weight_decay": cfg.weight_decay, "params": list(range(len(names)))}]}
+    th.save(agent_sd, str(tmp_path / "agent.th")); th.save(mixer_sd, str(tmp_path / "mixer.th")); th.save(opt_sd, str(tmp_path / "opt.th"))
+    learner.load_models(str(tmp_path))
+    for name, ref in st["agent"].items():                     # the reference loads agent.th into the target MAC too (:224-225)
+        assert th.equal(mac.agent.state_dict()[name].cpu(), ref), name
+        assert th.equal(learner.target_mac.agent.state_dict()[name].cpu(), ref), name
+    # the reference's uninterrupted run still had lagging targets at this point: put them in place, then step
+    learner.target_mac.agent.load_state_dict(st["tagent"], strict=False)
+    learner.target_mixer.load_state_dict(st["tmixer"], strict=False)
+    learner.last_target_update_episode = 2
+    th.manual_seed(g["case"]["seed"] + 7 + ck)
+    learner.train(batches[ck], t_env=ck, episode_num=ck)
+    th.cuda.synchronize()
+    for k in ("loss", "grad_norm"):
+        assert abs(logger.stats[k] - g["stats"][ck][k]) < 2e-4 * abs(g["stats"][ck][k]), k
+    _assert_state(g0, ck + 1, mac, learner, 5e-6)
 
 
 def test_target_update_copies_flat_buffer():

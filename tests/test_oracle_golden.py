@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import refil_oracle as orc
-from golden_util import CASES, GM_CASES, GM_TRAIN_CASES, POOL_CASES, load, rel_err
+from golden_util import CASES, GM_CASES, GM_TRAIN_CASES, POOL_CASES, TRAJ_CASES, load, load_traj, rel_err
 
 TOL = 2e-5   # fp32, different op order than the reference (shared fc1/K/V, fused masks)
 
@@ -57,6 +57,35 @@ def test_oracle_matches_reference(name):
         else:
             ref = float(z["gradnorm." + k])
             assert abs(gv.double().norm().item() - ref) < 1e-4 * max(ref, 1e-6), k
+            which, nm = k.split(".", 1)
+            post = (agent if which == "agent" else mixer)[nm].double()
+            assert abs(post.sum().item() - float(z["postsum." + k])) < 2e-6 * post.numel() ** 0.5 + 1e-6, k
+
+
+@pytest.mark.parametrize("name", TRAJ_CASES)
+def test_oracle_trajectory_matches_reference(name):
+    """Consecutive train() calls (q_learner.py:66-207): RMSprop with carried square_avg, weight decay
+    (torch.optim.RMSprop: g += wd * p after the clip), hard target syncs every target_update_interval episodes."""
+    g = load_traj(name)
+    cfg, case = g["cfg"], g["case"]
+    st = g["states"][0]
+    agent, mixer, tagent, tmixer = dict(st["agent"]), dict(st["mixer"]), dict(st["tagent"]), dict(st["tmixer"])
+    sq = {k: v.clone() for k, v in st["sq"].items()}
+    last_sync = 0
+    for s in range(g["n_steps"]):
+        out, grads, gnorm = orc.train_step(cfg, agent, mixer, tagent, tmixer, g["batches"][s], g["bits"][s], square_avg=sq)
+        if (s - last_sync) / case["target_update_interval"] >= 1.0:                   # q_learner.py:180-182, episode_num = s
+            tagent, tmixer, last_sync = {k: v.clone() for k, v in agent.items()}, {k: v.clone() for k, v in mixer.items()}, s
+        ref = g["stats"][s]
+        assert abs(out.loss.item() - ref["loss"]) < TOL * abs(ref["loss"]), s
+        assert abs(gnorm - ref["grad_norm"]) < 1e-4 * ref["grad_norm"], s
+        nxt = g["states"][s + 1]
+        for which, cur in (("agent", agent), ("mixer", mixer), ("tagent", tagent), ("tmixer", tmixer)):
+            for k, v in cur.items():
+                assert (v - nxt[which][k]).abs().max().item() < 3e-6, (s, which, k)
+        for k, v in sq.items():
+            assert rel_err(v, nxt["sq"][k]) < 1e-3 or nxt["sq"][k].abs().max() < 1e-12, (s, k)
+    assert not torch.equal(g["states"][-2]["tagent"]["fc1.weight"], g["states"][-2]["agent"]["fc1.weight"])   # targets lag at the checkpoint
 
 
 def test_partition_draw_matches_reference_rng_calls():

@@ -64,8 +64,8 @@ def ref_args(case):
         hypernet_embed=case["h"], mixing_embed_dim=case["M"],
         softmax_mixing_weights=case.get("softmax_mixing_weights", True), pooling_type=case.get("pooling_type"),
         double_q=case.get("double_q", True), gamma=0.99, lmbda=case.get("lmbda", 0.5), lr=0.0005, optim_alpha=0.99,
-        optim_eps=0.00001, weight_decay=0, grad_norm_clip=case.get("grad_norm_clip", 10),
-        target_update_interval=200, learner_log_interval=1,
+        optim_eps=0.00001, weight_decay=case.get("weight_decay", 0), grad_norm_clip=case.get("grad_norm_clip", 10),
+        target_update_interval=case.get("target_update_interval", 200), learner_log_interval=1,
         train_gt_factors=False, train_rand_gt_factors=False, test_gt_factors=False, obs_last_action=False,
         obs_agent_id=False, device="cpu",
     )
@@ -178,6 +178,80 @@ def run_case(name, case, out_dir):
     np.savez_compressed(path, **rec)
     print(f"{name}: loss={logger.stats['loss']:.6f} grad_norm={gn:.5f} clip_coef={coef:.4f} -> {path} "
           f"({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def run_traj_case(name, case, out_dir):
+    """A trajectory of consecutive QLearner.train calls (q_learner.py:66-207) on fresh seeded batches: RMSprop with a
+    non-zero square_avg, weight decay, a hard target sync in the middle of the run (target_update_interval), and a
+    "checkpoint" (what agent.th / mixer.th / opt.th would hold, as arrays) before the last step."""
+    from refil_amd.synthetic import make_batch
+    le_REGISTRY, mac_REGISTRY, EpisodeBatch, OneHot = import_reference()
+    args = ref_args(case)
+    B, T, n_steps, ck = case["B"], case["T"], case["n_steps"], case["checkpoint_after"]
+    scheme = {
+        "entities": {"vshape": case["ed"], "group": "entities"},
+        "obs_mask": {"vshape": case["ne"], "group": "entities", "dtype": th.uint8},
+        "entity_mask": {"vshape": case["ne"], "dtype": th.uint8},
+        "actions": {"vshape": (1,), "group": "agents", "dtype": th.long},
+        "avail_actions": {"vshape": (case["A"],), "group": "agents", "dtype": th.int},
+        "reward": {"vshape": (1,)},
+        "terminated": {"vshape": (1,), "dtype": th.uint8},
+    }
+    groups = {"agents": case["na"], "entities": case["ne"]}
+    preprocess = {"actions": ("actions_onehot", [OneHot(out_dim=case["A"])])}
+
+    def batch_of(step):
+        data = make_batch(B, T, case["ne"], seed=case["seed"] + 100 * step, na=case["na"], A=case["A"], ed=case["ed"],
+                          min_active=case.get("min_active", 1), death_p=case.get("death_p", 0.05))
+        batch = EpisodeBatch(scheme, groups, B, T + 1, preprocess=preprocess, device="cpu")
+        for k, v in data.items():
+            batch.data.transition_data[k] = v.clone()
+        batch.data.transition_data["actions_onehot"] = OneHot(case["A"]).transform(data["actions"])
+        return data, batch
+
+    _, batch0 = batch_of(0)
+    th.manual_seed(case["seed"] + 1000)
+    mac = mac_REGISTRY[args.mac](batch0.scheme, groups, args)
+    logger = _Logger()
+    learner = le_REGISTRY[args.learner](mac, batch0.scheme, logger, args)
+    with th.no_grad():
+        for p in list(learner.target_mac.parameters()) + list(learner.target_mixer.parameters()):
+            p.add_(0.05 * th.randn_like(p))
+    rec = {}
+
+    def snap(prefix):
+        for pre, sd in ((".agent.", mac.agent.state_dict()), (".mixer.", learner.mixer.state_dict()),
+                        (".tagent.", learner.target_mac.agent.state_dict()), (".tmixer.", learner.target_mixer.state_dict())):
+            for k, v in sd.items():
+                if "scale_factor" not in k:
+                    rec[prefix + pre + k] = v.numpy().copy()
+        names = [("agent", k, p) for k, p in mac.agent.named_parameters()] + \
+                [("mixer", k, p) for k, p in learner.mixer.named_parameters()]
+        for which, k, p in names:
+            st = learner.optimiser.state.get(p)
+            rec[f"{prefix}.sq.{which}.{k}"] = (st["square_avg"].numpy().copy() if st else np.zeros(tuple(p.shape), np.float32))
+
+    snap("s0")                               # state before the first call
+    for s in range(n_steps):
+        data, batch = batch_of(s)
+        for k, v in data.items():
+            rec[f"in{s}.{k}"] = v.numpy()
+        draw_seed = case["seed"] + 7 + s
+        th.manual_seed(draw_seed)
+        probs = th.rand(B, 1, 1).repeat(1, 1, case["ne"])
+        rec[f"bits{s}"] = th.bernoulli(probs).to(th.uint8).reshape(B, case["ne"]).numpy()
+        th.manual_seed(draw_seed)
+        learner.train(batch, t_env=s, episode_num=s)
+        for k, v in logger.stats.items():
+            rec[f"stat{s}.{k}"] = np.float64(v)
+        snap(f"s{s + 1}")                    # state after call s (s == checkpoint_after: the checkpoint contents)
+    case = dict(case, kind="traj")
+    rec["case"] = np.array(repr(case))
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **rec)
+    losses = " ".join(f"{rec[f'stat{s}.loss']:.5f}" for s in range(n_steps))
+    print(f"{name}: losses {losses} (checkpoint after call {ck}) -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
 def _import_group_matching():
@@ -343,13 +417,32 @@ CASES = {
                            pooling_type="max", death_p=0.2),
     "refil_mid": dict(imagine=True, B=4, T=12, ne=16, na=8, A=14, ed=38, d=64, heads=4, H=64, h=64, M=32, seed=15,
                       store_grads=False, min_active=3, death_p=0.02),
+    # mixer_non_lin = tanh (flex_qmix.py:66-67,107) with softmax and with abs mixing weights
+    "refil_tanh": dict(imagine=True, B=3, T=5, ne=6, na=3, A=5, ed=9, d=16, heads=4, H=64, h=16, M=32, seed=19,
+                       mixer_non_lin="tanh"),
+    "refil_tanh_abs": dict(imagine=True, B=3, T=4, ne=8, na=4, A=6, ed=11, d=16, heads=4, H=64, h=32, M=32, seed=20,
+                           mixer_non_lin="tanh", softmax_mixing_weights=False, death_p=0.2),
+    # the north-star widths (cfg-T entity sizes, d = h = 128, 4 heads) on a batch with 2048 entity rows, so that the
+    # HIP path takes its production kernel routes (weight-resident GEMM, streaming dW, MFMA attention <2,1,2>);
+    # grads as per-tensor norms + post-step parameter sums only (the weights alone are 3.5 MB)
+    "refil_d128": dict(imagine=True, B=4, T=15, ne=32, na=16, A=22, ed=62, d=128, heads=4, H=64, h=128, M=32, seed=21,
+                       store_grads=False, min_active=3, death_p=0.02),
+}
+
+# consecutive train() calls: non-zero RMSprop state, weight decay, target sync after calls 2 and 4 (episode_num 2, 4),
+# checkpoint contents before the last call
+TRAJ_CASES = {
+    "refil_traj5": dict(imagine=True, B=3, T=5, ne=6, na=3, A=5, ed=9, d=16, heads=4, H=64, h=16, M=32, seed=41,
+                        n_steps=5, checkpoint_after=4, weight_decay=1e-4, target_update_interval=2),
 }
 
 if __name__ == "__main__":
     out = os.path.join(REPO, "tests", "golden")
-    only = sys.argv[1:] or (list(CASES) + list(GM_CASES))
+    only = sys.argv[1:] or (list(CASES) + list(GM_CASES) + list(TRAJ_CASES))
     for nm in only:
         if nm in GM_CASES:
             run_gm_case(nm, GM_CASES[nm], out)
+        elif nm in TRAJ_CASES:
+            run_traj_case(nm, TRAJ_CASES[nm], out)
         else:
             run_case(nm, CASES[nm], out)
