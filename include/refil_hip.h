@@ -221,6 +221,15 @@ typedef struct refil_gemm_desc {
     /* optional second bias scaled per row (plain x W^T products only): C[r][:] += rowscale[r % rowscale_mod] * bias2[:]
      * (per-batch stride of bias2 = sBias). Used for bias terms that apply to a subset / a multiplicity of the rows. */
     const float* bias2; const float* rowscale; int32_t rowscale_mod;
+    /* optional ROW LIST (device memory): the product runs over the logical rows r in [0, *row_count) and row r lives at
+     * memory row row_index[r] (a_map / b_map / c_map are applied on top). For x W^T and dY W products the list addresses
+     * the rows of A and C (and aux) and M is only the upper bound of *row_count; for dY^T X (A_OUTC|B_OUTC) it addresses
+     * the reduction rows of A and B and K is the upper bound. The count never visits the host, so rows that cannot
+     * influence a training step (padded entities, steps after an episode's end) are skipped without a synchronisation.
+     * The list must be padded up to a multiple of 32 entries with the index of a scratch row that may be read (finite
+     * values) and overwritten. Supported by the weight-resident (bound M >= 256, N % 32 == 0, K <= 128, or <= 256 with
+     * RELU_BWD; no rowmask / bias2) and the streaming-dW kernels (splits >= 2); other shapes return an error. */
+    const int32_t* row_index; const int32_t* row_count;
 } refil_gemm_desc;
 
 int refil_gemm(const refil_gemm_desc* desc, void* stream);
@@ -263,6 +272,11 @@ typedef struct refil_attn_desc {
     const uint8_t* ent_mask0;                         /* [B,ne] entity_mask at t=0                 */
     const uint8_t* group_bits;                        /* [B,ne]                                    */
     const uint8_t* gt_mask;  int64_t gt_sB, gt_sT;    /* [B,T1,na,ne], for the *_GT* variants      */
+    /* optional row skipping (all NULL: every row is processed). t_last[b]: rows of episode b with t > t_last[b] are
+     * left untouched (forward and backward). kv_dead [R*ne] / q_dead [R*na]: rows of K,V / Q (and dO) whose producer
+     * skipped them; they are read as zeros whatever the buffers hold (a dead key must be masked in every variant, a dead
+     * query's output must be discarded by the caller). */
+    const int32_t* t_last; const uint8_t* kv_dead; const uint8_t* q_dead;
 } refil_attn_desc;
 
 int refil_attn_forward(const refil_attn_desc* desc, void* stream);
@@ -290,6 +304,9 @@ typedef struct refil_gru_desc {
     const float* dhs;        /* [(gb*T1+t)*na+i, H] external gradient on h_t (from fc3)           */
     float* dgi; float* dgh;  /* [(gb*T1+t)*na+i, 3H] outputs                                      */
     int32_t NR, T1, na, H;
+    /* optional: t_last[b] for b = gb % B -- the recurrence of episode b stops after step t_last[b] (forward: later
+     * hsx / save slots are left untouched; backward: starts there and writes zeros to dgi / dgh of the later steps). */
+    const int32_t* t_last; int32_t B;
 } refil_gru_desc;
 
 int refil_gru_forward(const refil_gru_desc* desc, void* stream);

@@ -71,6 +71,7 @@ class GemmDesc(C.Structure):
         ("a_map", RowMap), ("b_map", RowMap), ("c_map", RowMap),
         ("rowmask_mod", C.c_int32), ("batch", C.c_int32), ("splits", C.c_int32), ("flags", C.c_int32),
         ("bias2", C.c_void_p), ("rowscale", C.c_void_p), ("rowscale_mod", C.c_int32),
+        ("row_index", C.c_void_p), ("row_count", C.c_void_p),
     ]
 
 
@@ -85,6 +86,7 @@ class AttnDesc(C.Structure):
         ("obs_mask", C.c_void_p), ("om_sB", C.c_int64), ("om_sT", C.c_int64),
         ("ent_mask", C.c_void_p), ("ent_mask0", C.c_void_p), ("group_bits", C.c_void_p),
         ("gt_mask", C.c_void_p), ("gt_sB", C.c_int64), ("gt_sT", C.c_int64),
+        ("t_last", C.c_void_p), ("kv_dead", C.c_void_p), ("q_dead", C.c_void_p),
     ]
 
 
@@ -94,6 +96,7 @@ class GruDesc(C.Structure):
         ("save_r", C.c_void_p), ("save_z", C.c_void_p), ("save_n", C.c_void_p), ("save_ghn", C.c_void_p),
         ("dhs", C.c_void_p), ("dgi", C.c_void_p), ("dgh", C.c_void_p),
         ("NR", C.c_int32), ("T1", C.c_int32), ("na", C.c_int32), ("H", C.c_int32),
+        ("t_last", C.c_void_p), ("B", C.c_int32),
     ]
 
 

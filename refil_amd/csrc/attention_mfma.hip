@@ -41,9 +41,14 @@ struct AttnM {
     float* nact;       // forward: nact[r] = number of active agents of row r (weight of the bias terms downstream) or NULL
     int bcast_do;      // backward: dO is one row per r ([R, w]) shared by all agents of the row
     int zero_dead;     // forward: write zeros for inactive agents (the layer's post_mask, attention.py:66-67, applied early)
+    // row skipping (refil_attn_desc: t_last / kv_dead / q_dead)
+    const int* t_last; const uint8_t* kv_dead; const uint8_t* q_dead;
 };
 
-struct MaskLds { const uint8_t *emt, *em0, *gb, *om, *gt; };
+struct MaskLds { const uint8_t *emt, *em0, *gb, *om, *gt, *kd, *qd; };
+
+// bytes of the LDS mask region filled by load_masks: emt, em0, gb, kd, qd (ne each), om, gt (na * ne each)
+static inline size_t mask_region_bytes(int ne, int na) { return (5 * (size_t)ne + 2 * (size_t)na * ne + 15) & ~(size_t)15; }
 
 __device__ inline bool premask_m(int code, const MaskLds& s, int ne, int i, int j) {
     const bool in0 = s.em0[i] | s.em0[j];
@@ -86,12 +91,15 @@ template <int ROWS_PAD, int C4MAX>
 struct Stage {
     static constexpr int N = ROWS_PAD * C4MAX / 64;
     float4 v[N];
-    __device__ inline void load(const float* src, long row0, int rows, int ld, int col0, int hd, int lane) {
+    // dead (LDS, may be NULL): dead[r] != 0 -> row r was not computed by its producer (it cannot influence the result):
+    // it enters as zeros, whatever the buffer holds
+    __device__ inline void load(const float* src, long row0, int rows, int ld, int col0, int hd, int lane, const uint8_t* dead = nullptr) {
         const int c4n = hd >> 2;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int idx = lane + 64 * i, r = idx / C4MAX, c4 = idx % C4MAX;
-            const bool ok = r < rows && c4 < c4n;
+            bool ok = r < rows && c4 < c4n;
+            if (dead) ok = ok && dead[ok ? r : 0] == 0;
             const float* p = src + (row0 + (ok ? r : 0)) * (long)ld + col0 + (ok ? c4 : 0) * 4;
             const float4 t = *reinterpret_cast<const float4*>(p);
             v[i] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -220,13 +228,16 @@ __device__ inline void softmax_N(f32x4 (&sn)[NJT], const unsigned long long (&w)
 }
 
 __device__ inline void load_masks(const AttnM& p, uint8_t* base, MaskLds& m, int r, int tid, int nthreads, bool need_obs) {
-    uint8_t* emt = base; uint8_t* em0 = base + p.ne; uint8_t* gb = base + 2 * p.ne; uint8_t* om = base + 3 * p.ne;
+    uint8_t* emt = base; uint8_t* em0 = base + p.ne; uint8_t* gb = base + 2 * p.ne; uint8_t* kd = base + 3 * p.ne;
+    uint8_t* qd = base + 4 * p.ne; uint8_t* om = base + 5 * p.ne;
     uint8_t* gt = om + p.na * p.ne;
     const int b = r / p.T1, t = r % p.T1;
     for (int j = tid; j < p.ne; j += nthreads) {
         emt[j] = p.ent_mask ? p.ent_mask[(long)r * p.ne + j] : 0;
         em0[j] = p.ent_mask0 ? p.ent_mask0[(long)b * p.ne + j] : 0;
         gb[j] = p.group_bits ? p.group_bits[(long)b * p.ne + j] : 0;
+        kd[j] = p.kv_dead ? p.kv_dead[(long)r * p.ne + j] : 0;
+        if (j < p.na) qd[j] = p.q_dead ? p.q_dead[(long)r * p.na + j] : 0;
     }
     if (need_obs) {
         const uint8_t* src = p.obs_mask + b * p.om_sB + t * p.om_sT;
@@ -237,7 +248,11 @@ __device__ inline void load_masks(const AttnM& p, uint8_t* base, MaskLds& m, int
         for (int idx = tid; idx < p.na * p.ne; idx += nthreads) gt[idx] = src[idx];
     }
     m.emt = emt; m.em0 = em0; m.gb = gb; m.om = om; m.gt = gt;
+    m.kd = p.kv_dead ? kd : nullptr; m.qd = p.q_dead ? qd : nullptr;
 }
+
+// steps after an episode's last contributing step (refil_attn_desc.t_last) are skipped: their outputs stay untouched
+__device__ inline bool row_skipped(const AttnM& p, int r) { return p.t_last && (r % p.T1) > p.t_last[r / p.T1]; }
 
 __device__ inline bool uses_obs_m(const AttnM& p) {
     bool u = false;
@@ -253,6 +268,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
     const int r = blockIdx.x;
+    if (row_skipped(p, r)) return;
     const int pd = p.hd + 2;
     MaskLds m;
     load_masks(p, reinterpret_cast<uint8_t*>(smem + 4 * p.wave_floats), m, r, tid, 256, uses_obs_m(p));
@@ -273,9 +289,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
         {
             Stage<NAT * 16, 4 * NCT> sq;
             Stage<NJT * 16, 4 * NCT> sk, sv;
-            sq.load(p.Q, (long)r * p.na, p.na, p.ldq, head * p.hd, p.hd, lane);
-            sk.load(p.K, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane);
-            sv.load(p.V, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane);
+            sq.load(p.Q, (long)r * p.na, p.na, p.ldq, head * p.hd, p.hd, lane, m.qd);
+            sk.load(p.K, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane, m.kd);
+            sv.load(p.V, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane, m.kd);
             sq.store(Qs, p.hd, pd, lane); sk.store(Ks, p.hd, pd, lane); sv.store(Vs, p.hd, pd, lane);
         }
         f32x4 osum[NCT];
@@ -332,6 +348,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
     const int r = blockIdx.x;
+    if (row_skipped(p, r)) return;
     const int pd = p.hd + 2;
     MaskLds m;
     load_masks(p, reinterpret_cast<uint8_t*>(smem + 4 * p.wave_floats), m, r, tid, 256, uses_obs_m(p));
@@ -350,9 +367,9 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
         {
             Stage<NAT * 16, 4 * NCT> sq;
             Stage<NJT * 16, 4 * NCT> sk, sv;
-            sq.load(p.Q, (long)r * p.na, p.na, p.ldq, head * p.hd, p.hd, lane);
-            sk.load(p.K, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane);
-            sv.load(p.V, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane);
+            sq.load(p.Q, (long)r * p.na, p.na, p.ldq, head * p.hd, p.hd, lane, m.qd);
+            sk.load(p.K, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane, m.kd);
+            sv.load(p.V, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane, m.kd);
             sq.store(Qs, p.hd, pd, lane); sk.store(Ks, p.hd, pd, lane); sv.store(Vs, p.hd, pd, lane);
         }
         f32x4 dKt[NCT][NJT], dVt[NCT][NJT];     // [c 16ct+4q+reg][key 16jt+l15]
@@ -376,7 +393,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
             const float* dO0 = p.bcast_do ? p.dO + (long)r * p.ldo : p.dO;
             const long drow0 = p.bcast_do ? 0 : (long)r * p.na + 16 * at;
             const int dld = p.bcast_do ? 0 : p.ldo;
-            sd.load(dO0, drow0, na_t, dld, head * p.hd, p.hd, lane);
+            const uint8_t* ddead = (m.qd && !p.bcast_do) ? m.qd + 16 * at : nullptr;
+            sd.load(dO0, drow0, na_t, dld, head * p.hd, p.hd, lane, ddead);
             f32x4 sn0[NJT];
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt) sn0[jt] = dot_tile(Qs, 16 * at, Ks, 16 * jt, p.hd, pd, l15, q);   // S[agent][key]
@@ -385,7 +403,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
             for (int ct = 0; ct < NCT; ++ct) dQt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int v = 0; v < p.nvar; ++v) {
                 sd.store(Ds, p.hd, pd, lane);
-                if (v + 1 < p.nvar) sd.load(dO0 + (v + 1) * p.sO, drow0, na_t, dld, head * p.hd, p.hd, lane);
+                if (v + 1 < p.nvar) sd.load(dO0 + (v + 1) * p.sO, drow0, na_t, dld, head * p.hd, p.hd, lane, ddead);
                 f32x4 pn[NJT];
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt)
@@ -571,7 +589,7 @@ int pool_launch(const refil_attn_desc& d, int mode, bool bwd, hipStream_t st) {
     a.obs_mask = d.obs_mask; a.om_sB = d.om_sB; a.om_sT = d.om_sT;
     a.ent_mask = d.ent_mask; a.ent_mask0 = d.ent_mask0; a.group_bits = d.group_bits;
     a.gt_mask = d.gt_mask; a.gt_sB = d.gt_sB; a.gt_sT = d.gt_sT;
-    a.mask_floats = (int)(((3 * (size_t)d.ne + 2 * (size_t)d.na * d.ne + 15) & ~(size_t)15) / 4);
+    a.mask_floats = (int)(mask_region_bytes(d.ne, d.na) / 4);
     k.mode = mode; k.w = w; k.na_pad = d.na;
     const size_t smem = ((size_t)(bwd ? 2 : 1) * d.ne * w + a.mask_floats) * sizeof(float) + (size_t)3 * d.na * 8 + 16;
     REFIL_CHECK(smem <= 160 * 1024, "refil_pool: row tile does not fit LDS");
@@ -624,13 +642,14 @@ int attn_mfma_launch_ex(const refil_attn_desc& d, bool bwd, hipStream_t st, int 
     k.ent_mask = d.ent_mask; k.ent_mask0 = d.ent_mask0; k.group_bits = d.group_bits;
     k.gt_mask = d.gt_mask; k.gt_sB = d.gt_sB; k.gt_sT = d.gt_sT;
     k.sum_agents = sum_agents; k.nact = nact; k.bcast_do = bcast_do; k.zero_dead = zero_dead;
+    k.t_last = d.t_last; k.kv_dead = d.kv_dead; k.q_dead = d.q_dead;
     REFIL_CHECK(!zero_dead || d.ent_mask, "refil_attn: zeroing inactive agents needs ent_mask");
     REFIL_CHECK(!sum_agents || (!bwd && d.nvar == 1), "refil_attn: the agent-sum output is a forward, single-variant option");
     const int pd = d.hd + 2;
     // +16 floats of slack: fragment reads of a partial channel tile (hd < 16*nct) run past the last row
     k.wave_floats = ((nat * 16 + 2 * njt * 16 + (bwd ? 16 : 0)) * pd + 16 + 3) & ~3;
     if (bwd) k.wave_floats += 16 * (njt * 16 + 4);     // dS transposition tile at the end of the wave region
-    k.mask_floats = (int)(((3 * (size_t)d.ne + 2 * (size_t)d.na * d.ne + 15) & ~(size_t)15) / 4);
+    k.mask_floats = (int)(mask_region_bytes(d.ne, d.na) / 4);
     const size_t smem = (size_t)4 * k.wave_floats * 4 + (size_t)k.mask_floats * 4 + (size_t)3 * nat * 16 * 8;
     if (smem > 160 * 1024) return -1;
     const double unit = (double)d.R * d.heads * d.na * d.ne * d.hd;

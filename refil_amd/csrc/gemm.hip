@@ -418,6 +418,11 @@ static int launch_cfg_dw(const GemmK& k, hipStream_t st) {
     return 0;
 }
 
+static bool dw_stream_on() {
+    static const bool on = []() { const char* e = getenv("REFIL_GEMM_DWSTREAM"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
@@ -445,6 +450,9 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
     }
     static const bool wres = []() { const char* e = getenv("REFIL_GEMM_WRES"); return !(e && e[0] == '0'); }();
     if (wres && gemm_wres_eligible(d)) return gemm_wres_launch(d, st);
+    REFIL_CHECK(!d.row_index || (dw_stream_on() && gemm_dw_stream_eligible(d)),
+                "refil_gemm: row lists need the weight-resident or the streaming-dW kernel (M=%d N=%d K=%d flags=0x%x splits=%d)",
+                d.M, d.N, d.K, d.flags, d.splits);
     GemmK k;
     k.A = d.A; k.B = d.B; k.C = d.C; k.bias = d.bias; k.aux = d.aux; k.rowmask = d.rowmask;
     k.colsum = d.colsum; k.partial = d.partial;
@@ -468,7 +476,7 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
     // shapes +20 %, K=84 shapes -10 %)
     static const long big_min_blocks = []() { const char* e = getenv("REFIL_GEMM_BIG_MINBLK"); return e ? atol(e) : 200L; }();   // fewer big tiles than this leave CUs idle: use 128x128
     const long big_blocks = (long)cdiv(d.M, 256) * cdiv(d.N, 128) * d.batch * d.splits;
-    static const bool dw_stream = []() { const char* e = getenv("REFIL_GEMM_DWSTREAM"); return !(e && e[0] == '0'); }();
+    const bool dw_stream = dw_stream_on();
     const bool dw = (d.flags & REFIL_GEMM_A_OUTC) && (d.flags & REFIL_GEMM_B_OUTC) && !(d.flags & (REFIL_GEMM_RELU | REFIL_GEMM_RELU_BWD));
     if (dw_stream && gemm_dw_stream_eligible(d)) rc = gemm_dw_stream_launch(d, st);
     else if (dw && d.M <= 32 && d.N > 64) rc = launch_cfg_dw<1, 4, 1, 1>(k, st);

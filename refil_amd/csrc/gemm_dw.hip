@@ -23,6 +23,7 @@ struct DwStreamK {
     long sA, sB;
     RowMap amap, bmap;
     int splits, batch, colsum;
+    const int* ridx; const int* rcount;     // IDX: reduction row r < *rcount lives at row ridx[r] of both operands (before the maps)
 };
 
 // incremental version of RowMap: physical row offset (in elements) of logical rows r, r+2, r+4, ...
@@ -46,7 +47,10 @@ struct RowWalk {
     }
 };
 
-template <int WM, int WK, int D>
+// IDX: the reduction runs over an index list (rows that cannot contribute are skipped); its length is read from device
+// memory. The indices travel through their own ring, one ring period ahead of the operand prefetch, so the extra
+// indirection never sits between a request and its use.
+template <int WM, int WK, int D, bool IDX = false>
 __global__ __launch_bounds__(64 * WM * WK) void gemm_dw_stream_kernel(DwStreamK p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lane31 = lane & 31, hf = lane >> 5;
@@ -58,8 +62,9 @@ __global__ __launch_bounds__(64 * WM * WK) void gemm_dw_stream_kernel(DwStreamK 
     const float* __restrict__ B = p.B + bz * p.sB;
 
     // rows of this split: a multiple of 2 D per split so that the pipelined loop runs whole iterations
-    const int chunk = cdiv(cdiv(p.R, p.splits), 2 * D) * 2 * D;
-    const int rbeg = sp * chunk, rend = min(p.R, rbeg + chunk);
+    const int R = IDX ? *p.rcount : p.R;
+    const int chunk = cdiv(cdiv(R, p.splits), 2 * D) * 2 * D;
+    const int rbeg = sp * chunk, rend = min(R, rbeg + chunk);
     const int nfull = rend > rbeg ? (rend - rbeg) / (2 * D) : 0;       // iterations of D steps x 2 rows
 
     int ca[2], cb[2];
@@ -77,7 +82,42 @@ __global__ __launch_bounds__(64 * WM * WK) void gemm_dw_stream_kernel(DwStreamK 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float csum[2] = {0.f, 0.f};
 
-    if (nfull > 0) {
+    if (IDX && nfull > 0) {
+        // ri[s]: list entry of the row that slot s is refilled with NEXT (position rbeg + 2 (D it + s) + hf, one
+        // period ahead); positions past the split re-read its first entry (never consumed)
+        int ri[D];
+        const int pend = rbeg + nfull * 2 * D;
+        float ra[D][2], rb[D][2];
+#pragma unroll
+        for (int s = 0; s < D; ++s) ri[s] = p.ridx[rbeg + 2 * s + hf];
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const long oa = p.amap(ri[s]) * (long)p.lda, ob = p.bmap(ri[s]) * (long)p.ldb;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { ra[s][i] = A[oa + ca[i]]; rb[s][i] = B[ob + cb[i]]; }
+            const int pos = rbeg + 2 * (D + s) + hf;
+            ri[s] = p.ridx[pos < pend ? pos : rbeg];
+        }
+        for (int it = 0; it < nfull; ++it) {
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s][i], rb[s][j], acc[i][j], 0, 0, 0);
+                csum[0] += ra[s][0]; csum[1] += ra[s][1];
+                __builtin_amdgcn_sched_barrier(0);
+                const long oa = p.amap(ri[s]) * (long)p.lda, ob = p.bmap(ri[s]) * (long)p.ldb;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { ra[s][i] = A[oa + ca[i]]; rb[s][i] = B[ob + cb[i]]; }
+                const int pos = rbeg + 2 * (D * (it + 2) + s) + hf;
+                ri[s] = p.ridx[pos < pend ? pos : rbeg];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (!IDX && nfull > 0) {
         RowWalk wa, wb;                            // rows rbeg + hf, + 2, + 4, ... (the PREFETCH position)
         wa.init(p.amap, rbeg + hf, p.lda);
         wb.init(p.bmap, rbeg + hf, p.ldb);
@@ -114,7 +154,9 @@ __global__ __launch_bounds__(64 * WM * WK) void gemm_dw_stream_kernel(DwStreamK 
     for (int r2 = rbeg + nfull * 2 * D; r2 < rend; r2 += 2) {      // uniform trip count: MFMAs ignore EXEC
         const int r = r2 + hf;
         const bool ok = r < rend;
-        const long oa = p.amap(ok ? r : rbeg) * (long)p.lda, ob = p.bmap(ok ? r : rbeg) * (long)p.ldb;
+        int rr = ok ? r : rbeg;
+        if (IDX) rr = p.ridx[rr];
+        const long oa = p.amap(rr) * (long)p.lda, ob = p.bmap(rr) * (long)p.ldb;
         float va[2], vb[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -157,6 +199,7 @@ bool gemm_dw_stream_eligible(const refil_gemm_desc& d) {
     if (!(f & REFIL_GEMM_A_OUTC) || !(f & REFIL_GEMM_B_OUTC)) return false;
     if (f & (REFIL_GEMM_RELU | REFIL_GEMM_RELU_BWD)) return false;
     if (d.splits < 2 || !d.partial) return false;
+    if (d.row_index) return d.row_count != nullptr;  // a row list is only understood by this kernel
     if (d.M < 96 || d.N < 48) return false;         // thin outputs: the narrow LDS-tiled configurations of gemm.hip
     if (d.K < 4096) return false;
     return true;
@@ -169,21 +212,28 @@ int gemm_dw_stream_launch(const refil_gemm_desc& d, hipStream_t st) {
     auto mk = [](const refil_rowmap& m) { return m.grp ? RowMap{m.grp, m.gstride, m.off} : RowMap{1 << 30, 0, 0}; };
     k.amap = mk(d.a_map); k.bmap = mk(d.b_map);
     k.splits = d.splits; k.batch = d.batch; k.colsum = (d.flags & REFIL_GEMM_COLSUM_A) ? 1 : 0;
+    k.ridx = d.row_index; k.rcount = d.row_index ? d.row_count : nullptr;
+    const bool idx = d.row_index != nullptr;
     const bool wide = d.N > 64, tall = d.M >= 256;
     // wide + tall: 8 waves cover 256 x 128 of the output so that x (the B operand) is read once per workgroup -- two
     // 128-row workgroups would land on different XCDs and each fetch its own copy from HBM
-    const char* nm = wide ? (tall ? "gemm_dw_stream_kernel<4,2,16>" : "gemm_dw_stream_kernel<2,2,16>") : "gemm_dw_stream_kernel<4,1,16>";
+    const char* nm = idx ? (wide ? (tall ? "gemm_dw_stream_kernel<4,2,16,1>" : "gemm_dw_stream_kernel<2,2,16,1>") : "gemm_dw_stream_kernel<4,1,16,1>")
+                         : (wide ? (tall ? "gemm_dw_stream_kernel<4,2,16>" : "gemm_dw_stream_kernel<2,2,16>") : "gemm_dw_stream_kernel<4,1,16>");
     ProfScope prof(nm, 2.0 * d.M * d.N * d.K * d.batch,
-                   4.0 * d.batch * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N), st);
+                   4.0 * d.batch * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N), st,
+                   idx ? d.row_count : nullptr, (double)d.K);
     if (wide && tall) {
         dim3 grid(cdiv(d.N, 128), cdiv(d.M, 256), d.batch * d.splits);
-        hipLaunchKernelGGL((gemm_dw_stream_kernel<4, 2, 16>), grid, dim3(512), 0, st, k);
+        if (idx) hipLaunchKernelGGL((gemm_dw_stream_kernel<4, 2, 16, true>), grid, dim3(512), 0, st, k);
+        else hipLaunchKernelGGL((gemm_dw_stream_kernel<4, 2, 16>), grid, dim3(512), 0, st, k);
     } else if (wide) {
         dim3 grid(cdiv(d.N, 128), cdiv(d.M, 128), d.batch * d.splits);
-        hipLaunchKernelGGL((gemm_dw_stream_kernel<2, 2, 16>), grid, dim3(256), 0, st, k);
+        if (idx) hipLaunchKernelGGL((gemm_dw_stream_kernel<2, 2, 16, true>), grid, dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((gemm_dw_stream_kernel<2, 2, 16>), grid, dim3(256), 0, st, k);
     } else {
         dim3 grid(1, cdiv(d.M, 256), d.batch * d.splits);
-        hipLaunchKernelGGL((gemm_dw_stream_kernel<4, 1, 16>), grid, dim3(256), 0, st, k);
+        if (idx) hipLaunchKernelGGL((gemm_dw_stream_kernel<4, 1, 16, true>), grid, dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((gemm_dw_stream_kernel<4, 1, 16>), grid, dim3(256), 0, st, k);
     }
     REFIL_LAUNCH_CHECK();
     return 0;

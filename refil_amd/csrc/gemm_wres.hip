@@ -38,6 +38,8 @@ struct WresK {
     RowMap amap, cmap;
     int rowmask_mod, relu, ntiles;
     const float* bias2; const float* rowscale; int rowscale_mod;   // EPI 0: + rowscale[r % mod] * bias2
+    const int* ridx; const int* rcount;     // IDX: logical row r < *rcount lives at row ridx[r] (before amap / cmap); the list is
+                                            // padded to whole 32-row tiles with the index of a scratch row
 };
 
 constexpr int WR_WAVES = 8;
@@ -55,7 +57,11 @@ constexpr int vmcnt_only(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >
 // NPASS = 2 walks a row in two halves through the same NC register chunks. BT: W is [reduction][out] in memory
 // (backward product) and is transposed while staging. EPI 0: + bias, ReLU, row mask; EPI 1: * relu'(aux) (+ C if ACC).
 // B2: the row-scaled second bias of EPI 0 (only instantiated for TN <= 2: it costs registers the 128-wide tile needs).
-template <int TN, int NC, int NPASS, bool BT, int EPI, bool ACC, bool RMASK, bool B2>
+// IDX: the rows come from an index list whose length is read from device memory (rows that cannot influence the
+// step are skipped without a host round trip). A wave fetches the 32 indices of a tile with ONE load per lane, two
+// tiles ahead of their use, and the epilogue gets its row indices from the neighbouring lanes (ds_bpermute), so the
+// list adds no dependent load to the pipeline.
+template <int TN, int NC, int NPASS, bool BT, int EPI, bool ACC, bool RMASK, bool B2, bool IDX = false>
 __global__ __launch_bounds__(64 * WR_WAVES, 2) void gemm_wres_kernel(WresK p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -69,6 +75,8 @@ __global__ __launch_bounds__(64 * WR_WAVES, 2) void gemm_wres_kernel(WresK p) {
     const float* __restrict__ AUX = EPI == 1 ? p.aux + bz * p.sC : nullptr;
     float* Ws = lds;
     float* slab = lds + 32 * TN * KP + wave * 32 * WR_SLAB_P;
+    const int ntiles = IDX ? (*p.rcount + 31) >> 5 : p.ntiles;
+    if (IDX && ntiles == 0) return;                    // (uniform: before any barrier)
 
     // ---- stage the W slice (32 TN output columns x 8 NCT reduction indices, zero padded) once; loads batched 8 deep ----
     {
@@ -127,22 +135,27 @@ __global__ __launch_bounds__(64 * WR_WAVES, 2) void gemm_wres_kernel(WresK p) {
 
     const int stride = gridDim.x * WR_WAVES;
     int tile = blockIdx.x * WR_WAVES + wave;
-    const int last = p.ntiles - 1;
+    const int last = ntiles - 1;
     // k >= K (padding of the last chunk): the matching W columns in LDS are zero, so x only has to be FINITE there.
     // No select on the loaded value (it would make the compiler wait for every prefetch at the loop head): the
     // address is clamped to the row's last 16 bytes instead and those x values are multiplied by zeros.
     const int kmax = p.K - 4 - 4 * hf;
     float4 a[NC];
-    const float* csrc = A + p.amap(min(tile, last) * 32 + lane31) * (long)p.lda + 4 * hf;
+    // IDX: list entries of this wave's current / next tile (row of lane31); the one after next is requested in the loop
+    int currow = 0, nrow = 0;
+    if (IDX) { currow = p.ridx[min(tile, last) * 32 + lane31]; nrow = p.ridx[min(tile + stride, last) * 32 + lane31]; }
+    const float* csrc = A + p.amap(IDX ? currow : min(tile, last) * 32 + lane31) * (long)p.lda + 4 * hf;
 #pragma unroll
     for (int c = 0; c < NC; ++c) a[c] = *reinterpret_cast<const float4*>(csrc + min(8 * c, kmax));
 #pragma unroll
     for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(a[c].x), "+v"(a[c].y), "+v"(a[c].z), "+v"(a[c].w));   // (see the loop tail)
 
-    while (tile < p.ntiles) {
+    while (tile < ntiles) {
         const int next = tile + stride;
+        int nnrow = 0;
+        if (IDX) nnrow = p.ridx[min(next + stride, last) * 32 + lane31];
         // (a wave's last prefetch re-reads its own last tile: always a legal address, never consumed)
-        const float* nsrc = A + p.amap(min(next, last) * 32 + lane31) * (long)p.lda + 4 * hf;
+        const float* nsrc = A + p.amap(IDX ? nrow : min(next, last) * 32 + lane31) * (long)p.lda + 4 * hf;
         // epilogue addressing and operands of THIS tile, requested before the MFMAs so that nothing in the epilogue
         // waits on memory
         const int m0 = tile * 32;
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(64 * WR_WAVES, 2) void gemm_wres_kernel(WresK p) {
         float4 ax[EPI == 1 ? TN : 1][4], cx[ACC ? TN : 1][4];
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
-            const int m = m0 + ps * 8 + rsub;
+            const int m = IDX ? __shfl(currow, ps * 8 + rsub, 64) : m0 + ps * 8 + rsub;
             coff[ps] = p.cmap(m) * (long)p.ldc + n0 + 4 * c4;
             dead[ps] = 0;
             if (RMASK) dead[ps] = p.rowmask[m % p.rowmask_mod];
@@ -243,6 +256,7 @@ __global__ __launch_bounds__(64 * WR_WAVES, 2) void gemm_wres_kernel(WresK p) {
                 *reinterpret_cast<float4*>(C + coff[ps] + 32 * j) = outv[j][ps];
         tile = next;
         csrc = nsrc;
+        if (IDX) { currow = nrow; nrow = nnrow; }
     }
 }
 
@@ -257,7 +271,10 @@ bool gemm_wres_eligible(const refil_gemm_desc& d) {
     if (d.splits != 1 || d.K < 8 || (d.K % 4) != 0) return false;
     if (d.K > (rb ? 256 : 128)) return false;
     if ((d.lda % 4) || (d.ldb % 4) || (d.sA % 4) || (d.sB % 4) || !al16(d.A) || !al16(d.B)) return false;
-    if (d.M < 2048 || (d.M % 32) != 0 || (d.N % 32) != 0) return false;    // whole 32 x 32 tiles only; tiny calls: tiled kernel
+    if (d.M < (d.row_index ? 256 : 2048) || (d.N % 32) != 0) return false;  // tiny calls: tiled kernel
+    if (d.row_index) {        // row list (padded to whole tiles by its producer): plain forward products and dX through a ReLU
+        if (!d.row_count || d.rowmask || d.bias2 || (bt && !rb)) return false;
+    } else if ((d.M % 32) != 0) return false;                              // whole 32 x 32 tiles only
     if (!al16(d.C) || (d.ldc % 4) || (d.sC % 4)) return false;
     if (d.bias && (!al16(d.bias) || (d.sBias % 4))) return false;
     if (d.bias2 && (!al16(d.bias2) || (d.sBias % 4) || (d.N % 128) == 0)) return false;     // (no B2 instantiation of the 128-wide tile)
@@ -265,17 +282,17 @@ bool gemm_wres_eligible(const refil_gemm_desc& d) {
     return true;
 }
 
-template <int TN, int NC, int NPASS, bool BT, int EPI, bool ACC, bool RMASK, bool B2 = false>
+template <int TN, int NC, int NPASS, bool BT, int EPI, bool ACC, bool RMASK, bool B2 = false, bool IDX = false>
 static int wres_launch_i(const WresK& k, dim3 grid, hipStream_t st) {
     constexpr size_t smem = ((size_t)32 * TN * (8 * NC * NPASS + 4) + (size_t)WR_WAVES * 32 * WR_SLAB_P) * sizeof(float);
     static_assert(smem <= 160 * 1024, "W slice + slabs must fit the 160 KB LDS of a CU");
     static bool raised = false;                        // raise the dynamic-LDS cap of this instantiation once
     if (smem > 64 * 1024 && !raised) {
-        REFIL_HIP(hipFuncSetAttribute((const void*)gemm_wres_kernel<TN, NC, NPASS, BT, EPI, ACC, RMASK, B2>,
+        REFIL_HIP(hipFuncSetAttribute((const void*)gemm_wres_kernel<TN, NC, NPASS, BT, EPI, ACC, RMASK, B2, IDX>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         raised = true;
     }
-    hipLaunchKernelGGL((gemm_wres_kernel<TN, NC, NPASS, BT, EPI, ACC, RMASK, B2>), grid, dim3(64 * WR_WAVES), smem, st, k);
+    hipLaunchKernelGGL((gemm_wres_kernel<TN, NC, NPASS, BT, EPI, ACC, RMASK, B2, IDX>), grid, dim3(64 * WR_WAVES), smem, st, k);
     return 0;
 }
 
@@ -286,6 +303,7 @@ static int wres_launch_fwd(const WresK& k, dim3 grid, hipStream_t st) {
     const bool rm = k.rowmask != nullptr;
 #define FWD(NC)                                                                                                     \
     do {                                                                                                            \
+        if (k.ridx) return wres_launch_i<TN, NC, 1, false, 0, false, false, false, true>(k, grid, st);              \
         if (TN <= 2 && k.bias2)                                                                                     \
             return rm ? wres_launch_i<(TN <= 2 ? TN : 1), NC, 1, false, 0, false, true, true>(k, grid, st)          \
                       : wres_launch_i<(TN <= 2 ? TN : 1), NC, 1, false, 0, false, false, true>(k, grid, st);        \
@@ -311,7 +329,12 @@ static int wres_launch_bwd(const WresK& k, dim3 grid, hipStream_t st) {
 // backward products through a ReLU: dx = (dy W) * relu'(aux) (+ dx), reduction <= 256, TN = 2
 static int wres_launch_rbwd(const WresK& k, bool acc, dim3 grid, hipStream_t st) {
     const int nc = cdiv(k.K, 8);
-#define RB(NC, NP) return acc ? wres_launch_i<2, NC, NP, true, 1, true, false>(k, grid, st) : wres_launch_i<2, NC, NP, true, 1, false, false>(k, grid, st)
+#define RB(NC, NP)                                                                                                  \
+    do {                                                                                                            \
+        if (k.ridx) return acc ? wres_launch_i<2, NC, NP, true, 1, true, false, false, true>(k, grid, st)           \
+                               : wres_launch_i<2, NC, NP, true, 1, false, false, false, true>(k, grid, st);         \
+        return acc ? wres_launch_i<2, NC, NP, true, 1, true, false>(k, grid, st) : wres_launch_i<2, NC, NP, true, 1, false, false>(k, grid, st); \
+    } while (0)
     if (nc <= 8) RB(8, 1);
     if (nc <= 16) RB(16, 1);
     if (nc <= 24) RB(12, 2);
@@ -329,6 +352,7 @@ int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st) {
     k.rowmask_mod = d.rowmask_mod; k.relu = (d.flags & REFIL_GEMM_RELU) ? 1 : 0;
     k.bias2 = d.bias2; k.rowscale = d.rowscale; k.rowscale_mod = d.rowscale_mod > 0 ? d.rowscale_mod : 1;
     k.ntiles = d.M / 32;
+    k.ridx = d.row_index; k.rcount = d.row_index ? d.row_count : nullptr;
     const bool bt = d.flags & REFIL_GEMM_B_OUTC, rb = d.flags & REFIL_GEMM_RELU_BWD;
     int tn = (d.N % 128 == 0) ? 4 : ((d.N % 64 == 0) ? 2 : 1);
     if (rb) tn = 2;                                   // relu'(aux) (+ C) operands of a tile live in registers too
@@ -338,7 +362,7 @@ int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = 256; }
         return n;
     }();
-    int gx = min(cdiv(k.ntiles, WR_WAVES), max(1, n_cu / (gy * gz)));
+    int gx = min(cdiv(cdiv(d.M, 32), WR_WAVES), max(1, n_cu / (gy * gz)));
     // XCD-aware: workgroups are dealt round-robin to the 8 XCDs by linear id = x + gx (y + gy z). With gx a multiple
     // of 8 the column blocks y = 0, 1, .. that re-read the SAME rows of x (N > 128) land on the same XCD, so the
     // second read is an L2 hit instead of a second trip to HBM.
@@ -353,15 +377,16 @@ int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st) {
     static thread_local char names[64][64];
     static thread_local int n_names = 0;
     char nm[64];
-    snprintf(nm, sizeof(nm), "gemm_wres_kernel<%d,%d,%d,%d,%d,%d,%d,%d>", tn, ncp, npass, bt ? 1 : 0, rb ? 1 : 0,
-             (d.flags & REFIL_GEMM_ACCUM) ? 1 : 0, d.rowmask ? 1 : 0, d.bias2 ? 1 : 0);
+    snprintf(nm, sizeof(nm), d.row_index ? "gemm_wres_kernel<%d,%d,%d,%d,%d,%d,%d,%d,1>" : "gemm_wres_kernel<%d,%d,%d,%d,%d,%d,%d,%d>",
+             tn, ncp, npass, bt ? 1 : 0, rb ? 1 : 0, (d.flags & REFIL_GEMM_ACCUM) ? 1 : 0, d.rowmask ? 1 : 0, d.bias2 ? 1 : 0);
     const char* pname = nullptr;
     for (int i = 0; i < n_names; ++i)
         if (!strcmp(names[i], nm)) pname = names[i];
     if (!pname && n_names < 64) { strcpy(names[n_names], nm); pname = names[n_names++]; }
     if (!pname) pname = "gemm_wres_kernel";
     ProfScope prof(pname, 2.0 * d.M * d.N * d.K * d.batch,
-                   4.0 * d.batch * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N * (rb ? ((d.flags & REFIL_GEMM_ACCUM) ? 3.0 : 2.0) : 1.0)), st);
+                   4.0 * d.batch * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N * (rb ? ((d.flags & REFIL_GEMM_ACCUM) ? 3.0 : 2.0) : 1.0)), st,
+                   d.row_index ? d.row_count : nullptr, (double)d.M);
     int rc;
     if (rb) rc = wres_launch_rbwd(k, (d.flags & REFIL_GEMM_ACCUM) != 0, grid, st);
     else if (bt) rc = tn == 4 ? wres_launch_bwd<4>(k, grid, st) : (tn == 2 ? wres_launch_bwd<2>(k, grid, st) : wres_launch_bwd<1>(k, grid, st));

@@ -35,15 +35,32 @@ struct GruK {
     float* save_r; float* save_z; float* save_n; float* save_ghn;
     const float* dhs; float* dgi; float* dgh;
     int NR, T1, na;
+    const int* t_last; int B;     // optional: episode b = gb % B only needs steps t <= t_last[b]
 };
+// two independent recurrences (the live and the target agent's) in ONE launch: the first nblk0 workgroups run `a`,
+// the others `b` -- the two 100 us latency chains overlap instead of queueing behind each other
+struct GruK2 { GruK a, b; int nblk0; };
+
+// number of steps the rows [r0, r0 + GROWS) need: 1 + max over their episodes of t_last (all T1 without a bound)
+__device__ inline int tile_steps(const GruK& p, int r0) {
+    if (!p.t_last) return p.T1;
+    int tend = 0;
+    const int rl = min(r0 + GROWS, p.NR) - 1;
+    for (int gb = r0 / p.na; gb <= rl / p.na; ++gb) tend = max(tend, p.t_last[gb % p.B] + 1);
+    return min(tend, p.T1);
+}
 
 template <bool SAVE>
-__global__ __launch_bounds__(256) void gru_fwd_kernel(GruK p) {
+__global__ __launch_bounds__(256) void gru_fwd_kernel(GruK2 p2) {
     __shared__ __attribute__((aligned(16))) float hbuf[2][GROWS * HP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, c16 = lane & 15;
     const int c = wave * 16 + c16;           // hidden column owned by this lane
-    const int r0 = blockIdx.x * GROWS;
+    const bool second = (int)blockIdx.x >= p2.nblk0;
+    const GruK& p = second ? p2.b : p2.a;
+    const int r0 = (second ? blockIdx.x - p2.nblk0 : blockIdx.x) * GROWS;
+    const int tend = tile_steps(p, r0);
+    const bool save = SAVE && p.save_r != nullptr;
 
     // W_hh fragments: bw[g][s] = W_hh[g*64 + c][16q + s]. (The MFMA k order is a free permutation as long as both
     // operands agree: giving lane group q the CONTIGUOUS k range [16q, 16q+16) turns the 16 scalar LDS reads of the
@@ -76,10 +93,10 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruK p) {
             gcur[reg][g] = valid[reg] ? p.gi[gi_base[reg] * (3 * GH) + g * GH + c] : 0.f;
     __syncthreads();
 
-    for (int t = 0; t < p.T1; ++t) {
+    for (int t = 0; t < tend; ++t) {
         const float* hb = hbuf[t & 1];
         float* hn = hbuf[(t + 1) & 1];
-        if (t + 1 < p.T1) {
+        if (t + 1 < tend) {
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
@@ -124,7 +141,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruK p) {
         for (int reg = 0; reg < 4; ++reg) {
             if (valid[reg]) {
                 p.hsx[(hs_base[reg] + (long)(t + 1) * p.na) * GH + c] = hold[reg];
-                if (SAVE) {
+                if (save) {
                     const long o = (gi_base[reg] + (long)t * p.na) * GH + c;
                     p.save_r[o] = rgv[reg]; p.save_z[o] = zgv[reg]; p.save_n[o] = ngv[reg]; p.save_ghn[o] = ghv[reg];
                 }
@@ -145,6 +162,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruK p) {
     const int q = lane >> 4, c16 = lane & 15;
     const int c = wave * 16 + c16;
     const int r0 = blockIdx.x * GROWS;
+    const int tend = tile_steps(p, r0);
 
     // W_hh^T fragments: carry[row][c] += sum_k dgh[row][k] W_hh[k][c];  bw[s] = W_hh[48q+s][c]  (contiguous k range per lane group, see the forward kernel)
     float bw[48];
@@ -182,9 +200,22 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruK p) {
             }
         }
     };
-    fetch(cur, p.T1 - 1);
+    // steps the episode's loss cannot reach (t >= tend): exact zeros, what the full recurrence would have produced
+    for (int t = tend + (tid >> 6); t < p.T1; t += 4) {
+        for (int idx = lane; idx < GROWS * (3 * GH / 4); idx += 64) {
+            const int row = idx / (3 * GH / 4), c4 = idx % (3 * GH / 4);
+            const int rr = r0 + row;
+            if (rr < p.NR) {
+                const long o = (((long)(rr / p.na) * p.T1 + t) * p.na + rr % p.na) * (3 * GH) + 4 * c4;
+                *reinterpret_cast<float4*>(p.dgi + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(p.dgh + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    if (tend <= 0) return;
+    fetch(cur, tend - 1);
     int it = 0;
-    for (int t = p.T1 - 1; t >= 0; --t, ++it) {
+    for (int t = tend - 1; t >= 0; --t, ++it) {
         float* gb_w = gbuf[it & 1];
         if (t > 0) fetch(nxt, t - 1);
         float dhz[4], sv[4][4];
@@ -245,28 +276,44 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruK p) {
     }
 }
 
-int gru_forward_launch(const refil_gru_desc& d, hipStream_t st) {
+static int gru_check_fwd(const refil_gru_desc& d) {
     REFIL_CHECK(d.H == GH, "refil_gru: rnn_hidden_dim must be %d (got %d)", GH, d.H);
     REFIL_CHECK(d.gi && d.hsx && d.w_hh && d.b_hh, "refil_gru_forward: null pointer");
     REFIL_CHECK(d.NR > 0 && d.T1 > 0 && d.na > 0, "refil_gru_forward: bad sizes");
-    GruK k{d.gi, d.hsx, d.w_hh, d.b_hh, d.save_r, d.save_z, d.save_n, d.save_ghn, d.dhs, d.dgi, d.dgh, d.NR, d.T1, d.na};
-    const bool save = d.save_r != nullptr;
-    REFIL_CHECK(!save || (d.save_z && d.save_n && d.save_ghn), "refil_gru_forward: all four save buffers or none");
-    dim3 grid(cdiv(d.NR, GROWS));
-    ProfScope prof(save ? "gru_fwd_kernel<true>" : "gru_fwd_kernel<false>", 2.0 * d.NR * d.T1 * GH * 3 * GH,
-                   4.0 * d.NR * d.T1 * GH * (save ? 8.0 : 4.0), st);
+    REFIL_CHECK(!d.save_r || (d.save_z && d.save_n && d.save_ghn), "refil_gru_forward: all four save buffers or none");
+    REFIL_CHECK(!d.t_last || d.B > 0, "refil_gru: t_last needs B");
+    return 0;
+}
+static GruK gru_k(const refil_gru_desc& d) {
+    return GruK{d.gi, d.hsx, d.w_hh, d.b_hh, d.save_r, d.save_z, d.save_n, d.save_ghn, d.dhs, d.dgi, d.dgh, d.NR, d.T1, d.na, d.t_last, d.B};
+}
+
+// `second` (may be NULL): another, independent recurrence run by the same launch
+int gru_forward_launch2(const refil_gru_desc& d, const refil_gru_desc* second, hipStream_t st) {
+    if (int e = gru_check_fwd(d)) return e;
+    if (second) if (int e = gru_check_fwd(*second)) return e;
+    GruK2 k;
+    k.a = gru_k(d); k.b = second ? gru_k(*second) : k.a;
+    k.nblk0 = cdiv(d.NR, GROWS);
+    const bool save = d.save_r != nullptr || (second && second->save_r != nullptr);
+    const long rows_t = (long)d.NR * d.T1 + (second ? (long)second->NR * second->T1 : 0);
+    dim3 grid(k.nblk0 + (second ? cdiv(second->NR, GROWS) : 0));
+    ProfScope prof(save ? "gru_fwd_kernel<true>" : "gru_fwd_kernel<false>", 2.0 * rows_t * GH * 3 * GH,
+                   4.0 * rows_t * GH * (save ? 8.0 : 4.0), st);
     if (save) hipLaunchKernelGGL(gru_fwd_kernel<true>, grid, dim3(256), 0, st, k);
     else hipLaunchKernelGGL(gru_fwd_kernel<false>, grid, dim3(256), 0, st, k);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
+int gru_forward_launch(const refil_gru_desc& d, hipStream_t st) { return gru_forward_launch2(d, nullptr, st); }
 
 int gru_backward_launch(const refil_gru_desc& d, hipStream_t st) {
     REFIL_CHECK(d.H == GH, "refil_gru: rnn_hidden_dim must be %d (got %d)", GH, d.H);
     REFIL_CHECK(d.hsx && d.w_hh && d.save_r && d.save_z && d.save_n && d.save_ghn && d.dhs && d.dgi && d.dgh,
                 "refil_gru_backward: null pointer");
     REFIL_CHECK(d.NR > 0 && d.T1 > 0 && d.na > 0, "refil_gru_backward: bad sizes");
-    GruK k{d.gi, d.hsx, d.w_hh, d.b_hh, d.save_r, d.save_z, d.save_n, d.save_ghn, d.dhs, d.dgi, d.dgh, d.NR, d.T1, d.na};
+    REFIL_CHECK(!d.t_last || d.B > 0, "refil_gru: t_last needs B");
+    GruK k = gru_k(d);
     ProfScope prof("gru_bwd_kernel", 2.0 * d.NR * d.T1 * GH * 3 * GH, 4.0 * d.NR * d.T1 * GH * 12.0, st);
     hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv(d.NR, GROWS)), dim3(256), 0, st, k);
     REFIL_LAUNCH_CHECK();

@@ -26,6 +26,7 @@ int attn_forward_launch(const refil_attn_desc& d, hipStream_t st);
 int attn_backward_launch(const refil_attn_desc& d, hipStream_t st);
 int pool_launch(const refil_attn_desc& d, int mode, bool bwd, hipStream_t st);
 int gru_forward_launch(const refil_gru_desc& d, hipStream_t st);
+int gru_forward_launch2(const refil_gru_desc& d, const refil_gru_desc* second, hipStream_t st);   // two recurrences, one launch
 int gru_backward_launch(const refil_gru_desc& d, hipStream_t st);
 
 // entities || one-hot(prev action) -> xe [R*ne, Ep]; contiguous copies of the masks
@@ -36,6 +37,34 @@ struct PrepArgs {
     float* actf;   // [R*na] 1.0 for active agents, 0.0 for inactive ones (row weights of bias terms)
 };
 int prep_launch(const PrepArgs& a, hipStream_t st);
+
+// Row lists of a learner step: which (b, t, entity) rows can influence the loss. Everything is decided on the device
+// (no host round trip); consumers read the counts from device memory.
+//   t_last[b]   last step of episode b any loss term depends on: 1 + the last t < T with
+//               mask[b,t] = filled[b,t] * (1 - terminated[b,t-1]) != 0 (q_learner.py:68-72); steps t > t_last[b] are dead
+//               for the live AND the target nets (double-Q reads the live net at t+1, q_learner.py:121-126). -1: none.
+//   agent nets  entity (b,t,j) is needed as a key iff some agent row can attend to it under the least restrictive
+//               pre-mask (obs_mask[b,t,i,j] == 0 for some i; every imagined variant ORs more onto it,
+//               entity_rnn_agent.py:116-117), or it is an active agent itself (its own query row)
+//   hypernets   needed iff not (entity_mask[b,t,j] and entity_mask[b,0,j]): the plain mixer masks by the step's entity
+//               mask (flex_qmix.py:43-46), the imagined masks by the first step's (entity_rnn_agent.py:99-114)
+//   agents      query rows of active agents (entity_mask[b,t,i] == 0); inactive agents' outputs are zeroed by the
+//               post-mask (attention.py:66-67) and receive no gradient
+// Lists are in (b,t,entity) order (deterministic reductions) and padded to a multiple of 64 entries with `trash`
+// indices (one row past the logical buffer: readable, overwritable scratch).
+struct ListArgs {
+    refil_batch b;
+    int B, T1, ne, na, learner;            // learner = 0: no filled/terminated (every step is live)
+    int use_gt_obs;                        // dims.gt_obs_mask: the agent nets' pre-mask is gt_mask
+    const uint8_t* emc; const uint8_t* em0;   // contiguous entity masks written by prep (this step / step 0)
+    int* t_last;                           // [B]
+    uint8_t* kdead_a; uint8_t* kdead_h;    // [R*ne] 1 = K/V row of the agent nets / hypernets is not computed
+    int* cnt;                              // [3][R] per-row counts (scratch), lists: 0 agent-net entities, 1 hypernet entities, 2 agents
+    int* off;                              // [3][R+1] exclusive scans (scratch)
+    int* list_ea; int* list_eh; int* list_a;   // [NE+64], [NE+64], [NA+64]
+    int* counts;                           // [4]: the three list lengths, live (b,t) rows
+};
+int lists_launch(const ListArgs& a, hipStream_t st);
 
 // hsx slot 0 <- h0 (or zeros)
 int set_h0_launch(float* hsx, const float* h0, int GB, int T1, int na, int H, hipStream_t st);
@@ -88,6 +117,7 @@ struct TdArgs {
     const uint8_t* terminated; long tm_sB, tm_sT;
     const int64_t* filled; long fl_sB, fl_sT;
     float* gc_real; float* gc_im; float* targets; float* stats;
+    const int* t_last;                // optional [B]: rows with t > t_last[b] hold stale values (they have mask == 0)
     const float* ingroup_rows;        // optional [B,T] -> stats[REFIL_STAT_INGROUP_SUM]
     int B, T, imagine; float gamma, lmbda;
 };

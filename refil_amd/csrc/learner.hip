@@ -116,23 +116,29 @@ struct Work {
     float *dqva, *dhs, *dgi, *dgh, *dx3a, *dx2a, *daoa, *dqa, *dkva, *dx1a;
     float* partial;
     float* partial2;   // split-K scratch of the side (agent-chain) stream
+    // row lists (kernels.h: ListArgs): rows that cannot influence the step are skipped
+    int *t_last, *list_ea, *list_eh, *list_a, *counts, *lcnt, *loff;
+    uint8_t *kdead_a, *kdead_h;
 };
 
 struct Sizes {
     long R, NE, NA; int G, nv0, NV, E, Ep, nets;
+    long NEa, NAa;     // allocated rows of the entity-row / agent-row buffers the row-list GEMMs touch: the rows past
+                       // the logical end are the scratch rows the padded list entries point at
 };
 static Sizes sizes_of(const refil_dims& d) {
     Sizes s;
     s.R = (long)d.B * d.T1; s.NE = s.R * d.ne; s.NA = s.R * d.na;
     s.G = d.imagine ? 3 : 1; s.nv0 = s.G; s.nets = d.mixer_vdn ? 0 : (d.mixer_lin ? 2 : 4); s.NV = s.nets ? s.nv0 + s.nets - 1 : 0;
     s.E = in_dim(d); s.Ep = (int)rup(s.E, 4);
+    s.NEa = s.NE + 8; s.NAa = s.NA + 8;
     return s;
 }
 
 static void carve_agent(Arena& a, const refil_dims& d, const Sizes& s, int G, bool save, AgentBufs& b) {
-    b.x1 = a.take<float>(s.NE * d.d);
-    b.kv = a.take<float>(s.NE * 2 * d.d);
-    b.q = a.take<float>(s.NA * d.d);
+    b.x1 = a.take<float>(s.NEa * d.d);
+    b.kv = a.take<float>(s.NEa * 2 * d.d);
+    b.q = a.take<float>(s.NAa * d.d);
     b.ao = a.take<float>((long)G * s.NA * d.d);
     b.x2 = a.take<float>((long)G * s.NA * d.d);
     b.x3 = a.take<float>((long)G * s.NA * d.H);
@@ -147,9 +153,9 @@ static void carve_agent(Arena& a, const refil_dims& d, const Sizes& s, int G, bo
     b.wc = a.take<float>((long)d.H * d.d); b.bc = a.take<float>(d.H); b.bd = a.take<float>(d.H);
 }
 static void carve_hyper(Arena& a, const refil_dims& d, const Sizes& s, int NV, HyperBufs& b) {
-    b.x1 = a.take<float>(s.NE * s.nets * d.hyp);
-    b.kv = a.take<float>(s.nets * s.NE * 2 * d.hyp);
-    b.q = a.take<float>(s.nets * s.NA * d.hyp);
+    b.x1 = a.take<float>(s.NEa * s.nets * d.hyp);
+    b.kv = a.take<float>(s.nets * s.NEa * 2 * d.hyp);
+    b.q = a.take<float>(s.nets * s.NAa * d.hyp);
     b.ao = a.take<float>((long)NV * s.NA * d.hyp);
     b.x2 = a.take<float>((long)NV * s.NA * d.hyp);
     b.x3 = a.take<float>((long)NV * s.NA * d.M);
@@ -163,7 +169,7 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     const Sizes s = sizes_of(d);
     const long BT = (long)d.B * (d.T1 > 1 ? d.T1 - 1 : 1);
     memset(&w, 0, sizeof(w));
-    w.xe = a.take<float>(s.NE * s.Ep);
+    w.xe = a.take<float>(s.NEa * s.Ep);
     w.emc = a.take<uint8_t>(s.NE); w.amask = a.take<uint8_t>(s.NA); w.em0 = a.take<uint8_t>((long)d.B * d.ne);
     w.nact = a.take<float>(s.R);
     w.actf = a.take<float>(s.NA);
@@ -186,9 +192,9 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     w.dchosen = a.take<float>((long)s.G * BT * d.na);
     w.dx2h = a.take<float>((long)s.NV * s.NA * d.hyp);
     w.daoh = a.take<float>((long)s.NV * s.NA * d.hyp);
-    w.dqh = a.take<float>(s.nets * s.NA * d.hyp);
-    w.dkvh = a.take<float>(s.nets * s.NE * 2 * d.hyp);
-    w.dx1h = a.take<float>(s.NE * s.nets * d.hyp);
+    w.dqh = a.take<float>(s.nets * s.NAa * d.hyp);
+    w.dkvh = a.take<float>(s.nets * s.NEa * 2 * d.hyp);
+    w.dx1h = a.take<float>(s.NEa * s.nets * d.hyp);
     w.gwc = a.take<float>((long)s.nets * d.M * d.hyp);
     w.gbc = a.take<float>((long)s.nets * d.M);
     w.gwca = a.take<float>((long)d.H * d.d); w.gbca = a.take<float>(d.H); w.gbact = a.take<float>(d.H);
@@ -199,11 +205,15 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     w.dx3a = a.take<float>((long)s.G * s.NA * d.H);
     w.dx2a = a.take<float>((long)s.G * s.NA * d.d);
     w.daoa = a.take<float>((long)s.G * s.NA * d.d);
-    w.dqa = a.take<float>(s.NA * d.d);
-    w.dkva = a.take<float>(s.NE * 2 * d.d);
-    w.dx1a = a.take<float>(s.NE * d.d);
+    w.dqa = a.take<float>(s.NAa * d.d);
+    w.dkva = a.take<float>(s.NEa * 2 * d.d);
+    w.dx1a = a.take<float>(s.NEa * d.d);
     w.partial = a.take<float>(PARTIAL_FLOATS);
     w.partial2 = a.take<float>(PARTIAL_FLOATS);
+    w.t_last = a.take<int>(d.B);
+    w.list_ea = a.take<int>(s.NE + 64); w.list_eh = a.take<int>(s.NE + 64); w.list_a = a.take<int>(s.NA + 64);
+    w.counts = a.take<int>(4); w.lcnt = a.take<int>(3 * s.R); w.loff = a.take<int>(3 * (s.R + 1));
+    w.kdead_a = a.take<uint8_t>(s.NE); w.kdead_h = a.take<uint8_t>(s.NE);
 }
 
 static size_t workspace_bytes(const refil_dims& d, CarveMode mode) {
@@ -321,7 +331,25 @@ struct Ctx {
     // recurrent agent: x3 = relu(fc2(mask(out_trans(a)))) = relu(a W_c^T + b_2 + active * W_2 b_o) with a = 0 for inactive
     // agents (the attention kernel applies the post-mask): out_trans and its backward GEMMs disappear
     bool compose_agent;
+    // Row lists: the entity-row projections (fc1, K/V, their dX / dW) and the query projections run over the rows that
+    // can influence the loss only, attention and the recurrences stop after an episode's last contributing step.
+    // Learner steps of the flagship family at sizes where every listed GEMM takes the weight-resident / streaming
+    // kernels; REFIL_DENSE=1 switches it off (same results up to the summation order of the weight gradients).
+    bool lists;
 };
+
+struct RowList { const int* idx; const int* cnt; };
+static refil_gemm_desc with_rows(refil_gemm_desc g, const Ctx& c, RowList l) {
+    if (c.lists) { g.row_index = l.idx; g.row_count = l.cnt; }
+    return g;
+}
+static RowList rows_ea(const Ctx& c) { return RowList{c.w.list_ea, c.w.counts + 0}; }
+static RowList rows_eh(const Ctx& c) { return RowList{c.w.list_eh, c.w.counts + 1}; }
+static RowList rows_a(const Ctx& c) { return RowList{c.w.list_a, c.w.counts + 2}; }
+static void attn_rows(const Ctx& c, refil_attn_desc& a, bool hyper) {
+    if (!c.lists) return;
+    a.t_last = c.w.t_last; a.kv_dead = hyper ? c.w.kdead_h : c.w.kdead_a; a.q_dead = c.w.amask;
+}
 
 static refil_rowmap agent_rows(const Ctx& c) { return refil_rowmap{c.d.na, c.d.ne, 0}; }
 static refil_rowmap hs_rows(const Ctx& c, int off) { return refil_rowmap{c.d.T1 * c.d.na, (c.d.T1 + 1) * c.d.na, off}; }
@@ -341,11 +369,27 @@ static refil_attn_desc attn_base(const Ctx& c, int w) {
 // ------------------------------------------------------------------------------------------------
 // agent forward (entity_rnn_agent.py:31-64 with the G mask variants of :116-124)
 // ------------------------------------------------------------------------------------------------
-static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G, const float* h0) {
+enum { AG_PRE = 1, AG_GRU = 2, AG_POST = 4, AG_ALL = 7 };
+
+static refil_gru_desc agent_gru_desc(const Ctx& c, const float* P, const AgentBufs& b, int G) {
+    const refil_dims& d = c.d;
+    refil_gru_desc g;
+    memset(&g, 0, sizeof(g));
+    g.gi = b.gi; g.hsx = b.hsx; g.w_hh = P + c.L.ag_w_hh; g.b_hh = P + c.L.ag_b_hh;
+    g.save_r = b.sr; g.save_z = b.sz; g.save_n = b.sn; g.save_ghn = b.sg;
+    g.NR = G * d.B * d.na; g.T1 = d.T1; g.na = d.na; g.H = d.H;
+    if (c.lists) { g.t_last = c.w.t_last; g.B = d.B; }
+    return g;
+}
+
+// phases: AG_PRE everything up to the GRU input gates, AG_GRU the recurrence, AG_POST fc3 (the learner runs the live and
+// the target agent's recurrences in ONE launch between their PRE and POST parts)
+static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G, const float* h0, int phases = AG_ALL) {
     const refil_dims& d = c.d; const Sizes& s = c.s; const refil_param_layout& L = c.L;
     const int dd = d.d, H = d.H;
+    if (phases & AG_PRE) {
     // x1 = relu(fc1(entities))                                       :38
-    RUN(gemm_launch(linear(c.w.xe, s.Ep, P + L.ag_fc1_w, s.E, P + L.ag_fc1_b, b.x1, dd, s.NE, dd, s.E, REFIL_GEMM_RELU), c.st));
+    RUN(gemm_launch(with_rows(linear(c.w.xe, s.Ep, P + L.ag_fc1_w, s.E, P + L.ag_fc1_b, b.x1, dd, s.NE, dd, s.E, REFIL_GEMM_RELU), c, rows_ea(c)), c.st));
     if (d.pooling) {
         // EntityPoolingLayer: in_trans (with bias) on all entities, masked mean / max pool       attention.py:110-123
         RUN(gemm_launch(linear(b.x1, dd, P + L.ag_in_w, dd, P + L.ag_in_w + (long)dd * dd, b.kv, 2 * dd, s.NE, dd, dd, 0), c.st));
@@ -357,11 +401,11 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
         RUN(pool_launch(a, d.pooling, false, c.st));
     } else {
     // K,V for all entities; Q for the agents only                    attention.py:46-48
-    RUN(gemm_launch(linear(b.x1, dd, P + L.ag_in_w + (long)dd * dd, dd, nullptr, b.kv, 2 * dd, s.NE, 2 * dd, dd, 0), c.st));
+    RUN(gemm_launch(with_rows(linear(b.x1, dd, P + L.ag_in_w + (long)dd * dd, dd, nullptr, b.kv, 2 * dd, s.NE, 2 * dd, dd, 0), c, rows_ea(c)), c.st));
     {
         refil_gemm_desc g = linear(b.x1, dd, P + L.ag_in_w, dd, nullptr, b.q, dd, s.NA, dd, dd, 0);
         g.a_map = agent_rows(c);
-        RUN(gemm_launch(g, c.st));
+        RUN(gemm_launch(with_rows(g, c, rows_a(c)), c.st));
     }
     {
         refil_attn_desc a = attn_base(c, dd);
@@ -369,6 +413,7 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
         a.nvar = G; a.var[0] = REFIL_MASK_OBS;
         a.var[1] = group_code(d, 0, true);
         a.var[2] = group_code(d, 1, true);
+        attn_rows(c, a, false);
         if (c.compose_agent) {
             const int rc = attn_mfma_launch_ex(a, false, c.st, 0, nullptr, 0, 1);      // inactive agents -> exact zeros
             REFIL_CHECK(rc >= 0, "refil: agent attention shape not instantiated");
@@ -409,16 +454,11 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
     // gi = x3 W_ih^T + b_ih for all steps, then the persistent recurrence   :49-55
     RUN(gemm_launch(linear(b.x3, H, P + L.ag_w_ih, H, P + L.ag_b_ih, b.gi, 3 * H, (long)G * s.NA, 3 * H, H, 0), c.st));
     RUN(set_h0_launch(b.hsx, h0, G * d.B, d.T1, d.na, H, c.st));
-    {
-        refil_gru_desc g;
-        memset(&g, 0, sizeof(g));
-        g.gi = b.gi; g.hsx = b.hsx; g.w_hh = P + L.ag_w_hh; g.b_hh = P + L.ag_b_hh;
-        g.save_r = b.sr; g.save_z = b.sz; g.save_n = b.sn; g.save_ghn = b.sg;
-        g.NR = G * d.B * d.na; g.T1 = d.T1; g.na = d.na; g.H = H;
-        RUN(gru_forward_launch(g, c.st));
-    }
+    }   // AG_PRE
+    if (d.agent_ff) return 0;
+    if (phases & AG_GRU) RUN(gru_forward_launch(agent_gru_desc(c, P, b, G), c.st));
     // q = fc3(h), zero for inactive agents                            :57-60
-    {
+    if (phases & AG_POST) {
         refil_gemm_desc g = linear(b.hsx, H, P + L.ag_fc3_w, H, P + L.ag_fc3_b, b.qv, d.A, (long)G * s.NA, d.A, H, 0);
         g.a_map = hs_rows(c, d.na);
         g.rowmask = c.w.amask; g.rowmask_mod = (int)s.NA;
@@ -434,23 +474,24 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
 static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int nv0) {
     const refil_dims& d = c.d; const Sizes& s = c.s; const refil_param_layout& L = c.L;
     const int h = d.hyp, M = d.M, nets = s.nets;
-    RUN(gemm_launch(linear(c.w.xe, s.Ep, P + L.mix_fc1_w, s.E, P + L.mix_fc1_b, b.x1, nets * h, s.NE, nets * h, s.E, REFIL_GEMM_RELU), c.st));
+    RUN(gemm_launch(with_rows(linear(c.w.xe, s.Ep, P + L.mix_fc1_w, s.E, P + L.mix_fc1_b, b.x1, nets * h, s.NE, nets * h, s.E, REFIL_GEMM_RELU), c, rows_eh(c)), c.st));
     if (d.pooling) {
         refil_gemm_desc g = linear(b.x1, nets * h, P + L.mix_in_w, h, P + L.mix_in_w + (long)h * h, b.kv, 2 * h, s.NE, h, h, 0);
-        g.batch = nets; g.sA = h; g.sB = L.mix_in_w_stride; g.sBias = L.mix_in_w_stride; g.sC = s.NE * 2 * h;
+        g.batch = nets; g.sA = h; g.sB = L.mix_in_w_stride; g.sBias = L.mix_in_w_stride; g.sC = s.NEa * 2 * h;
         RUN(gemm_launch(g, c.st));
     } else {
         refil_gemm_desc g = linear(b.x1, nets * h, P + L.mix_in_w + (long)h * h, h, nullptr, b.kv, 2 * h, s.NE, 2 * h, h, 0);
-        g.batch = nets; g.sA = h; g.sB = L.mix_in_w_stride; g.sC = s.NE * 2 * h;
-        RUN(gemm_launch(g, c.st));
+        g.batch = nets; g.sA = h; g.sB = L.mix_in_w_stride; g.sC = s.NEa * 2 * h;
+        RUN(gemm_launch(with_rows(g, c, rows_eh(c)), c.st));
         refil_gemm_desc q = linear(b.x1, nets * h, P + L.mix_in_w, h, nullptr, b.q, h, s.NA, h, h, 0);
         q.a_map = agent_rows(c);
-        q.batch = nets; q.sA = h; q.sB = L.mix_in_w_stride; q.sC = s.NA * h;
-        RUN(gemm_launch(q, c.st));
+        q.batch = nets; q.sA = h; q.sB = L.mix_in_w_stride; q.sC = s.NAa * h;
+        RUN(gemm_launch(with_rows(q, c, rows_a(c)), c.st));
     }
     for (int n = 0; n < nets; ++n) {
         refil_attn_desc a = attn_base(c, h);
-        a.Q = b.q + (long)n * s.NA * h; a.K = b.kv + (long)n * s.NE * 2 * h; a.V = a.K + h;
+        attn_rows(c, a, true);
+        a.Q = b.q + (long)n * s.NAa * h; a.K = b.kv + (long)n * s.NEa * 2 * h; a.V = a.K + h;
         a.O = b.ao + (long)(n == 0 ? 0 : nv0 + n - 1) * s.NA * h; a.sO = s.NA * h;
         a.nvar = n == 0 ? nv0 : 1;
         a.var[0] = REFIL_MASK_ENTITY;
@@ -541,6 +582,7 @@ struct AttnBlockBwd {
     int var_first[3];                    // mask codes of net 0's variants
     int var_rest;                        // mask code of nets 1..3
     bool presum;                         // nets 1..3 run on agent-summed rows (Ctx::presum)
+    bool hyper;                          // which entity-row list / dead-key flags apply (hypernets or agent nets)
 };
 
 static int attn_block_backward(const Ctx& c, const AttnBlockBwd& k) {
@@ -564,11 +606,13 @@ static int attn_block_backward(const Ctx& c, const AttnBlockBwd& k) {
         gx.batch = batch; gx.sA = s.NA * w; gx.sB = k.out_w_stride; gx.sC = s.NA * w;
         RUN(gemm_launch(gx, c.st));
     }
+    const RowList re = k.hyper ? rows_eh(c) : rows_ea(c);
     for (int n = 0; n < k.nets; ++n) {
         refil_attn_desc a = attn_base(c, w);
-        a.Q = k.q + (long)n * s.NA * w; a.K = k.kv + (long)n * s.NE * 2 * w; a.V = a.K + w;
+        attn_rows(c, a, k.hyper);
+        a.Q = k.q + (long)n * s.NAa * w; a.K = k.kv + (long)n * s.NEa * 2 * w; a.V = a.K + w;
         a.dO = k.dao + (long)(n == 0 ? 0 : k.nv0 + n - 1) * s.NA * w; a.sO = s.NA * w;
-        a.dQ = k.dq + (long)n * s.NA * w; a.dK = k.dkv + (long)n * s.NE * 2 * w; a.dV = a.dK + w;
+        a.dQ = k.dq + (long)n * s.NAa * w; a.dK = k.dkv + (long)n * s.NEa * 2 * w; a.dV = a.dK + w;
         a.nvar = n == 0 ? k.nv0 : 1;
         if (n == 0) { a.var[0] = k.var_first[0]; a.var[1] = k.var_first[1]; a.var[2] = k.var_first[2]; }
         else a.var[0] = k.var_rest;
@@ -583,10 +627,10 @@ static int attn_block_backward(const Ctx& c, const AttnBlockBwd& k) {
         // EntityPoolingLayer: dW_in = dE^T x1, db_in = colsum(dE);  dx1 = relu'(x1) * (dE W_in)
         refil_gemm_desc g = linear_dw(k.dkv, 2 * w, k.x1, (int)ldx1, k.Gr + k.in_w, w, k.Gr + k.in_w + (long)w * w, s.NE, w, w,
                                       c.w.partial, k.nets);
-        g.sA = s.NE * 2 * w; g.sB = w; g.sC = k.in_w_stride; g.sColsum = k.in_w_stride;
+        g.sA = s.NEa * 2 * w; g.sB = w; g.sC = k.in_w_stride; g.sColsum = k.in_w_stride;
         RUN(gemm_launch(g, c.st));
         refil_gemm_desc x = linear_dx(k.dkv, 2 * w, k.P + k.in_w, w, k.dx1, (int)ldx1, s.NE, w, w, REFIL_GEMM_RELU_BWD);
-        x.aux = k.x1; x.batch = k.nets; x.sA = s.NE * 2 * w; x.sB = k.in_w_stride; x.sC = w;
+        x.aux = k.x1; x.batch = k.nets; x.sA = s.NEa * 2 * w; x.sB = k.in_w_stride; x.sC = w;
         RUN(gemm_launch(x, c.st));
         return 0;
     }
@@ -594,22 +638,22 @@ static int attn_block_backward(const Ctx& c, const AttnBlockBwd& k) {
     {
         refil_gemm_desc g = linear_dw(k.dkv, 2 * w, k.x1, (int)ldx1, k.Gr + k.in_w + (long)w * w, w, nullptr, s.NE, 2 * w, w,
                                       c.w.partial, k.nets);
-        g.sA = s.NE * 2 * w; g.sB = w; g.sC = k.in_w_stride;
-        RUN(gemm_launch(g, c.st));
+        g.sA = s.NEa * 2 * w; g.sB = w; g.sC = k.in_w_stride;
+        RUN(gemm_launch(with_rows(g, c, re), c.st));
         refil_gemm_desc q = linear_dw(k.dq, w, k.x1, (int)ldx1, k.Gr + k.in_w, w, nullptr, s.NA, w, w, c.w.partial, k.nets);
         q.b_map = refil_rowmap{d.na, d.ne, 0};
-        q.sA = s.NA * w; q.sB = w; q.sC = k.in_w_stride;
-        RUN(gemm_launch(q, c.st));
+        q.sA = s.NAa * w; q.sB = w; q.sC = k.in_w_stride;
+        RUN(gemm_launch(with_rows(q, c, rows_a(c)), c.st));
     }
     // dx1 = relu'(x1) * (dKV W_kv + scatter(dQ W_q))
     {
         refil_gemm_desc g = linear_dx(k.dkv, 2 * w, k.P + k.in_w + (long)w * w, w, k.dx1, (int)ldx1, s.NE, 2 * w, w, REFIL_GEMM_RELU_BWD);
-        g.aux = k.x1; g.batch = k.nets; g.sA = s.NE * 2 * w; g.sB = k.in_w_stride; g.sC = w;
-        RUN(gemm_launch(g, c.st));
+        g.aux = k.x1; g.batch = k.nets; g.sA = s.NEa * 2 * w; g.sB = k.in_w_stride; g.sC = w;
+        RUN(gemm_launch(with_rows(g, c, re), c.st));
         refil_gemm_desc q = linear_dx(k.dq, w, k.P + k.in_w, w, k.dx1, (int)ldx1, s.NA, w, w, REFIL_GEMM_RELU_BWD | REFIL_GEMM_ACCUM);
         q.aux = k.x1; q.c_map = refil_rowmap{d.na, d.ne, 0};
-        q.batch = k.nets; q.sA = s.NA * w; q.sB = k.in_w_stride; q.sC = w;
-        RUN(gemm_launch(q, c.st));
+        q.batch = k.nets; q.sA = s.NAa * w; q.sB = k.in_w_stride; q.sC = w;
+        RUN(gemm_launch(with_rows(q, c, rows_a(c)), c.st));
     }
     return 0;
 }
@@ -630,6 +674,16 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
     c.presum = presum_on && !dims->mixer_lin && !dims->mixer_vdn && !dims->pooling &&
                attn_mfma_supported(dims->ne, dims->na, dims->hyp / dims->heads);
     c.compose_agent = presum_on && !dims->agent_ff && !dims->pooling && attn_mfma_supported(dims->ne, dims->na, dims->d / dims->heads);
+    {
+        const char* de = getenv("REFIL_DENSE");
+        const refil_dims& d = *dims;
+        const int E = in_dim(d);
+        // every listed GEMM must take the weight-resident / streaming-dW kernels (gemm_wres_eligible): whole 32-column
+        // tiles, reductions <= 128 (<= 256 through the ReLU), 16-byte aligned rows, enough rows for a split reduction
+        const bool shapes = E % 4 == 0 && E <= 128 && d.d % 32 == 0 && d.d <= 128 && d.hyp % 32 == 0 && d.hyp <= 128 &&
+                            c.s.NE >= 2048 && c.s.NA >= 512;
+        c.lists = mode == CARVE_LEARNER && !(de && de[0] == '1') && shapes && c.presum && c.compose_agent;
+    }
     REFIL_CHECK(batch->entities && batch->entity_mask, "refil: batch.entities / entity_mask missing");
     REFIL_CHECK(!dims->entity_last_action || batch->actions, "refil: batch.actions missing");
     REFIL_CHECK((reinterpret_cast<uintptr_t>(ws) & 255) == 0, "refil: workspace must be 256-byte aligned");
@@ -687,6 +741,14 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
 
     // ---------------- forward ----------------
     RUN(run_prep(c, 1));
+    if (c.lists) {
+        ListArgs la;
+        memset(&la, 0, sizeof(la));
+        la.b = c.b; la.B = d.B; la.T1 = d.T1; la.ne = d.ne; la.na = d.na; la.learner = 1; la.use_gt_obs = d.gt_obs_mask;
+        la.emc = w.emc; la.em0 = w.em0; la.t_last = w.t_last; la.kdead_a = w.kdead_a; la.kdead_h = w.kdead_h;
+        la.cnt = w.lcnt; la.off = w.loff; la.list_ea = w.list_ea; la.list_eh = w.list_eh; la.list_a = w.list_a; la.counts = w.counts;
+        RUN(lists_launch(la, c.st));
+    }
     // The hypernet chain is the longer one, so IT goes to the side stream and is enqueued first: whichever
     // chain the host enqueues second starts several hundred microseconds late (the host needs that long to
     // push the ~40 launches of the first chain), and the agent chain has that much slack.
@@ -704,8 +766,18 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         RUN(hyper_forward(ch, params_target, w.th, 1));                           // target mixer hypernets
     }
     if (overlap) REFIL_HIP(hipEventRecord(sd->ev[1], sd->s));
-    RUN(agent_forward(ca, params_live, w.la, G, nullptr));                        // q_learner.py:86-89 / 107
-    RUN(agent_forward(ca, params_target, w.ta, 1, nullptr));                      // :111-113
+    if (!d.agent_ff && (G * d.B * d.na) % 16 == 0) {
+        // live (q_learner.py:86-89 / 107) and target (:111-113) agents; their two recurrences share one launch
+        RUN(agent_forward(ca, params_live, w.la, G, nullptr, AG_PRE));
+        RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_PRE));
+        const refil_gru_desc gl = agent_gru_desc(ca, params_live, w.la, G), gt = agent_gru_desc(ca, params_target, w.ta, 1);
+        RUN(gru_forward_launch2(gl, &gt, ca.st));
+        RUN(agent_forward(ca, params_live, w.la, G, nullptr, AG_POST));
+        RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_POST));
+    } else {
+        RUN(agent_forward(ca, params_live, w.la, G, nullptr));
+        RUN(agent_forward(ca, params_target, w.ta, 1, nullptr));
+    }
     {
         QSelArgs q;
         q.q = w.la.qv; q.tq = w.ta.qv; q.actions = c.b.actions; q.ac_sB = c.b.ac_sB; q.ac_sT = c.b.ac_sT;
@@ -728,6 +800,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         t.terminated = c.b.terminated; t.tm_sB = c.b.tm_sB; t.tm_sT = c.b.tm_sT;
         t.filled = c.b.filled; t.fl_sB = c.b.fl_sB; t.fl_sT = c.b.fl_sT;
         t.gc_real = w.gc_real; t.gc_im = w.gc_im; t.targets = w.targets; t.stats = stats;
+        t.t_last = c.lists ? w.t_last : nullptr;
         t.ingroup_rows = ml.ingroup_rows;
         t.B = d.B; t.T = T; t.imagine = d.imagine; t.gamma = d.gamma; t.lmbda = d.lmbda;
         RUN(td_loss_launch(t, c.st));                                             // :157-172
@@ -808,7 +881,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     }
     {
         AttnBlockBwd k;
-        k.w = h; k.nets = s.nets; k.nv0 = nv0; k.P = params_live; k.Gr = grads; k.presum = c.presum;
+        k.w = h; k.nets = s.nets; k.nv0 = nv0; k.P = params_live; k.Gr = grads; k.presum = c.presum; k.hyper = true;
         k.in_w = L.mix_in_w; k.in_w_stride = L.mix_in_w_stride; k.out_w = L.mix_out_w; k.out_w_stride = L.mix_out_w_stride;
         k.out_b = L.mix_out_b; k.out_b_stride = L.mix_out_b_stride;
         k.x1 = w.lh.x1; k.kv = w.lh.kv; k.q = w.lh.q; k.ao = w.lh.ao; k.dx2 = w.dx2h;
@@ -821,7 +894,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         // the four hypernet fc1 layers: dW = dx1^T xe (one [4h,E] GEMM), db = colsum(dx1)
         refil_gemm_desc g = linear_dw(w.dx1h, s.nets * h, w.xe, s.Ep, grads + L.mix_fc1_w, s.E, grads + L.mix_fc1_b, s.NE, s.nets * h, s.E,
                                       ch.w.partial, 1);
-        RUN(gemm_launch(g, ch.st));
+        RUN(gemm_launch(with_rows(g, ch, rows_eh(ch)), ch.st));
     }
     }
     // agent: chosen-Q gather + inactive-agent fill, then fc3
@@ -848,6 +921,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
             g.hsx = w.la.hsx; g.w_hh = params_live + L.ag_w_hh; g.b_hh = params_live + L.ag_b_hh;
             g.save_r = w.la.sr; g.save_z = w.la.sz; g.save_n = w.la.sn; g.save_ghn = w.la.sg;
             g.dhs = w.dhs; g.dgi = w.dgi; g.dgh = w.dgh; g.NR = G * d.B * d.na; g.T1 = d.T1; g.na = d.na; g.H = H;
+            if (c.lists) { g.t_last = w.t_last; g.B = d.B; }
             RUN(gru_backward_launch(g, ca.st));
             refil_gemm_desc ghh = linear_dw(w.dgh, 3 * H, w.la.hsx, H, grads + L.ag_w_hh, H, grads + L.ag_b_hh, rows, 3 * H, H, ca.w.partial, 1);
             ghh.b_map = hs_rows(c, 0);
@@ -883,6 +957,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         }
         AttnBlockBwd k;
         k.w = dd; k.nets = 1; k.nv0 = G; k.P = params_live; k.Gr = grads; k.presum = c.compose_agent;   // (d(attn out) already in daoa)
+        k.hyper = false;
         k.in_w = L.ag_in_w; k.in_w_stride = 0; k.out_w = L.ag_out_w; k.out_w_stride = 0; k.out_b = L.ag_out_b; k.out_b_stride = 0;
         k.x1 = w.la.x1; k.kv = w.la.kv; k.q = w.la.q; k.ao = w.la.ao; k.dx2 = w.dx2a;
         k.dao = w.daoa; k.dq = w.dqa; k.dkv = w.dkva; k.dx1 = w.dx1a;
@@ -891,7 +966,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         k.var_first[2] = group_code(d, 1, true);
         k.var_rest = REFIL_MASK_OBS;
         RUN(attn_block_backward(ca, k));
-        RUN(gemm_launch(linear_dw(w.dx1a, dd, w.xe, s.Ep, grads + L.ag_fc1_w, s.E, grads + L.ag_fc1_b, s.NE, dd, s.E, ca.w.partial, 1), ca.st));
+        RUN(gemm_launch(with_rows(linear_dw(w.dx1a, dd, w.xe, s.Ep, grads + L.ag_fc1_w, s.E, grads + L.ag_fc1_b, s.NE, dd, s.E, ca.w.partial, 1), ca, rows_ea(ca)), ca.st));
     }
     if (overlap) {                                                                 // join
         REFIL_HIP(hipEventRecord(sd->ev[3], sd->s));

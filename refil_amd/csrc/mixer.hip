@@ -67,6 +67,113 @@ int prep_launch(const PrepArgs& a, hipStream_t st) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// row lists (ListArgs in kernels.h)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lists_tlast_kernel(ListArgs a) {           // one wave per episode
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    const int T = a.T1 - 1;
+    int last = -1;
+    if (!a.learner) last = a.T1 - 1;
+    else {
+        for (int t = lane; t < T; t += 64) {
+            float m = (float)a.b.filled[b * a.b.fl_sB + t * a.b.fl_sT];
+            if (t > 0) m *= 1.0f - (float)a.b.terminated[b * a.b.tm_sB + (t - 1) * a.b.tm_sT];     // q_learner.py:71-72
+            if (m != 0.f) last = t + 1;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+    }
+    if (lane == 0) a.t_last[b] = last;
+}
+
+__global__ __launch_bounds__(256) void lists_flags_kernel(ListArgs a) {           // one wave per (b,t) row
+    const int lane = threadIdx.x & 63;
+    const long R = (long)a.B * a.T1;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int b = r / a.T1, t = r % a.T1;
+    const bool row_live = t <= a.t_last[b];
+    bool ka = false, kh = false, la = false;
+    if (lane < a.ne && row_live) {
+        const uint8_t emt = a.emc[r * a.ne + lane], em0 = a.em0[(long)b * a.ne + lane];
+        la = lane < a.na && emt == 0;
+        kh = !(emt && em0) || la;
+        const uint8_t* om = a.use_gt_obs ? a.b.gt_mask + b * a.b.gt_sB + t * a.b.gt_sT : a.b.obs_mask + b * a.b.om_sB + t * a.b.om_sT;
+        bool seen = false;
+        for (int i = 0; i < a.na; ++i) seen |= om[i * a.ne + lane] == 0;
+        ka = seen || la;
+    }
+    if (lane < a.ne) { a.kdead_a[r * a.ne + lane] = ka ? 0 : 1; a.kdead_h[r * a.ne + lane] = kh ? 0 : 1; }
+    const unsigned long long ba = __ballot(ka), bh = __ballot(kh), bl = __ballot(la);
+    if (lane == 0) { a.cnt[r] = __popcll(ba); a.cnt[R + r] = __popcll(bh); a.cnt[2 * R + r] = __popcll(bl); }
+}
+
+// exclusive scans of the three per-row count arrays (R <= ~10^4 rows: one workgroup), list lengths, padding
+__global__ __launch_bounds__(1024) void lists_scan_kernel(ListArgs a) {
+    __shared__ int part[1024];
+    __shared__ int live_rows;
+    const long R = (long)a.B * a.T1;
+    const int tid = threadIdx.x;
+    const int per = (int)cdivl(R, 1024);
+    const long r0 = (long)tid * per, r1 = min(R, r0 + per);
+    if (tid == 0) live_rows = 0;
+    for (int l = 0; l < 3; ++l) {
+        int s = 0;
+        for (long r = r0; r < r1; ++r) s += a.cnt[l * R + r];
+        part[tid] = s;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {                 // Hillis-Steele inclusive scan of the 1024 partial sums
+            const int v = tid >= o ? part[tid - o] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        int run = part[tid] - s;
+        for (long r = r0; r < r1; ++r) { a.off[l * (R + 1) + r] = run; run += a.cnt[l * R + r]; }
+        const int total = part[1023];
+        if (tid == 0) { a.off[l * (R + 1) + R] = total; a.counts[l] = total; }
+        int* list = l == 0 ? a.list_ea : (l == 1 ? a.list_eh : a.list_a);
+        const int trash = l == 2 ? (int)(R * a.na) : (int)(R * a.ne);
+        const int padded = (total + 63) & ~63;
+        if (tid < 64 && total + tid < padded) list[total + tid] = trash;
+        __syncthreads();
+    }
+    int lr = 0;
+    for (long r = r0; r < r1; ++r) lr += (int)(r % a.T1) <= a.t_last[r / a.T1] ? 1 : 0;
+    atomicAdd(&live_rows, lr);
+    __syncthreads();
+    if (tid == 0) a.counts[3] = live_rows;
+}
+
+__global__ __launch_bounds__(256) void lists_fill_kernel(ListArgs a) {            // one wave per (b,t) row
+    const int lane = threadIdx.x & 63;
+    const long R = (long)a.B * a.T1;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const bool in = lane < a.ne;
+    const bool ka = in && a.kdead_a[r * a.ne + lane] == 0, kh = in && a.kdead_h[r * a.ne + lane] == 0;
+    const bool row_live = (int)(r % a.T1) <= a.t_last[r / a.T1];
+    const bool la = row_live && lane < a.na && a.emc[r * a.ne + lane] == 0;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long ba = __ballot(ka), bh = __ballot(kh), bl = __ballot(la);
+    if (ka) a.list_ea[a.off[r] + __popcll(ba & below)] = (int)(r * a.ne + lane);
+    if (kh) a.list_eh[a.off[(R + 1) + r] + __popcll(bh & below)] = (int)(r * a.ne + lane);
+    if (la) a.list_a[a.off[2 * (R + 1) + r] + __popcll(bl & below)] = (int)(r * a.na + lane);
+}
+
+int lists_launch(const ListArgs& a, hipStream_t st) {
+    const long R = (long)a.B * a.T1;
+    ProfScope prof("lists_kernels", 0.0, 0.0, st);
+    hipLaunchKernelGGL(lists_tlast_kernel, dim3(cdiv(a.B, 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(lists_flags_kernel, dim3((int)cdivl(R, 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(lists_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(lists_fill_kernel, dim3((int)cdivl(R, 4)), dim3(256), 0, st, a);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
 __global__ void set_h0_kernel(float* hsx, const float* h0, int GB, int T1, int na, int H) {
     const long total = (long)GB * na * H;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -500,13 +607,18 @@ __global__ __launch_bounds__(1024) void td_loss_kernel(TdArgs a) {
         float mask = (float)a.filled[b * a.fl_sB + t * a.fl_sT];
         if (t > 0) mask *= 1.0f - (float)a.terminated[b * a.tm_sB + (t - 1) * a.tm_sT];
         const float term = (float)a.terminated[b * a.tm_sB + t * a.tm_sT];
-        const float target = a.reward[b * a.rw_sB + t * a.rw_sT] + a.gamma * (1.0f - term) * a.tq_tot[idx];
-        const float td = (a.q_tot[idx] - target) * mask;
+        // steps after an episode's last contributing step are skipped by the nets (stale values): they have mask == 0
+        // and enter every sum as exact zeros, like 0 * (finite value) does in the reference
+        const bool stale = a.t_last && t > a.t_last[b];
+        const float tq = (stale || (a.t_last && t + 1 > a.t_last[b])) ? 0.f : a.tq_tot[idx];
+        const float qt = stale ? 0.f : a.q_tot[idx];
+        const float target = a.reward[b * a.rw_sB + t * a.rw_sT] + a.gamma * (1.0f - term) * tq;
+        const float td = (qt - target) * mask;
         const float wr = a.imagine ? 1.0f - a.lmbda : 1.0f;
         a.gc_real[idx] = 2.0f * wr * td * mask;
-        s[0] += mask; s[1] += td * td; s[3] += fabsf(td); s[4] += a.q_tot[idx] * mask; s[5] += target * mask;
+        s[0] += mask; s[1] += td * td; s[3] += fabsf(td); s[4] += qt * mask; s[5] += target * mask;
         if (a.imagine) {
-            const float tdi = (a.q_tot_im[idx] - target) * mask;
+            const float tdi = ((stale ? 0.f : a.q_tot_im[idx]) - target) * mask;
             a.gc_im[idx] = 2.0f * a.lmbda * tdi * mask;
             s[2] += tdi * tdi;
         }

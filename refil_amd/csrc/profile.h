@@ -6,13 +6,16 @@
 namespace refil {
 
 bool prof_enabled();
-void prof_begin(const char* kernel, double flops, double bytes, hipStream_t st);
+// rows_dev / rows_max (optional): the launch runs over a device-side row list; flops / bytes are given for rows_max
+// rows and are scaled by *rows_dev / rows_max when the profile is collected (the count never visits the host earlier)
+void prof_begin(const char* kernel, double flops, double bytes, hipStream_t st, const int* rows_dev = nullptr, double rows_max = 0.0);
 void prof_end(hipStream_t st);
 
 struct ProfScope {
     hipStream_t st; bool on;
-    ProfScope(const char* kernel, double flops, double bytes, hipStream_t s) : st(s), on(prof_enabled()) {
-        if (on) prof_begin(kernel, flops, bytes, st);
+    ProfScope(const char* kernel, double flops, double bytes, hipStream_t s, const int* rows_dev = nullptr, double rows_max = 0.0)
+        : st(s), on(prof_enabled()) {
+        if (on) prof_begin(kernel, flops, bytes, st, rows_dev, rows_max);
     }
     ~ProfScope() { if (on) prof_end(st); }
 };

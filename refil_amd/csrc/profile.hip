@@ -11,14 +11,14 @@
 
 namespace refil {
 
-struct Rec { const char* name; double flops, bytes; hipEvent_t e0, e1; };
+struct Rec { const char* name; double flops, bytes; hipEvent_t e0, e1; const int* rows_dev; double rows_max; };
 static bool g_on = false;
 static std::vector<Rec> g_recs;
 
 bool prof_enabled() { return g_on; }
 
-void prof_begin(const char* kernel, double flops, double bytes, hipStream_t st) {
-    Rec r{kernel, flops, bytes, nullptr, nullptr};
+void prof_begin(const char* kernel, double flops, double bytes, hipStream_t st, const int* rows_dev, double rows_max) {
+    Rec r{kernel, flops, bytes, nullptr, nullptr, rows_dev, rows_max};
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
     hipEventRecord(r.e0, st);
     g_recs.push_back(r);
@@ -48,7 +48,13 @@ extern "C" int refil_profile_collect(refil_profile_entry* out, int max_entries) 
         if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { (void)hipGetLastError(); continue; }
         auto& e = agg[r.name];
         if (e.launches == 0) { memset(&e, 0, sizeof(e)); strncpy(e.name, r.name, sizeof(e.name) - 1); }
-        e.launches += 1; e.total_ms += ms; e.flops += r.flops; e.bytes += r.bytes;
+        double scale = 1.0;
+        if (r.rows_dev && r.rows_max > 0.0) {       // row-list launch: executed work = (live rows / bound) of the dense count
+            int n = 0;
+            if (hipMemcpy(&n, r.rows_dev, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) scale = n / r.rows_max;
+            else (void)hipGetLastError();
+        }
+        e.launches += 1; e.total_ms += ms; e.flops += scale * r.flops; e.bytes += scale * r.bytes;
     }
     int n = 0;
     for (auto& kv : agg) {

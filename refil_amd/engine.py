@@ -45,7 +45,9 @@ class Workspace:
     def get(self, nbytes: int) -> torch.Tensor:
         if self.buf is None or self.buf.numel() < nbytes:
             self.buf = None
-            self.buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            # zeroed once: rows the step skips (padded entities, steps after an episode's end) are never written, and
+            # whatever they hold is multiplied by exact zeros downstream -- it has to be finite
+            self.buf = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
         return self.buf
 
     def ptr_size(self, nbytes: int):

@@ -97,11 +97,11 @@ class QLearner:
             return None
         bits = th.bernoulli(p, generator=self.generator).to(th.uint8).reshape(B, ne)
         if self._bits_host is None or self._bits_host[0][0].shape != bits.shape:
-            self._bits_host = [(th.empty_like(bits).pin_memory(), th.cuda.Event()) for _ in range(4)]
+            self._bits_host = [(th.empty_like(bits).pin_memory(), th.cuda.Event()) for _ in range(16)]
             self._bits_slot = 0
         host, ev = self._bits_host[self._bits_slot]
         self._bits_slot = (self._bits_slot + 1) % len(self._bits_host)
-        ev.synchronize()                       # no-op unless the copy issued 4 steps ago is still pending
+        ev.synchronize()                       # no-op unless the copy issued 16 steps ago is still pending
         host.copy_(bits)
         dev = host.to(device, non_blocking=True)
         ev.record()

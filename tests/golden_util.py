@@ -74,6 +74,25 @@ def load_traj(name):
             "stats": [{kk[len(f"stat{k}."):]: float(z[kk]) for kk in z.files if kk.startswith(f"stat{k}.")} for k in range(n)]}
 
 
+def t_last_of(batch):
+    """[B] last step any loss term of the episode depends on: 1 + the last t < T with mask[b,t] != 0
+    (mask = filled * (1 - terminated[t-1]), q_learner.py:68-72); -1 if none. Outputs of later steps cannot influence
+    the training step and are unspecified in the HIP path (it skips them)."""
+    filled = batch["filled"][:, :-1, 0].float()
+    term = batch["terminated"][:, :-1, 0].float()
+    mask = filled.clone()
+    mask[:, 1:] = mask[:, 1:] * (1 - term[:, :-1])
+    T = mask.shape[1]
+    idx = torch.arange(1, T + 1)[None].expand_as(mask)
+    return torch.where(mask != 0, idx, torch.zeros_like(idx) - 1).max(dim=1)[0]
+
+
+def live_steps(batch):
+    """bool [B, T1]: steps t <= t_last[b]"""
+    T1 = batch["filled"].shape[1]
+    return torch.arange(T1)[None] <= t_last_of(batch)[:, None]
+
+
 def rel_err(a, b):
     a = torch.as_tensor(a, dtype=torch.float64)
     b = torch.as_tensor(b, dtype=torch.float64)

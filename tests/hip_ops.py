@@ -13,7 +13,7 @@ def _stream():
 
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, flags=0, bias=None, aux=None, rowmask=None, rowmask_mod=0,
          colsum=None, partial=None, batch=1, splits=1, sA=0, sB=0, sC=0, sBias=0, sColsum=0,
-         a_map=(0, 0, 0), b_map=(0, 0, 0), c_map=(0, 0, 0)):
+         a_map=(0, 0, 0), b_map=(0, 0, 0), c_map=(0, 0, 0), row_index=None, row_count=None):
     d = GemmDesc()
     d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C_out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
@@ -25,6 +25,8 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, flags=0, bias=None, aux=None, rowm
     d.sA, d.sB, d.sC, d.sBias, d.sColsum = sA, sB, sC, sBias, sColsum
     d.a_map, d.b_map, d.c_map = RowMap(*a_map), RowMap(*b_map), RowMap(*c_map)
     d.rowmask_mod, d.batch, d.splits, d.flags = rowmask_mod, batch, splits, flags
+    if row_index is not None:
+        d.row_index, d.row_count = row_index.data_ptr(), row_count.data_ptr()
     check(lib().refil_gemm(C.byref(d), _stream()), "refil_gemm")
 
 
@@ -42,6 +44,14 @@ def attn_desc(Q, K, V, ldq, ldkv, R, T1, ne, na, heads, hd, variants, obs_mask=N
     d.ent_mask0 = ent_mask0.data_ptr() if ent_mask0 is not None else None
     d.group_bits = group_bits.data_ptr() if group_bits is not None else None
     d._keep = [Q, K, V, obs_mask, ent_mask, ent_mask0, group_bits]   # the desc only holds raw addresses
+    return d
+
+
+def attn_skip(d, t_last=None, kv_dead=None, q_dead=None):
+    d._keep += [t_last, kv_dead, q_dead]
+    d.t_last = t_last.data_ptr() if t_last is not None else None
+    d.kv_dead = kv_dead.data_ptr() if kv_dead is not None else None
+    d.q_dead = q_dead.data_ptr() if q_dead is not None else None
     return d
 
 
@@ -79,6 +89,12 @@ def gru_desc(gi, hsx, w_hh, b_hh, NR, T1, na, H=64, saves=None, dhs=None, dgi=No
         d.dhs, d.dgi, d.dgh = dhs.data_ptr(), dgi.data_ptr(), dgh.data_ptr()
     d.NR, d.T1, d.na, d.H = NR, T1, na, H
     d._keep = [gi, hsx, w_hh, b_hh, saves, dhs, dgi, dgh]
+    return d
+
+
+def gru_skip(d, t_last, B):
+    d._keep.append(t_last)
+    d.t_last, d.B = t_last.data_ptr(), B
     return d
 
 

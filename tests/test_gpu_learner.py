@@ -6,7 +6,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from golden_util import CASES, GM_CASES, GM_TRAIN_CASES, POOL_CASES, TRAJ_CASES, load, load_traj, rel_err
+from golden_util import CASES, GM_CASES, GM_TRAIN_CASES, POOL_CASES, TRAJ_CASES, live_steps, load, load_traj, rel_err
 from oracle import refil_oracle as orc
 
 DEV = "cuda"
@@ -67,17 +67,21 @@ def test_learner_step_matches_reference_golden(name):
     r = run_hip_step(cfg, g["batch"], g["bits"], g["agent"], g["mixer"], g["tagent"], g["tmixer"])
     o, st = r["out"], r["stats"]
     B, T = case["B"], case["T"]
-    assert rel_err(o["q"], z["q"]) < TOL_FWD
-    assert rel_err(o["chosen_q"][0], z["chosen_q_real"]) < TOL_FWD
-    assert rel_err(o["target_max_q"], z["target_max_q"]) < TOL_FWD
-    assert rel_err(o["q_tot"], z["q_tot"][..., 0]) < TOL_FWD
-    assert rel_err(o["target_q_tot"], z["target_q_tot"][..., 0]) < TOL_FWD
+    # (outputs of steps after an episode's last contributing step are unspecified when the row lists are active)
+    live = live_steps(g["batch"])
+    lt, lt1 = live[:, :-1], live[:, 1:]
+    zt = lambda k: torch.from_numpy(z[k])
+    assert rel_err(o["q"] * live[None, :, :, None, None], zt("q") * live[None, :, :, None, None]) < TOL_FWD
+    assert rel_err(o["chosen_q"][0] * lt[:, :, None], zt("chosen_q_real") * lt[:, :, None]) < TOL_FWD
+    assert rel_err(o["target_max_q"] * lt1[:, :, None], zt("target_max_q") * lt1[:, :, None]) < TOL_FWD
+    assert rel_err(o["q_tot"] * lt, zt("q_tot")[..., 0] * lt) < TOL_FWD
+    assert rel_err(o["target_q_tot"] * lt1, zt("target_q_tot")[..., 0] * lt1) < TOL_FWD
     msum = st[0].item()
     q_loss = st[1].item() / msum
     if cfg.imagine:
         caq_im = torch.cat([o["chosen_q"][1], o["chosen_q"][2]], dim=2)
-        assert rel_err(caq_im, z["chosen_q_imagine"]) < TOL_FWD
-        assert rel_err(o["q_tot_imagine"], z["q_tot_imagine"][..., 0]) < TOL_FWD
+        assert rel_err(caq_im * lt[:, :, None], zt("chosen_q_imagine") * lt[:, :, None]) < TOL_FWD
+        assert rel_err(o["q_tot_imagine"] * lt, zt("q_tot_imagine")[..., 0] * lt) < TOL_FWD
         im_loss = st[2].item() / msum
         assert abs(im_loss - float(z["stat.im_loss"])) < TOL_FWD * abs(float(z["stat.im_loss"]))
         loss = (1 - cfg.lmbda) * q_loss + cfg.lmbda * im_loss
@@ -164,24 +168,30 @@ def test_production_size_step_matches_oracle(which):
                                                                   d=kw["d"], h=kw["d"])
     r = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, profile=True)
     names = " ".join(r["kernels"])
-    for sym in ("gemm_wres_kernel", "gemm_dw_stream_kernel", "attn_fwd_mfma", "attn_bwd_mfma", "gru_fwd_kernel", "gru_bwd_kernel"):
+    for sym in ("gemm_wres_kernel", "gemm_dw_stream_kernel", "attn_fwd_mfma", "attn_bwd_mfma", "gru_fwd_kernel", "gru_bwd_kernel",
+                "lists_kernels", ",1>"):        # ",1>": the row-list instantiations of the GEMM kernels
         assert sym in names, f"{which}: {sym} did not run (kernels: {sorted(r['kernels'])})"
     assert "attn_fwd_kernel" not in r["kernels"] and "attn_bwd_kernel" not in r["kernels"], "VALU attention fallback taken"
     a2, m2 = dict(agent), dict(mixer)
     torch.set_num_threads(min(16, torch.get_num_threads()))
     out, grads, gnorm = orc.train_step(cfg, a2, m2, tagent, tmixer, batch, bits)
     o, st = r["out"], r["stats"]
-    assert rel_err(o["q"], out.q.detach()) < TOL_FWD
-    assert rel_err(o["chosen_q"], out.chosen_q.detach()) < TOL_FWD
-    assert rel_err(o["target_max_q"], out.target_max_q) < TOL_FWD
-    assert rel_err(o["q_tot"], out.q_tot.detach()[..., 0]) < TOL_FWD
-    assert rel_err(o["target_q_tot"], out.target_q_tot[..., 0]) < TOL_FWD
-    assert rel_err(o["targets"], out.targets[..., 0]) < TOL_FWD
+    # steps after an episode's last contributing step are skipped by the HIP path (their outputs are unspecified):
+    # compare what can influence the loss. live[b,t]: t <= t_last[b]; step-(t+1) quantities need live[b,t+1].
+    live = live_steps(batch)
+    assert 0.5 < live.float().mean().item() < 1.0, "the synthetic batch should contain finished episodes"
+    lt, lt1 = live[:, :-1], live[:, 1:]
+    assert rel_err(o["q"] * live[None, :, :, None, None], out.q.detach() * live[None, :, :, None, None]) < TOL_FWD
+    assert rel_err(o["chosen_q"] * lt[None, :, :, None], out.chosen_q.detach() * lt[None, :, :, None]) < TOL_FWD
+    assert rel_err(o["target_max_q"] * lt1[:, :, None], out.target_max_q * lt1[:, :, None]) < TOL_FWD
+    assert rel_err(o["q_tot"] * lt, out.q_tot.detach()[..., 0] * lt) < TOL_FWD
+    assert rel_err(o["target_q_tot"] * lt1, out.target_q_tot[..., 0] * lt1) < TOL_FWD
+    assert rel_err(o["targets"] * lt1, out.targets[..., 0] * lt1) < TOL_FWD
     msum = st[0].item()
     assert abs(msum - out.mask.sum().item()) < 1e-6 * msum
     assert abs(st[1].item() / msum - out.q_loss.item()) < TOL_FWD * out.q_loss.item()
     if kw["imagine"]:
-        assert rel_err(o["q_tot_imagine"], out.q_tot_imagine.detach()[..., 0]) < TOL_FWD
+        assert rel_err(o["q_tot_imagine"] * lt, out.q_tot_imagine.detach()[..., 0] * lt) < TOL_FWD
         assert abs(st[2].item() / msum - out.im_loss.item()) < TOL_FWD * out.im_loss.item()
     assert abs(r["grad_norm"] - gnorm) < TOL_GRAD * gnorm
     gmax = max(v.abs().max().item() for v in grads.values())
@@ -236,6 +246,38 @@ def test_trajectory_matches_reference_golden(name):
             for k, v in cur.items():
                 ref_sq = nxt["sq"][which + "." + k]
                 assert rel_err(v.cpu(), ref_sq) < 2e-3 or ref_sq.abs().max() < 1e-12, (s, which, k)
+
+
+@pytest.mark.parametrize("B,T,ne,d,imagine", [(8, 20, 32, 128, True), (16, 40, 16, 64, True), (6, 30, 16, 128, False)])
+def test_row_skipping_equals_dense_schedule(B, T, ne, d, imagine):
+    """Rows that cannot influence the loss (padded entities, steps after an episode's end) are skipped (row lists,
+    learner.hip: Ctx::lists). Against the dense schedule (REFIL_DENSE=1): every output that can influence the loss is
+    bit-identical, the gradients agree up to the summation order of the weight-gradient reductions."""
+    import os
+    cfg, batch, bits, agent, mixer, tagent, tmixer = _oracle_case(B, T, ne, seed=77, imagine=imagine, d=d, h=d)
+    res = {}
+    for flag in ("0", "1"):
+        os.environ["REFIL_DENSE"] = flag
+        try:
+            res[flag] = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, profile=True)
+        finally:
+            os.environ.pop("REFIL_DENSE", None)
+    a, b = res["0"], res["1"]
+    assert "lists_kernels" in a["kernels"] and "lists_kernels" not in b["kernels"]
+    live = live_steps(batch)
+    lt, lt1 = live[:, :-1], live[:, 1:]
+    assert torch.equal(a["out"]["q"][:, live], b["out"]["q"][:, live])
+    assert torch.equal(a["out"]["chosen_q"][:, lt], b["out"]["chosen_q"][:, lt])
+    assert torch.equal(a["out"]["q_tot"][lt], b["out"]["q_tot"][lt])
+    assert torch.equal(a["out"]["target_q_tot"][lt1], b["out"]["target_q_tot"][lt1])
+    assert torch.equal(a["out"]["targets"][lt1], b["out"]["targets"][lt1])
+    for k in range(6):
+        assert abs(a["stats"][k].item() - b["stats"][k].item()) <= 1e-6 * abs(b["stats"][k].item()), k
+    gmax = max(v.abs().max().item() for v in b["grads"].values())
+    for k, gv in b["grads"].items():
+        assert (a["grads"][k] - gv).abs().max().item() < 2e-6 * gmax, k
+        assert (a["post"][k] - b["post"][k]).abs().max().item() < 1e-6, k
+    assert abs(a["grad_norm"] - b["grad_norm"]) < 1e-6 * b["grad_norm"]
 
 
 def test_time_truncated_strided_batch_equals_contiguous():
@@ -358,8 +400,9 @@ def test_config_matrix_matches_oracle(what):
     a2, m2 = dict(agent), dict(mixer)
     out, grads, gnorm = orc.train_step(cfg, a2, m2, tagent, tmixer, batch, bits)
     o, st = r["out"], r["stats"]
-    assert rel_err(o["chosen_q"], out.chosen_q.detach()) < TOL_FWD
-    assert rel_err(o["q_tot"], out.q_tot.detach()[..., 0]) < TOL_FWD
+    lt = live_steps(batch)[:, :-1]
+    assert rel_err(o["chosen_q"] * lt[None, :, :, None], out.chosen_q.detach() * lt[None, :, :, None]) < TOL_FWD
+    assert rel_err(o["q_tot"] * lt, out.q_tot.detach()[..., 0] * lt) < TOL_FWD
     msum = st[0].item()
     assert abs(st[1].item() / msum - out.q_loss.item()) < TOL_FWD * out.q_loss.item()
     assert abs(r["grad_norm"] - gnorm) < TOL_GRAD * gnorm
@@ -382,8 +425,10 @@ def test_algebraic_restructuring_equals_plain_path_at_mid_size():
         finally:
             os.environ.pop("REFIL_PRESUM", None)
     a, b = res["1"], res["0"]
+    live = live_steps(batch)
+    lm = {"chosen_q": live[None, :, :-1, None], "q_tot": live[:, :-1], "q_tot_imagine": live[:, :-1], "target_q_tot": live[:, 1:]}
     for k in ("chosen_q", "q_tot", "q_tot_imagine", "target_q_tot"):
-        assert rel_err(a["out"][k], b["out"][k]) < 2e-5, k
+        assert rel_err(a["out"][k] * lm[k], b["out"][k] * lm[k]) < 2e-5, k
     assert abs(a["grad_norm"] - b["grad_norm"]) < 2e-5 * b["grad_norm"]
     gmax = max(v.abs().max().item() for v in b["grads"].values())
     for k, gv in b["grads"].items():

@@ -366,3 +366,185 @@ def test_gru_forward_backward(GB, T1, na):
     hsx2[:, 0] = h0.to(DEV)
     hip_ops.gru_forward(hip_ops.gru_desc(gi, hsx2, whh, bhh, NR, T1, na))
     assert torch.equal(hsx2[:, 1:], hsx[:, 1:])
+
+
+# ------------------------------------------------------------------------------------------------
+# row lists (refil_gemm_desc.row_index / row_count) and row skipping (attention / GRU t_last, dead rows)
+# ------------------------------------------------------------------------------------------------
+def _row_list(M, frac, seed, trash):
+    """sorted random subset of [0, M) as a device list padded to a multiple of 64 with `trash`, and its device count"""
+    g = torch.Generator().manual_seed(seed)
+    keep = torch.nonzero(torch.rand(M, generator=g) < frac).flatten().to(torch.int32)
+    n = keep.numel()
+    padded = torch.full(((n + 63) // 64 * 64 + 64,), trash, dtype=torch.int32)
+    padded[:n] = keep
+    return keep.long(), padded.to(DEV), torch.tensor([n], dtype=torch.int32, device=DEV)
+
+
+@pytest.mark.parametrize("M,N,K,batch,frac", [(4096, 128, 84, 1, 0.45), (6400, 256, 128, 2, 0.6), (2048, 64, 52, 1, 0.3),
+                                              (4096, 512, 84, 1, 0.0), (4096, 128, 64, 1, 1.0)])
+def test_gemm_wres_forward_row_list(M, N, K, batch, frac):
+    """x W^T over a device-side row list: listed rows are computed, every other row of C stays untouched."""
+    import hip_ops
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M + 8, batch * K)
+    W = torch.randn(batch, N, K) / math.sqrt(K)
+    b = torch.randn(batch, N)
+    keep, lst, cnt = _row_list(M, frac, M + N, trash=M)
+    ref = torch.full((batch, M + 8, N), 7.0)
+    for n in range(batch):
+        ref[n, keep] = torch.relu(x[keep, n * K:(n + 1) * K] @ W[n].t() + b[n])
+    y = torch.full((batch, M + 8, N), 7.0, device=DEV)
+    hip_ops.gemm(x.to(DEV), W.to(DEV), y, M, N, K, batch * K, K, N, flags=GEMM_RELU, bias=b.to(DEV), batch=batch, sA=K,
+                 sB=N * K, sC=(M + 8) * N, sBias=N, row_index=lst, row_count=cnt)
+    _close(y[:, :M], ref[:, :M], what="wres forward (row list)")
+    assert torch.equal(y[:, :M].cpu() == 7.0, ref[:, :M] == 7.0), "rows outside the list were written"
+    # agent-row list on top of the agent-row map (the Q projection)
+    na, ne = 4, 8
+    R = M // na
+    xe = torch.randn(R * ne + 8, K)
+    keep2, lst2, cnt2 = _row_list(R * na, max(frac, 0.2), M + 1, trash=R * na)
+    ref2 = torch.zeros(R * na + 8, N)
+    ref2[keep2] = xe[:R * ne].view(R, ne, K)[:, :na].reshape(R * na, K)[keep2] @ W[0].t()
+    y2 = torch.zeros(R * na + 8, N, device=DEV)
+    hip_ops.gemm(xe.to(DEV), W[0].contiguous().to(DEV), y2, R * na, N, K, K, K, N, a_map=(na, ne, 0), row_index=lst2, row_count=cnt2)
+    _close(y2[:R * na], ref2[:R * na], what="wres forward (row list + row map)")
+
+
+@pytest.mark.parametrize("M,N,K,frac", [(4096, 128, 256, 0.45), (2048, 64, 128, 0.5), (4096, 128, 128, 0.7)])
+def test_gemm_wres_dx_relu_bwd_row_list(M, N, K, frac):
+    import hip_ops
+    torch.manual_seed(M + N + K + 5)
+    na, ne = 4, 8
+    R = M // ne
+    dy = torch.randn(M + 8, K)
+    W = torch.randn(K, N) / math.sqrt(K)
+    x1 = torch.randn(M + 8, N)
+    dq = torch.randn(R * na + 8, K)
+    Wq = torch.randn(K, N) / math.sqrt(K)
+    keep, lst, cnt = _row_list(M, frac, M + K, trash=M)
+    ref = torch.full((M + 8, N), 3.0)
+    ref[keep] = (dy[keep] @ W) * (x1[keep] > 0)
+    dx = torch.full((M + 8, N), 3.0, device=DEV)
+    x1d = x1.to(DEV)
+    hip_ops.gemm(dy.to(DEV), W.to(DEV), dx, M, N, K, K, N, N, flags=GEMM_B_OUTC | GEMM_RELU_BWD, aux=x1d, row_index=lst, row_count=cnt)
+    _close(dx[:M], ref[:M], what="wres dx relu-bwd (row list)")
+    if R * na >= 2048:                 # accumulate the query part on listed agent rows (scatter through c_map)
+        ent = torch.zeros(M, dtype=torch.bool); ent[keep] = True
+        ag = ent.view(R, ne)[:, :na].reshape(-1)                     # listed agents = agents whose entity row is listed
+        keepa = torch.nonzero(ag).flatten()
+        n = keepa.numel()
+        lsta = torch.full(((n + 63) // 64 * 64 + 64,), R * na, dtype=torch.int32); lsta[:n] = keepa.to(torch.int32)
+        add = torch.zeros(R, ne, N)
+        add[:, :na] = ((dq[:R * na] @ Wq) * (x1[:M].view(R, ne, N)[:, :na].reshape(R * na, N) > 0)).view(R, na, N) * ag.view(R, na, 1)
+        hip_ops.gemm(dq.to(DEV), Wq.to(DEV), dx, R * na, N, K, K, N, N, flags=GEMM_B_OUTC | GEMM_RELU_BWD | GEMM_ACCUM, aux=x1d,
+                     c_map=(na, ne, 0), row_index=lsta.to(DEV), row_count=torch.tensor([n], dtype=torch.int32, device=DEV))
+        _close(dx[:M], ref[:M] + add.view(M, N), what="wres dx accumulate (row list + c_map)")
+
+
+@pytest.mark.parametrize("Rr,N,K,splits,frac", [(40000, 256, 128, 64, 0.45), (20000, 64, 52, 32, 0.6), (8192, 512, 84, 16, 0.3),
+                                                (9000, 128, 128, 8, 0.0)])
+def test_gemm_dw_stream_row_list(Rr, N, K, splits, frac):
+    """dW = dy^T x and db = colsum(dy) over the listed rows only (everything else may hold garbage)."""
+    import hip_ops
+    torch.manual_seed(Rr + N + K)
+    dy = torch.randn(Rr + 8, N)
+    x = torch.randn(Rr + 8, K)
+    keep, lst, cnt = _row_list(Rr, frac, Rr + N, trash=Rr)
+    ref_w = dy[keep].double().t() @ x[keep].double()
+    ref_b = dy[keep].double().sum(0)
+    dead = torch.ones(Rr + 8, dtype=torch.bool); dead[keep] = False
+    dyd, xd = dy.clone(), x.clone()
+    dyd[dead] = float("nan"); xd[dead] = float("nan")              # rows outside the list must never be touched
+    dW = torch.full((N, K), float("nan"), device=DEV)
+    db = torch.full((N,), float("nan"), device=DEV)
+    partial = torch.zeros(splits * (N * K + N), device=DEV)
+    hip_ops.gemm(dyd.to(DEV), xd.to(DEV), dW, N, K, Rr, N, K, K, flags=GEMM_A_OUTC | GEMM_B_OUTC | GEMM_COLSUM_A, colsum=db,
+                 partial=partial, splits=splits, row_index=lst, row_count=cnt)
+    scale = max(ref_w.abs().max().item(), 1.0)
+    assert (dW.cpu().double() - ref_w).abs().max().item() <= 5e-5 * scale
+    assert (db.cpu().double() - ref_b).abs().max().item() <= 5e-5 * max(ref_b.abs().max().item(), 1.0)
+
+
+def test_gemm_row_list_rejected_by_the_tiled_kernel():
+    import hip_ops
+    x = torch.randn(100, 16, device=DEV); W = torch.randn(8, 16, device=DEV); y = torch.zeros(100, 8, device=DEV)
+    lst = torch.arange(128, dtype=torch.int32, device=DEV); cnt = torch.tensor([100], dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError, match="row lists"):
+        hip_ops.gemm(x, W, y, 100, 8, 16, 16, 16, 8, row_index=lst, row_count=cnt)
+
+
+def test_attention_row_skipping():
+    """t_last leaves the rows of finished episodes untouched; dead K/V and Q rows enter as zeros whatever they hold."""
+    import hip_ops
+    torch.manual_seed(5)
+    B, T1, ne, na, heads, hd = 3, 6, 32, 16, 4, 32
+    R, w = B * T1, heads * hd
+    em = torch.zeros(B, T1, ne, dtype=torch.uint8)
+    em[:, :, 10:16] = 1; em[:, :, 25:] = 1                          # padded agents / enemies
+    Q, K, V = torch.randn(R * na, w), torch.randn(R * ne, 2 * w), None
+    t_last = torch.tensor([5, 2, -1], dtype=torch.int32)
+    kv_dead = em.reshape(R * ne).clone()
+    q_dead = em[:, :, :na].reshape(R * na).clone()
+    Kd, Qd = K.clone(), Q.clone()
+    Kd[kv_dead.bool()] = float("nan"); Qd[q_dead.bool()] = float("nan")       # garbage in the skipped producers' rows
+    Kz, Qz = K.clone(), Q.clone()
+    Kz[kv_dead.bool()] = 0; Qz[q_dead.bool()] = 0
+    dO = torch.randn(R * na, w)
+    outs = []
+    for (Qx, Kx, skip) in ((Qz, Kz, False), (Qd, Kd, True)):
+        Qg, Kg = Qx.to(DEV), Kx.to(DEV)
+        d = hip_ops.attn_desc(Qg, Kg, Kg[:, w:], w, 2 * w, R, T1, ne, na, heads, hd, [MASK_ENTITY], ent_mask=em.view(R, ne).to(DEV))
+        if skip:
+            hip_ops.attn_skip(d, t_last.to(DEV), kv_dead.to(DEV), q_dead.to(DEV))
+        O = torch.full((R * na, w), 5.0, device=DEV)
+        hip_ops.attn_forward(d, O, w, R * na * w)
+        dQ = torch.full((R * na, w), 5.0, device=DEV); dKV = torch.full((R * ne, 2 * w), 5.0, device=DEV)
+        hip_ops.attn_backward(d, dO.to(DEV), w, R * na * w, dQ, dKV, dKV[:, w:])
+        outs.append((O.cpu().view(B, T1, na, w), dQ.cpu().view(B, T1, na, w), dKV.cpu().view(B, T1, ne, 2 * w)))
+    (O0, dQ0, dK0), (O1, dQ1, dK1) = outs
+    for b in range(B):
+        tl = int(t_last[b])
+        live_q = ~em[b, :tl + 1, :na].bool()
+        assert torch.equal(O1[b, :tl + 1][live_q], O0[b, :tl + 1][live_q])
+        assert torch.equal(dQ1[b, :tl + 1][live_q], dQ0[b, :tl + 1][live_q])
+        assert torch.equal(dK1[b, :tl + 1], dK0[b, :tl + 1])
+        assert torch.isfinite(O1[b, :tl + 1]).all() and torch.isfinite(dK1[b, :tl + 1]).all()
+        assert (O1[b, tl + 1:] == 5.0).all() and (dK1[b, tl + 1:] == 5.0).all() and (dQ1[b, tl + 1:] == 5.0).all()
+
+
+def test_gru_time_bounds():
+    """t_last: the recurrence of an episode stops after its last contributing step; BPTT starts there and zero-fills."""
+    import hip_ops
+    torch.manual_seed(11)
+    G, B, T1, na, H = 2, 3, 7, 16, 64
+    GB, NR = G * B, G * B * na
+    t_last = torch.tensor([6, 3, 0], dtype=torch.int32)
+    gi = torch.randn(GB * T1 * na, 3 * H, device=DEV)
+    whh, bhh = torch.randn(3 * H, H, device=DEV) / 8, torch.randn(3 * H, device=DEV) / 8
+    h0 = torch.randn(GB, na, H, device=DEV) / 2
+    dhs = torch.randn(GB, T1, na, H, device=DEV)
+    for gb in range(GB):
+        dhs[gb, int(t_last[gb % B]) + 1:] = 0                       # no loss term reaches the skipped steps
+    res = []
+    for skip in (False, True):
+        hsx = torch.full((GB, T1 + 1, na, H), 9.0, device=DEV); hsx[:, 0] = h0
+        saves = [torch.full((GB * T1 * na, H), 9.0, device=DEV) for _ in range(4)]
+        d = hip_ops.gru_desc(gi, hsx, whh, bhh, NR, T1, na, saves=saves)
+        if skip:
+            hip_ops.gru_skip(d, t_last.to(DEV), B)
+        hip_ops.gru_forward(d)
+        dgi = torch.full((GB * T1 * na, 3 * H), 9.0, device=DEV); dgh = torch.full((GB * T1 * na, 3 * H), 9.0, device=DEV)
+        d = hip_ops.gru_desc(gi, hsx, whh, bhh, NR, T1, na, saves=saves, dhs=dhs, dgi=dgi, dgh=dgh)
+        if skip:
+            hip_ops.gru_skip(d, t_last.to(DEV), B)
+        hip_ops.gru_backward(d)
+        res.append((hsx.cpu(), dgi.cpu().view(GB, T1, na, 3 * H), dgh.cpu().view(GB, T1, na, 3 * H)))
+    (h_full, gi_full, gh_full), (h_skip, gi_skip, gh_skip) = res
+    for gb in range(GB):
+        tl = int(t_last[gb % B])
+        assert torch.equal(h_skip[gb, :tl + 2], h_full[gb, :tl + 2])
+        assert (h_skip[gb, tl + 2:] == 9.0).all()
+        assert torch.equal(gi_skip[gb, :tl + 1], gi_full[gb, :tl + 1]) and torch.equal(gh_skip[gb, :tl + 1], gh_full[gb, :tl + 1])
+        assert (gi_skip[gb, tl + 1:] == 0).all() and (gh_skip[gb, tl + 1:] == 0).all()
+        assert gi_full[gb, tl + 1:].abs().max().item() == 0.0 if tl + 1 < T1 else True
