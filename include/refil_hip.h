@@ -226,7 +226,7 @@ typedef struct refil_gemm_desc {
      * the rows of A and C (and aux) and M is only the upper bound of *row_count; for dY^T X (A_OUTC|B_OUTC) it addresses
      * the reduction rows of A and B and K is the upper bound. The count never visits the host, so rows that cannot
      * influence a training step (padded entities, steps after an episode's end) are skipped without a synchronisation.
-     * The list must be padded up to a multiple of 32 entries with the index of a scratch row that may be read (finite
+     * The list must be padded up to a multiple of 64 entries plus 128 with the index of a scratch row that may be read (finite
      * values) and overwritten. Supported by the weight-resident (bound M >= 256, N % 32 == 0, K <= 128, or <= 256 with
      * RELU_BWD; no rowmask / bias2) and the streaming-dW kernels (splits >= 2); other shapes return an error. */
     const int32_t* row_index; const int32_t* row_count;

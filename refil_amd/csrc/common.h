@@ -45,13 +45,23 @@ __host__ __device__ inline long cdivl(long a, long b) { return (a + b - 1) / b; 
 
 // physical memory row of logical row r:  (r / grp) * gstride + (r % grp) + off.
 // Branch-free on purpose (it sits in the GEMM load path): the identity is encoded as grp = 2^30.
+// The quotient comes from a multiplication by magic = ceil(2^40 / grp) (exact for r * grp < 2^40, checked where the
+// map is built): an integer division costs ~20 VALU instructions per lane, and the row-list kernels evaluate a map
+// per lane per step right beside their MFMAs.
 struct RowMap {
     int grp, gstride, off;
+    unsigned long long magic;
     __host__ __device__ inline long operator()(int r) const {
-        const int q = r / grp;
+        const int q = (int)(((unsigned long long)(unsigned)r * magic) >> 40);
         return (long)q * gstride + (r - q * grp) + off;
     }
 };
+// identity (grp == 0) is encoded as grp = 2^30. rows = an upper bound of the logical row numbers the map will see.
+inline RowMap make_rowmap(int grp, int gstride, int off) {
+    if (!grp) { grp = 1 << 30; gstride = 0; off = 0; }
+    return RowMap{grp, gstride, off, ((1ull << 40) + (unsigned long long)grp - 1) / (unsigned long long)grp};
+}
+inline bool rowmap_exact(int grp, long rows) { return !grp || ((long)grp <= (1L << 20) && rows * (long)grp < (1L << 40)); }
 
 __device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // hardware-rate versions for the per-step GRU gate math (v_exp_f32 + v_rcp_f32, ~1 ulp each; both saturate

@@ -445,12 +445,18 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
                 "refil_gemm: bias2 needs rowscale / rowscale_mod and a plain x W^T product");
     REFIL_CHECK(!d.rowmask || d.rowmask_mod > 0, "refil_gemm: rowmask_mod must be > 0");
     {
+        const long rows = max((long)max(d.M, d.N), (long)d.K) + 64;
+        REFIL_CHECK(rowmap_exact(d.a_map.grp, rows) && rowmap_exact(d.b_map.grp, rows) && rowmap_exact(d.c_map.grp, rows),
+                    "refil_gemm: row map group too large for %ld rows", rows);
+    }
+    {
         const long rows = d.c_map.grp ? ((long)(d.M - 1) / d.c_map.grp) * d.c_map.gstride + d.c_map.grp + d.c_map.off : d.M;
         REFIL_CHECK(rows * (long)(d.splits > 1 ? d.N : d.ldc) < (1L << 32), "refil_gemm: C exceeds 2^32 elements per batch");
     }
     static const bool wres = []() { const char* e = getenv("REFIL_GEMM_WRES"); return !(e && e[0] == '0'); }();
     if (wres && gemm_wres_eligible(d)) return gemm_wres_launch(d, st);
-    REFIL_CHECK(!d.row_index || (dw_stream_on() && gemm_dw_stream_eligible(d)),
+    const bool dw4 = gemm_dw4_enabled() && gemm_dw4_eligible(d);
+    REFIL_CHECK(!d.row_index || dw4 || (dw_stream_on() && gemm_dw_stream_eligible(d)),
                 "refil_gemm: row lists need the weight-resident or the streaming-dW kernel (M=%d N=%d K=%d flags=0x%x splits=%d)",
                 d.M, d.N, d.K, d.flags, d.splits);
     GemmK k;
@@ -458,7 +464,7 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
     k.colsum = d.colsum; k.partial = d.partial;
     k.M = d.M; k.N = d.N; k.K = d.K; k.lda = d.lda; k.ldb = d.ldb; k.ldc = d.ldc;
     k.sA = d.sA; k.sB = d.sB; k.sC = d.sC; k.sBias = d.sBias; k.sColsum = d.sColsum;
-    auto mk = [](const refil_rowmap& m) { return m.grp ? RowMap{m.grp, m.gstride, m.off} : RowMap{1 << 30, 0, 0}; };
+    auto mk = [](const refil_rowmap& m) { return make_rowmap(m.grp, m.gstride, m.off); };
     k.amap = mk(d.a_map); k.bmap = mk(d.b_map); k.cmap = mk(d.c_map);
     k.rowmask_mod = d.rowmask_mod; k.batch = d.batch; k.splits = d.splits; k.flags = d.flags;
     k.bias2 = d.bias2; k.rowscale = d.rowscale; k.rowscale_mod = d.rowscale_mod > 0 ? d.rowscale_mod : 1;
@@ -478,7 +484,8 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
     const long big_blocks = (long)cdiv(d.M, 256) * cdiv(d.N, 128) * d.batch * d.splits;
     const bool dw_stream = dw_stream_on();
     const bool dw = (d.flags & REFIL_GEMM_A_OUTC) && (d.flags & REFIL_GEMM_B_OUTC) && !(d.flags & (REFIL_GEMM_RELU | REFIL_GEMM_RELU_BWD));
-    if (dw_stream && gemm_dw_stream_eligible(d)) rc = gemm_dw_stream_launch(d, st);
+    if (dw4) rc = gemm_dw4_launch(d, st);
+    else if (dw_stream && gemm_dw_stream_eligible(d)) rc = gemm_dw_stream_launch(d, st);
     else if (dw && d.M <= 32 && d.N > 64) rc = launch_cfg_dw<1, 4, 1, 1>(k, st);
     else if (dw && d.M <= 64 && d.N > 64) rc = launch_cfg_dw<2, 2, 1, 2>(k, st);
     else if (d.N > 64 && d.M >= 8192 && d.K >= 96 && big_tile && big_blocks >= big_min_blocks) rc = launch_cfg<4, 2, 2, 2>(k, st);

@@ -209,7 +209,7 @@ int gemm_dw_stream_launch(const refil_gemm_desc& d, hipStream_t st) {
     DwStreamK k;
     k.A = d.A; k.B = d.B; k.partial = d.partial;
     k.M = d.M; k.N = d.N; k.R = d.K; k.lda = d.lda; k.ldb = d.ldb; k.sA = d.sA; k.sB = d.sB;
-    auto mk = [](const refil_rowmap& m) { return m.grp ? RowMap{m.grp, m.gstride, m.off} : RowMap{1 << 30, 0, 0}; };
+    auto mk = [](const refil_rowmap& m) { return make_rowmap(m.grp, m.gstride, m.off); };
     k.amap = mk(d.a_map); k.bmap = mk(d.b_map);
     k.splits = d.splits; k.batch = d.batch; k.colsum = (d.flags & REFIL_GEMM_COLSUM_A) ? 1 : 0;
     k.ridx = d.row_index; k.rcount = d.row_index ? d.row_count : nullptr;

@@ -1,0 +1,365 @@
+// Weight-gradient GEMM, second generation:  dW[N_out, K_in] = dy[R, N_out]^T x[R, K_in]  (+ db = column sums of dy).
+//
+// gemm_dw.hip showed that for these products (tens of thousands of reduction rows, outputs of at most a few hundred
+// rows / columns) the operands can go from global memory straight into the MFMA operand registers -- the reduction
+// row is the slow index of both, so a plain global_load_dword per lane is coalesced AND already in
+// v_mfma_f32_32x32x2_f32 operand layout. What bounded that kernel was its register-level reuse: a wave owned 2 x 2
+// MFMA tiles, i.e. 4 operand loads per 4 MFMAs, and with 8 waves per CU the vector-memory pipe (256-byte wave loads),
+// not the matrix pipe, set the pace (0.3-0.35 of the fp32 MFMA rate).
+//
+// Here a wave owns TI x TJ tiles (up to 4 x 4 = 128 x 128 outputs, 256 accumulator registers -- gfx950's unified
+// 512-entry register file makes that a one-wave-per-SIMD kernel): 8 operand loads feed 16 MFMAs (1024 matrix-pipe
+// cycles), a quarter of the load traffic per FLOP, and the prefetch ring alone (D steps = D x 1024 cycles) covers
+// the HBM latency, so one wave per SIMD is enough. The four waves of a workgroup work on the SAME output tile and
+// split the rows of the workgroup's range between them; their accumulators are summed through LDS (fixed order:
+// deterministic) so that only ONE partial tile per workgroup goes to memory -- 4 x fewer partial bytes than one per
+// wave. The per-split partials are added up by reduce_partials_kernel (gemm.hip), as before.
+//
+// Operand loads are VECTORS along the output index: a lane fetches the TI (TJ) consecutive columns
+// m0 + TI * (lane % 32) + {0..TI-1} of its row with ONE 4/8/12/16-byte load and spreads them over its TI tiles -- tile i
+// then holds the output rows m0 + TI * k + i, a permutation that is undone for free when the tile is stored (and makes
+// the partial-tile stores 16-byte vectors as well). Two loads per step instead of eight: the 63 vector-memory
+// operations a wave can have in flight (vmcnt) now cover a 12-step prefetch ring instead of 6.
+//
+// Row lists (refil_gemm_desc.row_index): the reduction rows come from a device-side list whose length is read from
+// device memory; the indices travel through their own ring, one period ahead of the operand prefetch.
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+#include "kernels.h"
+#include "profile.h"
+
+namespace refil {
+
+
+constexpr int DW4_PASS = 128;     // accumulator registers summed through LDS per pass (at most 3 writer waves x 128 x 64 x 4 B = 96 KB)
+
+// prefetch ring depth (steps of 2 rows): bounded by the registers of the ring (D * (TI + TJ + 1))
+constexpr int dw4_depth(int ti, int tj) { return ti * tj >= 12 ? 12 : 16; }
+constexpr int dw4_pass(int ti, int tj) { return (ti * tj * 16 + ti + 7) / 8 * 8 < DW4_PASS ? (ti * tj * 16 + ti + 7) / 8 * 8 : DW4_PASS; }
+
+template <int T> struct VecT;
+template <> struct VecT<1> { float v[1]; };
+template <> struct __attribute__((aligned(8))) VecT<2> { float v[2]; };
+template <> struct VecT<3> { float v[3]; };
+template <> struct __attribute__((aligned(16))) VecT<4> { float v[4]; };
+// T consecutive floats at base[off] (base uniform, off a 32-bit element offset: the saddr + voffset addressing form, no
+// 64-bit address arithmetic per lane). 12-byte vectors are three dword loads (global_load_dwordx3 measured 1.7x slower).
+template <int T>
+__device__ inline VecT<T> ldv(const float* __restrict__ base, unsigned off) {
+    if (T == 3) {
+        VecT<T> r;
+        r.v[0] = base[off]; r.v[1] = base[off + 1]; r.v[T - 1] = base[off + T - 1];
+        return r;
+    }
+    return *reinterpret_cast<const VecT<T>*>(base + off);
+}
+
+// 32-bit row map: physical row of logical row r, quotient by multiplication (exact for r * grp < 2^32, checked on the
+// host); v_mul_hi_u32 + two 24-bit multiplies instead of the 64-bit sequence of RowMap
+struct RowMap32 {
+    unsigned grp, gstride, off, magic;
+    __device__ inline unsigned operator()(unsigned r) const {
+        const unsigned q = __umulhi(r, magic);
+        return __umul24(q, gstride) + (r - __umul24(q, grp)) + off;
+    }
+};
+
+struct Dw4K {
+    const float* A; const float* B; float* partial;
+    int M, N, R, lda, ldb;
+    long sA, sB;
+    RowMap32 amap, bmap;
+    int splits, batch, colsum;
+    const int* ridx; const int* rcount;
+};
+
+// WMT: waves of a workgroup side by side along the output rows (they walk the SAME reduction rows, so the x operand is
+// fetched from HBM once and hits the vector cache for the others); the remaining factor WKS = 4 / WMT splits the rows.
+template <int TI, int TJ, int WMT, bool IDX>
+__global__ __launch_bounds__(256, 1) void gemm_dw4_kernel(Dw4K p) {
+    extern __shared__ __attribute__((aligned(16))) float red[];          // [<= 3 writer waves][PASS][64]
+    constexpr int D = dw4_depth(TI, TJ), WKS = 4 / WMT, PASS = dw4_pass(TI, TJ);
+    constexpr int NM = TI * TJ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane31 = lane & 31, hf = lane >> 5;
+    const int wm = wave / WKS, wk = wave % WKS;
+    const int bz = blockIdx.z / p.splits, sp = blockIdx.z % p.splits;
+    const int m0 = (blockIdx.y * WMT + wm) * 32 * TI, n0 = blockIdx.x * 32 * TJ;
+    const float* __restrict__ A = p.A + bz * p.sA;
+    const float* __restrict__ B = p.B + bz * p.sB;
+
+    // rows of this split (a multiple of WKS * 2 D so that every wave's part runs whole ring periods), then of this wave
+    const int R = IDX ? *p.rcount : p.R;
+    const int chunk = cdiv(cdiv(R, p.splits), WKS * 2 * D) * WKS * 2 * D;
+    const int wchunk = chunk / WKS;
+    const int rbeg = min(R, sp * chunk + wk * wchunk), rend = min(R, rbeg + wchunk);
+    const int nfull = (rend - rbeg) / (2 * D);
+
+    // first column of this lane's TI (TJ) consecutive ones; lanes past the matrix edge re-read the last whole group
+    // (M % TI == 0, N % TJ == 0) and their results are simply not stored
+    const unsigned ca = min(m0 + TI * lane31, p.M - TI), cb = min(n0 + TJ * lane31, p.N - TJ);
+    const unsigned lda = p.lda, ldb = p.ldb;
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float csum[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) csum[i] = 0.f;
+
+    if (nfull > 0) {
+        // Software pipeline over steps g = 0, 1, .. (2 rows each): step g multiplies ring slot g % D and, in the middle of
+        // its MFMAs, fills slot (g - 1) % D -- consumed one step earlier -- with the rows of step g + D - 1. Loading the
+        // PREVIOUS slot leaves no register dependency between a step's loads and its MFMAs. All address arithmetic is
+        // 32-bit (element offsets from a uniform base, 24-bit multiplies): with one wave per SIMD every VALU instruction
+        // competes with the MFMA issue, and the 64-bit row-map / address sequences cost more cycles than the 16 MFMAs.
+        // Row lists: ri[s] = list entry slot s is filled with next (fetched one ring period ahead). The list is padded
+        // with scratch-row indices far enough for the prefetch to run past the end.
+        const unsigned rlast = (unsigned)(R - 1);
+        unsigned pf = rbeg + hf;                                          // position (list index / row) of the next fill
+        auto offsets = [&](unsigned row, unsigned& oa, unsigned& ob) {
+            oa = __umul24(p.amap(row), lda) + ca;
+            ob = __umul24(p.bmap(row), ldb) + cb;
+        };
+        unsigned ri[IDX ? D : 1];
+        VecT<TI> ra[D];
+        VecT<TJ> rb[D];
+#pragma unroll
+        for (int s = 0; s < D - 1; ++s) {                                 // steps 0 .. D-2
+            unsigned oa, ob;
+            offsets(IDX ? (unsigned)p.ridx[pf] : pf, oa, ob);
+            ra[s] = ldv<TI>(A, oa); rb[s] = ldv<TJ>(B, ob);
+            pf += 2;
+        }
+        if (IDX) {
+#pragma unroll
+            for (int s = 0; s < D; ++s) ri[(s + D - 1) % D] = p.ridx[pf + 2 * s];    // entries of steps D-1 .. 2D-2
+        }
+        for (int it = 0; it < nfull; ++it) {
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                const int sp_ = (s + D - 1) % D;                          // slot consumed by the previous step
+                unsigned oa, ob;
+                offsets(IDX ? ri[IDX ? sp_ : 0] : min(pf, rlast), oa, ob);
+#pragma unroll
+                for (int k = 0; k < NM; ++k)
+                    acc[k / TJ][k % TJ] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s].v[k / TJ], rb[s].v[k % TJ], acc[k / TJ][k % TJ], 0, 0, 0);
+                ra[sp_] = ldv<TI>(A, oa);
+                rb[sp_] = ldv<TJ>(B, ob);
+                if (IDX) ri[IDX ? sp_ : 0] = p.ridx[pf + 2 * D];
+                pf += 2;
+                // the schedule of this step: half of the MFMAs, the step's loads, the other half
+                __builtin_amdgcn_sched_group_barrier(0x008, (NM + 1) / 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, (TI == 3 ? 3 : 1) + (TJ == 3 ? 3 : 1) + (IDX ? 1 : 0), 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NM / 2, 0);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) csum[i] += ra[s].v[i];
+            }
+        }
+    }
+    // tail rows (fewer than 2 D): plain loop with zero fill
+    for (int r2 = rbeg + nfull * 2 * D; r2 < rend; r2 += 2) {      // wave-uniform trip count: MFMAs ignore EXEC
+        const int r = r2 + hf;
+        const bool ok = r < rend;
+        unsigned rr = ok ? r : rbeg;
+        if (IDX) rr = p.ridx[rr];
+        VecT<TI> va = ldv<TI>(A, __umul24(p.amap(rr), lda) + ca);
+        VecT<TJ> vb = ldv<TJ>(B, __umul24(p.bmap(rr), ldb) + cb);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) va.v[i] = ok ? va.v[i] : 0.f;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) vb.v[j] = ok ? vb.v[j] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(va.v[i], vb.v[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) csum[i] += va.v[i];
+    }
+
+    // ---- sum the WKS row-split waves' accumulators (and column sums) of each output tile through LDS into its wk = 0
+    //      wave, PASS registers per pass, fixed order (deterministic) ----
+    constexpr int NREG = TI * TJ * 16;
+    if (WKS > 1) {
+        float* mine = red + (size_t)(wm * (WKS - 1) + (wk - 1)) * PASS * 64;      // writer slot (wk > 0)
+        const float* theirs = red + (size_t)(wm * (WKS - 1)) * PASS * 64;         // first writer slot of this output tile
+#pragma unroll
+        for (int pass = 0; pass * PASS < NREG + TI; ++pass) {
+            if (wk > 0) {
+#pragma unroll
+                for (int k = 0; k < PASS; ++k) {
+                    const int f = pass * PASS + k;          // flat register index: accumulators first, then the column sums
+                    if (f < NREG) mine[k * 64 + lane] = acc[f / (16 * TJ)][(f / 16) % TJ][f % 16];
+                    else if (f < NREG + TI) mine[k * 64 + lane] = csum[f - NREG];
+                }
+            }
+            __syncthreads();
+            if (wk == 0) {
+#pragma unroll
+                for (int k = 0; k < PASS; ++k) {
+                    const int f = pass * PASS + k;
+                    if (f < NREG + TI) {
+                        float t = theirs[k * 64 + lane];
+#pragma unroll
+                        for (int w = 1; w < WKS - 1; ++w) t += theirs[(w * PASS + k) * 64 + lane];
+                        if (f < NREG) acc[f / (16 * TJ)][(f / 16) % TJ][f % 16] += t;
+                        else csum[f - NREG] += t;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (wk != 0 || m0 >= p.M) return;
+
+    // ---- partial tile of this split: partial[(bz * splits + sp)][M][N]. Register r of tile (i, j) is the output element
+    //      (row m0 + TI * ((r&3) + 8 (r>>2) + 4 hf) + i, column n0 + TJ * lane31 + j): TJ consecutive columns per lane ----
+    float* P = p.partial + ((long)bz * p.splits + sp) * p.M * p.N;
+    const int ncol = n0 + TJ * lane31;
+    const bool col_ok = ncol + TJ <= p.N;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + TI * ((r & 3) + 8 * (r >> 2) + 4 * hf) + i;
+            if (m < p.M && col_ok) {
+                VecT<TJ> o;
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) o.v[j] = acc[i][j][r];
+                *reinterpret_cast<VecT<TJ>*>(P + (long)m * p.N + ncol) = o;
+            }
+        }
+    if (p.colsum && blockIdx.x == 0) {
+        float* CS = p.partial + (long)p.batch * p.splits * p.M * p.N + ((long)bz * p.splits + sp) * p.M;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const float t = csum[i] + __shfl_xor(csum[i], 32, 64);      // rows of both halves
+            const int m = m0 + TI * lane31 + i;
+            if (hf == 0 && m0 + TI * lane31 + TI <= p.M) CS[m] = t;
+        }
+    }
+}
+
+// wave tile (ti x tj MFMA tiles: the count in [1,4] that wastes the fewest padded rows / columns, the larger on ties) and
+// waves side by side along the output rows
+static void dw4_shape(int M, int N, int& ti, int& tj, int& wmt) {
+    auto pick = [](int n) {
+        int best = 1, waste = 1 << 30;
+        for (int t = 1; t <= 4; ++t) {
+            const int w = cdiv(n, 32 * t) * 32 * t - n;
+            if (n % t == 0 && w <= waste) { waste = w; best = t; }       // (a lane owns t consecutive columns: n % t == 0)
+        }
+        return best;
+    };
+    ti = pick(M); tj = pick(N);
+    const int mt = cdiv(M, 32 * ti);
+    wmt = (mt >= 4 && ti == 4) ? 4 : ((mt >= 2 && ti >= 2) ? 2 : 1);       // (only these (ti, wmt) pairs are instantiated)
+}
+
+bool gemm_dw4_enabled() {
+    static const bool on = [] { const char* e = getenv("REFIL_GEMM_DW4"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+bool gemm_dw4_eligible(const refil_gemm_desc& d) {
+    const int f = d.flags;
+    if (!(f & REFIL_GEMM_A_OUTC) || !(f & REFIL_GEMM_B_OUTC)) return false;
+    if (f & (REFIL_GEMM_RELU | REFIL_GEMM_RELU_BWD)) return false;
+    if (d.splits < 2 || !d.partial) return false;
+    if (d.N < 16 || d.K < 2048) return false;         // (bias-like outputs / short reductions: the LDS-tiled kernel)
+    // Measured on MI355X (cfg-T shapes): the big wave tiles win when the output is large enough to give every CU a
+    // workgroup with a long row range (the four hypernets' in_trans / fc1 gradients: 181 -> 119, 70 -> 52, 96 -> 70 us);
+    // small outputs (agent nets, GRU, thin tails) are faster on the 2 x 2-tile streaming kernel / the LDS-tiled one.
+    static const long min_out = [] { const char* e = getenv("REFIL_DW4_MIN_OUT"); return e ? atol(e) : 40000L; }();
+    if ((long)d.batch * d.M * d.N < min_out) return false;
+    int ti, tj, wmt;
+    dw4_shape(d.M, d.N, ti, tj, wmt);
+    // the operand vectors (ti resp. tj consecutive floats; 3 floats need 4-byte alignment only) must be naturally aligned
+    auto vec_ok = [](const float* p, int ld, long sb, int t, int n) {
+        const int al = t == 4 ? 4 : (t == 2 ? 2 : 1);
+        return n >= t && (reinterpret_cast<uintptr_t>(p) % (4 * al)) == 0 && ld % al == 0 && sb % al == 0;
+    };
+    if (!vec_ok(d.A, d.lda, d.sA, ti, d.M) || !vec_ok(d.B, d.ldb, d.sB, tj, d.N)) return false;
+    // 32-bit element offsets, 24-bit multiplies, multiplicative row-map quotients
+    auto map_ok = [&](const refil_rowmap& m, int ld) {
+        const long rows = (long)d.K + 64;
+        const long phys = m.grp ? (rows / m.grp + 1) * (long)m.gstride + m.grp + m.off : rows;
+        return ld < (1 << 24) && phys < (1L << 24) && phys * ld < (1L << 32) && (!m.grp || (rows * m.grp < (1L << 32) && m.gstride < (1 << 24)));
+    };
+    if (!map_ok(d.a_map, d.lda) || !map_ok(d.b_map, d.ldb)) return false;
+    if (d.row_index && !d.row_count) return false;
+    return true;
+}
+
+// reduction splits of the dw4 kernel for an [M, N] output: one workgroup per CU (the LDS reduction buffer allows no more)
+int gemm_dw4_splits(int M, int N, int batch, long R) {
+    int ti, tj, wmt;
+    dw4_shape(M, N, ti, tj, wmt);
+    const long tiles = (long)cdiv(M, 32 * ti * wmt) * cdiv(N, 32 * tj) * batch;
+    static const long target = [] { const char* e = getenv("REFIL_DW4_TARGET"); return e ? atol(e) : 256L; }();
+    long splits = max(2L, target / tiles);
+    splits = min(splits, max(2L, R / 512));          // >= 512 rows per workgroup: the LDS reduction + partial tile are amortised
+    return (int)splits;
+}
+
+template <int TI, int TJ, int WMT>
+static int dw4_launch_w(const Dw4K& k, dim3 grid, hipStream_t st) {
+    constexpr size_t smem = (size_t)(4 - WMT) * dw4_pass(TI, TJ) * 64 * sizeof(float) + 16;
+    static bool raised = false;
+    if (!raised) {
+        REFIL_HIP(hipFuncSetAttribute((const void*)gemm_dw4_kernel<TI, TJ, WMT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        REFIL_HIP(hipFuncSetAttribute((const void*)gemm_dw4_kernel<TI, TJ, WMT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        raised = true;
+    }
+    if (k.ridx) hipLaunchKernelGGL((gemm_dw4_kernel<TI, TJ, WMT, true>), grid, dim3(256), smem, st, k);
+    else hipLaunchKernelGGL((gemm_dw4_kernel<TI, TJ, WMT, false>), grid, dim3(256), smem, st, k);
+    return 0;
+}
+template <int TI, int TJ>
+static int dw4_launch_t(const Dw4K& k, int wmt, dim3 grid, hipStream_t st) {
+    if (TI == 4 && wmt == 4) return dw4_launch_w<TI, TJ, (TI == 4 ? 4 : 1)>(k, grid, st);
+    if (TI >= 2 && wmt == 2) return dw4_launch_w<TI, TJ, (TI >= 2 ? 2 : 1)>(k, grid, st);
+    return dw4_launch_w<TI, TJ, 1>(k, grid, st);
+}
+
+int gemm_dw4_launch(const refil_gemm_desc& d, hipStream_t st) {
+    Dw4K k;
+    k.A = d.A; k.B = d.B; k.partial = d.partial;
+    k.M = d.M; k.N = d.N; k.R = d.K; k.lda = d.lda; k.ldb = d.ldb; k.sA = d.sA; k.sB = d.sB;
+    auto mk = [](const refil_rowmap& m) {
+        const unsigned grp = m.grp ? m.grp : (1u << 30);
+        return RowMap32{grp, m.grp ? (unsigned)m.gstride : 0u, m.grp ? (unsigned)m.off : 0u, (unsigned)(((1ull << 32) + grp - 1) / grp)};
+    };
+    k.amap = mk(d.a_map); k.bmap = mk(d.b_map);
+    k.splits = d.splits; k.batch = d.batch; k.colsum = (d.flags & REFIL_GEMM_COLSUM_A) ? 1 : 0;
+    k.ridx = d.row_index; k.rcount = d.row_index ? d.row_count : nullptr;
+    int ti, tj, wmt;
+    dw4_shape(d.M, d.N, ti, tj, wmt);
+    dim3 grid(cdiv(d.N, 32 * tj), cdiv(d.M, 32 * ti * wmt), d.batch * d.splits);
+    static thread_local char names[48][40];
+    static thread_local int n_names = 0;
+    char nm[40];
+    snprintf(nm, sizeof(nm), "gemm_dw4_kernel<%d,%d,%d,%d>", ti, tj, wmt, d.row_index ? 1 : 0);
+    const char* pname = nullptr;
+    for (int i = 0; i < n_names; ++i)
+        if (!strcmp(names[i], nm)) pname = names[i];
+    if (!pname && n_names < 48) { strcpy(names[n_names], nm); pname = names[n_names++]; }
+    if (!pname) pname = "gemm_dw4_kernel";
+    ProfScope prof(pname, 2.0 * d.M * d.N * d.K * d.batch, 4.0 * d.batch * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N), st,
+                   d.row_index ? d.row_count : nullptr, (double)d.K);
+    int rc = 1;
+#define CASE(I, J) if (ti == I && tj == J) rc = dw4_launch_t<I, J>(k, wmt, grid, st)
+    CASE(1, 1); CASE(1, 2); CASE(1, 3); CASE(1, 4); CASE(2, 1); CASE(2, 2); CASE(2, 3); CASE(2, 4);
+    CASE(3, 1); CASE(3, 2); CASE(3, 3); CASE(3, 4); CASE(4, 1); CASE(4, 2); CASE(4, 3); CASE(4, 4);
+#undef CASE
+    if (rc) return rc;
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace refil

@@ -347,7 +347,7 @@ int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st) {
     k.A = d.A; k.W = d.B; k.C = d.C; k.bias = d.bias; k.rowmask = d.rowmask; k.aux = d.aux;
     k.M = d.M; k.N = d.N; k.K = d.K; k.lda = d.lda; k.ldw = d.ldb; k.ldc = d.ldc;
     k.sA = d.sA; k.sW = d.sB; k.sC = d.sC; k.sBias = d.sBias;
-    auto mk = [](const refil_rowmap& m) { return m.grp ? RowMap{m.grp, m.gstride, m.off} : RowMap{1 << 30, 0, 0}; };
+    auto mk = [](const refil_rowmap& m) { return make_rowmap(m.grp, m.gstride, m.off); };
     k.amap = mk(d.a_map); k.cmap = mk(d.c_map);
     k.rowmask_mod = d.rowmask_mod; k.relu = (d.flags & REFIL_GEMM_RELU) ? 1 : 0;
     k.bias2 = d.bias2; k.rowscale = d.rowscale; k.rowscale_mod = d.rowscale_mod > 0 ? d.rowscale_mod : 1;

@@ -22,6 +22,11 @@ bool gemm_wres_eligible(const refil_gemm_desc& d);
 bool gemm_dw_stream_eligible(const refil_gemm_desc& d);
 int gemm_dw_stream_launch(const refil_gemm_desc& d, hipStream_t st);
 int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st);
+// second-generation weight-gradient kernel (gemm_dw4.hip): 4 x 4 MFMA tiles per wave, in-workgroup split reduction
+bool gemm_dw4_enabled();
+bool gemm_dw4_eligible(const refil_gemm_desc& d);
+int gemm_dw4_splits(int M, int N, int batch, long R);
+int gemm_dw4_launch(const refil_gemm_desc& d, hipStream_t st);
 int attn_forward_launch(const refil_attn_desc& d, hipStream_t st);
 int attn_backward_launch(const refil_attn_desc& d, hipStream_t st);
 int pool_launch(const refil_attn_desc& d, int mode, bool bwd, hipStream_t st);
@@ -50,7 +55,7 @@ int prep_launch(const PrepArgs& a, hipStream_t st);
 //               mask (flex_qmix.py:43-46), the imagined masks by the first step's (entity_rnn_agent.py:99-114)
 //   agents      query rows of active agents (entity_mask[b,t,i] == 0); inactive agents' outputs are zeroed by the
 //               post-mask (attention.py:66-67) and receive no gradient
-// Lists are in (b,t,entity) order (deterministic reductions) and padded to a multiple of 64 entries with `trash`
+// Lists are in (b,t,entity) order (deterministic reductions) and padded to a multiple of 64 entries plus 128 with `trash`
 // indices (one row past the logical buffer: readable, overwritable scratch).
 struct ListArgs {
     refil_batch b;
@@ -61,7 +66,7 @@ struct ListArgs {
     uint8_t* kdead_a; uint8_t* kdead_h;    // [R*ne] 1 = K/V row of the agent nets / hypernets is not computed
     int* cnt;                              // [3][R] per-row counts (scratch), lists: 0 agent-net entities, 1 hypernet entities, 2 agents
     int* off;                              // [3][R+1] exclusive scans (scratch)
-    int* list_ea; int* list_eh; int* list_a;   // [NE+64], [NE+64], [NA+64]
+    int* list_ea; int* list_eh; int* list_a;   // [NE+256], [NE+256], [NA+256]
     int* counts;                           // [4]: the three list lengths, live (b,t) rows
 };
 int lists_launch(const ListArgs& a, hipStream_t st);

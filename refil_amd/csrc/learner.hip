@@ -211,7 +211,7 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     w.partial = a.take<float>(PARTIAL_FLOATS);
     w.partial2 = a.take<float>(PARTIAL_FLOATS);
     w.t_last = a.take<int>(d.B);
-    w.list_ea = a.take<int>(s.NE + 64); w.list_eh = a.take<int>(s.NE + 64); w.list_a = a.take<int>(s.NA + 64);
+    w.list_ea = a.take<int>(s.NE + 256); w.list_eh = a.take<int>(s.NE + 256); w.list_a = a.take<int>(s.NA + 256);
     w.counts = a.take<int>(4); w.lcnt = a.take<int>(3 * s.R); w.loff = a.take<int>(3 * (s.R + 1));
     w.kdead_a = a.take<uint8_t>(s.NE); w.kdead_h = a.take<uint8_t>(s.NE);
 }
@@ -256,6 +256,12 @@ static refil_gemm_desc linear_dw(const float* dy, int lddy, const float* x, int 
     g.M = N; g.N = K; g.K = (int)R;
     g.flags = REFIL_GEMM_A_OUTC | REFIL_GEMM_B_OUTC | (db ? REFIL_GEMM_COLSUM_A : 0);
     g.colsum = db; g.partial = partial; g.batch = batch;
+    g.splits = 2;
+    if (gemm_dw4_enabled() && gemm_dw4_eligible(g)) {            // gemm_dw4.hip: one workgroup per CU
+        g.splits = gemm_dw4_splits(N, K, batch, R);
+        while (g.splits > 2 && (long)batch * g.splits * ((long)N * K + N) > PARTIAL_FLOATS) --g.splits;
+        return g;
+    }
     const int bn = K > 64 ? 128 : (K > 32 ? 64 : 32);
     const long tiles = (long)cdiv(N, 128) * cdiv(K, bn) * batch;
     static const long target = [] { const char* e = getenv("REFIL_DW_TARGET"); return e ? atol(e) : 1024L; }();

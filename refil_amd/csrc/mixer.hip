@@ -136,8 +136,8 @@ __global__ __launch_bounds__(1024) void lists_scan_kernel(ListArgs a) {
         if (tid == 0) { a.off[l * (R + 1) + R] = total; a.counts[l] = total; }
         int* list = l == 0 ? a.list_ea : (l == 1 ? a.list_eh : a.list_a);
         const int trash = l == 2 ? (int)(R * a.na) : (int)(R * a.ne);
-        const int padded = (total + 63) & ~63;
-        if (tid < 64 && total + tid < padded) list[total + tid] = trash;
+        const int padded = ((total + 63) & ~63) + 128;      // consumers prefetch list entries past the end (gemm_dw4.hip)
+        if (tid < 192 && total + tid < padded) list[total + tid] = trash;
         __syncthreads();
     }
     int lr = 0;

@@ -168,7 +168,8 @@ def test_production_size_step_matches_oracle(which):
                                                                   d=kw["d"], h=kw["d"])
     r = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, profile=True)
     names = " ".join(r["kernels"])
-    for sym in ("gemm_wres_kernel", "gemm_dw_stream_kernel", "attn_fwd_mfma", "attn_bwd_mfma", "gru_fwd_kernel", "gru_bwd_kernel",
+    assert "gemm_dw4_kernel" in names or "gemm_dw_stream_kernel" in names
+    for sym in ("gemm_wres_kernel", "attn_fwd_mfma", "attn_bwd_mfma", "gru_fwd_kernel", "gru_bwd_kernel",
                 "lists_kernels", ",1>"):        # ",1>": the row-list instantiations of the GEMM kernels
         assert sym in names, f"{which}: {sym} did not run (kernels: {sorted(r['kernels'])})"
     assert "attn_fwd_kernel" not in r["kernels"] and "attn_bwd_kernel" not in r["kernels"], "VALU attention fallback taken"

@@ -376,7 +376,7 @@ def _row_list(M, frac, seed, trash):
     g = torch.Generator().manual_seed(seed)
     keep = torch.nonzero(torch.rand(M, generator=g) < frac).flatten().to(torch.int32)
     n = keep.numel()
-    padded = torch.full(((n + 63) // 64 * 64 + 64,), trash, dtype=torch.int32)
+    padded = torch.full(((n + 63) // 64 * 64 + 128,), trash, dtype=torch.int32)
     padded[:n] = keep
     return keep.long(), padded.to(DEV), torch.tensor([n], dtype=torch.int32, device=DEV)
 
@@ -434,7 +434,7 @@ def test_gemm_wres_dx_relu_bwd_row_list(M, N, K, frac):
         ag = ent.view(R, ne)[:, :na].reshape(-1)                     # listed agents = agents whose entity row is listed
         keepa = torch.nonzero(ag).flatten()
         n = keepa.numel()
-        lsta = torch.full(((n + 63) // 64 * 64 + 64,), R * na, dtype=torch.int32); lsta[:n] = keepa.to(torch.int32)
+        lsta = torch.full(((n + 63) // 64 * 64 + 128,), R * na, dtype=torch.int32); lsta[:n] = keepa.to(torch.int32)
         add = torch.zeros(R, ne, N)
         add[:, :na] = ((dq[:R * na] @ Wq) * (x1[:M].view(R, ne, N)[:, :na].reshape(R * na, N) > 0)).view(R, na, N) * ag.view(R, na, 1)
         hip_ops.gemm(dq.to(DEV), Wq.to(DEV), dx, R * na, N, K, K, N, N, flags=GEMM_B_OUTC | GEMM_RELU_BWD | GEMM_ACCUM, aux=x1d,
@@ -548,3 +548,29 @@ def test_gru_time_bounds():
         assert torch.equal(gi_skip[gb, :tl + 1], gi_full[gb, :tl + 1]) and torch.equal(gh_skip[gb, :tl + 1], gh_full[gb, :tl + 1])
         assert (gi_skip[gb, tl + 1:] == 0).all() and (gh_skip[gb, tl + 1:] == 0).all()
         assert gi_full[gb, tl + 1:].abs().max().item() == 0.0 if tl + 1 < T1 else True
+
+
+@pytest.mark.parametrize("N,K", [(256, 128), (512, 84), (128, 128), (192, 64), (64, 128), (32, 128), (22, 64), (96, 96), (300, 40),
+                                 (128, 20), (64, 52)])
+@pytest.mark.parametrize("batch,use_list", [(1, False), (3, False), (1, True)])
+def test_gemm_dw4_tiles(N, K, batch, use_list):
+    """gemm_dw4.hip (every wave-tile shape TI x TJ): dW = dy^T x per batch (+ db), optionally over a row list."""
+    import hip_ops
+    torch.manual_seed(N * 7 + K + batch)
+    Rr, splits = 5000 + 37, 9
+    dy = torch.randn(Rr + 8, batch * N)
+    x = torch.randn(Rr + 8, batch * K)
+    if use_list:
+        keep, lst, cnt = _row_list(Rr, 0.5, N + K, trash=Rr)
+    else:
+        keep, lst, cnt = torch.arange(Rr), None, None
+    ref_w = torch.stack([dy[keep, n * N:(n + 1) * N].double().t() @ x[keep, n * K:(n + 1) * K].double() for n in range(batch)])
+    ref_b = torch.stack([dy[keep, n * N:(n + 1) * N].double().sum(0) for n in range(batch)])
+    dW = torch.full((batch, N, K), float("nan"), device=DEV)
+    db = torch.full((batch, N), float("nan"), device=DEV)
+    partial = torch.zeros(batch * splits * (N * K + N), device=DEV)
+    hip_ops.gemm(dy.to(DEV), x.to(DEV), dW, N, K, Rr, batch * N, batch * K, K, flags=GEMM_A_OUTC | GEMM_B_OUTC | GEMM_COLSUM_A,
+                 colsum=db, partial=partial, splits=splits, batch=batch, sA=N, sB=K, sC=N * K, sColsum=N, row_index=lst, row_count=cnt)
+    scale = max(ref_w.abs().max().item(), 1.0)
+    assert (dW.cpu().double() - ref_w).abs().max().item() <= 5e-5 * scale
+    assert (db.cpu().double() - ref_b).abs().max().item() <= 5e-5 * max(ref_b.abs().max().item(), 1.0)
