@@ -1,26 +1,28 @@
 """Learner-throughput bench of the MI355X-native REFIL hot path.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config cfgT|cfg2|cfg3|cfg4|cfg5] [--scaling weak|strong]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
-One "step" = one full QLearner.train() (reference: src/learners/q_learner.py:66-201) on a synthetic
-replay minibatch resident in HBM: live + target agent forward, mixers, TD loss, hand-written backward,
-(all-reduce when N > 1), clip + RMSprop, periodic target sync. Workload = the north-star shape
-(B=32 episodes per GPU, T=80 transitions, n_entities=32, attn/hypernet dim 128, REFIL); weak scaling:
-per-GPU batch fixed, value = transitions/s summed over all GPUs.
+One "step" = one full QLearner.train() (reference: src/learners/q_learner.py:66-201) on a synthetic replay minibatch
+resident in HBM: live + target agent forward, mixers, TD loss, hand-written backward, (all-reduce when N > 1),
+clip + RMSprop, periodic target sync. Default workload = the north-star shape of BASELINE.json (B=32 episodes per GPU,
+T=80 transitions, n_entities=32, attn/hypernet dim 128, REFIL); the other BASELINE.json configs are selected with
+--config (SURVEY.md section 8d "Configs restated"). Weak scaling by default (per-GPU batch fixed, value = transitions/s
+summed over all GPUs); --scaling strong fixes the GLOBAL batch (--global-batch, default 64) and shards it.
 
 Prints ONE JSON line (rank 0). Extra objects:
-  roofline     -- the kernel symbol with the largest share of GPU time, timed with HIP events on the
-                  launch stream by the library's profiler over K steps right after the timed region
-                  (events are kept out of the timed region itself so they cannot perturb `value`);
-                  achieved = algorithmic FLOPs per launch / mean launch duration; peak = 157.3 TFLOP/s
-                  (fp32 MFMA, MI355X_MICROARCH.md).
-  cpu_baseline -- oracle/refil_oracle.py (a fixture-pinned CPU port of the reference learner) timed on
-                  this box's host cores on a bounded sample of the same workload (N=1, rank 0 only).
+  roofline     -- the kernel symbol with the largest isolated GPU time per step, timed with HIP events on the launch
+                  stream by the library's profiler right after the timed region (events are kept out of the timed
+                  region itself so they cannot perturb `value`); achieved = FLOPs the kernel executes per launch
+                  (the rows that can influence the loss: the library skips the others) / mean launch duration;
+                  peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).
+  cpu_baseline -- oracle/refil_oracle.py (a fixture-pinned CPU port of the reference learner) timed on this box's host
+                  cores on a bounded sample of the same workload (N=1, rank 0 only).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 import types
@@ -32,14 +34,22 @@ import torch
 import torch.distributed as dist
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
-WORKLOAD = dict(B=32, T=80, ne=32, d=128, h=128, heads=4, H=64, M=32)
+# BASELINE.json configs. B = episodes per GPU under weak scaling.
+CONFIGS = {
+    "cfgT": dict(B=32, T=80, ne=32, d=128, h=128, imagine=True, what="north-star target shape (BASELINE.json north_star / metric)"),
+    "cfg2": dict(B=32, T=80, ne=16, d=64, h=64, imagine=True, what="BASELINE.json configs[1]"),
+    "cfg3": dict(B=64, T=80, ne=32, d=128, h=128, imagine=True, what="BASELINE.json configs[2], roofline run"),
+    "cfg4": dict(B=32, T=150, ne=16, d=128, h=128, imagine=False, what="BASELINE.json configs[3] shape: 3-8sz, qmix_atten (no imagination), T up to 150"),
+    "cfg5": dict(B=32, T=80, ne=48, d=128, h=128, imagine=True, what="BASELINE.json configs[4] scaled to 48 entities (MMM-shaped)"),
+}
+COMMON = dict(heads=4, H=64, M=32)
 
 
 def algorithmic_flops(B, T, ne, na, E, A, d, h, H, M, G):
     """SURVEY.md section 8d closed form (2mnk per GEMM, backward 2x / first layers 1x, targets forward-only)."""
     T1 = T + 1
 
-    def net(rows, w, V, tail, first_layer_bwd=True):
+    def net(rows, w, V, tail):
         fc1 = 2 * ne * E * w
         qkv = 2 * na * w * w + 4 * ne * w * w
         core = 4 * na * ne * w
@@ -56,10 +66,10 @@ def algorithmic_flops(B, T, ne, na, E, A, d, h, H, M, G):
     return la_f + la_b + ta_f + sum(f + b for f, b in lm) + sum(f for f, _ in tm)
 
 
-def make_args(dims):
+def make_args(dims, imagine):
     return types.SimpleNamespace(
-        agent="imagine_entity_attend_rnn", mac="entity_mac", learner="q_learner", mixer="flex_qmix", agent_output_type="q",
-        action_selector="epsilon_greedy", epsilon_start=1.0, epsilon_finish=0.05, epsilon_anneal_time=500000,
+        agent="imagine_entity_attend_rnn" if imagine else "entity_attend_rnn", mac="entity_mac", learner="q_learner", mixer="flex_qmix",
+        agent_output_type="q", action_selector="epsilon_greedy", epsilon_start=1.0, epsilon_finish=0.05, epsilon_anneal_time=500000,
         n_agents=dims["na"], n_actions=dims["A"], n_entities=dims["ne"], entity_shape=dims["ed"], entity_scheme=True,
         entity_last_action=True, gt_mask_avail=False, attn_embed_dim=dims["d"], attn_n_heads=dims["heads"],
         rnn_hidden_dim=dims["H"], hypernet_embed=dims["h"], mixing_embed_dim=dims["M"], softmax_mixing_weights=True,
@@ -76,15 +86,20 @@ class _Logger:
         pass
 
 
-def build(dims, B, T, seed, device):
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def build(dims, imagine, B, T, seed, device, shard=None):
+    """shard = (rank, world): strong scaling -- generate the GLOBAL batch of B episodes and keep this rank's slice."""
     from refil_amd.components.episode_buffer import EpisodeBatch
     from refil_amd.components.transforms import OneHot
     from refil_amd.controllers import REGISTRY as mac_REGISTRY
     from refil_amd.learners import REGISTRY as le_REGISTRY
     from refil_amd.synthetic import make_batch_fast
-    args = make_args(dims)
+    args = make_args(dims, imagine)
     data = make_batch_fast(B, T, dims["ne"], seed=seed)
+    if shard is not None:
+        r, n = shard
+        per = B // n
+        data = {k: v[r * per:(r + 1) * per].contiguous() for k, v in data.items()}
+        B = per
     scheme = {
         "entities": {"vshape": dims["ed"], "group": "entities"},
         "obs_mask": {"vshape": dims["ne"], "group": "entities", "dtype": torch.uint8},
@@ -106,33 +121,42 @@ def build(dims, B, T, seed, device):
     return args, batch, learner, data
 
 
-def cpu_baseline(dims, data_full, target_seconds=20.0):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(dims, imagine, data_full, target_seconds=20.0):
     """Time the CPU oracle (port of the reference learner) on a bounded sample of the same workload."""
     from oracle import refil_oracle as orc
     cfg = orc.Cfg(n_agents=dims["na"], n_entities=dims["ne"], n_actions=dims["A"], entity_shape=dims["ed"],
-                  attn_embed_dim=dims["d"], attn_n_heads=dims["heads"], hypernet_embed=dims["h"], imagine=True)
+                  attn_embed_dim=dims["d"], attn_n_heads=dims["heads"], hypernet_embed=dims["h"], imagine=imagine)
     agent = orc.init_params(orc.agent_param_shapes(cfg), 1)
     mixer = orc.init_params(orc.mixer_param_shapes(cfg), 2)
     tagent = orc.init_params(orc.agent_param_shapes(cfg), 3)
     tmixer = orc.init_params(orc.mixer_param_shapes(cfg), 4)
-    threads = torch.get_num_threads()
     T = data_full["entities"].shape[1] - 1
 
     def run(Bs, n):
         batch = {k: v[:Bs].contiguous() for k, v in data_full.items()}
         torch.manual_seed(0)
-        bits = orc.draw_partition_bits(Bs, dims["ne"])
+        bits = orc.draw_partition_bits(Bs, dims["ne"]) if imagine else None
         ts = []
         for _ in range(n):
             t0 = time.perf_counter()
             orc.train_step(cfg, dict(agent), dict(mixer), tagent, tmixer, batch, bits)
             ts.append(time.perf_counter() - t0)
         return ts
-    # pick the thread count that makes the CPU port fastest on this host (all cores is not always best
-    # for these small GEMMs); `cores` reports the count actually used
+    # pick the thread count that makes the CPU port fastest on this host (all cores is not always best for these
+    # small GEMMs); `cores` reports the count actually used, `host_cores` what the box has
     ncpu = os.cpu_count() or 1
-    cands = sorted({c for c in (8, 16, 32) if 1 <= c <= ncpu}) or [1]   # more threads only slow these small ops down
-    probe = None
+    cands = sorted({c for c in (8, 16, 32, 64) if 1 <= c <= ncpu}) or [1]
+    threads, probe = cands[0], None
     for c in cands:
         torch.set_num_threads(c)
         t = run(4, 2)[-1]                                  # 2nd run: thread pool warm
@@ -140,27 +164,33 @@ def cpu_baseline(dims, data_full, target_seconds=20.0):
             threads, probe = c, t
     torch.set_num_threads(threads)
     per_ep = probe / 4
-    Bs = 32
-    while Bs > 4 and per_ep * Bs * 3 > target_seconds:
+    Bfull = data_full["entities"].shape[0]
+    Bs = Bfull
+    while Bs > 4 and per_ep * Bs * 7 > target_seconds:
         Bs //= 2
-    ts = run(Bs, 3)
-    best = sorted(ts)[len(ts) // 2]
-    return {"value": round(Bs * T / best, 1), "unit": "transitions/s", "cores": threads, "kind": "port",
-            "sample": f"median of 3 oracle train steps on B={Bs} of the bench batch (T={T}, ne={dims['ne']}, d={dims['d']}), "
-                      f"fp32 torch CPU, {threads} threads", "ms_per_step": round(best * 1e3, 1)}
+    ts = run(Bs, 7)[2:]                                    # 2 warm-up + 5 timed
+    best = statistics.median(ts)
+    return {"value": round(Bs * T / best, 1), "unit": "transitions/s", "cores": threads, "host_cores": ncpu, "cpu_model": cpu_model(),
+            "kind": "port",
+            "sample": f"median of 5 oracle train steps (after 2 warm-ups) on B={Bs} of the bench batch (T={T}, ne={dims['ne']}, "
+                      f"d={dims['d']}), fp32 torch CPU, {threads} threads (fastest of {cands})", "ms_per_step": round(best * 1e3, 1)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="cfgT", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--global-batch", type=int, default=64, help="episodes of the whole job under --scaling strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--batch", type=int, default=0, help="episodes per GPU instead of the north-star 32 (e.g. 64 = BASELINE.json "
-                    "configs[2]); the default line always uses 32")
+    ap.add_argument("--batch", type=int, default=0, help="episodes per GPU instead of the config's")
     ap.add_argument("--serial", action="store_true", help="serialise the two chains on one stream for the whole run "
                     "(kernel-quality profiling: in-situ == isolated); the default overlaps them")
+    ap.add_argument("--traffic-json", default=None, help="rocprofv3 PMC summary (tools/pmc_summarize.py) of THIS build to quote "
+                    "roofline.traffic from; without it traffic is null (never a stale file)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,8 +205,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if one_gpu else "nccl"
         if one_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -185,12 +217,22 @@ def main():
 
     from refil_amd import _lib
     from refil_amd.synthetic import sc2_shape_law
-    W = dict(WORKLOAD, B=a.batch) if a.batch > 0 else WORKLOAD
+    W = dict(CONFIGS[a.config], **COMMON)
+    if a.batch > 0:
+        W["B"] = a.batch
     law = sc2_shape_law(W["ne"])
     dims = dict(ne=W["ne"], na=law["n_agents"], A=law["n_actions"], ed=law["entity_shape"], d=W["d"], h=W["h"],
                 heads=W["heads"], H=W["H"], M=W["M"])
-    B, T = W["B"], W["T"]
-    args, batch, learner, data = build(dims, B, T, seed=100 + rank, device=device)
+    T = W["T"]
+    if a.scaling == "strong":
+        assert a.global_batch % world == 0, "--global-batch must be a multiple of the number of GPUs"
+        B = a.global_batch // world                        # per rank
+        args, batch, learner, data = build(dims, W["imagine"], a.global_batch, T, seed=100, device=device, shard=(rank, world))
+        global_B = a.global_batch
+    else:
+        B = W["B"]
+        args, batch, learner, data = build(dims, W["imagine"], B, T, seed=100 + rank, device=device)
+        global_B = B * world
 
     if a.serial:
         _lib.lib().refil_set_overlap(0)
@@ -206,12 +248,16 @@ def main():
     for i in range(a.warmup):
         step(i)
     barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(a.steps):
         step(a.warmup + i)
-    host_enqueue = time.perf_counter() - t0          # host time to enqueue K steps (no sync inside)
+        marks[i + 1].record()                              # (an event record costs ~1 us; the per-step medians come from these)
+    host_enqueue = time.perf_counter() - t0                # host time to enqueue K steps (no sync inside)
     barrier()
     elapsed = time.perf_counter() - t0
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
     profiled = not a.no_profile       # every rank runs the extra passes (train() all-reduces); rank 0 reports
     ents, nprof = [], max(3, min(a.steps, 10))
     if profiled:
@@ -226,14 +272,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     ms_per_step = elapsed / a.steps * 1e3
-    value = world * B * T * a.steps / elapsed
+    value = global_B * T * a.steps / elapsed
+    rows = learner._engine.row_counts(learner._last_dims)
 
     E = dims["ed"] + dims["A"]
-    flops_step = algorithmic_flops(B, T, dims["ne"], dims["na"], E, dims["A"], dims["d"], dims["h"], dims["H"], dims["M"], 3)
+    G = 3 if W["imagine"] else 1
+    flops_step = algorithmic_flops(B, T, dims["ne"], dims["na"], E, dims["A"], dims["d"], dims["h"], dims["H"], dims["M"], G)
     roofline = None
     kernels = None
     if profiled:
-        ents.sort(key=lambda e: -e["total_ms"])
         tot = sum(e["total_ms"] for e in ents)
         # second pass with the two streams serialised: every kernel alone on the GPU (kernel quality). These
         # are the durations rocprofv3 --kernel-trace reports for the same steps (and for a whole `--serial` run)
@@ -244,65 +291,74 @@ def main():
         iso = {e["name"]: e for e in _lib.profile_collect()}
         _lib.profile_enable(False)
         _lib.lib().refil_set_overlap(0 if a.serial else -1)
+        ents.sort(key=lambda e: -(iso.get(e["name"], e)["total_ms"]))       # by the kernel's own (isolated) cost
         kernels = []
-        for e in ents[:8]:
+        for e in ents[:10]:
             k = {"name": e["name"], "launches_per_step": e["launches"] // nprof, "ms_per_step": round(e["total_ms"] / nprof, 4),
                  "avg_us": round(1e3 * e["total_ms"] / e["launches"], 2),
                  "tflops": round(e["flops"] / (e["total_ms"] * 1e-3) / 1e12, 2) if e["flops"] > 0 else None}
             x = iso.get(e["name"])
             if x:
+                k["ms_per_step_isolated"] = round(x["total_ms"] / nprof, 4)
                 k["avg_us_isolated"] = round(1e3 * x["total_ms"] / x["launches"], 2)
                 if x["flops"] > 0:
                     k["tflops_isolated"] = round(x["flops"] / (x["total_ms"] * 1e-3) / 1e12, 2)
             kernels.append(k)
         iso_total = sum(x["total_ms"] for x in iso.values()) / nprof
-        dom = ents[0]
-        traffic = None          # HBM bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 runs)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            traffic = pmc.get(dom["name"], {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-        ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-        roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes/launch (PMC 2*FETCH_SIZE+WRITE_SIZE, profiles/r01_pmc_traffic.json)",
-                    "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
-                    "achieved_isolated": kernels[0].get("tflops_isolated"),
-                    "frac_isolated": round((kernels[0].get("tflops_isolated") or 0.0) / PEAK_FP32_MFMA_TFLOPS, 4),
+        dom = next((e for e in ents if e["flops"] > 0), ents[0])            # dominant MFMA kernel (largest isolated time)
+        dom_iso = iso.get(dom["name"], dom)
+        traffic = None
+        if a.traffic_json:
+            traffic = json.load(open(a.traffic_json))["kernels"].get(dom["name"], {}).get("hbm_bytes_per_launch")
+        ach_iso = dom_iso["flops"] / (dom_iso["total_ms"] * 1e-3) / 1e12
+        ach_situ = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+        roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach_iso, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach_iso / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE via --traffic-json; null: not collected in this run)",
+                    "algorithmic_bytes_per_launch": round(dom_iso["bytes"] / dom_iso["launches"]),
+                    "achieved_in_situ": round(ach_situ, 2), "frac_in_situ": round(ach_situ / PEAK_FP32_MFMA_TFLOPS, 4),
                     "launches_per_step": dom["launches"] // nprof,
-                    "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
-                    "avg_launch_us_isolated": kernels[0].get("avg_us_isolated"),
-                    "flops_per_launch": dom["flops"] / dom["launches"],
-                    "share_of_gpu_time": round(dom["total_ms"] / tot, 3),
-                    "gpu_ms_per_step_all_kernels": round(tot / nprof, 3),
-                    "gpu_ms_per_step_all_kernels_isolated": round(iso_total, 3),
+                    "avg_launch_us": round(1e3 * dom_iso["total_ms"] / dom_iso["launches"], 2),
+                    "avg_launch_us_in_situ": round(1e3 * dom["total_ms"] / dom["launches"], 2),
+                    "flops_per_launch": dom_iso["flops"] / dom_iso["launches"],
+                    "share_of_gpu_time": round(dom_iso["total_ms"] / (iso_total * nprof), 3),
+                    "gpu_ms_per_step_all_kernels_in_situ": round(tot / nprof, 3),
+                    "gpu_ms_per_step_all_kernels": round(iso_total, 3),
                     "step_frac_of_mfma_roofline": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                     "streams": "serialised (--serial)" if a.serial else "agent and hypernet chains overlap on two streams",
-                    "measured": f"HIP events on the launch streams, {nprof} steps right after the timed region. `achieved` / "
-                                "`avg_launch_us` are in situ: with the two chains overlapping a launch shares the GPU with the "
-                                "other stream's kernels (and the event markers themselves wait behind them), so this is a lower "
-                                f"bound on kernel quality. `*_isolated` repeats the {nprof} steps with the streams serialised: "
-                                "each kernel alone on the GPU, the duration rocprofv3 --kernel-trace reports for it "
-                                "(profiles/r01_rocprofv3_kernel_stats_serial.csv is the whole run under --serial)"}
+                    "measured": f"HIP events on the launch streams, {nprof} steps right after the timed region. `achieved` / `avg_launch_us`: "
+                                "the streams serialised, each kernel alone on the GPU = the duration rocprofv3 --kernel-trace reports for it "
+                                "(profiles/README.md); FLOPs = what the launch executes (row-list launches: the listed rows, read back "
+                                "from the device). `*_in_situ`: both chains overlapping as in the timed region -- a launch shares the GPU "
+                                "with the other stream's kernels, a lower bound on kernel quality. `step_frac_of_mfma_roofline` = the DENSE "
+                                "algorithmic FLOPs of SURVEY.md section 8d / step time / peak (row skipping makes it exceed the kernels' own fractions)"}
     if world > 1:
         dist.barrier()
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(dims, data)
+        cpu = cpu_baseline(dims, W["imagine"], data)
 
     if rank == 0:
+        nE, nA = rows["entity_rows"], rows["all_agent_rows"]
         out = {
             "metric": "learner transitions/sec (B x T per full QLearner.train step)", "value": round(value, 1),
             "unit": "transitions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 3), "host_enqueue_ms_per_step": round(host_enqueue / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic replay (B={B}/GPU, T={T}, n_entities={dims['ne']}, n_agents={dims['na']}, "
-                                   f"d={dims['d']}, hypernet={dims['h']}), refil learner (imagine agent + flex_qmix), "
-                                   f"BASELINE.json north-star shape",
-                       "global_batch": B * world, "seq_len": T, "parallelism": f"dp{world}",
+            "ms_per_step": round(ms_per_step, 3), "median_ms_per_step": round(statistics.median(per_step), 3),
+            "host_enqueue_ms_per_step": round(host_enqueue / a.steps * 1e3, 3), "higher_is_better": True, "scaling": a.scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.config}: synthetic replay (B={B}/GPU, T={T}, n_entities={dims['ne']}, n_agents={dims['na']}, "
+                                   f"d={dims['d']}, hypernet={dims['h']}), {'refil' if W['imagine'] else 'qmix_atten'} learner "
+                                   f"({'imagine agent' if W['imagine'] else 'entity_attend_rnn agent'} + flex_qmix), {W['what']}",
+                       "global_batch": global_B, "seq_len": T, "parallelism": f"dp{world}",
+                       "world_size": dist.get_world_size() if world > 1 else 1, "backend": backend,
                        "algorithmic_gflop_per_step_per_gpu": round(flops_step / 1e9, 2)},
+            "rows": {"lists_active": bool(rows["lists"]), "live_step_frac": round(rows["live_steps"] / max(rows["steps"], 1), 4),
+                     "entity_rows_frac_agent_nets": round(rows["entity_rows_agent"] / max(nE, 1), 4),
+                     "entity_rows_frac_hypernets": round(rows["entity_rows_hyper"] / max(nE, 1), 4),
+                     "agent_query_rows_frac": round(rows["agent_rows"] / max(nA, 1), 4),
+                     "note": "fractions of the dense (b,t,entity) rows the step processes: rows that cannot influence the loss are "
+                             "skipped on the device, results equal the dense schedule (tests/test_gpu_learner.py::test_row_skipping_equals_dense_schedule)"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         if cpu:

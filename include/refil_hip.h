@@ -149,6 +149,14 @@ int refil_learner_forward_backward(const refil_dims* dims, const refil_batch* ba
                                    float* grads, void* workspace, size_t workspace_bytes,
                                    const refil_debug_out* debug, void* stream);
 
+/* Diagnostics (synchronises the stream): which rows the LAST refil_learner_forward_backward on this workspace / dims
+ * actually processed. The step skips rows that cannot influence the loss -- entity rows no query can attend to, query rows
+ * of inactive agents, steps after an episode's last loss-carrying step -- through device-side row lists (no host round
+ * trip; results identical to the dense schedule up to the summation order of the weight gradients; REFIL_DENSE=1 turns
+ * it off). out[0..5] = {lists active, entity rows (agent nets), entity rows (hypernets), agent rows, live (b,t) rows,
+ * B*T1}; with lists inactive the dense counts are returned. */
+int refil_learner_row_counts(const refil_dims* dims, void* workspace, size_t workspace_bytes, int32_t* out, void* stream);
+
 /* clip_grad_norm_ + RMSprop.step on the flat buffers (q_learner.py:37-38,177-178):
  *   g = grads[0:n] / grads[n + REFIL_STAT_MASK_SUM];  norm = ||g||_2  (stored to grads[n+GRAD_NORM]);
  *   g *= min(1, clip / (norm + 1e-6));  g += weight_decay * p;
@@ -183,6 +191,18 @@ int refil_mixer_forward(const refil_dims* dims, const refil_batch* batch, int32_
                         const float* params, const float* agent_qs, const float* agent_qs_imagine,
                         float* q_tot, float* q_tot_imagine, float* ingroup_sum,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Device-side replay sampling: for every field copy the sampled episodes from the ring storage into a staging
+ * minibatch, dst[b] <- src[episode_ids[b]] (reference: ReplayBuffer.sample -> EpisodeBatch.__getitem__,
+ * src/components/episode_buffer.py:123-159,233-240; one index_select per field there). Byte-level: a field is
+ * [capacity, src_episode_bytes] in the buffer and [B, dst_episode_bytes] in the staging batch; copy_bytes (<= both)
+ * allows copying only the first max_t steps. episode_ids: int64 on the device, values in [0, capacity). */
+typedef struct refil_gather_field {
+    const void* src; void* dst;
+    int64_t src_episode_bytes, dst_episode_bytes, copy_bytes;
+} refil_gather_field;
+int refil_replay_gather(const refil_gather_field* fields, int32_t n_fields, const int64_t* episode_ids,
+                        int32_t B, int64_t capacity, void* stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* 4. building-block operators                                                                 */

@@ -100,6 +100,11 @@ class GruDesc(C.Structure):
     ]
 
 
+class GatherField(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_episode_bytes", C.c_int64), ("dst_episode_bytes", C.c_int64),
+                ("copy_bytes", C.c_int64)]
+
+
 class ProfileEntry(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
                 ("bytes", C.c_double)]
@@ -111,7 +116,8 @@ EXPORTS = [
     "refil_clip_rmsprop_step", "refil_agent_workspace_bytes", "refil_agent_forward",
     "refil_mixer_workspace_bytes", "refil_mixer_forward", "refil_gemm", "refil_attn_forward",
     "refil_attn_backward", "refil_pool_forward", "refil_pool_backward", "refil_gru_forward", "refil_gru_backward", "refil_last_error", "refil_version",
-    "refil_profile_enable", "refil_profile_collect", "refil_set_overlap", "refil_release_streams",
+    "refil_profile_enable", "refil_profile_collect", "refil_set_overlap", "refil_release_streams", "refil_replay_gather",
+    "refil_learner_row_counts",
 ]
 
 _lib = None
@@ -153,6 +159,8 @@ def lib():
     L.refil_gru_forward.argtypes = [C.POINTER(GruDesc), C.c_void_p]
     L.refil_gru_backward.argtypes = [C.POINTER(GruDesc), C.c_void_p]
     L.refil_set_overlap.argtypes = [C.c_int]
+    L.refil_learner_row_counts.argtypes = [C.POINTER(Dims), C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.c_void_p]
+    L.refil_replay_gather.argtypes = [C.POINTER(GatherField), C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
     L.refil_profile_enable.argtypes = [C.c_int]
     L.refil_profile_collect.argtypes = [C.POINTER(ProfileEntry), C.c_int]
     _lib = L

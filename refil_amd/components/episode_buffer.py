@@ -177,7 +177,51 @@ class ReplayBuffer(EpisodeBatch):
         if self.episodes_in_buffer == batch_size:
             return self[:batch_size]
         ep_ids = np.random.choice(self.episodes_in_buffer, batch_size, replace=False)     # uniform, w/o replacement
+        if th.device(self.device).type == "cuda":
+            return self._gather(ep_ids)
         return self[ep_ids]
+
+    # -- device-resident sampling -----------------------------------------
+    def _gather(self, ep_ids):
+        """The sampled episodes, copied by ONE HIP launch (refil_replay_gather) into a staging minibatch that is
+        reused by later calls with the same batch size (fixed addresses: no allocation per step). Same contents as the
+        reference's `self[ep_ids]` (episode_buffer.py:123-159); the reference's max_t_filled() trim (run.py:266-273) --
+        a host synchronisation per step -- is not needed, the learner skips finished episodes' steps on the device."""
+        import ctypes as C
+        from .. import _lib
+        n = len(ep_ids)
+        st = self._staging.get(n) if hasattr(self, "_staging") else None
+        if st is None:
+            if not hasattr(self, "_staging"):
+                self._staging = {}
+            batch = EpisodeBatch(self.scheme, self.groups, n, self.max_seq_length, device=self.device,
+                                 data=SimpleNamespace(
+                                     transition_data={k: th.zeros((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device)
+                                                      for k, v in self.data.transition_data.items()},
+                                     episode_data={k: th.zeros((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device)
+                                                   for k, v in self.data.episode_data.items()}))
+            ids_host = [(th.empty(n, dtype=th.int64).pin_memory(), th.cuda.Event()) for _ in range(8)]
+            ids_dev = th.empty(n, dtype=th.int64, device=self.device)
+            fields = (_lib.GatherField * 32)()
+            nf = 0
+            for store_src, store_dst in ((self.data.transition_data, batch.data.transition_data),
+                                         (self.data.episode_data, batch.data.episode_data)):
+                for k, src in store_src.items():
+                    dst = store_dst[k]
+                    assert src.is_contiguous() and dst.is_contiguous()
+                    eb = src[0].numel() * src.element_size()
+                    fields[nf] = _lib.GatherField(src.data_ptr(), dst.data_ptr(), eb, eb, eb)
+                    nf += 1
+            st = self._staging[n] = {"batch": batch, "ids_host": ids_host, "ids_dev": ids_dev, "fields": fields, "nf": nf, "slot": 0}
+        host, ev = st["ids_host"][st["slot"]]
+        st["slot"] = (st["slot"] + 1) % len(st["ids_host"])
+        ev.synchronize()                                   # (the async upload issued 8 samples ago has long completed)
+        host.copy_(th.from_numpy(np.ascontiguousarray(ep_ids, dtype=np.int64)))
+        st["ids_dev"].copy_(host, non_blocking=True)
+        ev.record()
+        _lib.check(_lib.lib().refil_replay_gather(st["fields"], C.c_int32(st["nf"]), _lib.ptr(st["ids_dev"]), C.c_int32(n),
+                                                  C.c_int64(self.buffer_size), _lib.current_stream_ptr()), "refil_replay_gather")
+        return st["batch"]
 
     def __repr__(self):
         return (f"ReplayBuffer. {self.episodes_in_buffer}/{self.buffer_size} episodes. "

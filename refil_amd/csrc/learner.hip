@@ -990,6 +990,27 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
     return rc;
 }
 
+// Diagnostics of the row lists of the LAST learner step run on `workspace` with these dims (synchronises `stream`):
+// out[0..5] = {row lists active (0/1), listed entity rows of the agent nets, of the hypernets, listed agent rows,
+//              live (b,t) rows, B * T1}. Benchmarks report the live-row fractions next to the dense FLOP count.
+extern "C" int refil_learner_row_counts(const refil_dims* dims, void* workspace, size_t workspace_bytes_, int32_t* out, void* stream) {
+    REFIL_CHECK(dims && workspace && out, "refil_learner_row_counts: null argument");
+    if (int e = check_dims(*dims)) return e;
+    Ctx c;
+    refil_batch dummy;
+    memset(&dummy, 0, sizeof(dummy));
+    dummy.entities = reinterpret_cast<const float*>(workspace); dummy.entity_mask = reinterpret_cast<const uint8_t*>(workspace);
+    dummy.actions = reinterpret_cast<const int64_t*>(workspace);
+    if (int e = make_ctx(c, dims, &dummy, workspace, workspace_bytes_, CARVE_LEARNER, stream)) return e;
+    out[0] = c.lists ? 1 : 0; out[5] = (int32_t)c.s.R;
+    out[1] = (int32_t)c.s.NE; out[2] = (int32_t)c.s.NE; out[3] = (int32_t)c.s.NA; out[4] = (int32_t)c.s.R;
+    if (c.lists) {
+        REFIL_HIP(hipMemcpyAsync(out + 1, c.w.counts, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c.st));
+        REFIL_HIP(hipStreamSynchronize(c.st));
+    }
+    return 0;
+}
+
 // Destroys this thread's side streams and events (all devices). Safe to call at any time: they are re-created lazily.
 extern "C" int refil_release_streams(void) {
     int cur = 0;

@@ -89,6 +89,17 @@ class LearnerEngine:
             C.byref(dbg) if dbg is not None else None, _lib.current_stream_ptr()), "refil_learner_forward_backward")
         return out
 
+    def row_counts(self, dims: Dims):
+        """Row-list diagnostics of the last forward_backward with these dims (host sync; benchmarks / tests only)."""
+        nbytes = lib().refil_learner_workspace_bytes(C.byref(dims))
+        wp, wsz = self.ws.ptr_size(nbytes)
+        out = (C.c_int32 * 6)()
+        check(lib().refil_learner_row_counts(C.byref(dims), wp, wsz, out, _lib.current_stream_ptr()), "refil_learner_row_counts")
+        keys = ("lists", "entity_rows_agent", "entity_rows_hyper", "agent_rows", "live_steps", "steps")
+        d = dict(zip(keys, list(out)))
+        d["entity_rows"], d["all_agent_rows"] = dims.B * dims.T1 * dims.ne, dims.B * dims.T1 * dims.na
+        return d
+
     # -- q_learner.py:177-178 ------------------------------------------------------------------
     def clip_rmsprop(self, params: torch.Tensor, grads: torch.Tensor, square_avg: torch.Tensor, n: int, lr: float,
                      alpha: float, eps: float, weight_decay: float, clip: float):

@@ -140,6 +140,7 @@ class QLearner:
         if dims.imagine:        # (rand() is drawn even when train_gt_factors ignores it: the reference consumes the RNG too)
             bits = group_bits.to(dev).to(th.uint8).contiguous() if group_bits is not None else \
                 self._draw_partition(B, args.n_entities, dev, bernoulli=dims.gt_factors != 1)
+        self._last_dims = dims
         self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads)
         # data parallel over episodes: ONE all-reduce(SUM) of [grads | stat sums]; the global
         # sum(mask) normaliser is applied afterwards by the optimiser kernel (q_learner.py:165)

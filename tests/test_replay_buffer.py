@@ -1,0 +1,103 @@
+"""ReplayBuffer (reference: src/components/episode_buffer.py:206-246): ring insertion with wrap-around, uniform sampling
+without replacement -- host logic on CPU; the device-side gather (refil_replay_gather) on the GPU."""
+import numpy as np
+import pytest
+import torch as th
+
+from refil_amd.components.episode_buffer import EpisodeBatch, ReplayBuffer
+from refil_amd.components.transforms import OneHot
+
+
+def _scheme(ne=6, na=3, ed=5, A=4):
+    scheme = {
+        "entities": {"vshape": ed, "group": "entities"},
+        "obs_mask": {"vshape": ne, "group": "entities", "dtype": th.uint8},
+        "entity_mask": {"vshape": ne, "dtype": th.uint8},
+        "actions": {"vshape": (1,), "group": "agents", "dtype": th.long},
+        "avail_actions": {"vshape": (A,), "group": "agents", "dtype": th.int},
+        "reward": {"vshape": (1,)},
+        "terminated": {"vshape": (1,), "dtype": th.uint8},
+        "epsilon": {"vshape": (1,), "episode_const": True},
+    }
+    return scheme, {"agents": na, "entities": ne}, {"actions": ("actions_onehot", [OneHot(out_dim=A)])}
+
+
+def _episodes(n, T1, tag0, device="cpu", ne=6, na=3, ed=5, A=4):
+    scheme, groups, pre = _scheme(ne, na, ed, A)
+    b = EpisodeBatch(scheme, groups, n, T1, preprocess=pre, device=device)
+    g = th.Generator().manual_seed(tag0)
+    data = {
+        "entities": th.randn(n, T1, ne, ed, generator=g), "obs_mask": (th.rand(n, T1, ne, ne, generator=g) < 0.3).to(th.uint8),
+        "entity_mask": (th.rand(n, T1, ne, generator=g) < 0.3).to(th.uint8), "actions": th.randint(0, A, (n, T1, na, 1), generator=g),
+        "avail_actions": th.ones(n, T1, na, A, dtype=th.int), "terminated": th.zeros(n, T1, 1, dtype=th.uint8),
+        "reward": th.arange(n, dtype=th.float32).view(n, 1, 1).expand(n, T1, 1) + tag0,          # tags the episode
+    }
+    b.update(data)
+    b.update({"epsilon": th.full((n, 1), float(tag0))})
+    return b
+
+
+def test_ring_insert_wraps_around_like_reference():
+    scheme, groups, pre = _scheme()
+    buf = ReplayBuffer(scheme, groups, 5, 4, preprocess=pre)
+    assert not buf.can_sample(1)
+    buf.insert_episode_batch(_episodes(3, 4, 100))
+    assert buf.episodes_in_buffer == 3 and buf.buffer_index == 3 and buf.can_sample(3) and not buf.can_sample(4)
+    buf.insert_episode_batch(_episodes(4, 4, 200))                     # 2 fit, 2 wrap to slots 0, 1 (episode_buffer.py:225-228)
+    assert buf.episodes_in_buffer == 5 and buf.buffer_index == 2
+    tags = buf["reward"][:, 0, 0].tolist()
+    assert tags == [202.0, 203.0, 102.0, 200.0, 201.0]
+    assert buf["epsilon"][:, 0].tolist() == [200.0, 200.0, 100.0, 200.0, 200.0]
+    assert (buf["filled"] == 1).all()
+    oh = buf["actions_onehot"]
+    assert th.equal(oh.argmax(-1, keepdim=True), buf["actions"]) and (oh.sum(-1) == 1).all()   # preprocess ran on insert
+
+
+def test_sample_is_uniform_without_replacement():
+    scheme, groups, pre = _scheme()
+    buf = ReplayBuffer(scheme, groups, 8, 3, preprocess=pre)
+    buf.insert_episode_batch(_episodes(8, 3, 0))
+    np.random.seed(3)
+    s = buf.sample(5)
+    assert s.batch_size == 5 and s.max_seq_length == 3
+    tags = s["reward"][:, 0, 0].tolist()
+    assert len(set(tags)) == 5 and all(0 <= t < 8 for t in tags)
+    np.random.seed(3)
+    ids = np.random.choice(8, 5, replace=False)                          # the reference's draw (episode_buffer.py:238)
+    assert tags == [float(i) for i in ids]
+    full = buf.sample(8)                                                 # batch == buffer: the first batch_size episodes, in order (:235-236)
+    assert full["reward"][:, 0, 0].tolist() == [float(i) for i in range(8)]
+
+
+@pytest.mark.gpu
+def test_device_gather_equals_fancy_indexing():
+    scheme, groups, pre = _scheme(ne=8, na=4, ed=7, A=5)
+    buf = ReplayBuffer(scheme, groups, 12, 9, preprocess=pre, device="cuda")
+    buf.insert_episode_batch(_episodes(7, 9, 10, device="cuda", ne=8, na=4, ed=7, A=5))
+    buf.insert_episode_batch(_episodes(9, 9, 50, device="cuda", ne=8, na=4, ed=7, A=5))      # wraps
+    assert buf.episodes_in_buffer == 12 and buf.buffer_index == 4
+    for seed in (1, 2, 3):
+        np.random.seed(seed)
+        got = buf.sample(6)                                   # refil_replay_gather
+        np.random.seed(seed)
+        ids = np.random.choice(12, 6, replace=False)
+        ref = buf[ids]                                        # the reference's path
+        th.cuda.synchronize()
+        assert set(got.data.transition_data) == set(ref.data.transition_data)
+        for k, v in ref.data.transition_data.items():
+            assert th.equal(got.data.transition_data[k], v), k
+        for k, v in ref.data.episode_data.items():
+            assert th.equal(got.data.episode_data[k], v), k
+        assert got.batch_size == 6 and got.max_seq_length == 9 and got["entities"].data_ptr() == buf._staging[6]["batch"]["entities"].data_ptr()
+    a = buf.sample(6)["entities"].data_ptr()
+    assert a == buf.sample(6)["entities"].data_ptr()          # the staging minibatch is reused: fixed addresses
+
+
+@pytest.mark.gpu
+def test_gather_rejects_bad_arguments():
+    import ctypes as C
+    from refil_amd import _lib
+    f = (_lib.GatherField * 1)(_lib.GatherField(0, 0, 16, 16, 16))
+    ids = th.zeros(2, dtype=th.int64, device="cuda")
+    assert _lib.lib().refil_replay_gather(f, 1, _lib.ptr(ids), 2, 4, None) != 0
+    assert b"field 0" in _lib.lib().refil_last_error()
