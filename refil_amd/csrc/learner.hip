@@ -292,6 +292,12 @@ static int group_code(const refil_dims& d, int which, bool with_obs) {
 struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // Weight-gradient streams: nothing but the optimiser consumes dW / db, so the dW GEMMs (and their split
+    // reductions) of each chain are forked onto their own stream as soon as their operands exist instead of sitting
+    // in the chain's launch order in front of the dX GEMMs that ARE on the critical path.
+    hipStream_t g[2] = {nullptr, nullptr};
+    hipEvent_t pool[32] = {};
+    int next_ev = 0;
     bool ok = false;
 };
 constexpr int MAX_DEVICES = 16;
@@ -309,6 +315,8 @@ static int side_stream(SideStream*& out) {
         const char* pe = getenv("REFIL_SIDE_PRIO");
         REFIL_HIP(hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, (pe && pe[0] == '1') ? hi : 0));
         for (auto& e : sd.ev) REFIL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& g : sd.g) REFIL_HIP(hipStreamCreateWithPriority(&g, hipStreamNonBlocking, 0));
+        for (auto& e : sd.pool) REFIL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         sd.ok = true;
     }
     out = &sd;
@@ -318,7 +326,18 @@ static int side_stream(SideStream*& out) {
 static void side_stream_rejoin(SideStream* sd, hipStream_t main) {
     if (!sd || !sd->ok) return;
     if (hipEventRecord(sd->ev[3], sd->s) == hipSuccess) (void)hipStreamWaitEvent(main, sd->ev[3], 0);
+    for (int i = 0; i < 2; ++i)
+        if (hipEventRecord(sd->pool[i], sd->g[i]) == hipSuccess) (void)hipStreamWaitEvent(main, sd->pool[i], 0);
     (void)hipGetLastError();
+}
+// `to` waits for everything enqueued on `from` so far (no-op when they are the same stream)
+static int stream_after(SideStream* sd, hipStream_t from, hipStream_t to) {
+    if (from == to || !sd) return 0;
+    hipEvent_t e = sd->pool[sd->next_ev];
+    sd->next_ev = (sd->next_ev + 1) % 32;
+    REFIL_HIP(hipEventRecord(e, from));
+    REFIL_HIP(hipStreamWaitEvent(to, e, 0));
+    return 0;
 }
 static int g_overlap = -1;      // -1: follow the environment, 0/1: set by refil_set_overlap
 static bool overlap_enabled() {
@@ -342,7 +361,16 @@ struct Ctx {
     // Learner steps of the flagship family at sizes where every listed GEMM takes the weight-resident / streaming
     // kernels; REFIL_DENSE=1 switches it off (same results up to the summation order of the weight gradients).
     bool lists;
+    // weight-gradient stream of this chain (== st when the chains are serialised) and its split-reduction scratch
+    hipStream_t gst; float* gpartial; SideStream* sd;
 };
+
+// weight gradients (+ their reductions) leave the chain: forked behind everything enqueued on the chain so far
+static int launch_dw(const Ctx& c, refil_gemm_desc g) {
+    g.partial = c.gpartial;
+    if (int e = stream_after(c.sd, c.st, c.gst)) return e;
+    return gemm_launch(g, c.gst);
+}
 
 struct RowList { const int* idx; const int* cnt; };
 static refil_gemm_desc with_rows(refil_gemm_desc g, const Ctx& c, RowList l) {
@@ -605,7 +633,7 @@ static int attn_block_backward(const Ctx& c, const AttnBlockBwd& k) {
                                        k.Gr + k.out_w + net0 * k.out_w_stride, w, k.Gr + k.out_b + net0 * k.out_b_stride,
                                        rows, w, w, c.w.partial, batch);
         gw.sA = s.NA * w; gw.sB = s.NA * w; gw.sC = k.out_w_stride; gw.sColsum = k.out_b_stride;
-        RUN(gemm_launch(gw, c.st));
+        RUN(launch_dw(c, gw));
         // d(attn_out) = dx2 W_out
         refil_gemm_desc gx = linear_dx(k.dx2 + voff * s.NA * w, w, k.P + k.out_w + net0 * k.out_w_stride, w,
                                        k.dao + voff * s.NA * w, w, rows, w, w, 0);
@@ -634,7 +662,7 @@ static int attn_block_backward(const Ctx& c, const AttnBlockBwd& k) {
         refil_gemm_desc g = linear_dw(k.dkv, 2 * w, k.x1, (int)ldx1, k.Gr + k.in_w, w, k.Gr + k.in_w + (long)w * w, s.NE, w, w,
                                       c.w.partial, k.nets);
         g.sA = s.NEa * 2 * w; g.sB = w; g.sC = k.in_w_stride; g.sColsum = k.in_w_stride;
-        RUN(gemm_launch(g, c.st));
+        RUN(launch_dw(c, g));
         refil_gemm_desc x = linear_dx(k.dkv, 2 * w, k.P + k.in_w, w, k.dx1, (int)ldx1, s.NE, w, w, REFIL_GEMM_RELU_BWD);
         x.aux = k.x1; x.batch = k.nets; x.sA = s.NEa * 2 * w; x.sB = k.in_w_stride; x.sC = w;
         RUN(gemm_launch(x, c.st));
@@ -645,11 +673,11 @@ static int attn_block_backward(const Ctx& c, const AttnBlockBwd& k) {
         refil_gemm_desc g = linear_dw(k.dkv, 2 * w, k.x1, (int)ldx1, k.Gr + k.in_w + (long)w * w, w, nullptr, s.NE, 2 * w, w,
                                       c.w.partial, k.nets);
         g.sA = s.NEa * 2 * w; g.sB = w; g.sC = k.in_w_stride;
-        RUN(gemm_launch(with_rows(g, c, re), c.st));
+        RUN(launch_dw(c, with_rows(g, c, re)));
         refil_gemm_desc q = linear_dw(k.dq, w, k.x1, (int)ldx1, k.Gr + k.in_w, w, nullptr, s.NA, w, w, c.w.partial, k.nets);
         q.b_map = refil_rowmap{d.na, d.ne, 0};
         q.sA = s.NAa * w; q.sB = w; q.sC = k.in_w_stride;
-        RUN(gemm_launch(with_rows(q, c, rows_a(c)), c.st));
+        RUN(launch_dw(c, with_rows(q, c, rows_a(c))));
     }
     // dx1 = relu'(x1) * (dKV W_kv + scatter(dQ W_q))
     {
@@ -674,6 +702,7 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
     REFIL_CHECK(dims && batch && ws, "refil: null dims/batch/workspace");
     if (int e = check_dims(*dims)) return e;
     c.d = *dims; c.s = sizes_of(*dims); c.b = *batch; c.st = (hipStream_t)stream;
+    c.gst = c.st; c.gpartial = nullptr; c.sd = nullptr;
     param_layout(c.d, c.L);
     const char* pe = getenv("REFIL_PRESUM");          // read per call: tests compare both paths in one process
     const bool presum_on = !(pe && pe[0] == '0');
@@ -761,9 +790,13 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     Ctx ca = c;                       // agent chain: caller's stream
     Ctx ch = c;                       // hypernet chain: side stream + its own split-K scratch
     const bool overlap = overlap_enabled();
+    ca.gpartial = w.partial; ch.gpartial = w.partial2;
     if (overlap) {
         RUN(side_stream(sd));
-        ch.st = sd->s; ch.w.partial = w.partial2;
+        sd->next_ev = 2;                                   // (pool[0..1]: the final joins of the two weight-gradient streams)
+        ch.st = sd->s; ch.gst = sd->s; ca.sd = ch.sd = sd;
+        static const bool gstreams = [] { const char* e = getenv("REFIL_GRADSTREAM"); return !(e && e[0] == '0'); }();
+        if (gstreams) { ch.gst = sd->g[1]; ca.gst = sd->g[0]; }
         REFIL_HIP(hipEventRecord(sd->ev[0], c.st));
         REFIL_HIP(hipStreamWaitEvent(sd->s, sd->ev[0], 0));
     }
@@ -845,16 +878,16 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         // composed tails (x3 = mask(a W_c^T + b_c)): G_c = g3^T a, g_c = colsum(g3) (weighted by n_act on the summed rows),
         // d(attention output) = g3 W_c straight into daoh; compose_backward turns (G_c, g_c) into the four parameter gradients
         refil_gemm_desc gw = linear_dw(w.dx3h, M, w.lh.ao, h, w.gwc, h, w.gbc, (long)nv0 * s.NA, M, h, ch.w.partial, 1);
-        RUN(gemm_launch(gw, ch.st));
+        RUN(launch_dw(ch, gw));
         refil_gemm_desc gx = linear_dx(w.dx3h, M, w.lh.wc, h, w.daoh, h, (long)nv0 * s.NA, M, h, 0);
         RUN(gemm_launch(gx, ch.st));
         const long o3 = (long)nv0 * s.NA * M, oh = (long)nv0 * s.NA * h;
         refil_gemm_desc gw1 = linear_dw(w.dx3h + o3, M, w.lh.ao + oh, h, w.gwc + (long)M * h, h, nullptr, s.R, M, h, ch.w.partial, s.nets - 1);
         gw1.sA = s.NA * M; gw1.sB = s.NA * h; gw1.sC = (long)M * h;
-        RUN(gemm_launch(gw1, ch.st));
+        RUN(launch_dw(ch, gw1));
         refil_gemm_desc gb1 = linear_dw(w.dx3h + o3, M, w.nact, 1, w.gbc + M, 1, nullptr, s.R, M, 1, ch.w.partial, s.nets - 1);
         gb1.sA = s.NA * M; gb1.sB = 0; gb1.sC = M;
-        RUN(gemm_launch(gb1, ch.st));
+        RUN(launch_dw(ch, gb1));
         refil_gemm_desc gx1 = linear_dx(w.dx3h + o3, M, w.lh.wc + (long)M * h, h, w.daoh + oh, h, s.R, M, h, 0);
         gx1.batch = s.nets - 1; gx1.sA = s.NA * M; gx1.sB = (long)M * h; gx1.sC = s.NA * h;
         RUN(gemm_launch(gx1, ch.st));
@@ -865,7 +898,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         ca.Gc = w.gwc; ca.gc = w.gbc;
         ca.dW2 = grads + L.mix_fc2_w; ca.db2 = grads + L.mix_fc2_b; ca.dWo = grads + L.mix_out_w; ca.dbo = grads + L.mix_out_b;
         ca.nets = s.nets; ca.M = M; ca.h = h;
-        RUN(compose_backward_launch(ca, ch.st));
+        RUN(compose_backward_launch(ca, ch.gst));          // (consumes G_c / g_c: stays behind them on the weight-gradient stream)
     } else {
     // hypernet tails: fc2 (flex_qmix.py:49)
     for (int part = 0; part < 2; ++part) {
@@ -877,7 +910,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
                                        grads + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h,
                                        grads + L.mix_fc2_b + net0 * L.mix_fc2_b_stride, rows, M, h, ch.w.partial, batch);
         gw.sA = s.NA * M; gw.sB = s.NA * h; gw.sC = L.mix_fc2_w_stride; gw.sColsum = L.mix_fc2_b_stride;
-        RUN(gemm_launch(gw, ch.st));
+        RUN(launch_dw(ch, gw));
         refil_gemm_desc gx = linear_dx(w.dx3h + voff * s.NA * M, M, params_live + L.mix_fc2_w + net0 * L.mix_fc2_w_stride, h,
                                        w.dx2h + voff * s.NA * h, h, rows, M, h, 0);
         gx.batch = batch; gx.sA = s.NA * M; gx.sB = L.mix_fc2_w_stride; gx.sC = s.NA * h;
@@ -900,7 +933,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         // the four hypernet fc1 layers: dW = dx1^T xe (one [4h,E] GEMM), db = colsum(dx1)
         refil_gemm_desc g = linear_dw(w.dx1h, s.nets * h, w.xe, s.Ep, grads + L.mix_fc1_w, s.E, grads + L.mix_fc1_b, s.NE, s.nets * h, s.E,
                                       ch.w.partial, 1);
-        RUN(gemm_launch(with_rows(g, ch, rows_eh(ch)), ch.st));
+        RUN(launch_dw(ch, with_rows(g, ch, rows_eh(ch))));
     }
     }
     // agent: chosen-Q gather + inactive-agent fill, then fc3
@@ -912,14 +945,14 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         const long rows = (long)G * s.NA;
         if (d.agent_ff) {
             // feed-forward agent: q = fc2(x2), x2 = relu(masked out_trans)  (entity_ff_agent.py:44-52)
-            RUN(gemm_launch(linear_dw(w.dqva, d.A, w.la.x2, dd, grads + L.ag_fc2_w, dd, grads + L.ag_fc2_b, rows, d.A, dd, ca.w.partial, 1), ca.st));
+            RUN(launch_dw(ca, linear_dw(w.dqva, d.A, w.la.x2, dd, grads + L.ag_fc2_w, dd, grads + L.ag_fc2_b, rows, d.A, dd, ca.w.partial, 1)));
             refil_gemm_desc gx2 = linear_dx(w.dqva, d.A, params_live + L.ag_fc2_w, dd, w.dx2a, dd, rows, d.A, dd, REFIL_GEMM_RELU_BWD);
             gx2.aux = w.la.x2;                 // x2 = 0 on inactive rows, so relu' also applies the row mask
             RUN(gemm_launch(gx2, ca.st));
         } else {
             refil_gemm_desc gw = linear_dw(w.dqva, d.A, w.la.hsx, H, grads + L.ag_fc3_w, H, grads + L.ag_fc3_b, rows, d.A, H, ca.w.partial, 1);
             gw.b_map = hs_rows(c, d.na);
-            RUN(gemm_launch(gw, ca.st));
+            RUN(launch_dw(ca, gw));
             RUN(gemm_launch(linear_dx(w.dqva, d.A, params_live + L.ag_fc3_w, H, w.dhs, H, rows, d.A, H, 0), ca.st));
             // BPTT
             refil_gru_desc g;
@@ -931,18 +964,18 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
             RUN(gru_backward_launch(g, ca.st));
             refil_gemm_desc ghh = linear_dw(w.dgh, 3 * H, w.la.hsx, H, grads + L.ag_w_hh, H, grads + L.ag_b_hh, rows, 3 * H, H, ca.w.partial, 1);
             ghh.b_map = hs_rows(c, 0);
-            RUN(gemm_launch(ghh, ca.st));
-            RUN(gemm_launch(linear_dw(w.dgi, 3 * H, w.la.x3, H, grads + L.ag_w_ih, H, grads + L.ag_b_ih, rows, 3 * H, H, ca.w.partial, 1), ca.st));
+            RUN(launch_dw(ca, ghh));
+            RUN(launch_dw(ca, linear_dw(w.dgi, 3 * H, w.la.x3, H, grads + L.ag_w_ih, H, grads + L.ag_b_ih, rows, 3 * H, H, ca.w.partial, 1)));
             refil_gemm_desc gx3 = linear_dx(w.dgi, 3 * H, params_live + L.ag_w_ih, H, w.dx3a, H, rows, 3 * H, H, REFIL_GEMM_RELU_BWD);
             gx3.aux = w.la.x3;
             RUN(gemm_launch(gx3, ca.st));
             if (c.compose_agent) {
                 // composed fc2 o out_trans: G_c = dx3^T a (a = 0 on inactive rows), colsum over all rows -> db_2, over the
                 // active rows -> the b_o terms; d(attention out) = dx3 W_c on the active rows
-                RUN(gemm_launch(linear_dw(w.dx3a, H, w.la.ao, dd, w.gwca, dd, w.gbca, rows, H, dd, ca.w.partial, 1), ca.st));
+                RUN(launch_dw(ca, linear_dw(w.dx3a, H, w.la.ao, dd, w.gwca, dd, w.gbca, rows, H, dd, ca.w.partial, 1)));
                 refil_gemm_desc gb = linear_dw(w.dx3a, H, w.actf, 1, w.gbact, 1, nullptr, rows, H, 1, ca.w.partial, 1);
                 gb.b_map = refil_rowmap{(int)s.NA, 0, 0};          // the G mask copies share the [NA] activity vector
-                RUN(gemm_launch(gb, ca.st));
+                RUN(launch_dw(ca, gb));
                 refil_gemm_desc gx2 = linear_dx(w.dx3a, H, w.la.wc, dd, w.daoa, dd, rows, H, dd, 0);
                 gx2.rowmask = w.amask; gx2.rowmask_mod = (int)s.NA;
                 RUN(gemm_launch(gx2, ca.st));
@@ -952,10 +985,10 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
                 cb.Gc = w.gwca; cb.gc = w.gbact; cb.gc_b2 = w.gbca;
                 cb.dW2 = grads + L.ag_fc2_w; cb.db2 = grads + L.ag_fc2_b; cb.dWo = grads + L.ag_out_w; cb.dbo = grads + L.ag_out_b;
                 cb.nets = 1; cb.M = H; cb.h = dd;
-                RUN(compose_backward_launch(cb, ca.st));
+                RUN(compose_backward_launch(cb, ca.gst));
             } else {
             // fc2
-            RUN(gemm_launch(linear_dw(w.dx3a, H, w.la.x2, dd, grads + L.ag_fc2_w, dd, grads + L.ag_fc2_b, rows, H, dd, ca.w.partial, 1), ca.st));
+            RUN(launch_dw(ca, linear_dw(w.dx3a, H, w.la.x2, dd, grads + L.ag_fc2_w, dd, grads + L.ag_fc2_b, rows, H, dd, ca.w.partial, 1)));
             refil_gemm_desc gx2 = linear_dx(w.dx3a, H, params_live + L.ag_fc2_w, dd, w.dx2a, dd, rows, H, dd, 0);
             gx2.rowmask = w.amask; gx2.rowmask_mod = (int)s.NA;
             RUN(gemm_launch(gx2, ca.st));
@@ -972,11 +1005,15 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         k.var_first[2] = group_code(d, 1, true);
         k.var_rest = REFIL_MASK_OBS;
         RUN(attn_block_backward(ca, k));
-        RUN(gemm_launch(with_rows(linear_dw(w.dx1a, dd, w.xe, s.Ep, grads + L.ag_fc1_w, s.E, grads + L.ag_fc1_b, s.NE, dd, s.E, ca.w.partial, 1), ca, rows_ea(ca)), ca.st));
+        RUN(launch_dw(ca, with_rows(linear_dw(w.dx1a, dd, w.xe, s.Ep, grads + L.ag_fc1_w, s.E, grads + L.ag_fc1_b, s.NE, dd, s.E, ca.w.partial, 1), ca, rows_ea(ca))));
     }
-    if (overlap) {                                                                 // join
+    if (overlap) {                                                                 // join: hypernet chain, both weight-gradient streams
         REFIL_HIP(hipEventRecord(sd->ev[3], sd->s));
         REFIL_HIP(hipStreamWaitEvent(c.st, sd->ev[3], 0));
+        for (int i = 0; i < 2; ++i) {
+            REFIL_HIP(hipEventRecord(sd->pool[i], sd->g[i]));
+            REFIL_HIP(hipStreamWaitEvent(c.st, sd->pool[i], 0));
+        }
     }
     return 0;
 }
@@ -1021,6 +1058,8 @@ extern "C" int refil_release_streams(void) {
         if (hipSetDevice(dev) == hipSuccess) {
             (void)hipStreamSynchronize(sd.s);
             for (auto& e : sd.ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+            for (auto& e : sd.pool) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+            for (auto& g : sd.g) { if (g) { (void)hipStreamSynchronize(g); (void)hipStreamDestroy(g); } g = nullptr; }
             (void)hipStreamDestroy(sd.s);
         }
         sd.s = nullptr; sd.ok = false;
