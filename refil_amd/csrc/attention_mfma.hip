@@ -25,9 +25,19 @@
 
 namespace refil {
 
-struct AttnM {
+// One launch serves up to ATTN_MAX_NETS attention blocks that share the rows and the masks (the four hypernets of a
+// mixer): the mask words of a row are built once, the per-(net, head) jobs of a row are spread over the 4 waves, and a
+// wave fetches the operands of its next job while it works on the current one.
+constexpr int ATTN_MAX_NETS = 8;
+struct AttnNet {
     const float* Q; const float* K; const float* V; float* O; const float* dO;
     float* dQ; float* dK; float* dV;
+    int nvar;          // mask variants of this net: variants 0 .. nvar-1 of the launch (a single-variant net uses variant 0)
+    int sum_agents;    // forward (nvar = 1): O[r][:] = sum over agents of the attention output (row r of a [R, w] matrix)
+    int bcast_do;      // backward: dO is one row per r ([R, w]) shared by all agents of the row
+};
+struct AttnM {
+    AttnNet net[ATTN_MAX_NETS]; int nnets;
     int ldq, ldkv, ldo; long sO;
     int R, T1, ne, na, heads, hd, nvar; int var[3];
     const uint8_t* obs_mask; long om_sB, om_sT;
@@ -36,10 +46,8 @@ struct AttnM {
     int wave_floats;   // LDS floats per wave region
     int mask_floats;   // LDS floats of the mask byte region (the mask words follow it)
     // hypernets in 'vector' / 'scalar' mode only use the SUM of their per-agent outputs (flex_qmix.py:51-56), and every
-    // layer between the attention core and that sum is linear, so the sum can be taken right here:
-    int sum_agents;    // forward (nvar = 1): O[r][:] = sum over agents of the attention output (row r of a [R, w] matrix)
+    // layer between the attention core and that sum is linear, so the sum can be taken right here (AttnNet::sum_agents)
     float* nact;       // forward: nact[r] = number of active agents of row r (weight of the bias terms downstream) or NULL
-    int bcast_do;      // backward: dO is one row per r ([R, w]) shared by all agents of the row
     int zero_dead;     // forward: write zeros for inactive agents (the layer's post_mask, attention.py:66-67, applied early)
     // row skipping (refil_attn_desc: t_last / kv_dead / q_dead)
     const int* t_last; const uint8_t* kv_dead; const uint8_t* q_dead;
@@ -285,15 +293,22 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
     float* Ks = Qs + NAT * 16 * pd;
     float* Vs = Ks + NJT * 16 * pd;
     const float inv_scale = 1.0f / sqrtf((float)p.hd);
-    for (int head = wave; head < p.heads; head += 4) {
-        {
-            Stage<NAT * 16, 4 * NCT> sq;
-            Stage<NJT * 16, 4 * NCT> sk, sv;
-            sq.load(p.Q, (long)r * p.na, p.na, p.ldq, head * p.hd, p.hd, lane, m.qd);
-            sk.load(p.K, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane, m.kd);
-            sv.load(p.V, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane, m.kd);
-            sq.store(Qs, p.hd, pd, lane); sk.store(Ks, p.hd, pd, lane); sv.store(Vs, p.hd, pd, lane);
-        }
+    const int njobs = p.nnets * p.heads;                   // job = (net, head); a wave takes jobs wave, wave + 4, ...
+    Stage<NAT * 16, 4 * NCT> sq;
+    Stage<NJT * 16, 4 * NCT> sk, sv;
+    auto fetch = [&](int job) {
+        const AttnNet& n = p.net[job / p.heads];
+        const int head = job % p.heads;
+        sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * p.hd, p.hd, lane, m.qd);
+        sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane, m.kd);
+        sv.load(n.V, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane, m.kd);
+    };
+    if (wave < njobs) fetch(wave);
+    for (int job = wave; job < njobs; job += 4) {
+        const AttnNet& n = p.net[job / p.heads];
+        const int head = job % p.heads;
+        sq.store(Qs, p.hd, pd, lane); sk.store(Ks, p.hd, pd, lane); sv.store(Vs, p.hd, pd, lane);
+        if (job + 4 < njobs) fetch(job + 4);               // in flight while this job is computed (LDS is read, not written, below)
         f32x4 osum[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) osum[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -303,14 +318,14 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
             f32x4 st0[NJT];
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt) st0[jt] = dot_tile(Ks, 16 * jt, Qs, 16 * at, p.hd, pd, l15, q);
-            for (int v = 0; v < p.nvar; ++v) {
+            for (int v = 0; v < n.nvar; ++v) {
                 f32x4 pt[NJT];
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) pt[jt][reg] = st0[jt][reg] * inv_scale;   // attention.py:54
                 softmax_T<NJT>(pt, mw[v * NAT * 16 + agent], q);
-                float* O = p.O + v * p.sO;
+                float* O = n.O + v * p.sO;
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
                     // O^T[c][agent] = sum_key V[key][c] P^T[key][agent]; virtual k (jt,reg | q) <-> key 16jt+4q+reg
@@ -321,7 +336,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
                         for (int reg = 0; reg < 4; ++reg)
                             o = MFMA16(Vs[(16 * jt + 4 * q + reg) * pd + 16 * ct + l15], pt[jt][reg], o);
                     const int c = 16 * ct + 4 * q;
-                    if (p.sum_agents) {          // padded / inactive agents have P = 0, hence o = 0: plain sum over the 16 lanes
+                    if (n.sum_agents) {          // padded / inactive agents have P = 0, hence o = 0: plain sum over the 16 lanes
 #pragma unroll
                         for (int e = 0; e < 4; ++e) osum[ct][e] += group16_sum(o[e]);
                     } else if (agent < p.na && c < p.hd) {
@@ -331,14 +346,15 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
                 }
             }
         }
-        if (p.sum_agents && l15 == 0) {
+        if (n.sum_agents && l15 == 0) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const int c = 16 * ct + 4 * q;
                 if (c < p.hd)
-                    *reinterpret_cast<float4*>(p.O + (long)r * p.ldo + head * p.hd + c) = make_float4(osum[ct][0], osum[ct][1], osum[ct][2], osum[ct][3]);
+                    *reinterpret_cast<float4*>(n.O + (long)r * p.ldo + head * p.hd + c) = make_float4(osum[ct][0], osum[ct][1], osum[ct][2], osum[ct][3]);
             }
         }
+        __builtin_amdgcn_wave_barrier();                   // (the next job's operands overwrite the wave's LDS tiles)
     }
 }
 
@@ -363,13 +379,16 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
     constexpr int TP = NJT * 16 + 4;         // pitch of the dS transposition tile (16 agents x keys)
     float* Ts = Qs + p.wave_floats - 16 * TP;
     const float inv_scale = 1.0f / sqrtf((float)p.hd);
-    for (int head = wave; head < p.heads; head += 4) {
+    const int njobs = p.nnets * p.heads;                   // job = (net, head); a wave takes jobs wave, wave + 4, ...
+    for (int job = wave; job < njobs; job += 4) {
+        const AttnNet& n = p.net[job / p.heads];
+        const int head = job % p.heads;
         {
             Stage<NAT * 16, 4 * NCT> sq;
             Stage<NJT * 16, 4 * NCT> sk, sv;
-            sq.load(p.Q, (long)r * p.na, p.na, p.ldq, head * p.hd, p.hd, lane, m.qd);
-            sk.load(p.K, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane, m.kd);
-            sv.load(p.V, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane, m.kd);
+            sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * p.hd, p.hd, lane, m.qd);
+            sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane, m.kd);
+            sv.load(n.V, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane, m.kd);
             sq.store(Qs, p.hd, pd, lane); sk.store(Ks, p.hd, pd, lane); sv.store(Vs, p.hd, pd, lane);
         }
         f32x4 dKt[NCT][NJT], dVt[NCT][NJT];     // [c 16ct+4q+reg][key 16jt+l15]
@@ -390,10 +409,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
             const int na_t = min(16, p.na - 16 * at);
             Stage<16, 4 * NCT> sd;
             // (bcast_do: one dO row per (b,t), shared by its agents -- leading dimension 0 re-reads the same row)
-            const float* dO0 = p.bcast_do ? p.dO + (long)r * p.ldo : p.dO;
-            const long drow0 = p.bcast_do ? 0 : (long)r * p.na + 16 * at;
-            const int dld = p.bcast_do ? 0 : p.ldo;
-            const uint8_t* ddead = (m.qd && !p.bcast_do) ? m.qd + 16 * at : nullptr;
+            const float* dO0 = n.bcast_do ? n.dO + (long)r * p.ldo : n.dO;
+            const long drow0 = n.bcast_do ? 0 : (long)r * p.na + 16 * at;
+            const int dld = n.bcast_do ? 0 : p.ldo;
+            const uint8_t* ddead = (m.qd && !n.bcast_do) ? m.qd + 16 * at : nullptr;
             sd.load(dO0, drow0, na_t, dld, head * p.hd, p.hd, lane, ddead);
             f32x4 sn0[NJT];
 #pragma unroll
@@ -401,9 +420,9 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
             f32x4 dQt[NCT];                           // [c][agent 16at+l15]
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) dQt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int v = 0; v < p.nvar; ++v) {
+            for (int v = 0; v < n.nvar; ++v) {
                 sd.store(Ds, p.hd, pd, lane);
-                if (v + 1 < p.nvar) sd.load(dO0 + (v + 1) * p.sO, drow0, na_t, dld, head * p.hd, p.hd, lane, ddead);
+                if (v + 1 < n.nvar) sd.load(dO0 + (v + 1) * p.sO, drow0, na_t, dld, head * p.hd, p.hd, lane, ddead);
                 f32x4 pn[NJT];
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt)
@@ -455,7 +474,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
             for (int ct = 0; ct < NCT; ++ct) {
                 const int c = 16 * ct + 4 * q;
                 if (agentT < p.na && c < p.hd)
-                    *reinterpret_cast<float4*>(p.dQ + ((long)r * p.na + agentT) * p.ldq + head * p.hd + c) =
+                    *reinterpret_cast<float4*>(n.dQ + ((long)r * p.na + agentT) * p.ldq + head * p.hd + c) =
                         make_float4(dQt[ct][0], dQt[ct][1], dQt[ct][2], dQt[ct][3]);
             }
         }
@@ -466,10 +485,11 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
                 const int key = 16 * jt + l15, c = 16 * ct + 4 * q;
                 if (key < p.ne && c < p.hd) {
                     const long off = ((long)r * p.ne + key) * p.ldkv + head * p.hd + c;
-                    *reinterpret_cast<float4*>(p.dK + off) = make_float4(dKt[ct][jt][0], dKt[ct][jt][1], dKt[ct][jt][2], dKt[ct][jt][3]);
-                    *reinterpret_cast<float4*>(p.dV + off) = make_float4(dVt[ct][jt][0], dVt[ct][jt][1], dVt[ct][jt][2], dVt[ct][jt][3]);
+                    *reinterpret_cast<float4*>(n.dK + off) = make_float4(dKt[ct][jt][0], dKt[ct][jt][1], dKt[ct][jt][2], dKt[ct][jt][3]);
+                    *reinterpret_cast<float4*>(n.dV + off) = make_float4(dVt[ct][jt][0], dVt[ct][jt][1], dVt[ct][jt][2], dVt[ct][jt][3]);
                 }
             }
+        __builtin_amdgcn_wave_barrier();                   // (the next job's operands overwrite the wave's LDS tiles)
     }
 }
 
@@ -490,7 +510,7 @@ __device__ inline void pool_stage(const PoolK& k, float* E, int r, int tid) {
     const int w4 = k.w >> 2;
     for (int idx = tid; idx < p.ne * w4; idx += 256) {
         const int j = idx / w4, c4 = idx - j * w4;
-        *reinterpret_cast<float4*>(E + j * k.w + 4 * c4) = *reinterpret_cast<const float4*>(p.K + ((long)r * p.ne + j) * p.ldkv + 4 * c4);
+        *reinterpret_cast<float4*>(E + j * k.w + 4 * c4) = *reinterpret_cast<const float4*>(p.net[0].K + ((long)r * p.ne + j) * p.ldkv + 4 * c4);
     }
 }
 
@@ -516,7 +536,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolK k) {
             const float x = ((word >> j) & 1ull) ? 0.f : E[j * k.w + c];
             acc = k.mode == 2 ? fmaxf(acc, x) : acc + x;
         }
-        p.O[v * p.sO + ((long)r * p.na + i) * p.ldo + c] = k.mode == 2 ? acc : acc * inv_ne;
+        p.net[0].O[v * p.sO + ((long)r * p.na + i) * p.ldo + c] = k.mode == 2 ? acc : acc * inv_ne;
     }
 }
 
@@ -542,7 +562,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolK k) {
         for (int v = 0; v < p.nvar; ++v)
             for (int i = 0; i < p.na; ++i) {
                 const unsigned long long word = mw[v * k.na_pad + i];
-                const float g = p.dO[v * p.sO + ((long)r * p.na + i) * p.ldo + c];
+                const float g = p.net[0].dO[v * p.sO + ((long)r * p.na + i) * p.ldo + c];
                 if (k.mode == 2) {
                     float best = -INFINITY; int jb = 0;
                     for (int j = 0; j < p.ne; ++j) {
@@ -561,7 +581,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(PoolK k) {
     const int w4 = k.w >> 2;
     for (int idx = tid; idx < p.ne * w4; idx += 256) {
         const int j = idx / w4, c4 = idx - j * w4;
-        *reinterpret_cast<float4*>(p.dK + ((long)r * p.ne + j) * p.ldkv + 4 * c4) = *reinterpret_cast<const float4*>(G + j * k.w + 4 * c4);
+        *reinterpret_cast<float4*>(p.net[0].dK + ((long)r * p.ne + j) * p.ldkv + 4 * c4) = *reinterpret_cast<const float4*>(G + j * k.w + 4 * c4);
     }
 }
 
@@ -583,7 +603,7 @@ int pool_launch(const refil_attn_desc& d, int mode, bool bwd, hipStream_t st) {
     PoolK k;
     AttnM& a = k.a;
     memset(&a, 0, sizeof(a));
-    a.K = d.K; a.O = d.O; a.dO = d.dO; a.dK = d.dK; a.ldkv = d.ldkv; a.ldo = d.ldo; a.sO = d.sO;
+    a.net[0].K = d.K; a.net[0].O = d.O; a.net[0].dO = d.dO; a.net[0].dK = d.dK; a.nnets = 1; a.ldkv = d.ldkv; a.ldo = d.ldo; a.sO = d.sO;
     a.R = d.R; a.T1 = d.T1; a.ne = d.ne; a.na = d.na; a.heads = d.heads; a.hd = d.hd; a.nvar = d.nvar;
     for (int v = 0; v < 3; ++v) a.var[v] = d.var[v];
     a.obs_mask = d.obs_mask; a.om_sB = d.om_sB; a.om_sT = d.om_sT;
@@ -627,24 +647,44 @@ bool attn_mfma_supported(int ne, int na, int hd) {
     return (j == 1 && a == 1 && c <= 2) || (j == 2 && a == 1 && c <= 2) || (a == 2 && c == 2 && j >= 2 && j <= 4);
 }
 
-int attn_mfma_launch_ex(const refil_attn_desc& d, bool bwd, hipStream_t st, int sum_agents, float* nact, int bcast_do, int zero_dead);
 int attn_mfma_launch(const refil_attn_desc& d, bool bwd, hipStream_t st) { return attn_mfma_launch_ex(d, bwd, st, 0, nullptr, 0, 0); }
 
-// returns -1 when the tile shape is not instantiated (caller falls back to the VALU kernel)
 int attn_mfma_launch_ex(const refil_attn_desc& d, bool bwd, hipStream_t st, int sum_agents, float* nact, int bcast_do, int zero_dead) {
+    AttnNetOpts o{sum_agents, bcast_do};
+    return attn_mfma_launch_multi(&d, &o, 1, bwd, st, nact, zero_dead);
+}
+
+// n attention blocks in one launch (same rows, masks, widths and leading dimensions; descs[0] carries the mask variants,
+// the others are single-variant nets under its variant 0). Returns -1 when the tile shape is not instantiated (caller
+// falls back to the VALU kernel).
+int attn_mfma_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts, int n, bool bwd, hipStream_t st, float* nact, int zero_dead) {
+    REFIL_CHECK(descs && opts && n >= 1 && n <= ATTN_MAX_NETS, "refil_attn: 1..%d nets per launch", ATTN_MAX_NETS);
+    const refil_attn_desc& d = descs[0];
     const int njt = tiles16(d.ne), nat = tiles16(d.na), nct = tiles16(d.hd);
     AttnM k;
-    k.Q = d.Q; k.K = d.K; k.V = d.V; k.O = d.O; k.dO = d.dO; k.dQ = d.dQ; k.dK = d.dK; k.dV = d.dV;
+    memset(&k, 0, sizeof(k));
+    k.nnets = n;
+    for (int i = 0; i < n; ++i) {
+        const refil_attn_desc& e = descs[i];
+        REFIL_CHECK(e.R == d.R && e.T1 == d.T1 && e.ne == d.ne && e.na == d.na && e.heads == d.heads && e.hd == d.hd && e.ldq == d.ldq &&
+                    e.ldkv == d.ldkv && e.ldo == d.ldo && e.sO == d.sO && e.obs_mask == d.obs_mask && e.ent_mask == d.ent_mask &&
+                    e.ent_mask0 == d.ent_mask0 && e.group_bits == d.group_bits && e.gt_mask == d.gt_mask && e.t_last == d.t_last &&
+                    e.kv_dead == d.kv_dead && e.q_dead == d.q_dead, "refil_attn: nets of one launch must share rows, masks and strides");
+        REFIL_CHECK(i == 0 || (e.nvar == 1 && e.var[0] == d.var[0]), "refil_attn: nets after the first are single-variant under variant 0");
+        REFIL_CHECK(!opts[i].sum_agents || (!bwd && e.nvar == 1), "refil_attn: the agent-sum output is a forward, single-variant option");
+        AttnNet& t = k.net[i];
+        t.Q = e.Q; t.K = e.K; t.V = e.V; t.O = e.O; t.dO = e.dO; t.dQ = e.dQ; t.dK = e.dK; t.dV = e.dV;
+        t.nvar = e.nvar; t.sum_agents = opts[i].sum_agents; t.bcast_do = opts[i].bcast_do;
+    }
     k.ldq = d.ldq; k.ldkv = d.ldkv; k.ldo = d.ldo; k.sO = d.sO;
     k.R = d.R; k.T1 = d.T1; k.ne = d.ne; k.na = d.na; k.heads = d.heads; k.hd = d.hd; k.nvar = d.nvar;
     for (int v = 0; v < 3; ++v) k.var[v] = d.var[v];
     k.obs_mask = d.obs_mask; k.om_sB = d.om_sB; k.om_sT = d.om_sT;
     k.ent_mask = d.ent_mask; k.ent_mask0 = d.ent_mask0; k.group_bits = d.group_bits;
     k.gt_mask = d.gt_mask; k.gt_sB = d.gt_sB; k.gt_sT = d.gt_sT;
-    k.sum_agents = sum_agents; k.nact = nact; k.bcast_do = bcast_do; k.zero_dead = zero_dead;
+    k.nact = nact; k.zero_dead = zero_dead;
     k.t_last = d.t_last; k.kv_dead = d.kv_dead; k.q_dead = d.q_dead;
     REFIL_CHECK(!zero_dead || d.ent_mask, "refil_attn: zeroing inactive agents needs ent_mask");
-    REFIL_CHECK(!sum_agents || (!bwd && d.nvar == 1), "refil_attn: the agent-sum output is a forward, single-variant option");
     const int pd = d.hd + 2;
     // +16 floats of slack: fragment reads of a partial channel tile (hd < 16*nct) run past the last row
     k.wave_floats = ((nat * 16 + 2 * njt * 16 + (bwd ? 16 : 0)) * pd + 16 + 3) & ~3;
@@ -652,9 +692,13 @@ int attn_mfma_launch_ex(const refil_attn_desc& d, bool bwd, hipStream_t st, int 
     k.mask_floats = (int)(mask_region_bytes(d.ne, d.na) / 4);
     const size_t smem = (size_t)4 * k.wave_floats * 4 + (size_t)k.mask_floats * 4 + (size_t)3 * nat * 16 * 8;
     if (smem > 160 * 1024) return -1;
-    const double unit = (double)d.R * d.heads * d.na * d.ne * d.hd;
-    ProfScope prof(bwd ? "attn_bwd_mfma" : "attn_fwd_mfma", unit * (bwd ? 2.0 + 8.0 * d.nvar : 2.0 + 2.0 * d.nvar),
-                   4.0 * d.R * d.heads * d.hd * (bwd ? d.na * (2.0 + d.nvar) + 4.0 * d.ne : d.na * (1.0 + d.nvar) + 2.0 * d.ne), st);
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double unit = (double)d.R * d.heads * d.na * d.ne * d.hd;
+        flops += unit * (bwd ? 2.0 + 8.0 * descs[i].nvar : 2.0 + 2.0 * descs[i].nvar);
+        bytes += 4.0 * d.R * d.heads * d.hd * (bwd ? d.na * (2.0 + descs[i].nvar) + 4.0 * d.ne : d.na * (1.0 + descs[i].nvar) + 2.0 * d.ne);
+    }
+    ProfScope prof(bwd ? "attn_bwd_mfma" : "attn_fwd_mfma", flops, bytes, st);
 #define CASE(J, A, C) if (njt == J && nat == A && nct == C) return launch_pair<J, A, C>(k, bwd, smem, st)
     CASE(1, 1, 1); CASE(1, 1, 2); CASE(2, 1, 1); CASE(2, 1, 2); CASE(2, 2, 2); CASE(3, 2, 2); CASE(4, 2, 2);
 #undef CASE

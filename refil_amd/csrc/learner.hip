@@ -522,21 +522,34 @@ static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int n
         q.batch = nets; q.sA = h; q.sB = L.mix_in_w_stride; q.sC = s.NAa * h;
         RUN(gemm_launch(with_rows(q, c, rows_a(c)), c.st));
     }
-    for (int n = 0; n < nets; ++n) {
-        refil_attn_desc a = attn_base(c, h);
-        attn_rows(c, a, true);
-        a.Q = b.q + (long)n * s.NAa * h; a.K = b.kv + (long)n * s.NEa * 2 * h; a.V = a.K + h;
-        a.O = b.ao + (long)(n == 0 ? 0 : nv0 + n - 1) * s.NA * h; a.sO = s.NA * h;
-        a.nvar = n == 0 ? nv0 : 1;
-        a.var[0] = REFIL_MASK_ENTITY;
-        a.var[1] = group_code(d, 0, false);
-        a.var[2] = group_code(d, 1, false);
-        if (d.pooling) RUN(pool_launch(a, d.pooling, false, c.st));
-        else if (c.presum && n > 0) {
-            const int rc = attn_mfma_launch_ex(a, false, c.st, 1, c.w.nact, 0, 0);      // O = sum over agents, [R, h]
-            REFIL_CHECK(rc >= 0, "refil: agent-sum attention shape not instantiated");
-            if (rc) return rc;
-        } else RUN(attn_forward_launch(a, c.st));
+    {
+        // the hypernets' attention cores: ONE launch when the matrix-core kernel covers the shape (shared mask words, jobs
+        // of a row pipelined), else one launch per net
+        refil_attn_desc ad[4];
+        AttnNetOpts ao[4];
+        for (int n = 0; n < nets; ++n) {
+            refil_attn_desc a = attn_base(c, h);
+            attn_rows(c, a, true);
+            a.Q = b.q + (long)n * s.NAa * h; a.K = b.kv + (long)n * s.NEa * 2 * h; a.V = a.K + h;
+            a.O = b.ao + (long)(n == 0 ? 0 : nv0 + n - 1) * s.NA * h; a.sO = s.NA * h;
+            a.nvar = n == 0 ? nv0 : 1;
+            a.var[0] = REFIL_MASK_ENTITY;
+            a.var[1] = group_code(d, 0, false);
+            a.var[2] = group_code(d, 1, false);
+            ad[n] = a;
+            ao[n] = AttnNetOpts{(c.presum && n > 0) ? 1 : 0, 0};
+        }
+        int rc = -1;
+        if (!d.pooling && attn_mfma_supported(d.ne, d.na, h / d.heads))
+            rc = attn_mfma_launch_multi(ad, ao, nets, false, c.st, c.presum ? c.w.nact : nullptr, 0);
+        if (rc > 0) return rc;
+        if (rc < 0) {
+            REFIL_CHECK(!c.presum, "refil: agent-sum attention shape not instantiated");
+            for (int n = 0; n < nets; ++n) {
+                if (d.pooling) RUN(pool_launch(ad[n], d.pooling, false, c.st));
+                else RUN(attn_forward_launch(ad[n], c.st));
+            }
+        }
     }
     if (c.presum) {
         // out_trans o fc2 is one linear map per hypernet: x3 = mask(a W_c^T + b_c), W_c = W_2 W_o (kernels.h: ComposeArgs).
@@ -641,21 +654,32 @@ static int attn_block_backward(const Ctx& c, const AttnBlockBwd& k) {
         RUN(gemm_launch(gx, c.st));
     }
     const RowList re = k.hyper ? rows_eh(c) : rows_ea(c);
-    for (int n = 0; n < k.nets; ++n) {
-        refil_attn_desc a = attn_base(c, w);
-        attn_rows(c, a, k.hyper);
-        a.Q = k.q + (long)n * s.NAa * w; a.K = k.kv + (long)n * s.NEa * 2 * w; a.V = a.K + w;
-        a.dO = k.dao + (long)(n == 0 ? 0 : k.nv0 + n - 1) * s.NA * w; a.sO = s.NA * w;
-        a.dQ = k.dq + (long)n * s.NAa * w; a.dK = k.dkv + (long)n * s.NEa * 2 * w; a.dV = a.dK + w;
-        a.nvar = n == 0 ? k.nv0 : 1;
-        if (n == 0) { a.var[0] = k.var_first[0]; a.var[1] = k.var_first[1]; a.var[2] = k.var_first[2]; }
-        else a.var[0] = k.var_rest;
-        if (d.pooling) RUN(pool_launch(a, d.pooling, true, c.st));       // d(in_trans output) -> dkv (first w columns)
-        else if (k.presum && n > 0) {
-            const int rc = attn_mfma_launch_ex(a, true, c.st, 0, nullptr, 1, 0);       // dO: one row per (b,t) for all its agents
-            REFIL_CHECK(rc >= 0, "refil: broadcast-dO attention shape not instantiated");
-            if (rc) return rc;
-        } else RUN(attn_backward_launch(a, c.st));
+    {
+        refil_attn_desc ad[4];
+        AttnNetOpts ao[4];
+        for (int n = 0; n < k.nets; ++n) {
+            refil_attn_desc a = attn_base(c, w);
+            attn_rows(c, a, k.hyper);
+            a.Q = k.q + (long)n * s.NAa * w; a.K = k.kv + (long)n * s.NEa * 2 * w; a.V = a.K + w;
+            a.dO = k.dao + (long)(n == 0 ? 0 : k.nv0 + n - 1) * s.NA * w; a.sO = s.NA * w;
+            a.dQ = k.dq + (long)n * s.NAa * w; a.dK = k.dkv + (long)n * s.NEa * 2 * w; a.dV = a.dK + w;
+            a.nvar = n == 0 ? k.nv0 : 1;
+            a.var[0] = k.var_first[0]; a.var[1] = k.var_first[1]; a.var[2] = k.var_first[2];
+            if (n > 0) a.var[0] = k.var_rest;
+            ad[n] = a;
+            ao[n] = AttnNetOpts{0, (k.presum && n > 0) ? 1 : 0};       // presum: dO is one row per (b,t) for all its agents
+        }
+        int rc = -1;
+        if (!d.pooling && attn_mfma_supported(d.ne, d.na, w / d.heads) && (k.nets == 1 || k.var_rest == k.var_first[0]))
+            rc = attn_mfma_launch_multi(ad, ao, k.nets, true, c.st, nullptr, 0);
+        if (rc > 0) return rc;
+        if (rc < 0) {
+            REFIL_CHECK(!(k.presum && k.nets > 1), "refil: broadcast-dO attention shape not instantiated");
+            for (int n = 0; n < k.nets; ++n) {
+                if (d.pooling) RUN(pool_launch(ad[n], d.pooling, true, c.st));       // d(in_trans output) -> dkv (first w columns)
+                else RUN(attn_backward_launch(ad[n], c.st));
+            }
+        }
     }
     if (d.pooling) {
         // EntityPoolingLayer: dW_in = dE^T x1, db_in = colsum(dE);  dx1 = relu'(x1) * (dE W_in)
