@@ -297,9 +297,16 @@ typedef struct refil_attn_desc {
      * skipped them; they are read as zeros whatever the buffers hold (a dead key must be masked in every variant, a dead
      * query's output must be discarded by the caller). */
     const int32_t* t_last; const uint8_t* kv_dead; const uint8_t* q_dead;
+    /* optional: the mask words of every row built ahead of the launch by refil_attn_mask_words (one 64-bit word per
+     * (row, variant, agent), bit j = key j masked; agents padded to a multiple of 16) and three words per row (dead K/V
+     * rows, dead Q rows, inactive entities). Several launches that share the masks (forward / backward, live / target nets)
+     * then skip their mask phase. mask_words_nvar = variants stored per row (>= nvar; 0: nvar). */
+    const void* mask_words; const void* row_bits; int32_t mask_words_nvar;
 } refil_attn_desc;
 
 int refil_attn_forward(const refil_attn_desc* desc, void* stream);
+/* mask_words: [R][nvar][16*ceil(na/16)] uint64, row_bits: [R][3] uint64 (see refil_attn_desc) for the variants of desc */
+int refil_attn_mask_words(const refil_attn_desc* desc, void* mask_words, void* row_bits, void* stream);
 int refil_attn_backward(const refil_attn_desc* desc, void* stream);
 
 /* Masked entity pooling core of EntityPoolingLayer (attention.py:114-123) under the same mask variants:

@@ -87,6 +87,7 @@ class AttnDesc(C.Structure):
         ("ent_mask", C.c_void_p), ("ent_mask0", C.c_void_p), ("group_bits", C.c_void_p),
         ("gt_mask", C.c_void_p), ("gt_sB", C.c_int64), ("gt_sT", C.c_int64),
         ("t_last", C.c_void_p), ("kv_dead", C.c_void_p), ("q_dead", C.c_void_p),
+        ("mask_words", C.c_void_p), ("row_bits", C.c_void_p), ("mask_words_nvar", C.c_int32),
     ]
 
 
@@ -117,7 +118,7 @@ EXPORTS = [
     "refil_mixer_workspace_bytes", "refil_mixer_forward", "refil_gemm", "refil_attn_forward",
     "refil_attn_backward", "refil_pool_forward", "refil_pool_backward", "refil_gru_forward", "refil_gru_backward", "refil_last_error", "refil_version",
     "refil_profile_enable", "refil_profile_collect", "refil_set_overlap", "refil_release_streams", "refil_replay_gather",
-    "refil_learner_row_counts",
+    "refil_learner_row_counts", "refil_attn_mask_words",
 ]
 
 _lib = None
@@ -154,6 +155,7 @@ def lib():
     L.refil_gemm.argtypes = [C.POINTER(GemmDesc), C.c_void_p]
     L.refil_attn_forward.argtypes = [C.POINTER(AttnDesc), C.c_void_p]
     L.refil_attn_backward.argtypes = [C.POINTER(AttnDesc), C.c_void_p]
+    L.refil_attn_mask_words.argtypes = [C.POINTER(AttnDesc), C.c_void_p, C.c_void_p, C.c_void_p]
     L.refil_pool_forward.argtypes = [C.POINTER(AttnDesc), C.c_int32, C.c_void_p]
     L.refil_pool_backward.argtypes = [C.POINTER(AttnDesc), C.c_int32, C.c_void_p]
     L.refil_gru_forward.argtypes = [C.POINTER(GruDesc), C.c_void_p]

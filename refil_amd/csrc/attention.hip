@@ -364,6 +364,12 @@ int attn_backward_launch(const refil_attn_desc& d, hipStream_t st) {
 
 }  // namespace refil
 
+extern "C" int refil_attn_mask_words(const refil_attn_desc* desc, void* mask_words, void* row_bits, void* stream) {
+    REFIL_CHECK(desc, "refil_attn_mask_words: null desc");
+    return refil::attn_mask_words_launch(*desc, static_cast<unsigned long long*>(mask_words), static_cast<unsigned long long*>(row_bits),
+                                         (hipStream_t)stream);
+}
+
 extern "C" int refil_attn_forward(const refil_attn_desc* desc, void* stream) {
     REFIL_CHECK(desc, "refil_attn_forward: null desc");
     return refil::attn_forward_launch(*desc, (hipStream_t)stream);

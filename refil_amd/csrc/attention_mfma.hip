@@ -51,6 +51,12 @@ struct AttnM {
     int zero_dead;     // forward: write zeros for inactive agents (the layer's post_mask, attention.py:66-67, applied early)
     // row skipping (refil_attn_desc: t_last / kv_dead / q_dead)
     const int* t_last; const uint8_t* kv_dead; const uint8_t* q_dead;
+    // mask words built ahead of the launch (refil_attn_desc.mask_words / row_bits, attn_mask_words_launch): the kernels
+    // then start with their operand loads instead of a mask phase (byte loads, two barriers, one ballot per agent and variant)
+    const unsigned long long* mwords;    // [R][mw_nvar][16 NAT] (a launch uses the first nvar variants of a row)
+    int mw_nvar;
+    const unsigned long long* rbits;     // [R][3]: dead K/V rows, dead Q rows, inactive entities of the step (bit j)
+    unsigned long long* mwords_out; unsigned long long* rbits_out;      // attn_mask_words_kernel outputs
 };
 
 struct MaskLds { const uint8_t *emt, *em0, *gb, *om, *gt, *kd, *qd; };
@@ -99,29 +105,29 @@ template <int ROWS_PAD, int C4MAX>
 struct Stage {
     static constexpr int N = ROWS_PAD * C4MAX / 64;
     float4 v[N];
-    // dead (LDS, may be NULL): dead[r] != 0 -> row r was not computed by its producer (it cannot influence the result):
-    // it enters as zeros, whatever the buffer holds
-    __device__ inline void load(const float* src, long row0, int rows, int ld, int col0, int hd, int lane, const uint8_t* dead = nullptr) {
+    __device__ inline void load(const float* src, long row0, int rows, int ld, int col0, int hd, int lane) {
         const int c4n = hd >> 2;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int idx = lane + 64 * i, r = idx / C4MAX, c4 = idx % C4MAX;
-            bool ok = r < rows && c4 < c4n;
-            if (dead) ok = ok && dead[ok ? r : 0] == 0;
+            const bool ok = r < rows && c4 < c4n;
             const float* p = src + (row0 + (ok ? r : 0)) * (long)ld + col0 + (ok ? c4 : 0) * 4;
             const float4 t = *reinterpret_cast<const float4*>(p);
             v[i] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    __device__ inline void store(float* dst, int hd, int pd, int lane) const {
+    // dead: bit r set -> row r was not computed by its producer (it cannot influence the result): it enters as zeros,
+    // whatever the buffer holds (applied here, not at the load: the loads are issued before the words are known)
+    __device__ inline void store(float* dst, int hd, int pd, int lane, unsigned long long dead = 0ull) const {
         const int c4n = hd >> 2;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int idx = lane + 64 * i, r = idx / C4MAX, c4 = idx % C4MAX;
             if (c4 < c4n) {
+                const bool z = (dead >> r) & 1ull;
                 float2* d = reinterpret_cast<float2*>(dst + r * pd + c4 * 4);
-                d[0] = make_float2(v[i].x, v[i].y);
-                d[1] = make_float2(v[i].z, v[i].w);
+                d[0] = z ? make_float2(0.f, 0.f) : make_float2(v[i].x, v[i].y);
+                d[1] = z ? make_float2(0.f, 0.f) : make_float2(v[i].z, v[i].w);
             }
         }
     }
@@ -269,6 +275,45 @@ __device__ inline bool uses_obs_m(const AttnM& p) {
     return u;
 }
 
+static inline int tiles16(int n) { return (n + 15) / 16; }
+
+// The mask state of a row: the mask words (LDS or precomputed in global memory) and three row words
+struct RowMasks { const unsigned long long* mw; unsigned long long kdw, qdw, emtw; };
+
+// in-kernel mask phase (no precomputed words): bytes -> LDS -> one ballot per (variant, agent); two barriers
+__device__ inline RowMasks mask_phase(const AttnM& p, float* smem, int na_pad, int r, int tid) {
+    MaskLds m;
+    load_masks(p, reinterpret_cast<uint8_t*>(smem + 4 * p.wave_floats), m, r, tid, 256, uses_obs_m(p));
+    unsigned long long* mw = reinterpret_cast<unsigned long long*>(smem + 4 * p.wave_floats + p.mask_floats);
+    __syncthreads();
+    build_mask_words(p, m, mw, na_pad, tid);
+    const int lane = tid & 63;
+    RowMasks rm;
+    rm.mw = mw;
+    rm.kdw = __ballot(m.kd && lane < p.ne && m.kd[lane < p.ne ? lane : 0]);
+    rm.qdw = __ballot(m.qd && lane < p.na && m.qd[lane < p.na ? lane : 0]);
+    rm.emtw = __ballot(lane < p.ne && m.emt[lane < p.ne ? lane : 0]);
+    __syncthreads();
+    return rm;
+}
+__device__ inline RowMasks mask_words_of(const AttnM& p, int na_pad, int r) {
+    RowMasks rm;
+    rm.mw = p.mwords + (long)r * p.mw_nvar * na_pad;
+    rm.kdw = p.rbits[3 * (long)r]; rm.qdw = p.rbits[3 * (long)r + 1]; rm.emtw = p.rbits[3 * (long)r + 2];
+    return rm;
+}
+
+// Builds the mask words of every row ONCE for all the attention launches of a step that share them (forward, backward,
+// live and target nets): mwords_out [R][nvar][na_pad], rbits_out [R][3].
+__global__ __launch_bounds__(256) void attn_mask_words_kernel(AttnM p, int na_pad) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    if (row_skipped(p, r)) return;
+    const RowMasks rm = mask_phase(p, smem, na_pad, r, tid);
+    for (int i = tid; i < p.nvar * na_pad; i += 256) p.mwords_out[(long)r * p.nvar * na_pad + i] = rm.mw[i];
+    if (tid == 0) { p.rbits_out[3 * (long)r] = rm.kdw; p.rbits_out[3 * (long)r + 1] = rm.qdw; p.rbits_out[3 * (long)r + 2] = rm.emtw; }
+}
+
 // NJT/NAT/NCT: 16-tiles along keys / agents / head channels
 template <int NJT, int NAT, int NCT>
 __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
@@ -278,36 +323,28 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
     const int r = blockIdx.x;
     if (row_skipped(p, r)) return;
     const int pd = p.hd + 2;
-    MaskLds m;
-    load_masks(p, reinterpret_cast<uint8_t*>(smem + 4 * p.wave_floats), m, r, tid, 256, uses_obs_m(p));
-    unsigned long long* mw = reinterpret_cast<unsigned long long*>(smem + 4 * p.wave_floats + p.mask_floats);
-    __syncthreads();
-    build_mask_words(p, m, mw, NAT * 16, tid);
-    __syncthreads();
-    if (p.nact && tid == 0) {
-        int n = 0;
-        for (int i = 0; i < p.na; ++i) n += m.emt[i] ? 0 : 1;
-        p.nact[r] = (float)n;
-    }
-    float* Qs = smem + wave * p.wave_floats;
-    float* Ks = Qs + NAT * 16 * pd;
-    float* Vs = Ks + NJT * 16 * pd;
-    const float inv_scale = 1.0f / sqrtf((float)p.hd);
     const int njobs = p.nnets * p.heads;                   // job = (net, head); a wave takes jobs wave, wave + 4, ...
     Stage<NAT * 16, 4 * NCT> sq;
     Stage<NJT * 16, 4 * NCT> sk, sv;
     auto fetch = [&](int job) {
         const AttnNet& n = p.net[job / p.heads];
         const int head = job % p.heads;
-        sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * p.hd, p.hd, lane, m.qd);
-        sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane, m.kd);
-        sv.load(n.V, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane, m.kd);
+        sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * p.hd, p.hd, lane);
+        sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane);
+        sv.load(n.V, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane);
     };
-    if (wave < njobs) fetch(wave);
+    if (wave < njobs) fetch(wave);                         // the first job's operands are in flight during the mask phase
+    const RowMasks rm = p.mwords ? mask_words_of(p, NAT * 16, r) : mask_phase(p, smem, NAT * 16, r, tid);
+    const unsigned long long* mw = rm.mw;
+    if (p.nact && tid == 0) p.nact[r] = (float)__popcll(~rm.emtw & ((p.na >= 64) ? ~0ull : ((1ull << p.na) - 1ull)));
+    float* Qs = smem + wave * p.wave_floats;
+    float* Ks = Qs + NAT * 16 * pd;
+    float* Vs = Ks + NJT * 16 * pd;
+    const float inv_scale = 1.0f / sqrtf((float)p.hd);
     for (int job = wave; job < njobs; job += 4) {
         const AttnNet& n = p.net[job / p.heads];
         const int head = job % p.heads;
-        sq.store(Qs, p.hd, pd, lane); sk.store(Ks, p.hd, pd, lane); sv.store(Vs, p.hd, pd, lane);
+        sq.store(Qs, p.hd, pd, lane, rm.qdw); sk.store(Ks, p.hd, pd, lane, rm.kdw); sv.store(Vs, p.hd, pd, lane, rm.kdw);
         if (job + 4 < njobs) fetch(job + 4);               // in flight while this job is computed (LDS is read, not written, below)
         f32x4 osum[NCT];
 #pragma unroll
@@ -340,7 +377,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) osum[ct][e] += group16_sum(o[e]);
                     } else if (agent < p.na && c < p.hd) {
-                        if (p.zero_dead && m.emt[agent]) o = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (p.zero_dead && ((rm.emtw >> agent) & 1ull)) o = f32x4{0.f, 0.f, 0.f, 0.f};
                         *reinterpret_cast<float4*>(O + ((long)r * p.na + agent) * p.ldo + head * p.hd + c) = make_float4(o[0], o[1], o[2], o[3]);
                     }
                 }
@@ -366,12 +403,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
     const int r = blockIdx.x;
     if (row_skipped(p, r)) return;
     const int pd = p.hd + 2;
-    MaskLds m;
-    load_masks(p, reinterpret_cast<uint8_t*>(smem + 4 * p.wave_floats), m, r, tid, 256, uses_obs_m(p));
-    unsigned long long* mw = reinterpret_cast<unsigned long long*>(smem + 4 * p.wave_floats + p.mask_floats);
-    __syncthreads();
-    build_mask_words(p, m, mw, NAT * 16, tid);
-    __syncthreads();
+    const RowMasks rm = p.mwords ? mask_words_of(p, NAT * 16, r) : mask_phase(p, smem, NAT * 16, r, tid);
+    const unsigned long long* mw = rm.mw;
     float* Qs = smem + wave * p.wave_floats;
     float* Ks = Qs + NAT * 16 * pd;
     float* Vs = Ks + NJT * 16 * pd;
@@ -386,10 +419,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
         {
             Stage<NAT * 16, 4 * NCT> sq;
             Stage<NJT * 16, 4 * NCT> sk, sv;
-            sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * p.hd, p.hd, lane, m.qd);
-            sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane, m.kd);
-            sv.load(n.V, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane, m.kd);
-            sq.store(Qs, p.hd, pd, lane); sk.store(Ks, p.hd, pd, lane); sv.store(Vs, p.hd, pd, lane);
+            sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * p.hd, p.hd, lane);
+            sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane);
+            sv.load(n.V, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane);
+            sq.store(Qs, p.hd, pd, lane, rm.qdw); sk.store(Ks, p.hd, pd, lane, rm.kdw); sv.store(Vs, p.hd, pd, lane, rm.kdw);
         }
         f32x4 dKt[NCT][NJT], dVt[NCT][NJT];     // [c 16ct+4q+reg][key 16jt+l15]
 #pragma unroll
@@ -412,8 +445,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
             const float* dO0 = n.bcast_do ? n.dO + (long)r * p.ldo : n.dO;
             const long drow0 = n.bcast_do ? 0 : (long)r * p.na + 16 * at;
             const int dld = n.bcast_do ? 0 : p.ldo;
-            const uint8_t* ddead = (m.qd && !n.bcast_do) ? m.qd + 16 * at : nullptr;
-            sd.load(dO0, drow0, na_t, dld, head * p.hd, p.hd, lane, ddead);
+            const unsigned long long ddead = n.bcast_do ? 0ull : (rm.qdw >> (16 * at));
+            sd.load(dO0, drow0, na_t, dld, head * p.hd, p.hd, lane);
             f32x4 sn0[NJT];
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt) sn0[jt] = dot_tile(Qs, 16 * at, Ks, 16 * jt, p.hd, pd, l15, q);   // S[agent][key]
@@ -421,8 +454,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) dQt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int v = 0; v < n.nvar; ++v) {
-                sd.store(Ds, p.hd, pd, lane);
-                if (v + 1 < n.nvar) sd.load(dO0 + (v + 1) * p.sO, drow0, na_t, dld, head * p.hd, p.hd, lane, ddead);
+                sd.store(Ds, p.hd, pd, lane, ddead);
+                if (v + 1 < n.nvar) sd.load(dO0 + (v + 1) * p.sO, drow0, na_t, dld, head * p.hd, p.hd, lane);
                 f32x4 pn[NJT];
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt)
@@ -627,7 +660,6 @@ int pool_launch(const refil_attn_desc& d, int mode, bool bwd, hipStream_t st) {
     return 0;
 }
 
-static inline int tiles16(int n) { return (n + 15) / 16; }
 
 template <int NJT, int NAT, int NCT>
 static int launch_pair(const AttnM& k, bool bwd, size_t smem, hipStream_t st) {
@@ -654,6 +686,28 @@ int attn_mfma_launch_ex(const refil_attn_desc& d, bool bwd, hipStream_t st, int 
     return attn_mfma_launch_multi(&d, &o, 1, bwd, st, nact, zero_dead);
 }
 
+// mask words of all rows for the variants of `d` (attn_mask_words_kernel): mwords [R][nvar][16 ceil(na/16)], rbits [R][3]
+int attn_mask_words_launch(const refil_attn_desc& d, unsigned long long* mwords, unsigned long long* rbits, hipStream_t st) {
+    REFIL_CHECK(mwords && rbits && d.nvar >= 1 && d.nvar <= 3, "refil_attn_mask_words: bad arguments");
+    AttnM k;
+    memset(&k, 0, sizeof(k));
+    k.R = d.R; k.T1 = d.T1; k.ne = d.ne; k.na = d.na; k.heads = d.heads; k.hd = d.hd; k.nvar = d.nvar;
+    for (int v = 0; v < 3; ++v) k.var[v] = d.var[v];
+    k.obs_mask = d.obs_mask; k.om_sB = d.om_sB; k.om_sT = d.om_sT;
+    k.ent_mask = d.ent_mask; k.ent_mask0 = d.ent_mask0; k.group_bits = d.group_bits;
+    k.gt_mask = d.gt_mask; k.gt_sB = d.gt_sB; k.gt_sT = d.gt_sT;
+    k.t_last = d.t_last; k.kv_dead = d.kv_dead; k.q_dead = d.q_dead;
+    k.mwords_out = mwords; k.rbits_out = rbits;
+    k.wave_floats = 0;
+    k.mask_floats = (int)(mask_region_bytes(d.ne, d.na) / 4);
+    const int na_pad = tiles16(d.na) * 16;
+    const size_t smem = (size_t)k.mask_floats * 4 + (size_t)3 * na_pad * 8;
+    ProfScope prof("attn_mask_words_kernel", 0.0, 0.0, st);
+    hipLaunchKernelGGL(attn_mask_words_kernel, dim3(d.R), dim3(256), smem, st, k, na_pad);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
 // n attention blocks in one launch (same rows, masks, widths and leading dimensions; descs[0] carries the mask variants,
 // the others are single-variant nets under its variant 0). Returns -1 when the tile shape is not instantiated (caller
 // falls back to the VALU kernel).
@@ -669,7 +723,8 @@ int attn_mfma_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts
         REFIL_CHECK(e.R == d.R && e.T1 == d.T1 && e.ne == d.ne && e.na == d.na && e.heads == d.heads && e.hd == d.hd && e.ldq == d.ldq &&
                     e.ldkv == d.ldkv && e.ldo == d.ldo && e.sO == d.sO && e.obs_mask == d.obs_mask && e.ent_mask == d.ent_mask &&
                     e.ent_mask0 == d.ent_mask0 && e.group_bits == d.group_bits && e.gt_mask == d.gt_mask && e.t_last == d.t_last &&
-                    e.kv_dead == d.kv_dead && e.q_dead == d.q_dead, "refil_attn: nets of one launch must share rows, masks and strides");
+                    e.kv_dead == d.kv_dead && e.q_dead == d.q_dead && e.mask_words == d.mask_words && e.row_bits == d.row_bits,
+                    "refil_attn: nets of one launch must share rows, masks and strides");
         REFIL_CHECK(i == 0 || (e.nvar == 1 && e.var[0] == d.var[0]), "refil_attn: nets after the first are single-variant under variant 0");
         REFIL_CHECK(!opts[i].sum_agents || (!bwd && e.nvar == 1), "refil_attn: the agent-sum output is a forward, single-variant option");
         AttnNet& t = k.net[i];
@@ -684,7 +739,10 @@ int attn_mfma_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts
     k.gt_mask = d.gt_mask; k.gt_sB = d.gt_sB; k.gt_sT = d.gt_sT;
     k.nact = nact; k.zero_dead = zero_dead;
     k.t_last = d.t_last; k.kv_dead = d.kv_dead; k.q_dead = d.q_dead;
-    REFIL_CHECK(!zero_dead || d.ent_mask, "refil_attn: zeroing inactive agents needs ent_mask");
+    k.mwords = reinterpret_cast<const unsigned long long*>(d.mask_words); k.rbits = reinterpret_cast<const unsigned long long*>(d.row_bits);
+    k.mw_nvar = d.mask_words_nvar > 0 ? d.mask_words_nvar : d.nvar;
+    REFIL_CHECK(!d.mask_words || (d.row_bits && k.mw_nvar >= d.nvar), "refil_attn: mask_words needs row_bits and >= nvar variants per row");
+    REFIL_CHECK(!zero_dead || d.ent_mask || d.mask_words, "refil_attn: zeroing inactive agents needs ent_mask");
     const int pd = d.hd + 2;
     // +16 floats of slack: fragment reads of a partial channel tile (hd < 16*nct) run past the last row
     k.wave_floats = ((nat * 16 + 2 * njt * 16 + (bwd ? 16 : 0)) * pd + 16 + 3) & ~3;

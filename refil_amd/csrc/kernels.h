@@ -147,6 +147,7 @@ int compose_backward_launch(const ComposeArgs& a, hipStream_t st);
 // attention_mfma.hip: matrix-core attention with the agent-sum / broadcast-dO options; -1 = tile shape not instantiated
 bool attn_mfma_supported(int ne, int na, int hd);
 int attn_mfma_launch_ex(const refil_attn_desc& d, bool bwd, hipStream_t st, int sum_agents, float* nact, int bcast_do, int zero_dead);
+int attn_mask_words_launch(const refil_attn_desc& d, unsigned long long* mwords, unsigned long long* rbits, hipStream_t st);
 // several attention blocks that share rows and masks (the hypernets of a mixer) in ONE launch
 struct AttnNetOpts { int sum_agents, bcast_do; };
 int attn_mfma_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts, int n, bool bwd, hipStream_t st, float* nact, int zero_dead);

@@ -119,6 +119,8 @@ struct Work {
     // row lists (kernels.h: ListArgs): rows that cannot influence the step are skipped
     int *t_last, *list_ea, *list_eh, *list_a, *counts, *lcnt, *loff;
     uint8_t *kdead_a, *kdead_h;
+    // mask words of the step, built once for all attention launches (attention_mfma.hip: attn_mask_words_kernel)
+    unsigned long long *mw_a, *rb_a, *mw_h, *rb_h;
 };
 
 struct Sizes {
@@ -214,6 +216,11 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     w.list_ea = a.take<int>(s.NE + 256); w.list_eh = a.take<int>(s.NE + 256); w.list_a = a.take<int>(s.NA + 256);
     w.counts = a.take<int>(4); w.lcnt = a.take<int>(3 * s.R); w.loff = a.take<int>(3 * (s.R + 1));
     w.kdead_a = a.take<uint8_t>(s.NE); w.kdead_h = a.take<uint8_t>(s.NE);
+    {
+        const long na_pad = (d.na + 15) / 16 * 16;
+        w.mw_a = a.take<unsigned long long>(s.R * 3 * na_pad); w.rb_a = a.take<unsigned long long>(s.R * 3);
+        w.mw_h = a.take<unsigned long long>(s.R * 3 * na_pad); w.rb_h = a.take<unsigned long long>(s.R * 3);
+    }
 }
 
 static size_t workspace_bytes(const refil_dims& d, CarveMode mode) {
@@ -361,6 +368,7 @@ struct Ctx {
     // Learner steps of the flagship family at sizes where every listed GEMM takes the weight-resident / streaming
     // kernels; REFIL_DENSE=1 switches it off (same results up to the summation order of the weight gradients).
     bool lists;
+    bool mwords;       // the step's mask words are precomputed (learner steps on the matrix-core attention path)
     // weight-gradient stream of this chain (== st when the chains are serialised) and its split-reduction scratch
     hipStream_t gst; float* gpartial; SideStream* sd;
 };
@@ -381,8 +389,8 @@ static RowList rows_ea(const Ctx& c) { return RowList{c.w.list_ea, c.w.counts + 
 static RowList rows_eh(const Ctx& c) { return RowList{c.w.list_eh, c.w.counts + 1}; }
 static RowList rows_a(const Ctx& c) { return RowList{c.w.list_a, c.w.counts + 2}; }
 static void attn_rows(const Ctx& c, refil_attn_desc& a, bool hyper) {
-    if (!c.lists) return;
-    a.t_last = c.w.t_last; a.kv_dead = hyper ? c.w.kdead_h : c.w.kdead_a; a.q_dead = c.w.amask;
+    if (c.lists) { a.t_last = c.w.t_last; a.kv_dead = hyper ? c.w.kdead_h : c.w.kdead_a; a.q_dead = c.w.amask; }
+    if (c.mwords) { a.mask_words = hyper ? c.w.mw_h : c.w.mw_a; a.row_bits = hyper ? c.w.rb_h : c.w.rb_a; a.mask_words_nvar = c.s.G; }
 }
 
 static refil_rowmap agent_rows(const Ctx& c) { return refil_rowmap{c.d.na, c.d.ne, 0}; }
@@ -742,6 +750,9 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
         const bool shapes = E % 4 == 0 && E <= 128 && d.d % 32 == 0 && d.d <= 128 && d.hyp % 32 == 0 && d.hyp <= 128 &&
                             c.s.NE >= 2048 && c.s.NA >= 512;
         c.lists = mode == CARVE_LEARNER && !(de && de[0] == '1') && shapes && c.presum && c.compose_agent;
+        const char* me = getenv("REFIL_MASKWORDS");
+        c.mwords = mode == CARVE_LEARNER && !(me && me[0] == '0') && !d.pooling && !d.mixer_vdn &&
+                   attn_mfma_supported(d.ne, d.na, d.d / d.heads) && attn_mfma_supported(d.ne, d.na, d.hyp / d.heads);
     }
     REFIL_CHECK(batch->entities && batch->entity_mask, "refil: batch.entities / entity_mask missing");
     REFIL_CHECK(!dims->entity_last_action || batch->actions, "refil: batch.actions missing");
@@ -807,6 +818,18 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         la.emc = w.emc; la.em0 = w.em0; la.t_last = w.t_last; la.kdead_a = w.kdead_a; la.kdead_h = w.kdead_h;
         la.cnt = w.lcnt; la.off = w.loff; la.list_ea = w.list_ea; la.list_eh = w.list_eh; la.list_a = w.list_a; la.counts = w.counts;
         RUN(lists_launch(la, c.st));
+    }
+    if (c.mwords) {
+        // mask words of every row, once per step: agent nets (observability variants) and hypernets (entity variants)
+        for (int hyper = 0; hyper < 2; ++hyper) {
+            refil_attn_desc a = attn_base(c, hyper ? d.hyp : d.d);
+            if (c.lists) { a.t_last = w.t_last; a.kv_dead = hyper ? w.kdead_h : w.kdead_a; a.q_dead = w.amask; }
+            a.nvar = s.G;
+            a.var[0] = hyper ? REFIL_MASK_ENTITY : REFIL_MASK_OBS;
+            a.var[1] = group_code(d, 0, !hyper);
+            a.var[2] = group_code(d, 1, !hyper);
+            RUN(attn_mask_words_launch(a, hyper ? w.mw_h : w.mw_a, hyper ? w.rb_h : w.rb_a, c.st));
+        }
     }
     // The hypernet chain is the longer one, so IT goes to the side stream and is enqueued first: whichever
     // chain the host enqueues second starts several hundred microseconds late (the host needs that long to

@@ -104,3 +104,14 @@ def gru_forward(d):
 
 def gru_backward(d):
     check(lib().refil_gru_backward(C.byref(d), _stream()), "refil_gru_backward")
+
+
+def attn_mask_words(d: AttnDesc, na):
+    """precompute the mask words of desc's variants (refil_attn_mask_words) and attach them to the desc"""
+    na_pad = (na + 15) // 16 * 16
+    mw = torch.zeros(d.R * d.nvar * na_pad, dtype=torch.int64, device="cuda")
+    rb = torch.zeros(d.R * 3, dtype=torch.int64, device="cuda")
+    check(lib().refil_attn_mask_words(C.byref(d), ptr(mw), ptr(rb), _stream()), "refil_attn_mask_words")
+    d._keep += [mw, rb]
+    d.mask_words, d.row_bits, d.mask_words_nvar = mw.data_ptr(), rb.data_ptr(), d.nvar
+    return d

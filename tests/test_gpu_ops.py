@@ -574,3 +574,31 @@ def test_gemm_dw4_tiles(N, K, batch, use_list):
     scale = max(ref_w.abs().max().item(), 1.0)
     assert (dW.cpu().double() - ref_w).abs().max().item() <= 5e-5 * scale
     assert (db.cpu().double() - ref_b).abs().max().item() <= 5e-5 * max(ref_b.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("ne,na,heads,hd,variants", [(32, 16, 4, 32, (MASK_OBS, MASK_OBS_WITHIN, MASK_OBS_INTERACT)),
+                                                     (16, 8, 4, 16, (MASK_ENTITY, MASK_WITHIN, MASK_INTERACT)), (48, 24, 4, 32, (MASK_ENTITY,))])
+def test_attention_precomputed_mask_words(ne, na, heads, hd, variants):
+    """refil_attn_mask_words + mask_words / row_bits in the desc == the in-kernel mask phase, bit for bit."""
+    import hip_ops
+    torch.manual_seed(ne + na)
+    B, T1 = 2, 5
+    R, w = B * T1, heads * hd
+    em = (torch.rand(B, T1, ne) < 0.3).to(torch.uint8)
+    obs = (torch.rand(B, T1, ne, ne) < 0.4).to(torch.uint8)
+    gb = (torch.rand(B, ne) < 0.5).to(torch.uint8)
+    Q, K = torch.randn(R * na, w, device=DEV), torch.randn(R * ne, 2 * w, device=DEV)
+    dO = torch.randn(len(variants), R * na, w, device=DEV)
+    res = []
+    for pre in (False, True):
+        d = hip_ops.attn_desc(Q, K, K[:, w:], w, 2 * w, R, T1, ne, na, heads, hd, list(variants), obs_mask=obs.to(DEV),
+                              ent_mask=em.view(R, ne).to(DEV), ent_mask0=em[:, 0].contiguous().to(DEV), group_bits=gb.to(DEV))
+        if pre:
+            hip_ops.attn_mask_words(d, na)
+        O = torch.zeros(len(variants), R * na, w, device=DEV)
+        hip_ops.attn_forward(d, O, w, R * na * w)
+        dQ = torch.zeros(R * na, w, device=DEV); dKV = torch.zeros(R * ne, 2 * w, device=DEV)
+        hip_ops.attn_backward(d, dO, w, R * na * w, dQ, dKV, dKV[:, w:])
+        res.append((O.cpu(), dQ.cpu(), dKV.cpu()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
