@@ -140,6 +140,7 @@ __device__ inline f32x4 dot_tile(const float* X, int rowbase, const float* Y, in
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const float* xp = X + (rowbase + l15) * pd + q;
     const float* yp = Y + (colbase + l15) * pd + q;
+#pragma unroll
     for (int s = 0; s < (hd >> 2); ++s) acc = MFMA16(xp[4 * s], yp[4 * s], acc);
     return acc;
 }
@@ -315,23 +316,25 @@ __global__ __launch_bounds__(256) void attn_mask_words_kernel(AttnM p, int na_pa
 }
 
 // NJT/NAT/NCT: 16-tiles along keys / agents / head channels
-template <int NJT, int NAT, int NCT>
+// HDX: the head dimension is exactly 16 NCT (compile-time: the fragment loops unroll and their LDS reads are batched)
+template <int NJT, int NAT, int NCT, bool HDX>
 __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
     const int r = blockIdx.x;
     if (row_skipped(p, r)) return;
-    const int pd = p.hd + 2;
+    const int hd = HDX ? 16 * NCT : p.hd;
+    const int pd = hd + 2;
     const int njobs = p.nnets * p.heads;                   // job = (net, head); a wave takes jobs wave, wave + 4, ...
     Stage<NAT * 16, 4 * NCT> sq;
     Stage<NJT * 16, 4 * NCT> sk, sv;
     auto fetch = [&](int job) {
         const AttnNet& n = p.net[job / p.heads];
         const int head = job % p.heads;
-        sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * p.hd, p.hd, lane);
-        sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane);
-        sv.load(n.V, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane);
+        sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * hd, hd, lane);
+        sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane);
+        sv.load(n.V, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane);
     };
     if (wave < njobs) fetch(wave);                         // the first job's operands are in flight during the mask phase
     const RowMasks rm = p.mwords ? mask_words_of(p, NAT * 16, r) : mask_phase(p, smem, NAT * 16, r, tid);
@@ -340,11 +343,11 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
     float* Qs = smem + wave * p.wave_floats;
     float* Ks = Qs + NAT * 16 * pd;
     float* Vs = Ks + NJT * 16 * pd;
-    const float inv_scale = 1.0f / sqrtf((float)p.hd);
+    const float inv_scale = 1.0f / sqrtf((float)hd);
     for (int job = wave; job < njobs; job += 4) {
         const AttnNet& n = p.net[job / p.heads];
         const int head = job % p.heads;
-        sq.store(Qs, p.hd, pd, lane, rm.qdw); sk.store(Ks, p.hd, pd, lane, rm.kdw); sv.store(Vs, p.hd, pd, lane, rm.kdw);
+        sq.store(Qs, hd, pd, lane, rm.qdw); sk.store(Ks, hd, pd, lane, rm.kdw); sv.store(Vs, hd, pd, lane, rm.kdw);
         if (job + 4 < njobs) fetch(job + 4);               // in flight while this job is computed (LDS is read, not written, below)
         f32x4 osum[NCT];
 #pragma unroll
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
             const int agent = 16 * at + l15;
             f32x4 st0[NJT];
 #pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) st0[jt] = dot_tile(Ks, 16 * jt, Qs, 16 * at, p.hd, pd, l15, q);
+            for (int jt = 0; jt < NJT; ++jt) st0[jt] = dot_tile(Ks, 16 * jt, Qs, 16 * at, hd, pd, l15, q);
             for (int v = 0; v < n.nvar; ++v) {
                 f32x4 pt[NJT];
 #pragma unroll
@@ -376,9 +379,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
                     if (n.sum_agents) {          // padded / inactive agents have P = 0, hence o = 0: plain sum over the 16 lanes
 #pragma unroll
                         for (int e = 0; e < 4; ++e) osum[ct][e] += group16_sum(o[e]);
-                    } else if (agent < p.na && c < p.hd) {
+                    } else if (agent < p.na && c < hd) {
                         if (p.zero_dead && ((rm.emtw >> agent) & 1ull)) o = f32x4{0.f, 0.f, 0.f, 0.f};
-                        *reinterpret_cast<float4*>(O + ((long)r * p.na + agent) * p.ldo + head * p.hd + c) = make_float4(o[0], o[1], o[2], o[3]);
+                        *reinterpret_cast<float4*>(O + ((long)r * p.na + agent) * p.ldo + head * hd + c) = make_float4(o[0], o[1], o[2], o[3]);
                     }
                 }
             }
@@ -387,22 +390,23 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const int c = 16 * ct + 4 * q;
-                if (c < p.hd)
-                    *reinterpret_cast<float4*>(n.O + (long)r * p.ldo + head * p.hd + c) = make_float4(osum[ct][0], osum[ct][1], osum[ct][2], osum[ct][3]);
+                if (c < hd)
+                    *reinterpret_cast<float4*>(n.O + (long)r * p.ldo + head * hd + c) = make_float4(osum[ct][0], osum[ct][1], osum[ct][2], osum[ct][3]);
             }
         }
         __builtin_amdgcn_wave_barrier();                   // (the next job's operands overwrite the wave's LDS tiles)
     }
 }
 
-template <int NJT, int NAT, int NCT>
+template <int NJT, int NAT, int NCT, bool HDX>
 __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
     const int r = blockIdx.x;
     if (row_skipped(p, r)) return;
-    const int pd = p.hd + 2;
+    const int hd = HDX ? 16 * NCT : p.hd;
+    const int pd = hd + 2;
     const RowMasks rm = p.mwords ? mask_words_of(p, NAT * 16, r) : mask_phase(p, smem, NAT * 16, r, tid);
     const unsigned long long* mw = rm.mw;
     float* Qs = smem + wave * p.wave_floats;
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
     float* Ds = Vs + NJT * 16 * pd;          // dO of one (variant, agent tile): 16 rows
     constexpr int TP = NJT * 16 + 4;         // pitch of the dS transposition tile (16 agents x keys)
     float* Ts = Qs + p.wave_floats - 16 * TP;
-    const float inv_scale = 1.0f / sqrtf((float)p.hd);
+    const float inv_scale = 1.0f / sqrtf((float)hd);
     const int njobs = p.nnets * p.heads;                   // job = (net, head); a wave takes jobs wave, wave + 4, ...
     for (int job = wave; job < njobs; job += 4) {
         const AttnNet& n = p.net[job / p.heads];
@@ -419,10 +423,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
         {
             Stage<NAT * 16, 4 * NCT> sq;
             Stage<NJT * 16, 4 * NCT> sk, sv;
-            sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * p.hd, p.hd, lane);
-            sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane);
-            sv.load(n.V, (long)r * p.ne, p.ne, p.ldkv, head * p.hd, p.hd, lane);
-            sq.store(Qs, p.hd, pd, lane, rm.qdw); sk.store(Ks, p.hd, pd, lane, rm.kdw); sv.store(Vs, p.hd, pd, lane, rm.kdw);
+            sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * hd, hd, lane);
+            sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane);
+            sv.load(n.V, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane);
+            sq.store(Qs, hd, pd, lane, rm.qdw); sk.store(Ks, hd, pd, lane, rm.kdw); sv.store(Vs, hd, pd, lane, rm.kdw);
         }
         f32x4 dKt[NCT][NJT], dVt[NCT][NJT];     // [c 16ct+4q+reg][key 16jt+l15]
 #pragma unroll
@@ -446,16 +450,16 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
             const long drow0 = n.bcast_do ? 0 : (long)r * p.na + 16 * at;
             const int dld = n.bcast_do ? 0 : p.ldo;
             const unsigned long long ddead = n.bcast_do ? 0ull : (rm.qdw >> (16 * at));
-            sd.load(dO0, drow0, na_t, dld, head * p.hd, p.hd, lane);
+            sd.load(dO0, drow0, na_t, dld, head * hd, hd, lane);
             f32x4 sn0[NJT];
 #pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) sn0[jt] = dot_tile(Qs, 16 * at, Ks, 16 * jt, p.hd, pd, l15, q);   // S[agent][key]
+            for (int jt = 0; jt < NJT; ++jt) sn0[jt] = dot_tile(Qs, 16 * at, Ks, 16 * jt, hd, pd, l15, q);   // S[agent][key]
             f32x4 dQt[NCT];                           // [c][agent 16at+l15]
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) dQt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int v = 0; v < n.nvar; ++v) {
-                sd.store(Ds, p.hd, pd, lane, ddead);
-                if (v + 1 < n.nvar) sd.load(dO0 + (v + 1) * p.sO, drow0, na_t, dld, head * p.hd, p.hd, lane);
+                sd.store(Ds, hd, pd, lane, ddead);
+                if (v + 1 < n.nvar) sd.load(dO0 + (v + 1) * p.sO, drow0, na_t, dld, head * hd, hd, lane);
                 f32x4 pn[NJT];
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt)
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
                 float rdN[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt) {
-                    dsn[jt] = dot_tile(Ds, 0, Vs, 16 * jt, p.hd, pd, l15, q);
+                    dsn[jt] = dot_tile(Ds, 0, Vs, 16 * jt, hd, pd, l15, q);
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) rdN[reg] += pn[jt][reg] * dsn[jt][reg];
                 }
@@ -506,8 +510,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const int c = 16 * ct + 4 * q;
-                if (agentT < p.na && c < p.hd)
-                    *reinterpret_cast<float4*>(n.dQ + ((long)r * p.na + agentT) * p.ldq + head * p.hd + c) =
+                if (agentT < p.na && c < hd)
+                    *reinterpret_cast<float4*>(n.dQ + ((long)r * p.na + agentT) * p.ldq + head * hd + c) =
                         make_float4(dQt[ct][0], dQt[ct][1], dQt[ct][2], dQt[ct][3]);
             }
         }
@@ -516,8 +520,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt) {
                 const int key = 16 * jt + l15, c = 16 * ct + 4 * q;
-                if (key < p.ne && c < p.hd) {
-                    const long off = ((long)r * p.ne + key) * p.ldkv + head * p.hd + c;
+                if (key < p.ne && c < hd) {
+                    const long off = ((long)r * p.ne + key) * p.ldkv + head * hd + c;
                     *reinterpret_cast<float4*>(n.dK + off) = make_float4(dKt[ct][jt][0], dKt[ct][jt][1], dKt[ct][jt][2], dKt[ct][jt][3]);
                     *reinterpret_cast<float4*>(n.dV + off) = make_float4(dVt[ct][jt][0], dVt[ct][jt][1], dVt[ct][jt][2], dVt[ct][jt][3]);
                 }
@@ -661,17 +665,21 @@ int pool_launch(const refil_attn_desc& d, int mode, bool bwd, hipStream_t st) {
 }
 
 
-template <int NJT, int NAT, int NCT>
-static int launch_pair(const AttnM& k, bool bwd, size_t smem, hipStream_t st) {
+template <int NJT, int NAT, int NCT, bool HDX>
+static int launch_pair_x(const AttnM& k, bool bwd, size_t smem, hipStream_t st) {
     if (bwd) {
-        if (smem > 64 * 1024) REFIL_HIP(hipFuncSetAttribute((const void*)attn_bwd_mfma<NJT, NAT, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((attn_bwd_mfma<NJT, NAT, NCT>), dim3(k.R), dim3(256), smem, st, k);
+        if (smem > 64 * 1024) REFIL_HIP(hipFuncSetAttribute((const void*)attn_bwd_mfma<NJT, NAT, NCT, HDX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((attn_bwd_mfma<NJT, NAT, NCT, HDX>), dim3(k.R), dim3(256), smem, st, k);
     } else {
-        if (smem > 64 * 1024) REFIL_HIP(hipFuncSetAttribute((const void*)attn_fwd_mfma<NJT, NAT, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((attn_fwd_mfma<NJT, NAT, NCT>), dim3(k.R), dim3(256), smem, st, k);
+        if (smem > 64 * 1024) REFIL_HIP(hipFuncSetAttribute((const void*)attn_fwd_mfma<NJT, NAT, NCT, HDX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((attn_fwd_mfma<NJT, NAT, NCT, HDX>), dim3(k.R), dim3(256), smem, st, k);
     }
     REFIL_LAUNCH_CHECK();
     return 0;
+}
+template <int NJT, int NAT, int NCT>
+static int launch_pair(const AttnM& k, bool bwd, size_t smem, hipStream_t st) {
+    return k.hd == 16 * NCT ? launch_pair_x<NJT, NAT, NCT, true>(k, bwd, smem, st) : launch_pair_x<NJT, NAT, NCT, false>(k, bwd, smem, st);
 }
 
 bool attn_mfma_supported(int ne, int na, int hd) {
