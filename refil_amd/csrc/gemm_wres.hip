@@ -272,8 +272,8 @@ bool gemm_wres_eligible(const refil_gemm_desc& d) {
     if (d.K > (rb ? 256 : 128)) return false;
     if ((d.lda % 4) || (d.ldb % 4) || (d.sA % 4) || (d.sB % 4) || !al16(d.A) || !al16(d.B)) return false;
     if (d.M < (d.row_index ? 256 : 2048) || (d.N % 32) != 0) return false;  // tiny calls: tiled kernel
-    if (d.row_index) {        // row list (padded to whole tiles by its producer): plain forward products and dX through a ReLU
-        if (!d.row_count || d.rowmask || d.bias2 || (bt && !rb)) return false;
+    if (d.row_index) {        // row list (padded to whole tiles by its producer)
+        if (!d.row_count || (d.rowmask && d.bias2)) return false;
     } else if ((d.M % 32) != 0) return false;                              // whole 32 x 32 tiles only
     if (!al16(d.C) || (d.ldc % 4) || (d.sC % 4)) return false;
     if (d.bias && (!al16(d.bias) || (d.sBias % 4))) return false;
@@ -303,7 +303,9 @@ static int wres_launch_fwd(const WresK& k, dim3 grid, hipStream_t st) {
     const bool rm = k.rowmask != nullptr;
 #define FWD(NC)                                                                                                     \
     do {                                                                                                            \
-        if (k.ridx) return wres_launch_i<TN, NC, 1, false, 0, false, false, false, true>(k, grid, st);              \
+        if (k.ridx && TN <= 2 && k.bias2) return wres_launch_i<(TN <= 2 ? TN : 1), NC, 1, false, 0, false, false, true, true>(k, grid, st); \
+        if (k.ridx) return rm ? wres_launch_i<TN, NC, 1, false, 0, false, true, false, true>(k, grid, st)          \
+                              : wres_launch_i<TN, NC, 1, false, 0, false, false, false, true>(k, grid, st);        \
         if (TN <= 2 && k.bias2)                                                                                     \
             return rm ? wres_launch_i<(TN <= 2 ? TN : 1), NC, 1, false, 0, false, true, true>(k, grid, st)          \
                       : wres_launch_i<(TN <= 2 ? TN : 1), NC, 1, false, 0, false, false, true>(k, grid, st);        \
@@ -320,7 +322,12 @@ template <int TN>
 static int wres_launch_bwd(const WresK& k, dim3 grid, hipStream_t st) {
     const int nc = cdiv(k.K, 8);
     const bool rm = k.rowmask != nullptr;
-#define BWD(NC) return rm ? wres_launch_i<TN, NC, 1, true, 0, false, true>(k, grid, st) : wres_launch_i<TN, NC, 1, true, 0, false, false>(k, grid, st)
+#define BWD(NC)                                                                                                     \
+    do {                                                                                                            \
+        if (k.ridx) return rm ? wres_launch_i<TN, NC, 1, true, 0, false, true, false, true>(k, grid, st)            \
+                              : wres_launch_i<TN, NC, 1, true, 0, false, false, false, true>(k, grid, st);          \
+        return rm ? wres_launch_i<TN, NC, 1, true, 0, false, true>(k, grid, st) : wres_launch_i<TN, NC, 1, true, 0, false, false>(k, grid, st); \
+    } while (0)
     if (nc <= 4) BWD(4);
     if (nc <= 8) BWD(8);
     BWD(16);

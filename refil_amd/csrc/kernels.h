@@ -67,7 +67,15 @@ struct ListArgs {
     int* cnt;                              // [3][R] per-row counts (scratch), lists: 0 agent-net entities, 1 hypernet entities, 2 agents
     int* off;                              // [3][R+1] exclusive scans (scratch)
     int* list_ea; int* list_eh; int* list_a;   // [NE+256], [NE+256], [NA+256]
-    int* counts;                           // [4]: the three list lengths, live (b,t) rows
+    int* counts;                           // [8]: the three list lengths, live (b,t) rows, then the derived lists' lengths
+    // derived agent-row lists for the layers behind the attention cores (rows = variant * NA + agent row):
+    //   list_t   agent rows (b,t,i) of live steps whose agent is active at SOME live step of the episode: the recurrent
+    //            tail (fc2, GRU input gates, their gradients) -- an agent that is never active never produces a Q-value
+    //            that is used (entity_rnn_agent.py:57-60) and its hidden state feeds nothing else
+    //   rep[k]   `copies` shifted copies of list_a (src 0) or list_t (src 1): entry = src[j] + c * NA, padded with `trash`
+    uint8_t* ever;                         // [B*na] scratch: agent active at some live step
+    int* list_t;                           // [NA+256]
+    struct Rep { int* list; int src, copies, trash; } rep[4];   // lengths -> counts[4 + k]; list = NULL: unused
 };
 int lists_launch(const ListArgs& a, hipStream_t st);
 

@@ -118,7 +118,8 @@ struct Work {
     float* partial2;   // split-K scratch of the side (agent-chain) stream
     // row lists (kernels.h: ListArgs): rows that cannot influence the step are skipped
     int *t_last, *list_ea, *list_eh, *list_a, *counts, *lcnt, *loff;
-    uint8_t *kdead_a, *kdead_h;
+    int *list_t, *list_t3, *list_h, *list_ht;      // agent-row lists of the layers behind the attention cores (kernels.h: ListArgs)
+    uint8_t *kdead_a, *kdead_h, *ever;
     // mask words of the step, built once for all attention launches (attention_mfma.hip: attn_mask_words_kernel)
     unsigned long long *mw_a, *rb_a, *mw_h, *rb_h;
 };
@@ -141,10 +142,10 @@ static void carve_agent(Arena& a, const refil_dims& d, const Sizes& s, int G, bo
     b.x1 = a.take<float>(s.NEa * d.d);
     b.kv = a.take<float>(s.NEa * 2 * d.d);
     b.q = a.take<float>(s.NAa * d.d);
-    b.ao = a.take<float>((long)G * s.NA * d.d);
+    b.ao = a.take<float>(((long)G * s.NA + 8) * d.d);            // (+8: scratch rows behind the agent-row lists' padding)
     b.x2 = a.take<float>((long)G * s.NA * d.d);
-    b.x3 = a.take<float>((long)G * s.NA * d.H);
-    b.gi = a.take<float>((long)G * s.NA * 3 * d.H);
+    b.x3 = a.take<float>(((long)G * s.NA + 8) * d.H);
+    b.gi = a.take<float>(((long)G * s.NA + 8) * 3 * d.H);
     b.hsx = a.take<float>((long)G * d.B * (d.T1 + 1) * d.na * d.H);
     b.sr = b.sz = b.sn = b.sg = nullptr;
     if (save) {
@@ -158,9 +159,9 @@ static void carve_hyper(Arena& a, const refil_dims& d, const Sizes& s, int NV, H
     b.x1 = a.take<float>(s.NEa * s.nets * d.hyp);
     b.kv = a.take<float>(s.nets * s.NEa * 2 * d.hyp);
     b.q = a.take<float>(s.nets * s.NAa * d.hyp);
-    b.ao = a.take<float>((long)NV * s.NA * d.hyp);
+    b.ao = a.take<float>(((long)NV * s.NA + 8) * d.hyp);
     b.x2 = a.take<float>((long)NV * s.NA * d.hyp);
-    b.x3 = a.take<float>((long)NV * s.NA * d.M);
+    b.x3 = a.take<float>(((long)NV * s.NA + 8) * d.M);
     b.wc = a.take<float>((long)s.nets * d.M * d.hyp);
     b.bc = a.take<float>((long)s.nets * d.M);
 }
@@ -190,10 +191,10 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     w.tmax = a.take<float>(BT * d.na);
     w.q_tot = a.take<float>(BT); w.q_tot_im = a.take<float>(BT); w.tq_tot = a.take<float>(BT);
     w.gc_real = a.take<float>(BT); w.gc_im = a.take<float>(BT); w.targets = a.take<float>(BT); w.ingroup = a.take<float>(BT);
-    w.dx3h = a.take<float>((long)s.NV * s.NA * d.M);
+    w.dx3h = a.take<float>(((long)s.NV * s.NA + 8) * d.M);
     w.dchosen = a.take<float>((long)s.G * BT * d.na);
     w.dx2h = a.take<float>((long)s.NV * s.NA * d.hyp);
-    w.daoh = a.take<float>((long)s.NV * s.NA * d.hyp);
+    w.daoh = a.take<float>(((long)s.NV * s.NA + 8) * d.hyp);
     w.dqh = a.take<float>(s.nets * s.NAa * d.hyp);
     w.dkvh = a.take<float>(s.nets * s.NEa * 2 * d.hyp);
     w.dx1h = a.take<float>(s.NEa * s.nets * d.hyp);
@@ -202,11 +203,11 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     w.gwca = a.take<float>((long)d.H * d.d); w.gbca = a.take<float>(d.H); w.gbact = a.take<float>(d.H);
     w.dqva = a.take<float>((long)s.G * s.NA * d.A);
     w.dhs = a.take<float>((long)s.G * s.NA * d.H);
-    w.dgi = a.take<float>((long)s.G * s.NA * 3 * d.H);
+    w.dgi = a.take<float>(((long)s.G * s.NA + 8) * 3 * d.H);
     w.dgh = a.take<float>((long)s.G * s.NA * 3 * d.H);
-    w.dx3a = a.take<float>((long)s.G * s.NA * d.H);
+    w.dx3a = a.take<float>(((long)s.G * s.NA + 8) * d.H);
     w.dx2a = a.take<float>((long)s.G * s.NA * d.d);
-    w.daoa = a.take<float>((long)s.G * s.NA * d.d);
+    w.daoa = a.take<float>(((long)s.G * s.NA + 8) * d.d);
     w.dqa = a.take<float>(s.NAa * d.d);
     w.dkva = a.take<float>(s.NEa * 2 * d.d);
     w.dx1a = a.take<float>(s.NEa * d.d);
@@ -214,8 +215,10 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     w.partial2 = a.take<float>(PARTIAL_FLOATS);
     w.t_last = a.take<int>(d.B);
     w.list_ea = a.take<int>(s.NE + 256); w.list_eh = a.take<int>(s.NE + 256); w.list_a = a.take<int>(s.NA + 256);
-    w.counts = a.take<int>(4); w.lcnt = a.take<int>(3 * s.R); w.loff = a.take<int>(3 * (s.R + 1));
-    w.kdead_a = a.take<uint8_t>(s.NE); w.kdead_h = a.take<uint8_t>(s.NE);
+    w.counts = a.take<int>(8); w.lcnt = a.take<int>(4 * s.R); w.loff = a.take<int>(4 * (s.R + 1));
+    w.list_t = a.take<int>(s.NA + 256); w.list_t3 = a.take<int>((long)s.G * s.NA + 256);
+    w.list_h = a.take<int>((long)s.nv0 * s.NA + 256); w.list_ht = a.take<int>(s.NA + 256);
+    w.kdead_a = a.take<uint8_t>(s.NE); w.kdead_h = a.take<uint8_t>(s.NE); w.ever = a.take<uint8_t>((long)d.B * d.na);
     {
         const long na_pad = (d.na + 15) / 16 * 16;
         w.mw_a = a.take<unsigned long long>(s.R * 3 * na_pad); w.rb_a = a.take<unsigned long long>(s.R * 3);
@@ -388,6 +391,10 @@ static refil_gemm_desc with_rows(refil_gemm_desc g, const Ctx& c, RowList l) {
 static RowList rows_ea(const Ctx& c) { return RowList{c.w.list_ea, c.w.counts + 0}; }
 static RowList rows_eh(const Ctx& c) { return RowList{c.w.list_eh, c.w.counts + 1}; }
 static RowList rows_a(const Ctx& c) { return RowList{c.w.list_a, c.w.counts + 2}; }
+// rows variant * NA + (b,t,i) of the recurrent tail of an agent evaluated under G mask variants (ListArgs::list_t)
+static RowList rows_t(const Ctx& c, int G) { return G == 1 ? RowList{c.w.list_t, c.w.counts + 7} : RowList{c.w.list_t3, c.w.counts + 4}; }
+// rows variant * NA + (b,t,i) of hyper_w_1's per-agent tail under nv0 mask variants (active agents of live steps)
+static RowList rows_h(const Ctx& c, int nv0) { return nv0 == c.s.nv0 ? RowList{c.w.list_h, c.w.counts + 5} : RowList{c.w.list_ht, c.w.counts + 6}; }
 static void attn_rows(const Ctx& c, refil_attn_desc& a, bool hyper) {
     if (c.lists) { a.t_last = c.w.t_last; a.kv_dead = hyper ? c.w.kdead_h : c.w.kdead_a; a.q_dead = c.w.amask; }
     if (c.mwords) { a.mask_words = hyper ? c.w.mw_h : c.w.mw_a; a.row_bits = hyper ? c.w.rb_h : c.w.rb_a; a.mask_words_nvar = c.s.G; }
@@ -482,7 +489,7 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
         RUN(compose_forward_launch(ca, c.st));
         refil_gemm_desc g = linear(b.ao, dd, b.wc, dd, P + L.ag_fc2_b, b.x3, H, (long)G * s.NA, H, dd, REFIL_GEMM_RELU);
         g.bias2 = b.bd; g.rowscale = c.w.actf; g.rowscale_mod = (int)s.NA;
-        RUN(gemm_launch(g, c.st));
+        RUN(gemm_launch(with_rows(g, c, rows_t(c, G)), c.st));
     } else {
     // x2 = out_trans(attn) with inactive agents zeroed                attention.py:65-67
     {
@@ -494,7 +501,11 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
     RUN(gemm_launch(linear(b.x2, dd, P + L.ag_fc2_w, dd, P + L.ag_fc2_b, b.x3, H, (long)G * s.NA, H, dd, REFIL_GEMM_RELU), c.st));
     }
     // gi = x3 W_ih^T + b_ih for all steps, then the persistent recurrence   :49-55
-    RUN(gemm_launch(linear(b.x3, H, P + L.ag_w_ih, H, P + L.ag_b_ih, b.gi, 3 * H, (long)G * s.NA, 3 * H, H, 0), c.st));
+    {
+        refil_gemm_desc g = linear(b.x3, H, P + L.ag_w_ih, H, P + L.ag_b_ih, b.gi, 3 * H, (long)G * s.NA, 3 * H, H, 0);
+        if (c.compose_agent) g = with_rows(g, c, rows_t(c, G));       // (x3 exists on the listed rows only)
+        RUN(gemm_launch(g, c.st));
+    }
     RUN(set_h0_launch(b.hsx, h0, G * d.B, d.T1, d.na, H, c.st));
     }   // AG_PRE
     if (d.agent_ff) return 0;
@@ -570,7 +581,7 @@ static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int n
         RUN(compose_forward_launch(ca, c.st));
         refil_gemm_desc g = linear(b.ao, h, b.wc, h, b.bc, b.x3, M, (long)nv0 * s.NA, M, h, 0);
         g.rowmask = c.w.amask; g.rowmask_mod = (int)s.NA;
-        RUN(gemm_launch(g, c.st));
+        RUN(gemm_launch(with_rows(g, c, rows_h(c, nv0)), c.st));
         refil_gemm_desc f = linear(b.ao + (long)nv0 * s.NA * h, h, b.wc + (long)M * h, h, nullptr, b.x3 + (long)nv0 * s.NA * M, M, s.R, M, h, 0);
         f.batch = nets - 1; f.sA = s.NA * h; f.sB = (long)M * h; f.sC = s.NA * M;
         f.bias2 = b.bc + M; f.sBias = M; f.rowscale = c.w.nact; f.rowscale_mod = (int)s.R;      // + n_act[r] * b_c
@@ -817,6 +828,10 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         la.b = c.b; la.B = d.B; la.T1 = d.T1; la.ne = d.ne; la.na = d.na; la.learner = 1; la.use_gt_obs = d.gt_obs_mask;
         la.emc = w.emc; la.em0 = w.em0; la.t_last = w.t_last; la.kdead_a = w.kdead_a; la.kdead_h = w.kdead_h;
         la.cnt = w.lcnt; la.off = w.loff; la.list_ea = w.list_ea; la.list_eh = w.list_eh; la.list_a = w.list_a; la.counts = w.counts;
+        la.ever = w.ever; la.list_t = w.list_t;
+        la.rep[0] = ListArgs::Rep{w.list_t3, 1, s.G, (int)(s.G * s.NA)};
+        la.rep[1] = ListArgs::Rep{w.list_h, 0, s.nv0, (int)(s.NV * s.NA)};
+        la.rep[2] = ListArgs::Rep{w.list_ht, 0, 1, (int)(s.nets * s.NA)};
         RUN(lists_launch(la, c.st));
     }
     if (c.mwords) {
@@ -925,9 +940,9 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         // composed tails (x3 = mask(a W_c^T + b_c)): G_c = g3^T a, g_c = colsum(g3) (weighted by n_act on the summed rows),
         // d(attention output) = g3 W_c straight into daoh; compose_backward turns (G_c, g_c) into the four parameter gradients
         refil_gemm_desc gw = linear_dw(w.dx3h, M, w.lh.ao, h, w.gwc, h, w.gbc, (long)nv0 * s.NA, M, h, ch.w.partial, 1);
-        RUN(launch_dw(ch, gw));
+        RUN(launch_dw(ch, with_rows(gw, ch, rows_h(ch, nv0))));
         refil_gemm_desc gx = linear_dx(w.dx3h, M, w.lh.wc, h, w.daoh, h, (long)nv0 * s.NA, M, h, 0);
-        RUN(gemm_launch(gx, ch.st));
+        RUN(gemm_launch(with_rows(gx, ch, rows_h(ch, nv0)), ch.st));
         const long o3 = (long)nv0 * s.NA * M, oh = (long)nv0 * s.NA * h;
         refil_gemm_desc gw1 = linear_dw(w.dx3h + o3, M, w.lh.ao + oh, h, w.gwc + (long)M * h, h, nullptr, s.R, M, h, ch.w.partial, s.nets - 1);
         gw1.sA = s.NA * M; gw1.sB = s.NA * h; gw1.sC = (long)M * h;
@@ -999,7 +1014,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         } else {
             refil_gemm_desc gw = linear_dw(w.dqva, d.A, w.la.hsx, H, grads + L.ag_fc3_w, H, grads + L.ag_fc3_b, rows, d.A, H, ca.w.partial, 1);
             gw.b_map = hs_rows(c, d.na);
-            RUN(launch_dw(ca, gw));
+            RUN(launch_dw(ca, with_rows(gw, ca, rows_t(ca, G))));
             RUN(gemm_launch(linear_dx(w.dqva, d.A, params_live + L.ag_fc3_w, H, w.dhs, H, rows, d.A, H, 0), ca.st));
             // BPTT
             refil_gru_desc g;
@@ -1011,21 +1026,23 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
             RUN(gru_backward_launch(g, ca.st));
             refil_gemm_desc ghh = linear_dw(w.dgh, 3 * H, w.la.hsx, H, grads + L.ag_w_hh, H, grads + L.ag_b_hh, rows, 3 * H, H, ca.w.partial, 1);
             ghh.b_map = hs_rows(c, 0);
-            RUN(launch_dw(ca, ghh));
-            RUN(launch_dw(ca, linear_dw(w.dgi, 3 * H, w.la.x3, H, grads + L.ag_w_ih, H, grads + L.ag_b_ih, rows, 3 * H, H, ca.w.partial, 1)));
+            const bool tl = c.compose_agent;           // (the listed rows are the ones the forward computed x3 on)
+            RUN(launch_dw(ca, tl ? with_rows(ghh, ca, rows_t(ca, G)) : ghh));
+            refil_gemm_desc gih = linear_dw(w.dgi, 3 * H, w.la.x3, H, grads + L.ag_w_ih, H, grads + L.ag_b_ih, rows, 3 * H, H, ca.w.partial, 1);
+            RUN(launch_dw(ca, tl ? with_rows(gih, ca, rows_t(ca, G)) : gih));
             refil_gemm_desc gx3 = linear_dx(w.dgi, 3 * H, params_live + L.ag_w_ih, H, w.dx3a, H, rows, 3 * H, H, REFIL_GEMM_RELU_BWD);
             gx3.aux = w.la.x3;
-            RUN(gemm_launch(gx3, ca.st));
+            RUN(gemm_launch(tl ? with_rows(gx3, ca, rows_t(ca, G)) : gx3, ca.st));
             if (c.compose_agent) {
                 // composed fc2 o out_trans: G_c = dx3^T a (a = 0 on inactive rows), colsum over all rows -> db_2, over the
                 // active rows -> the b_o terms; d(attention out) = dx3 W_c on the active rows
-                RUN(launch_dw(ca, linear_dw(w.dx3a, H, w.la.ao, dd, w.gwca, dd, w.gbca, rows, H, dd, ca.w.partial, 1)));
+                RUN(launch_dw(ca, with_rows(linear_dw(w.dx3a, H, w.la.ao, dd, w.gwca, dd, w.gbca, rows, H, dd, ca.w.partial, 1), ca, rows_t(ca, G))));
                 refil_gemm_desc gb = linear_dw(w.dx3a, H, w.actf, 1, w.gbact, 1, nullptr, rows, H, 1, ca.w.partial, 1);
                 gb.b_map = refil_rowmap{(int)s.NA, 0, 0};          // the G mask copies share the [NA] activity vector
-                RUN(launch_dw(ca, gb));
+                RUN(launch_dw(ca, with_rows(gb, ca, rows_t(ca, G))));
                 refil_gemm_desc gx2 = linear_dx(w.dx3a, H, w.la.wc, dd, w.daoa, dd, rows, H, dd, 0);
                 gx2.rowmask = w.amask; gx2.rowmask_mod = (int)s.NA;
-                RUN(gemm_launch(gx2, ca.st));
+                RUN(gemm_launch(with_rows(gx2, ca, rows_t(ca, G)), ca.st));
                 ComposeArgs cb;
                 memset(&cb, 0, sizeof(cb));
                 cb.W2 = params_live + L.ag_fc2_w; cb.b2 = params_live + L.ag_fc2_b; cb.Wo = params_live + L.ag_out_w; cb.bo = params_live + L.ag_out_b;

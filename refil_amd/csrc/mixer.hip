@@ -88,6 +88,16 @@ __global__ __launch_bounds__(256) void lists_tlast_kernel(ListArgs a) {         
     if (lane == 0) a.t_last[b] = last;
 }
 
+__global__ __launch_bounds__(256) void lists_ever_kernel(ListArgs a) {            // one wave per episode, lane = agent
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    bool any = false;
+    const int tl = a.t_last[b];
+    if (lane < a.na)
+        for (int t = 0; t <= tl; ++t) any |= a.emc[((long)b * a.T1 + t) * a.ne + lane] == 0;
+    if (lane < a.na) a.ever[(long)b * a.na + lane] = any ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void lists_flags_kernel(ListArgs a) {           // one wave per (b,t) row
     const int lane = threadIdx.x & 63;
     const long R = (long)a.B * a.T1;
@@ -106,8 +116,9 @@ __global__ __launch_bounds__(256) void lists_flags_kernel(ListArgs a) {         
         ka = seen || la;
     }
     if (lane < a.ne) { a.kdead_a[r * a.ne + lane] = ka ? 0 : 1; a.kdead_h[r * a.ne + lane] = kh ? 0 : 1; }
-    const unsigned long long ba = __ballot(ka), bh = __ballot(kh), bl = __ballot(la);
-    if (lane == 0) { a.cnt[r] = __popcll(ba); a.cnt[R + r] = __popcll(bh); a.cnt[2 * R + r] = __popcll(bl); }
+    const bool lt = row_live && lane < a.na && a.ever[(long)b * a.na + lane];
+    const unsigned long long ba = __ballot(ka), bh = __ballot(kh), bl = __ballot(la), bt = __ballot(lt);
+    if (lane == 0) { a.cnt[r] = __popcll(ba); a.cnt[R + r] = __popcll(bh); a.cnt[2 * R + r] = __popcll(bl); a.cnt[3 * R + r] = __popcll(bt); }
 }
 
 // exclusive scans of the three per-row count arrays (R <= ~10^4 rows: one workgroup), list lengths, padding
@@ -119,7 +130,7 @@ __global__ __launch_bounds__(1024) void lists_scan_kernel(ListArgs a) {
     const int per = (int)cdivl(R, 1024);
     const long r0 = (long)tid * per, r1 = min(R, r0 + per);
     if (tid == 0) live_rows = 0;
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < 4; ++l) {
         int s = 0;
         for (long r = r0; r < r1; ++r) s += a.cnt[l * R + r];
         part[tid] = s;
@@ -133,9 +144,9 @@ __global__ __launch_bounds__(1024) void lists_scan_kernel(ListArgs a) {
         int run = part[tid] - s;
         for (long r = r0; r < r1; ++r) { a.off[l * (R + 1) + r] = run; run += a.cnt[l * R + r]; }
         const int total = part[1023];
-        if (tid == 0) { a.off[l * (R + 1) + R] = total; a.counts[l] = total; }
-        int* list = l == 0 ? a.list_ea : (l == 1 ? a.list_eh : a.list_a);
-        const int trash = l == 2 ? (int)(R * a.na) : (int)(R * a.ne);
+        if (tid == 0) { a.off[l * (R + 1) + R] = total; a.counts[l < 3 ? l : 7] = total; }
+        int* list = l == 0 ? a.list_ea : (l == 1 ? a.list_eh : (l == 2 ? a.list_a : a.list_t));
+        const int trash = l >= 2 ? (int)(R * a.na) : (int)(R * a.ne);
         const int padded = ((total + 63) & ~63) + 128;      // consumers prefetch list entries past the end (gemm_dw4.hip)
         if (tid < 192 && total + tid < padded) list[total + tid] = trash;
         __syncthreads();
@@ -161,15 +172,33 @@ __global__ __launch_bounds__(256) void lists_fill_kernel(ListArgs a) {          
     if (ka) a.list_ea[a.off[r] + __popcll(ba & below)] = (int)(r * a.ne + lane);
     if (kh) a.list_eh[a.off[(R + 1) + r] + __popcll(bh & below)] = (int)(r * a.ne + lane);
     if (la) a.list_a[a.off[2 * (R + 1) + r] + __popcll(bl & below)] = (int)(r * a.na + lane);
+    const bool lt = row_live && lane < a.na && a.ever[(r / a.T1) * a.na + lane];
+    const unsigned long long bt = __ballot(lt);
+    if (lt) a.list_t[a.off[3 * (R + 1) + r] + __popcll(bt & below)] = (int)(r * a.na + lane);
+}
+
+// shifted copies of an agent-row list (ListArgs::rep): grid.y = which, grid-stride over the padded length
+__global__ __launch_bounds__(256) void lists_rep_kernel(ListArgs a) {
+    const ListArgs::Rep rp = a.rep[blockIdx.y];
+    if (!rp.list) return;
+    const int n = a.counts[rp.src ? 7 : 2];
+    const int* src = rp.src ? a.list_t : a.list_a;
+    const long NA = (long)a.B * a.T1 * a.na;
+    const int total = n * rp.copies, padded = ((total + 63) & ~63) + 128;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < padded; k += gridDim.x * blockDim.x)
+        rp.list[k] = k < total ? src[k % n] + (int)((k / n) * NA) : rp.trash;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.counts[4 + blockIdx.y] = total;
 }
 
 int lists_launch(const ListArgs& a, hipStream_t st) {
     const long R = (long)a.B * a.T1;
     ProfScope prof("lists_kernels", 0.0, 0.0, st);
     hipLaunchKernelGGL(lists_tlast_kernel, dim3(cdiv(a.B, 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(lists_ever_kernel, dim3(cdiv(a.B, 4)), dim3(256), 0, st, a);
     hipLaunchKernelGGL(lists_flags_kernel, dim3((int)cdivl(R, 4)), dim3(256), 0, st, a);
     hipLaunchKernelGGL(lists_scan_kernel, dim3(1), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(lists_fill_kernel, dim3((int)cdivl(R, 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(lists_rep_kernel, dim3(64, 4), dim3(256), 0, st, a);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
