@@ -41,7 +41,7 @@ struct PrepArgs {
     float* xe; uint8_t* emc; uint8_t* amask; uint8_t* em0;
     float* actf;   // [R*na] 1.0 for active agents, 0.0 for inactive ones (row weights of bias terms)
 };
-int prep_launch(const PrepArgs& a, hipStream_t st);
+int prep_launch(const PrepArgs& a, hipStream_t st, int phases = 3, const uint8_t* skip_a = nullptr, const uint8_t* skip_h = nullptr);
 
 // Row lists of a learner step: which (b, t, entity) rows can influence the loss. Everything is decided on the device
 // (no host round trip); consumers read the counts from device memory.
@@ -118,6 +118,8 @@ struct MixArgs {
     int B, T1, T, t_off, na, M, imagine, softmax_w, tanh_nl;
     int lin;                          // LinearFlexQMixer (flex_qmix.py:136-172): x_wf/x_b1 unused
     float* ingroup_rows;              // lin + imagine: per-(b,t) in-group weight mass sum_{i<na} w1[i] (or NULL)
+    const int* t_last;                // optional [B]: steps t > t_last[b] were skipped upstream (they carry no loss): their
+                                      // q_tot is written as 0 and they receive exact-zero gradients
     int presum;                       // x_wf / x_b1 / x_v (and their gradients) are ONE row per (b,t): the sum over the
                                       // active agents of the hypernet output, [R, M] instead of [R*na, M]
 };

@@ -629,6 +629,7 @@ static MixArgs mix_args(const Ctx& c, const HyperBufs& b, int nv0, const float* 
     m.imagine = (nv0 == 3 && G_qs == 3) ? 1 : 0;
     m.softmax_w = d.softmax_mixing_weights; m.tanh_nl = d.mixer_tanh;
     m.presum = c.presum ? 1 : 0;
+    m.t_last = c.lists ? c.w.t_last : nullptr;
     return m;
 }
 
@@ -774,12 +775,13 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
     return 0;
 }
 
-static int run_prep(const Ctx& c, int first_step_zero) {
+static int run_prep(const Ctx& c, int first_step_zero, int phases = 3) {
     PrepArgs p;
     p.b = c.b; p.B = c.d.B; p.T1 = c.d.T1; p.ne = c.d.ne; p.na = c.d.na; p.ed = c.d.ed; p.A = c.d.A; p.Ep = c.s.Ep;
     p.last_action = c.d.entity_last_action; p.first_step_zero = first_step_zero;
     p.xe = c.w.xe; p.emc = c.w.emc; p.amask = c.w.amask; p.actf = c.w.actf; p.em0 = c.w.em0;
-    return prep_launch(p, c.st);
+    const bool skip = c.lists && (phases & 2);
+    return prep_launch(p, c.st, phases, skip ? c.w.kdead_a : nullptr, skip ? c.w.kdead_h : nullptr);
 }
 
 }  // namespace refil
@@ -821,7 +823,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     REFIL_HIP(hipMemsetAsync(grads, 0, (L.total + REFIL_NSTAT) * sizeof(float), c.st));
 
     // ---------------- forward ----------------
-    RUN(run_prep(c, 1));
+    RUN(run_prep(c, 1, c.lists ? 1 : 3));                  // (with row lists: masks first, the input rows the lists keep afterwards)
     if (c.lists) {
         ListArgs la;
         memset(&la, 0, sizeof(la));
@@ -833,6 +835,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         la.rep[1] = ListArgs::Rep{w.list_h, 0, s.nv0, (int)(s.NV * s.NA)};
         la.rep[2] = ListArgs::Rep{w.list_ht, 0, 1, (int)(s.nets * s.NA)};
         RUN(lists_launch(la, c.st));
+        RUN(run_prep(c, 1, 2));
     }
     if (c.mwords) {
         // mask words of every row, once per step: agent nets (observability variants) and hypernets (entity variants)

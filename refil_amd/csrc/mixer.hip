@@ -22,13 +22,17 @@ __device__ inline float wave_max(float v) {
 // ------------------------------------------------------------------------------------------------
 // prep: entities || one-hot(previous action)  (entity_controller.py:13-27 == q_learner.py:50-60)
 // ------------------------------------------------------------------------------------------------
-__global__ void prep_kernel(PrepArgs a) {
+// phases: 1 = the contiguous mask copies (needed by the row lists), 2 = entities || one-hot(previous action); rows that
+// both the agent nets' and the hypernets' row lists skip (skip_a & skip_h, may be NULL) are not assembled
+__global__ void prep_kernel(PrepArgs a, int phases, const uint8_t* skip_a, const uint8_t* skip_h) {
     const long R = (long)a.B * a.T1;
     const long total = R * a.ne * a.Ep;
     const long stride = (long)gridDim.x * blockDim.x;
+    if (phases & 2)
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += stride) {
         const int c = idx % a.Ep;
         const long row = idx / a.Ep;
+        if (skip_a && skip_a[row] && skip_h[row]) continue;
         const int e = row % a.ne;
         const long r = row / a.ne;
         const int b = r / a.T1, t = r % a.T1;
@@ -47,6 +51,7 @@ __global__ void prep_kernel(PrepArgs a) {
         a.xe[idx] = v;
     }
     const long tot2 = R * a.ne;
+    if (phases & 1)
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < tot2; idx += stride) {
         const int e = idx % a.ne;
         const long r = idx / a.ne;
@@ -58,11 +63,11 @@ __global__ void prep_kernel(PrepArgs a) {
     }
 }
 
-int prep_launch(const PrepArgs& a, hipStream_t st) {
-    const long total = (long)a.B * a.T1 * a.ne * a.Ep;
+int prep_launch(const PrepArgs& a, hipStream_t st, int phases, const uint8_t* skip_a, const uint8_t* skip_h) {
+    const long total = (phases & 2) ? (long)a.B * a.T1 * a.ne * a.Ep : (long)a.B * a.T1 * a.ne;
     const int blocks = (int)min((long)4096, cdivl(total, 256));
     ProfScope prof_prep_kernel("prep_kernel", 0.0, 0.0, st);
-    hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, st, a, phases, skip_a, skip_h);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
@@ -385,6 +390,10 @@ __global__ __launch_bounds__(64 * MIXW) void mix_fwd_kernel(MixArgs a) {
     const int m = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool act = m < a.M;
     const long rr = (long)b * a.T1 + t + a.t_off;
+    if (a.t_last && t + a.t_off > a.t_last[b]) {            // (uniform) a step nothing upstream computed
+        if (threadIdx.x == 0) { a.q_tot[bt] = 0.f; if (a.imagine) a.q_tot_im[bt] = 0.f; }
+        return;
+    }
     const long base = rr * a.na * a.M;
     const long qbase = (long)bt * a.na;
     const MixRow o = mix_row_forward(a, base, qbase, m, act, wave, red);
@@ -409,7 +418,11 @@ __global__ __launch_bounds__(64 * MIXW) void mix_bwd_kernel(MixArgs a) {
     const long base = (long)r * a.na * a.M;
     const int t = tt - a.t_off;
     const int nvar = a.imagine ? 3 : 1;
-    if (t < 0 || t >= a.T) {
+    const bool skipped = a.t_last && tt > a.t_last[b];      // (uniform) inside the range but after the episode's last loss-carrying step
+    if (skipped && t >= 0 && t < a.T && m == 0)
+        for (int i = wave; i < a.na; i += MIXW)
+            for (int v = 0; v < nvar; ++v) a.dqs[(long)v * a.B * a.T * a.na + ((long)b * a.T + t) * a.na + i] = 0.f;
+    if (t < 0 || t >= a.T || skipped) {
         if (act) {
             for (int i = wave; i < a.na; i += MIXW) {
                 const long o = base + (long)i * a.M + m;
