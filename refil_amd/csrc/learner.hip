@@ -322,10 +322,16 @@ static int side_stream(SideStream*& out) {
         REFIL_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         // Both chains are throughput-bound GEMM trains now, so the side stream runs at the default priority (measured:
         // 3.65 vs 3.69 ms/step with the highest priority). REFIL_SIDE_PRIO=1 restores the high-priority stream.
-        const char* pe = getenv("REFIL_SIDE_PRIO");
-        REFIL_HIP(hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, (pe && pe[0] == '1') ? hi : 0));
+        // REFIL_SIDE_PRIO / REFIL_GRAD_PRIO: 1 = highest, -1 = lowest priority of the hypernet-chain / weight-gradient streams
+        // relative to the caller's stream (which carries the agent chain, the longer dependency chain of the step)
+        auto prio = [&](const char* name, int dflt) {
+            const char* e = getenv(name);
+            const int v = e ? atoi(e) : dflt;
+            return v > 0 ? hi : (v < 0 ? lo : 0);
+        };
+        REFIL_HIP(hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, prio("REFIL_SIDE_PRIO", 0)));
         for (auto& e : sd.ev) REFIL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (auto& g : sd.g) REFIL_HIP(hipStreamCreateWithPriority(&g, hipStreamNonBlocking, 0));
+        for (auto& g : sd.g) REFIL_HIP(hipStreamCreateWithPriority(&g, hipStreamNonBlocking, prio("REFIL_GRAD_PRIO", 0)));
         for (auto& e : sd.pool) REFIL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         sd.ok = true;
     }
@@ -374,6 +380,7 @@ struct Ctx {
     bool mwords;       // the step's mask words are precomputed (learner steps on the matrix-core attention path)
     // weight-gradient stream of this chain (== st when the chains are serialised) and its split-reduction scratch
     hipStream_t gst; float* gpartial; SideStream* sd;
+    hipStream_t mwst;  // stream the step's mask words are built on (the chain waits for it right before its first attention launch)
 };
 
 // weight gradients (+ their reductions) leave the chain: forked behind everything enqueued on the chain so far
@@ -463,6 +470,7 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
         a.var[1] = group_code(d, 0, true);
         a.var[2] = group_code(d, 1, true);
         attn_rows(c, a, false);
+        RUN(stream_after(c.sd, c.mwst, c.st));
         if (c.compose_agent) {
             const int rc = attn_mfma_launch_ex(a, false, c.st, 0, nullptr, 0, 1);      // inactive agents -> exact zeros
             REFIL_CHECK(rc >= 0, "refil: agent attention shape not instantiated");
@@ -559,6 +567,7 @@ static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int n
             ao[n] = AttnNetOpts{(c.presum && n > 0) ? 1 : 0, 0};
         }
         int rc = -1;
+        RUN(stream_after(c.sd, c.mwst, c.st));
         if (!d.pooling && attn_mfma_supported(d.ne, d.na, h / d.heads))
             rc = attn_mfma_launch_multi(ad, ao, nets, false, c.st, c.presum ? c.w.nact : nullptr, 0);
         if (rc > 0) return rc;
@@ -746,7 +755,7 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
     REFIL_CHECK(dims && batch && ws, "refil: null dims/batch/workspace");
     if (int e = check_dims(*dims)) return e;
     c.d = *dims; c.s = sizes_of(*dims); c.b = *batch; c.st = (hipStream_t)stream;
-    c.gst = c.st; c.gpartial = nullptr; c.sd = nullptr;
+    c.gst = c.st; c.gpartial = nullptr; c.sd = nullptr; c.mwst = c.st;
     param_layout(c.d, c.L);
     const char* pe = getenv("REFIL_PRESUM");          // read per call: tests compare both paths in one process
     const bool presum_on = !(pe && pe[0] == '0');
@@ -823,6 +832,30 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     REFIL_HIP(hipMemsetAsync(grads, 0, (L.total + REFIL_NSTAT) * sizeof(float), c.st));
 
     // ---------------- forward ----------------
+    // Streams (REFIL_NO_OVERLAP=1 / refil_set_overlap(0) serialise everything on the caller's stream):
+    //   caller's stream  live agent (3 mask variants)          -> Q selection, mixing, loss -> agent backward
+    //   sd->s            live + target hypernets                                            -> hypernet backward
+    //   sd->g[0]         the agent nets' mask words, target agent;  in the backward: the agent chain's weight gradients
+    //   sd->g[1]         the hypernets' mask words;                 in the backward: the hypernet chain's weight gradients
+    // so that the latency-bound kernels (the recurrences: <= 128 workgroups) always have GEMM trains of other chains beside them.
+    Ctx ca = c;                       // live agent chain: caller's stream
+    Ctx ch = c;                       // hypernet chain: side stream + its own split-K scratch
+    Ctx ct = c;                       // target agent (forward only)
+    const bool overlap = overlap_enabled();
+    ca.gpartial = w.partial; ch.gpartial = w.partial2;
+    if (overlap) {
+        RUN(side_stream(sd));
+        sd->next_ev = 2;                                   // (pool[0..1]: the final joins of the two weight-gradient streams)
+        ch.st = sd->s; ch.gst = sd->s; ca.sd = ch.sd = ct.sd = sd;
+        static const bool gstreams = [] { const char* e = getenv("REFIL_GRADSTREAM"); return !(e && e[0] == '0'); }();
+        if (gstreams) { ch.gst = sd->g[1]; ca.gst = sd->g[0]; }
+        // REFIL_FWD3=1: the target agent on its own stream (measured slower at cfg-T: 2.42 vs 2.37 ms -- three GEMM trains
+        // thrash each other's L2 more than the lone recurrence at the end of the forward costs)
+        static const bool fwd3 = [] { const char* e = getenv("REFIL_FWD3"); return e && e[0] == '1'; }();
+        static const bool mwside = [] { const char* e = getenv("REFIL_MW_SIDE"); return !(e && e[0] == '0'); }();
+        if (fwd3) ct.st = sd->g[0];
+        if (mwside || fwd3) { ca.mwst = ct.mwst = sd->g[0]; ch.mwst = sd->g[1]; }
+    }
     RUN(run_prep(c, 1, c.lists ? 1 : 3));                  // (with row lists: masks first, the input rows the lists keep afterwards)
     if (c.lists) {
         ListArgs la;
@@ -835,10 +868,10 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         la.rep[1] = ListArgs::Rep{w.list_h, 0, s.nv0, (int)(s.NV * s.NA)};
         la.rep[2] = ListArgs::Rep{w.list_ht, 0, 1, (int)(s.nets * s.NA)};
         RUN(lists_launch(la, c.st));
-        RUN(run_prep(c, 1, 2));
     }
     if (c.mwords) {
-        // mask words of every row, once per step: agent nets (observability variants) and hypernets (entity variants)
+        // mask words of every row, once per step: agent nets (observability variants) and hypernets (entity variants);
+        // they are needed by the first attention launches only, so they are built beside the first projections
         for (int hyper = 0; hyper < 2; ++hyper) {
             refil_attn_desc a = attn_base(c, hyper ? d.hyp : d.d);
             if (c.lists) { a.t_last = w.t_last; a.kv_dead = hyper ? w.kdead_h : w.kdead_a; a.q_dead = w.amask; }
@@ -846,32 +879,26 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
             a.var[0] = hyper ? REFIL_MASK_ENTITY : REFIL_MASK_OBS;
             a.var[1] = group_code(d, 0, !hyper);
             a.var[2] = group_code(d, 1, !hyper);
-            RUN(attn_mask_words_launch(a, hyper ? w.mw_h : w.mw_a, hyper ? w.rb_h : w.rb_a, c.st));
+            const hipStream_t ms = hyper ? ch.mwst : ca.mwst;
+            RUN(stream_after(sd, c.st, ms));
+            RUN(attn_mask_words_launch(a, hyper ? w.mw_h : w.mw_a, hyper ? w.rb_h : w.rb_a, ms));
         }
     }
-    // The hypernet chain is the longer one, so IT goes to the side stream and is enqueued first: whichever
-    // chain the host enqueues second starts several hundred microseconds late (the host needs that long to
-    // push the ~40 launches of the first chain), and the agent chain has that much slack.
-    Ctx ca = c;                       // agent chain: caller's stream
-    Ctx ch = c;                       // hypernet chain: side stream + its own split-K scratch
-    const bool overlap = overlap_enabled();
-    ca.gpartial = w.partial; ch.gpartial = w.partial2;
-    if (overlap) {
-        RUN(side_stream(sd));
-        sd->next_ev = 2;                                   // (pool[0..1]: the final joins of the two weight-gradient streams)
-        ch.st = sd->s; ch.gst = sd->s; ca.sd = ch.sd = sd;
-        static const bool gstreams = [] { const char* e = getenv("REFIL_GRADSTREAM"); return !(e && e[0] == '0'); }();
-        if (gstreams) { ch.gst = sd->g[1]; ca.gst = sd->g[0]; }
-        REFIL_HIP(hipEventRecord(sd->ev[0], c.st));
-        REFIL_HIP(hipStreamWaitEvent(sd->s, sd->ev[0], 0));
-    }
+    if (c.lists) RUN(run_prep(c, 1, 2));
+    RUN(stream_after(sd, c.st, ch.st));                    // fork: inputs assembled
+    RUN(stream_after(sd, c.st, ct.st));
     if (!d.mixer_vdn) {
         RUN(hyper_forward(ch, params_live, w.lh, nv0));                           // live mixer hypernets
         RUN(hyper_forward(ch, params_target, w.th, 1));                           // target mixer hypernets
     }
     if (overlap) REFIL_HIP(hipEventRecord(sd->ev[1], sd->s));
-    if (!d.agent_ff && (G * d.B * d.na) % 16 == 0) {
-        // live (q_learner.py:86-89 / 107) and target (:111-113) agents; their two recurrences share one launch
+    if (ct.st != ca.st) {
+        // live (q_learner.py:86-89 / 107) and target (:111-113) agents side by side on their own streams
+        RUN(agent_forward(ct, params_target, w.ta, 1, nullptr));
+        RUN(agent_forward(ca, params_live, w.la, G, nullptr));
+        RUN(stream_after(sd, ct.st, ca.st));
+    } else if (!d.agent_ff && (G * d.B * d.na) % 16 == 0) {
+        // one stream: the two recurrences share one launch
         RUN(agent_forward(ca, params_live, w.la, G, nullptr, AG_PRE));
         RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_PRE));
         const refil_gru_desc gl = agent_gru_desc(ca, params_live, w.la, G), gt = agent_gru_desc(ca, params_target, w.ta, 1);

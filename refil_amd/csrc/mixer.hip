@@ -93,14 +93,18 @@ __global__ __launch_bounds__(256) void lists_tlast_kernel(ListArgs a) {         
     if (lane == 0) a.t_last[b] = last;
 }
 
-__global__ __launch_bounds__(256) void lists_ever_kernel(ListArgs a) {            // one wave per episode, lane = agent
-    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= a.B) return;
+__global__ __launch_bounds__(256) void lists_ever_kernel(ListArgs a) {            // one workgroup per episode: lane = agent, wave = step mod 4
+    __shared__ int any_s[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x;
+    if (threadIdx.x < 64) any_s[threadIdx.x] = 0;
+    __syncthreads();
     bool any = false;
     const int tl = a.t_last[b];
     if (lane < a.na)
-        for (int t = 0; t <= tl; ++t) any |= a.emc[((long)b * a.T1 + t) * a.ne + lane] == 0;
-    if (lane < a.na) a.ever[(long)b * a.na + lane] = any ? 1 : 0;
+        for (int t = wave; t <= tl; t += 4) any |= a.emc[((long)b * a.T1 + t) * a.ne + lane] == 0;
+    if (any) any_s[lane] = 1;                              // (benign race: every writer stores 1)
+    __syncthreads();
+    if (threadIdx.x < a.na) a.ever[(long)b * a.na + threadIdx.x] = any_s[threadIdx.x] ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void lists_flags_kernel(ListArgs a) {           // one wave per (b,t) row
@@ -126,41 +130,40 @@ __global__ __launch_bounds__(256) void lists_flags_kernel(ListArgs a) {         
     if (lane == 0) { a.cnt[r] = __popcll(ba); a.cnt[R + r] = __popcll(bh); a.cnt[2 * R + r] = __popcll(bl); a.cnt[3 * R + r] = __popcll(bt); }
 }
 
-// exclusive scans of the three per-row count arrays (R <= ~10^4 rows: one workgroup), list lengths, padding
+// exclusive scans of the four per-row count arrays (R <= ~10^4 rows: one workgroup, 256 threads per list), list lengths, padding
 __global__ __launch_bounds__(1024) void lists_scan_kernel(ListArgs a) {
-    __shared__ int part[1024];
+    __shared__ int part[4][256];
     __shared__ int live_rows;
     const long R = (long)a.B * a.T1;
-    const int tid = threadIdx.x;
-    const int per = (int)cdivl(R, 1024);
+    const int l = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const int per = (int)cdivl(R, 256);
     const long r0 = (long)tid * per, r1 = min(R, r0 + per);
-    if (tid == 0) live_rows = 0;
-    for (int l = 0; l < 4; ++l) {
-        int s = 0;
-        for (long r = r0; r < r1; ++r) s += a.cnt[l * R + r];
-        part[tid] = s;
+    if (threadIdx.x == 0) live_rows = 0;
+    int s = 0;
+    for (long r = r0; r < r1; ++r) s += a.cnt[l * R + r];
+    part[l][tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {                      // Hillis-Steele inclusive scan of the 256 partial sums of each list
+        const int v = tid >= o ? part[l][tid - o] : 0;
         __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {                 // Hillis-Steele inclusive scan of the 1024 partial sums
-            const int v = tid >= o ? part[tid - o] : 0;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
-        }
-        int run = part[tid] - s;
-        for (long r = r0; r < r1; ++r) { a.off[l * (R + 1) + r] = run; run += a.cnt[l * R + r]; }
-        const int total = part[1023];
-        if (tid == 0) { a.off[l * (R + 1) + R] = total; a.counts[l < 3 ? l : 7] = total; }
-        int* list = l == 0 ? a.list_ea : (l == 1 ? a.list_eh : (l == 2 ? a.list_a : a.list_t));
-        const int trash = l >= 2 ? (int)(R * a.na) : (int)(R * a.ne);
-        const int padded = ((total + 63) & ~63) + 128;      // consumers prefetch list entries past the end (gemm_dw4.hip)
-        if (tid < 192 && total + tid < padded) list[total + tid] = trash;
+        part[l][tid] += v;
         __syncthreads();
     }
-    int lr = 0;
-    for (long r = r0; r < r1; ++r) lr += (int)(r % a.T1) <= a.t_last[r / a.T1] ? 1 : 0;
-    atomicAdd(&live_rows, lr);
+    int run = part[l][tid] - s;
+    for (long r = r0; r < r1; ++r) { a.off[l * (R + 1) + r] = run; run += a.cnt[l * R + r]; }
+    const int total = part[l][255];
+    if (tid == 0) { a.off[l * (R + 1) + R] = total; a.counts[l < 3 ? l : 7] = total; }
+    int* list = l == 0 ? a.list_ea : (l == 1 ? a.list_eh : (l == 2 ? a.list_a : a.list_t));
+    const int trash = l >= 2 ? (int)(R * a.na) : (int)(R * a.ne);
+    const int padded = ((total + 63) & ~63) + 128;          // consumers prefetch list entries past the end (gemm_dw4.hip)
+    if (tid < 192 && total + tid < padded) list[total + tid] = trash;
+    if (l == 0) {
+        int lr = 0;
+        for (long r = r0; r < r1; ++r) lr += (int)(r % a.T1) <= a.t_last[r / a.T1] ? 1 : 0;
+        atomicAdd(&live_rows, lr);
+    }
     __syncthreads();
-    if (tid == 0) a.counts[3] = live_rows;
+    if (threadIdx.x == 0) a.counts[3] = live_rows;
 }
 
 __global__ __launch_bounds__(256) void lists_fill_kernel(ListArgs a) {            // one wave per (b,t) row
@@ -199,7 +202,7 @@ int lists_launch(const ListArgs& a, hipStream_t st) {
     const long R = (long)a.B * a.T1;
     ProfScope prof("lists_kernels", 0.0, 0.0, st);
     hipLaunchKernelGGL(lists_tlast_kernel, dim3(cdiv(a.B, 4)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(lists_ever_kernel, dim3(cdiv(a.B, 4)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(lists_ever_kernel, dim3(a.B), dim3(256), 0, st, a);
     hipLaunchKernelGGL(lists_flags_kernel, dim3((int)cdivl(R, 4)), dim3(256), 0, st, a);
     hipLaunchKernelGGL(lists_scan_kernel, dim3(1), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(lists_fill_kernel, dim3((int)cdivl(R, 4)), dim3(256), 0, st, a);

@@ -6,7 +6,11 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'prep_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'lists_tlast_kernel' in r['Kernel_Name']]
+if len(idx) >= 2:                       # steps with row lists: prep (masks) runs right before the lists
+    idx = [i - 1 for i in idx]
+else:
+    idx = [i for i, r in enumerate(rows) if 'prep_kernel' in r['Kernel_Name']]
 s, e = idx[-2], idx[-1]
 t0 = int(rows[s]['Start_Timestamp'])
 qs = sorted(set(r['Queue_Id'] for r in rows[s:e]))
