@@ -250,6 +250,8 @@ typedef struct refil_gemm_desc {
      * values) and overwritten. Supported by the weight-resident (bound M >= 256, N % 32 == 0, K <= 128, or <= 256 with
      * RELU_BWD; no rowmask / bias2) and the streaming-dW kernels (splits >= 2); other shapes return an error. */
     const int32_t* row_index; const int32_t* row_count;
+    int32_t row_count_hint;   /* host-side guess of *row_count (e.g. the previous step's value), 0 = unknown: only shapes
+                                 the launch grid / tile width, never the result */
 } refil_gemm_desc;
 
 int refil_gemm(const refil_gemm_desc* desc, void* stream);

@@ -71,7 +71,7 @@ class GemmDesc(C.Structure):
         ("a_map", RowMap), ("b_map", RowMap), ("c_map", RowMap),
         ("rowmask_mod", C.c_int32), ("batch", C.c_int32), ("splits", C.c_int32), ("flags", C.c_int32),
         ("bias2", C.c_void_p), ("rowscale", C.c_void_p), ("rowscale_mod", C.c_int32),
-        ("row_index", C.c_void_p), ("row_count", C.c_void_p),
+        ("row_index", C.c_void_p), ("row_count", C.c_void_p), ("row_count_hint", C.c_int32),
     ]
 
 

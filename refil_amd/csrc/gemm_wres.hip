@@ -363,13 +363,21 @@ int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st) {
     const bool bt = d.flags & REFIL_GEMM_B_OUTC, rb = d.flags & REFIL_GEMM_RELU_BWD;
     int tn = (d.N % 128 == 0) ? 4 : ((d.N % 64 == 0) ? 2 : 1);
     if (rb) tn = 2;                                   // relu'(aux) (+ C) operands of a tile live in registers too
-    const int gy = d.N / (32 * tn), gz = d.batch;
     static const int n_cu = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = 256; }
         return n;
     }();
-    int gx = min(cdiv(cdiv(d.M, 32), WR_WAVES), max(1, n_cu / (gy * gz)));
+    // rows the launch is expected to process: the list length of the previous step when the caller passes it (a hint)
+    long rows = d.M;
+    if (d.row_index && d.row_count_hint > 0) rows = min((long)d.M, (long)d.row_count_hint + d.row_count_hint / 8 + 64);
+    const long tiles = cdivl(rows, 32);
+    // a (32 x 32 TN) tile occupies a wave for ~4 TN K microseconds: with fewer than ~1.5 tiles per wave of the chip the
+    // launch is all prologue and quantisation -- use narrower tiles (more of them) instead
+    if (!rb && d.row_index)
+        while (tn > 1 && tiles * (d.N / (32 * tn)) * d.batch * 2 < 3L * n_cu * WR_WAVES && !(tn == 2 && d.bias2 && false)) tn >>= 1;
+    const int gy = d.N / (32 * tn), gz = d.batch;
+    int gx = (int)min(cdivl(tiles, WR_WAVES), (long)max(1, n_cu / (gy * gz)));
     // XCD-aware: workgroups are dealt round-robin to the 8 XCDs by linear id = x + gx (y + gy z). With gx a multiple
     // of 8 the column blocks y = 0, 1, .. that re-read the SAME rows of x (N > 128) land on the same XCD, so the
     // second read is an L2 hit instead of a second trip to HBM.

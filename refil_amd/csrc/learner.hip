@@ -390,18 +390,37 @@ static int launch_dw(const Ctx& c, refil_gemm_desc g) {
     return gemm_launch(g, c.gst);
 }
 
-struct RowList { const int* idx; const int* cnt; };
+// List lengths of an earlier step, copied back asynchronously into pinned host memory (one slot per device): a HINT
+// for sizing the next steps' launch grids -- never waited for, never used for anything a result depends on.
+static thread_local int* g_hint[MAX_DEVICES] = {};
+static int* row_hints() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) { (void)hipGetLastError(); return nullptr; }
+    if (!g_hint[dev]) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 8 * sizeof(int), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        memset(p, 0, 8 * sizeof(int));
+        g_hint[dev] = static_cast<int*>(p);
+    }
+    return g_hint[dev];
+}
+
+struct RowList { const int* idx; const int* cnt; int which; };      // which: index into the counts array (= the hint slot)
 static refil_gemm_desc with_rows(refil_gemm_desc g, const Ctx& c, RowList l) {
-    if (c.lists) { g.row_index = l.idx; g.row_count = l.cnt; }
+    if (c.lists) {
+        g.row_index = l.idx; g.row_count = l.cnt;
+        const int* h = row_hints();
+        g.row_count_hint = h ? h[l.which] : 0;
+    }
     return g;
 }
-static RowList rows_ea(const Ctx& c) { return RowList{c.w.list_ea, c.w.counts + 0}; }
-static RowList rows_eh(const Ctx& c) { return RowList{c.w.list_eh, c.w.counts + 1}; }
-static RowList rows_a(const Ctx& c) { return RowList{c.w.list_a, c.w.counts + 2}; }
+static RowList rows_ea(const Ctx& c) { return RowList{c.w.list_ea, c.w.counts + 0, 0}; }
+static RowList rows_eh(const Ctx& c) { return RowList{c.w.list_eh, c.w.counts + 1, 1}; }
+static RowList rows_a(const Ctx& c) { return RowList{c.w.list_a, c.w.counts + 2, 2}; }
 // rows variant * NA + (b,t,i) of the recurrent tail of an agent evaluated under G mask variants (ListArgs::list_t)
-static RowList rows_t(const Ctx& c, int G) { return G == 1 ? RowList{c.w.list_t, c.w.counts + 7} : RowList{c.w.list_t3, c.w.counts + 4}; }
+static RowList rows_t(const Ctx& c, int G) { return G == 1 ? RowList{c.w.list_t, c.w.counts + 7, 7} : RowList{c.w.list_t3, c.w.counts + 4, 4}; }
 // rows variant * NA + (b,t,i) of hyper_w_1's per-agent tail under nv0 mask variants (active agents of live steps)
-static RowList rows_h(const Ctx& c, int nv0) { return nv0 == c.s.nv0 ? RowList{c.w.list_h, c.w.counts + 5} : RowList{c.w.list_ht, c.w.counts + 6}; }
+static RowList rows_h(const Ctx& c, int nv0) { return nv0 == c.s.nv0 ? RowList{c.w.list_h, c.w.counts + 5, 5} : RowList{c.w.list_ht, c.w.counts + 6, 6}; }
 static void attn_rows(const Ctx& c, refil_attn_desc& a, bool hyper) {
     if (c.lists) { a.t_last = c.w.t_last; a.kv_dead = hyper ? c.w.kdead_h : c.w.kdead_a; a.q_dead = c.w.amask; }
     if (c.mwords) { a.mask_words = hyper ? c.w.mw_h : c.w.mw_a; a.row_bits = hyper ? c.w.rb_h : c.w.rb_a; a.mask_words_nvar = c.s.G; }
@@ -868,6 +887,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         la.rep[1] = ListArgs::Rep{w.list_h, 0, s.nv0, (int)(s.NV * s.NA)};
         la.rep[2] = ListArgs::Rep{w.list_ht, 0, 1, (int)(s.nets * s.NA)};
         RUN(lists_launch(la, c.st));
+        if (int* h = row_hints()) REFIL_HIP(hipMemcpyAsync(h, w.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, c.st));
     }
     if (c.mwords) {
         // mask words of every row, once per step: agent nets (observability variants) and hypernets (entity variants);
