@@ -305,18 +305,38 @@ def main():
                     k["tflops_isolated"] = round(x["flops"] / (x["total_ms"] * 1e-3) / 1e12, 2)
             kernels.append(k)
         iso_total = sum(x["total_ms"] for x in iso.values()) / nprof
-        dom = next((e for e in ents if e["flops"] > 0), ents[0])            # dominant MFMA kernel (largest isolated time)
+        dom = next((e for e in ents if e["flops"] > 0), ents[0])            # dominant kernel (largest isolated time per step)
         dom_iso = iso.get(dom["name"], dom)
         traffic = None
         if a.traffic_json:
             traffic = json.load(open(a.traffic_json))["kernels"].get(dom["name"], {}).get("hbm_bytes_per_launch")
-        ach_iso = dom_iso["flops"] / (dom_iso["total_ms"] * 1e-3) / 1e12
-        ach_situ = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-        roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach_iso, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach_iso / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+        # which roof bounds it: the projections are matrix-core work; the attention cores / recurrences / mixing kernels move
+        # far more bytes per FLOP than the 157 TFLOP/s : 8 TB/s ridge (19.7 FLOP/B) -- HBM. Row-list GEMMs report the FLOPs /
+        # bytes of the rows they process; the attention launches skip finished steps: scaled by the live-step fraction.
+        hbm_bound = dom["name"].split("<")[0] in ("attn_fwd_mfma", "attn_bwd_mfma", "attn_fwd_kernel", "attn_bwd_kernel", "gru_fwd_kernel",
+                                                   "gru_bwd_kernel", "mix_fwd_kernel", "mix_bwd_kernel", "reduce_partials_kernel")
+        live = rows["live_steps"] / max(rows["steps"], 1) if dom["name"].startswith("attn_") else 1.0
+        if hbm_bound:
+            per_launch = live * dom_iso["bytes"] / dom_iso["launches"]
+            ach_iso = per_launch / (1e-3 * dom_iso["total_ms"] / dom_iso["launches"]) / 1e9
+            ach_situ = per_launch / (1e-3 * dom["total_ms"] / dom["launches"]) / 1e9
+            peak, unit = 8000.0, "GB/s"
+        else:
+            ach_iso = dom_iso["flops"] / (dom_iso["total_ms"] * 1e-3) / 1e12
+            ach_situ = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+            peak, unit = PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
+        gemm = next((e for e in ents if e["name"].startswith("gemm_") and e["flops"] > 0), None)     # the heaviest projection kernel as well
+        gemm_iso = iso.get(gemm["name"], gemm) if gemm else None
+        roofline = {"kernel": dom["name"], "bound": "hbm" if hbm_bound else "mfma", "achieved": round(ach_iso, 2), "peak": peak,
+                    "unit": unit, "frac": round(ach_iso / peak, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE via --traffic-json; null: not collected in this run)",
-                    "algorithmic_bytes_per_launch": round(dom_iso["bytes"] / dom_iso["launches"]),
-                    "achieved_in_situ": round(ach_situ, 2), "frac_in_situ": round(ach_situ / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "algorithmic_bytes_per_launch": round(live * dom_iso["bytes"] / dom_iso["launches"]),
+                    "achieved_in_situ": round(ach_situ, 2), "frac_in_situ": round(ach_situ / peak, 4),
+                    "heaviest_gemm": None if not gemm else {
+                        "kernel": gemm["name"], "bound": "mfma", "launches_per_step": gemm["launches"] // nprof,
+                        "achieved": round(gemm_iso["flops"] / (gemm_iso["total_ms"] * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(gemm_iso["flops"] / (gemm_iso["total_ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "avg_launch_us": round(1e3 * gemm_iso["total_ms"] / gemm_iso["launches"], 2)},
                     "launches_per_step": dom["launches"] // nprof,
                     "avg_launch_us": round(1e3 * dom_iso["total_ms"] / dom_iso["launches"], 2),
                     "avg_launch_us_in_situ": round(1e3 * dom["total_ms"] / dom["launches"], 2),

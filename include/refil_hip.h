@@ -149,6 +149,14 @@ int refil_learner_forward_backward(const refil_dims* dims, const refil_batch* ba
                                    float* grads, void* workspace, size_t workspace_bytes,
                                    const refil_debug_out* debug, void* stream);
 
+/* Data-parallel overlap (optional). The flat gradient buffer is [agent | mixer | REFIL_NSTAT stat sums]; the mixer part
+ * and the stat sums are final as soon as the hypernets' backward is, long before the agent's BPTT finishes. A hook set
+ * here is called by refil_learner_forward_backward (on the calling thread, during enqueue) once every kernel writing
+ * grads[agent_total : total + REFIL_NSTAT] has been enqueued; `stream` is the HIP stream on which they complete, so a
+ * collective enqueued behind that stream reduces the mixer bucket while the agent chain is still running. NULL: off. */
+typedef void (*refil_grads_hook)(void* user, void* stream);
+int refil_set_mixer_grads_hook(refil_grads_hook hook, void* user);
+
 /* Diagnostics (synchronises the stream): which rows the LAST refil_learner_forward_backward on this workspace / dims
  * actually processed. The step skips rows that cannot influence the loss -- entity rows no query can attend to, query rows
  * of inactive agents, steps after an episode's last loss-carrying step -- through device-side row lists (no host round

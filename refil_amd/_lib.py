@@ -106,6 +106,9 @@ class GatherField(C.Structure):
                 ("copy_bytes", C.c_int64)]
 
 
+GRADS_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+
+
 class ProfileEntry(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
                 ("bytes", C.c_double)]
@@ -118,7 +121,7 @@ EXPORTS = [
     "refil_mixer_workspace_bytes", "refil_mixer_forward", "refil_gemm", "refil_attn_forward",
     "refil_attn_backward", "refil_pool_forward", "refil_pool_backward", "refil_gru_forward", "refil_gru_backward", "refil_last_error", "refil_version",
     "refil_profile_enable", "refil_profile_collect", "refil_set_overlap", "refil_release_streams", "refil_replay_gather",
-    "refil_learner_row_counts", "refil_attn_mask_words",
+    "refil_learner_row_counts", "refil_attn_mask_words", "refil_set_mixer_grads_hook",
 ]
 
 _lib = None
@@ -161,6 +164,7 @@ def lib():
     L.refil_gru_forward.argtypes = [C.POINTER(GruDesc), C.c_void_p]
     L.refil_gru_backward.argtypes = [C.POINTER(GruDesc), C.c_void_p]
     L.refil_set_overlap.argtypes = [C.c_int]
+    L.refil_set_mixer_grads_hook.argtypes = [GRADS_HOOK, C.c_void_p]
     L.refil_learner_row_counts.argtypes = [C.POINTER(Dims), C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.c_void_p]
     L.refil_replay_gather.argtypes = [C.POINTER(GatherField), C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
     L.refil_profile_enable.argtypes = [C.c_int]

@@ -355,6 +355,11 @@ static int stream_after(SideStream* sd, hipStream_t from, hipStream_t to) {
     REFIL_HIP(hipStreamWaitEvent(to, e, 0));
     return 0;
 }
+// Data parallelism: the mixer's gradients (+ the stat sums) are complete long before the agent's BPTT is; this hook lets
+// the caller start their all-reduce at that point, on the stream they complete on (refil_set_mixer_grads_hook).
+static thread_local refil_grads_hook g_mixer_hook = nullptr;
+static thread_local void* g_mixer_hook_user = nullptr;
+
 static int g_overlap = -1;      // -1: follow the environment, 0/1: set by refil_set_overlap
 static bool overlap_enabled() {
     if (g_overlap >= 0) return g_overlap != 0;
@@ -817,6 +822,10 @@ static int run_prep(const Ctx& c, int first_step_zero, int phases = 3) {
 using namespace refil;
 
 extern "C" const char* refil_last_error(void) { return g_err; }
+extern "C" int refil_set_mixer_grads_hook(refil_grads_hook hook, void* user) {
+    g_mixer_hook = hook; g_mixer_hook_user = user;
+    return 0;
+}
 extern "C" int refil_set_overlap(int on) { g_overlap = on < 0 ? -1 : (on != 0); return 0; }
 extern "C" int refil_version(void) { return 1; }
 
@@ -1047,6 +1056,11 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
                                       ch.w.partial, 1);
         RUN(launch_dw(ch, with_rows(g, ch, rows_eh(ch))));
     }
+    }
+    // every kernel that writes a mixer gradient (and, earlier, the stat sums) is enqueued: on ch.gst they are complete
+    if (g_mixer_hook) {
+        RUN(stream_after(sd, ch.st, ch.gst));
+        g_mixer_hook(g_mixer_hook_user, (void*)ch.gst);
     }
     // agent: chosen-Q gather + inactive-agent fill, then fc3
     {

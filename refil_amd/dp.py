@@ -32,6 +32,52 @@ def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
+class BucketedAllReduce:
+    """Two-bucket version of allreduce_sum_ (REFIL_DP_BUCKETS=1): [mixer grads | stats] is reduced as soon as the
+    hypernets' backward has been enqueued -- on the stream those gradients complete on, i.e. underneath the agent's
+    BPTT -- and [agent grads] after the step (SURVEY.md section 8e topology note). Same sums, same result.
+
+        ar = BucketedAllReduce(flat, n_agent)        # flat = [agent | mixer | stats]
+        with ar:                                     # installs the library hook for this step
+            engine.forward_backward(...)
+        ar.finish()                                  # reduces the agent bucket, waits for the mixer bucket
+    """
+
+    def __init__(self, flat: torch.Tensor, n_agent: int):
+        from . import _lib
+        self.flat, self.n_agent = flat, n_agent
+        self.work = None
+        self._cb = _lib.GRADS_HOOK(self._hook)       # keep the ctypes thunk alive
+        self._lib = _lib
+
+    def _hook(self, user, stream):
+        if world() == 1:
+            return
+        ext = torch.cuda.ExternalStream(stream, device=self.flat.device) if stream else torch.cuda.current_stream()
+        with torch.cuda.stream(ext):                 # the collective is ordered behind the mixer gradients' stream
+            self.work = dist.all_reduce(self.flat[self.n_agent:], op=dist.ReduceOp.SUM, async_op=True)
+
+    def __enter__(self):
+        self.work = None
+        self._lib.check(self._lib.lib().refil_set_mixer_grads_hook(self._cb, None), "refil_set_mixer_grads_hook")
+        return self
+
+    def __exit__(self, *exc):
+        self._lib.lib().refil_set_mixer_grads_hook(self._lib.GRADS_HOOK(0), None)
+        return False
+
+    def finish(self):
+        if world() == 1:
+            return self.flat
+        dist.all_reduce(self.flat[:self.n_agent], op=dist.ReduceOp.SUM)
+        if self.work is not None:
+            self.work.wait()                         # (the current stream waits for the mixer bucket)
+            self.work = None
+        else:                                        # the hook did not fire (no mixer): reduce the rest now
+            dist.all_reduce(self.flat[self.n_agent:], op=dist.ReduceOp.SUM)
+        return self.flat
+
+
 def mean_scalar(x) -> float:
     """Mean over ranks of a per-shard scalar diagnostic (log steps only; equal shard sizes)."""
     if world() == 1:

@@ -5,6 +5,7 @@ parallelism, one C-ABI call for clip + RMSprop. No autograd, no torch.optim.
 from __future__ import annotations
 
 import copy
+import os
 
 import torch as th
 from .. import _lib, dp
@@ -73,6 +74,7 @@ class QLearner:
                     n *= s
                 named[name].grad = g[off:off + n].view(*shape)
         self._bits_host = None
+        self._buckets = None
         self._flat_ready = True
 
     def _check_flat(self):
@@ -141,10 +143,18 @@ class QLearner:
             bits = group_bits.to(dev).to(th.uint8).contiguous() if group_bits is not None else \
                 self._draw_partition(B, args.n_entities, dev, bernoulli=dims.gt_factors != 1)
         self._last_dims = dims
-        self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads)
-        # data parallel over episodes: ONE all-reduce(SUM) of [grads | stat sums]; the global
-        # sum(mask) normaliser is applied afterwards by the optimiser kernel (q_learner.py:165)
-        dp.allreduce_sum_(self.grads)
+        # data parallel over episodes: all-reduce(SUM) of [grads | stat sums]; the global sum(mask) normaliser is
+        # applied afterwards by the optimiser kernel (q_learner.py:165). One collective after the step, or
+        # (REFIL_DP_BUCKETS=1) the mixer bucket underneath the agent's BPTT + the agent bucket after the step.
+        if dp.world() > 1 and os.environ.get("REFIL_DP_BUCKETS") == "1":
+            if self._buckets is None:
+                self._buckets = dp.BucketedAllReduce(self.grads, self._na)
+            with self._buckets:
+                self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads)
+            self._buckets.finish()
+        else:
+            self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads)
+            dp.allreduce_sum_(self.grads)
         self._engine.clip_rmsprop(self.flat_live, self.grads, self.square_avg, self._n, args.lr, args.optim_alpha,
                                   args.optim_eps, args.weight_decay, args.grad_norm_clip)
         self._step_count += 1

@@ -55,7 +55,17 @@ def _train(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def _run(world):
+def _run(world, env=None):
+    for k, v in (env or {}).items():
+        os.environ[k] = v
+    try:
+        return _run_inner(world)
+    finally:
+        for k in (env or {}):
+            os.environ.pop(k, None)
+
+
+def _run_inner(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -67,6 +77,18 @@ def _run(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     return out
+
+
+@pytest.mark.timeout(600)
+def test_bucketed_allreduce_equals_single_allreduce():
+    """REFIL_DP_BUCKETS=1: [mixer grads | stats] all-reduced from the library's mixer-gradient hook (on the stream they
+    complete on, underneath the agent's BPTT), [agent grads] after the step -- same parameters as ONE all-reduce."""
+    ref = _run(2)
+    two = _run(2, env={"REFIL_DP_BUCKETS": "1"})
+    assert (two[0][0] == two[1][0]).all(), "replicas diverged"
+    assert (two[0][0] == ref[0][0]).all(), "bucketed all-reduce changed the result"
+    for k in ("loss", "grad_norm"):
+        assert two[0][1][k] == ref[0][1][k], k
 
 
 @pytest.mark.timeout(600)

@@ -1,25 +1,34 @@
 #!/bin/bash
-# Run ON THE GPU BOX from the repo root (gpurun -- 'bash tools/collect_profiles.sh r01'):
-#   1. default bench (JSON line with roofline + cpu_baseline)      -> gpurun_out/<tag>_bench_n1.json
-#   2. rocprofv3 --kernel-trace --stats of the same command        -> gpurun_out/<tag>_stats/
-#   2b. the same under --serial (streams serialised: bench's HIP-event durations == rocprofv3's)
-#   3. PMC passes FETCH_SIZE / WRITE_SIZE (kernel-trace only, each in its own run) -> gpurun_out/<tag>_pmc_*/
-# Copy the summaries into profiles/ afterwards (tools/pmc_summarize.py folds step 3).
-TAG=${1:-r01}
+# Run ON THE GPU BOX from the repo root (gpurun -- 'bash tools/collect_profiles.sh r02'):
+#   1. rocprofv3 --kernel-trace --stats of the default bench, overlapped and --serial      -> gpurun_out/<tag>_stats*/
+#   2. PMC passes FETCH_SIZE / WRITE_SIZE (kernel-trace only, each in its own run)          -> gpurun_out/<tag>_pmc_*/
+#   3. per-dispatch timeline of one step (serial and overlapped)                            -> gpurun_out/<tag>_timeline_*.txt
+#   4. the bench line of every BASELINE.json config (cfgT with the CPU baseline and the PMC traffic of step 2)
+# Copy the summaries into profiles/ afterwards (tools/pmc_summarize.py folds step 2).
+TAG=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-python bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err
-tail -c 600 $OUT/${TAG}_bench_n1.json
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o p -- \
-    python $ROOT/bench.py --no-cpu-baseline > $OUT/${TAG}_stats.log 2>&1
+    python $ROOT/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_n1_under_rocprofv3.json 2> $OUT/${TAG}_stats.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_serial -o p -- \
-    python $ROOT/bench.py --no-cpu-baseline --serial > $OUT/${TAG}_stats_serial.log 2>&1
+    python $ROOT/bench.py --no-cpu-baseline --serial > $OUT/${TAG}_bench_n1_serial_under_rocprofv3.json 2> $OUT/${TAG}_stats_serial.log
 for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -o p -- \
-        python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile > $OUT/${TAG}_pmc_$c.log 2>&1
+        python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --serial > $OUT/${TAG}_pmc_$c.log 2>&1
 done
 cd $ROOT
-find $OUT/${TAG}_stats $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE -name "*.csv" | head -20
+python tools/trace_step.py $(find $OUT/${TAG}_stats_serial -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_timeline_serial.txt
+python tools/trace_step.py $(find $OUT/${TAG}_stats -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_timeline_overlapped.txt
+cp $(find $OUT/${TAG}_stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_rocprofv3_kernel_stats.csv
+cp $(find $OUT/${TAG}_stats_serial -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_rocprofv3_kernel_stats_serial.csv
+python tools/pmc_summarize.py $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_traffic.json
+rm -rf $OUT/${TAG}_stats $OUT/${TAG}_stats_serial $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE
+python bench.py --traffic-json $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_bench_cfgT.json 2> $OUT/${TAG}_bench_cfgT.err
+for c in cfg2 cfg3 cfg4 cfg5; do
+    python bench.py --config $c > $OUT/${TAG}_bench_$c.json 2> $OUT/${TAG}_bench_$c.err
+done
+python bench.py --serial --no-cpu-baseline > $OUT/${TAG}_bench_cfgT_serial.json 2>/dev/null
+ls -la $OUT | grep ${TAG}_

@@ -51,15 +51,25 @@ def fold(d):
 
 def main():
     fd, wd, out = sys.argv[1:4]
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 5           # learner steps in the profiled run (2 warm-up + 3)
     F, W = fold(fd), fold(wd)
     ks = {}
+    total = 0.0
+    seen = set()
+    for f in glob.glob(os.path.join(fd, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            total += 2 * float(r["Counter_Value"]) * 1024.0
+    for f in glob.glob(os.path.join(wd, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            total += float(r["Counter_Value"]) * 1024.0
     for k in sorted(set(F) | set(W)):
         f = F[k][0] / max(F[k][1], 1)
         w = W[k][0] / max(W[k][1], 1)
         ks[k] = {"fetch_bytes_per_launch_raw": round(f), "write_bytes_per_launch_raw": round(w),
                  "hbm_bytes_per_launch": round(2 * f + w), "launches_sampled": max(F[k][1], W[k][1])}
     json.dump({"note": __doc__.strip().split("\n\n")[-1].replace("\n", " "), "command": "python bench.py --steps 3 --warmup 2 "
-               "--no-cpu-baseline --no-profile", "kernels": ks}, open(out, "w"), indent=1)
+               "--no-cpu-baseline --no-profile --serial", "steps_profiled": steps,
+               "hbm_bytes_per_step_all_kernels": round(total / steps), "kernels": ks}, open(out, "w"), indent=1)
     print(f"{len(ks)} kernels -> {out}")
 
 

@@ -11,7 +11,10 @@ if len(idx) >= 2:                       # steps with row lists: prep (masks) run
     idx = [i - 1 for i in idx]
 else:
     idx = [i for i, r in enumerate(rows) if 'prep_kernel' in r['Kernel_Name']]
-s, e = idx[-2], idx[-1]
+# which step: --step K (K-th step start of the run), default the one at 40 % of the run (inside bench.py's timed region;
+# the last steps of a bench run are its serialised profiling passes)
+k = int(sys.argv[sys.argv.index('--step') + 1]) if '--step' in sys.argv else int(0.4 * len(idx))
+s, e = idx[k], idx[k + 1]
 t0 = int(rows[s]['Start_Timestamp'])
 qs = sorted(set(r['Queue_Id'] for r in rows[s:e]))
 
