@@ -329,11 +329,33 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
     const int njobs = p.nnets * p.heads;                   // job = (net, head); a wave takes jobs wave, wave + 4, ...
     Stage<NAT * 16, 4 * NCT> sq;
     Stage<NJT * 16, 4 * NCT> sk, sv;
+    // HDX: the K and Q operands of S^T = K Q^T never touch LDS. In the v_mfma_f32_16x16x4_f32 operand layouts lane
+    // (l15, q) supplies row l15 of its tile at reduction index k = q of every step; the k order is a free permutation,
+    // so lane group q takes the CONTIGUOUS channels 4 NCT q .. 4 NCT (q+1) - 1 of "its" K row (key 16 jt + l15) and of
+    // "its" Q row (agent 16 at + l15): NCT 16-byte global loads per tile, already in operand layout.
+    float4 kf[HDX ? NJT : 1][NCT], qf[HDX ? NAT : 1][NCT];
     auto fetch = [&](int job) {
         const AttnNet& n = p.net[job / p.heads];
         const int head = job % p.heads;
-        sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * hd, hd, lane);
-        sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane);
+        if (HDX) {
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                const int key = 16 * jt + l15;
+                const float* src = n.K + ((long)r * p.ne + (key < p.ne ? key : 0)) * p.ldkv + head * hd + 4 * NCT * q;
+#pragma unroll
+                for (int u = 0; u < NCT; ++u) kf[HDX ? jt : 0][u] = *reinterpret_cast<const float4*>(src + 4 * u);
+            }
+#pragma unroll
+            for (int at = 0; at < NAT; ++at) {
+                const int ag = 16 * at + l15;
+                const float* src = n.Q + ((long)r * p.na + (ag < p.na ? ag : 0)) * p.ldq + head * hd + 4 * NCT * q;
+#pragma unroll
+                for (int u = 0; u < NCT; ++u) qf[HDX ? at : 0][u] = *reinterpret_cast<const float4*>(src + 4 * u);
+            }
+        } else {
+            sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * hd, hd, lane);
+            sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane);
+        }
         sv.load(n.V, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane);
     };
     if (wave < njobs) fetch(wave);                         // the first job's operands are in flight during the mask phase
@@ -347,8 +369,33 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
     for (int job = wave; job < njobs; job += 4) {
         const AttnNet& n = p.net[job / p.heads];
         const int head = job % p.heads;
-        sq.store(Qs, hd, pd, lane, rm.qdw); sk.store(Ks, hd, pd, lane, rm.kdw); sv.store(Vs, hd, pd, lane, rm.kdw);
-        if (job + 4 < njobs) fetch(job + 4);               // in flight while this job is computed (LDS is read, not written, below)
+        f32x4 stt[HDX ? NAT : 1][NJT];                     // HDX: all S^T tiles of the job, straight from the operand registers
+        if (HDX) {
+            sv.store(Vs, hd, pd, lane, rm.kdw);
+#pragma unroll
+            for (int at = 0; at < NAT; ++at) {
+                const int ag = 16 * at + l15;
+                const bool qz = ag >= p.na || ((rm.qdw >> ag) & 1ull);           // padded / skipped query row: zeros
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    const int key = 16 * jt + l15;
+                    const bool kz = key >= p.ne || ((rm.kdw >> key) & 1ull);     // padded / skipped key row: zeros
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < NCT; ++u) {
+                        const float4 kv = kf[HDX ? jt : 0][u], qv = qf[HDX ? at : 0][u];
+                        acc = MFMA16(kz ? 0.f : kv.x, qz ? 0.f : qv.x, acc);
+                        acc = MFMA16(kz ? 0.f : kv.y, qz ? 0.f : qv.y, acc);
+                        acc = MFMA16(kz ? 0.f : kv.z, qz ? 0.f : qv.z, acc);
+                        acc = MFMA16(kz ? 0.f : kv.w, qz ? 0.f : qv.w, acc);
+                    }
+                    stt[HDX ? at : 0][jt] = acc;
+                }
+            }
+        } else {
+            sq.store(Qs, hd, pd, lane, rm.qdw); sk.store(Ks, hd, pd, lane, rm.kdw); sv.store(Vs, hd, pd, lane, rm.kdw);
+        }
+        if (job + 4 < njobs) fetch(job + 4);               // in flight while this job is computed (operand registers / LDS are free)
         f32x4 osum[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) osum[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -357,7 +404,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
             const int agent = 16 * at + l15;
             f32x4 st0[NJT];
 #pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) st0[jt] = dot_tile(Ks, 16 * jt, Qs, 16 * at, hd, pd, l15, q);
+            for (int jt = 0; jt < NJT; ++jt) st0[jt] = HDX ? stt[HDX ? at : 0][jt] : dot_tile(Ks, 16 * jt, Qs, 16 * at, hd, pd, l15, q);
             for (int v = 0; v < n.nvar; ++v) {
                 f32x4 pt[NJT];
 #pragma unroll
