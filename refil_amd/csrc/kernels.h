@@ -61,7 +61,9 @@ struct ListArgs {
     refil_batch b;
     int B, T1, ne, na, learner;            // learner = 0: no filled/terminated (every step is live)
     int use_gt_obs;                        // dims.gt_obs_mask: the agent nets' pre-mask is gt_mask
-    const uint8_t* emc; const uint8_t* em0;   // contiguous entity masks written by prep (this step / step 0)
+    uint8_t* emc; uint8_t* em0;            // contiguous entity masks (this step / step 0): WRITTEN here (prep phase 1 is folded in)
+    uint8_t* amask; float* actf;           // [R*na] agent mask copy / 1.0 for active agents: written here as well
+    int* hint_out;                         // optional: device-visible pinned host memory [8] receiving a copy of `counts`
     int* t_last;                           // [B]
     uint8_t* kdead_a; uint8_t* kdead_h;    // [R*ne] 1 = K/V row of the agent nets / hypernets is not computed
     int* cnt;                              // [3][R] per-row counts (scratch), lists: 0 agent-net entities, 1 hypernet entities, 2 agents

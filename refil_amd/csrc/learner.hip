@@ -398,12 +398,24 @@ static int launch_dw(const Ctx& c, refil_gemm_desc g) {
 // List lengths of an earlier step, copied back asynchronously into pinned host memory (one slot per device): a HINT
 // for sizing the next steps' launch grids -- never waited for, never used for anything a result depends on.
 static thread_local int* g_hint[MAX_DEVICES] = {};
+static thread_local int* g_hint_dev[MAX_DEVICES] = {};      // the same memory as the device sees it
+static int* row_hints();
+static int* row_hints_dev() {
+    int dev = 0;
+    if (!row_hints() || hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (!g_hint_dev[dev]) {
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, g_hint[dev], 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        g_hint_dev[dev] = static_cast<int*>(d);
+    }
+    return g_hint_dev[dev];
+}
 static int* row_hints() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) { (void)hipGetLastError(); return nullptr; }
     if (!g_hint[dev]) {
         void* p = nullptr;
-        if (hipHostMalloc(&p, 8 * sizeof(int), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipHostMalloc(&p, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         memset(p, 0, 8 * sizeof(int));
         g_hint[dev] = static_cast<int*>(p);
     }
@@ -884,19 +896,30 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         if (fwd3) ct.st = sd->g[0];
         if (mwside || fwd3) { ca.mwst = ct.mwst = sd->g[0]; ch.mwst = sd->g[1]; }
     }
-    RUN(run_prep(c, 1, c.lists ? 1 : 3));                  // (with row lists: masks first, the input rows the lists keep afterwards)
-    if (c.lists) {
+    if (!c.lists) RUN(run_prep(c, 1, 3));
+    else {
+        // Row lists: four small dependent launches (their kernels also write the contiguous mask copies). The input
+        // assembly does not depend on them: it runs beside them on an idle stream (all rows: cheaper than waiting for the lists).
+        const hipStream_t ps = overlap ? sd->g[0] : c.st;
+        RUN(stream_after(sd, c.st, ps));
+        {
+            Ctx cp = c;
+            cp.st = ps; cp.lists = false;
+            RUN(run_prep(cp, 1, 2));
+        }
         ListArgs la;
         memset(&la, 0, sizeof(la));
         la.b = c.b; la.B = d.B; la.T1 = d.T1; la.ne = d.ne; la.na = d.na; la.learner = 1; la.use_gt_obs = d.gt_obs_mask;
-        la.emc = w.emc; la.em0 = w.em0; la.t_last = w.t_last; la.kdead_a = w.kdead_a; la.kdead_h = w.kdead_h;
+        la.emc = w.emc; la.em0 = w.em0; la.amask = w.amask; la.actf = w.actf;
+        la.t_last = w.t_last; la.kdead_a = w.kdead_a; la.kdead_h = w.kdead_h;
         la.cnt = w.lcnt; la.off = w.loff; la.list_ea = w.list_ea; la.list_eh = w.list_eh; la.list_a = w.list_a; la.counts = w.counts;
         la.ever = w.ever; la.list_t = w.list_t;
         la.rep[0] = ListArgs::Rep{w.list_t3, 1, s.G, (int)(s.G * s.NA)};
         la.rep[1] = ListArgs::Rep{w.list_h, 0, s.nv0, (int)(s.NV * s.NA)};
         la.rep[2] = ListArgs::Rep{w.list_ht, 0, 1, (int)(s.nets * s.NA)};
+        la.hint_out = row_hints_dev();
         RUN(lists_launch(la, c.st));
-        if (int* h = row_hints()) REFIL_HIP(hipMemcpyAsync(h, w.counts, 8 * sizeof(int), hipMemcpyDeviceToHost, c.st));
+        RUN(stream_after(sd, ps, c.st));                   // (the chains fork from c.st: they start with the inputs assembled)
     }
     if (c.mwords) {
         // mask words of every row, once per step: agent nets (observability variants) and hypernets (entity variants);
@@ -913,7 +936,6 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
             RUN(attn_mask_words_launch(a, hyper ? w.mw_h : w.mw_a, hyper ? w.rb_h : w.rb_a, ms));
         }
     }
-    if (c.lists) RUN(run_prep(c, 1, 2));
     RUN(stream_after(sd, c.st, ch.st));                    // fork: inputs assembled
     RUN(stream_after(sd, c.st, ct.st));
     if (!d.mixer_vdn) {

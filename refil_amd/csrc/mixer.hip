@@ -75,33 +75,33 @@ int prep_launch(const PrepArgs& a, hipStream_t st, int phases, const uint8_t* sk
 // ------------------------------------------------------------------------------------------------
 // row lists (ListArgs in kernels.h)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lists_tlast_kernel(ListArgs a) {           // one wave per episode
-    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= a.B) return;
-    const int T = a.T1 - 1;
-    int last = -1;
-    if (!a.learner) last = a.T1 - 1;
-    else {
-        for (int t = lane; t < T; t += 64) {
-            float m = (float)a.b.filled[b * a.b.fl_sB + t * a.b.fl_sT];
-            if (t > 0) m *= 1.0f - (float)a.b.terminated[b * a.b.tm_sB + (t - 1) * a.b.tm_sT];     // q_learner.py:71-72
-            if (m != 0.f) last = t + 1;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
-    }
-    if (lane == 0) a.t_last[b] = last;
-}
-
-__global__ __launch_bounds__(256) void lists_ever_kernel(ListArgs a) {            // one workgroup per episode: lane = agent, wave = step mod 4
+// per episode: t_last, the step-0 entity mask copy, which agents are active at some live step
+__global__ __launch_bounds__(256) void lists_episode_kernel(ListArgs a) {         // one workgroup per episode
     __shared__ int any_s[64];
+    __shared__ int tl_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x;
     if (threadIdx.x < 64) any_s[threadIdx.x] = 0;
+    if (wave == 0) {
+        const int T = a.T1 - 1;
+        int last = -1;
+        if (!a.learner) last = a.T1 - 1;
+        else {
+            for (int t = lane; t < T; t += 64) {
+                float m = (float)a.b.filled[b * a.b.fl_sB + t * a.b.fl_sT];
+                if (t > 0) m *= 1.0f - (float)a.b.terminated[b * a.b.tm_sB + (t - 1) * a.b.tm_sT];     // q_learner.py:71-72
+                if (m != 0.f) last = t + 1;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+        }
+        if (lane == 0) { a.t_last[b] = last; tl_s = last; }
+        if (lane < a.ne) a.em0[(long)b * a.ne + lane] = a.b.entity_mask[b * a.b.em_sB + lane];
+    }
     __syncthreads();
+    const int tl = tl_s;
     bool any = false;
-    const int tl = a.t_last[b];
     if (lane < a.na)
-        for (int t = wave; t <= tl; t += 4) any |= a.emc[((long)b * a.T1 + t) * a.ne + lane] == 0;
+        for (int t = wave; t <= tl; t += 4) any |= a.b.entity_mask[b * a.b.em_sB + t * a.b.em_sT + lane] == 0;
     if (any) any_s[lane] = 1;                              // (benign race: every writer stores 1)
     __syncthreads();
     if (threadIdx.x < a.na) a.ever[(long)b * a.na + threadIdx.x] = any_s[threadIdx.x] ? 1 : 0;
@@ -115,8 +115,14 @@ __global__ __launch_bounds__(256) void lists_flags_kernel(ListArgs a) {         
     const int b = r / a.T1, t = r % a.T1;
     const bool row_live = t <= a.t_last[b];
     bool ka = false, kh = false, la = false;
+    uint8_t emt = 1;
+    if (lane < a.ne) {                                     // (prep phase 1: contiguous copies of the step's masks)
+        emt = a.b.entity_mask[b * a.b.em_sB + t * a.b.em_sT + lane];
+        a.emc[r * a.ne + lane] = emt;
+        if (lane < a.na) { a.amask[r * a.na + lane] = emt; a.actf[r * a.na + lane] = emt ? 0.f : 1.f; }
+    }
     if (lane < a.ne && row_live) {
-        const uint8_t emt = a.emc[r * a.ne + lane], em0 = a.em0[(long)b * a.ne + lane];
+        const uint8_t em0 = a.em0[(long)b * a.ne + lane];
         la = lane < a.na && emt == 0;
         kh = !(emt && em0) || la;
         const uint8_t* om = a.use_gt_obs ? a.b.gt_mask + b * a.b.gt_sB + t * a.b.gt_sT : a.b.obs_mask + b * a.b.om_sB + t * a.b.om_sT;
@@ -164,6 +170,18 @@ __global__ __launch_bounds__(1024) void lists_scan_kernel(ListArgs a) {
     }
     __syncthreads();
     if (threadIdx.x == 0) a.counts[3] = live_rows;
+    // derived lists (ListArgs::rep): lengths, padding; the entries themselves are written by lists_fill_kernel
+    if (l == 2 || l == 3) {
+        for (int k = 0; k < 4; ++k) {
+            const ListArgs::Rep rp = a.rep[k];
+            if (!rp.list || rp.src != (l == 3 ? 1 : 0)) continue;
+            const int tot = total * rp.copies, pad = ((tot + 63) & ~63) + 128;
+            if (tid == 0) a.counts[4 + k] = tot;
+            if (tid < 192 && tot + tid < pad) rp.list[tot + tid] = rp.trash;
+        }
+    }
+    __syncthreads();
+    if (a.hint_out && threadIdx.x < 8) a.hint_out[threadIdx.x] = a.counts[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void lists_fill_kernel(ListArgs a) {            // one wave per (b,t) row
@@ -179,34 +197,32 @@ __global__ __launch_bounds__(256) void lists_fill_kernel(ListArgs a) {          
     const unsigned long long ba = __ballot(ka), bh = __ballot(kh), bl = __ballot(la);
     if (ka) a.list_ea[a.off[r] + __popcll(ba & below)] = (int)(r * a.ne + lane);
     if (kh) a.list_eh[a.off[(R + 1) + r] + __popcll(bh & below)] = (int)(r * a.ne + lane);
-    if (la) a.list_a[a.off[2 * (R + 1) + r] + __popcll(bl & below)] = (int)(r * a.na + lane);
+    const long NA = R * a.na;
+    if (la) {
+        const int pos = a.off[2 * (R + 1) + r] + __popcll(bl & below), total = a.off[2 * (R + 1) + R];
+        a.list_a[pos] = (int)(r * a.na + lane);
+        for (int k = 0; k < 4; ++k)                           // shifted copies (ListArgs::rep with src 0)
+            if (a.rep[k].list && a.rep[k].src == 0)
+                for (int c = 0; c < a.rep[k].copies; ++c) a.rep[k].list[c * total + pos] = (int)(r * a.na + lane + c * NA);
+    }
     const bool lt = row_live && lane < a.na && a.ever[(r / a.T1) * a.na + lane];
     const unsigned long long bt = __ballot(lt);
-    if (lt) a.list_t[a.off[3 * (R + 1) + r] + __popcll(bt & below)] = (int)(r * a.na + lane);
-}
-
-// shifted copies of an agent-row list (ListArgs::rep): grid.y = which, grid-stride over the padded length
-__global__ __launch_bounds__(256) void lists_rep_kernel(ListArgs a) {
-    const ListArgs::Rep rp = a.rep[blockIdx.y];
-    if (!rp.list) return;
-    const int n = a.counts[rp.src ? 7 : 2];
-    const int* src = rp.src ? a.list_t : a.list_a;
-    const long NA = (long)a.B * a.T1 * a.na;
-    const int total = n * rp.copies, padded = ((total + 63) & ~63) + 128;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < padded; k += gridDim.x * blockDim.x)
-        rp.list[k] = k < total ? src[k % n] + (int)((k / n) * NA) : rp.trash;
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.counts[4 + blockIdx.y] = total;
+    if (lt) {
+        const int pos = a.off[3 * (R + 1) + r] + __popcll(bt & below), total = a.off[3 * (R + 1) + R];
+        a.list_t[pos] = (int)(r * a.na + lane);
+        for (int k = 0; k < 4; ++k)
+            if (a.rep[k].list && a.rep[k].src == 1)
+                for (int c = 0; c < a.rep[k].copies; ++c) a.rep[k].list[c * total + pos] = (int)(r * a.na + lane + c * NA);
+    }
 }
 
 int lists_launch(const ListArgs& a, hipStream_t st) {
     const long R = (long)a.B * a.T1;
     ProfScope prof("lists_kernels", 0.0, 0.0, st);
-    hipLaunchKernelGGL(lists_tlast_kernel, dim3(cdiv(a.B, 4)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(lists_ever_kernel, dim3(a.B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(lists_episode_kernel, dim3(a.B), dim3(256), 0, st, a);
     hipLaunchKernelGGL(lists_flags_kernel, dim3((int)cdivl(R, 4)), dim3(256), 0, st, a);
     hipLaunchKernelGGL(lists_scan_kernel, dim3(1), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(lists_fill_kernel, dim3((int)cdivl(R, 4)), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(lists_rep_kernel, dim3(64, 4), dim3(256), 0, st, a);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
