@@ -61,6 +61,9 @@ typedef struct refil_dims {
     int32_t pooling;                 /* 0: EntityAttentionLayer; 1 / 2: EntityPoolingLayer 'mean' / 'max'
                                         (attention.py:82-132, pooling_type of default.yaml:43). The in_trans slot of
                                         the parameter layout then holds W[w,w] followed by its bias[w].      */
+    int32_t mixer_none;              /* 1: args.mixer = None (q_learner.py:19-21,131): no mixing network, the TD loss is taken
+                                        per agent on [B,T,n_agents] (mask expanded, :161). Not with imagine (the reference's
+                                        shapes do not broadcast there) */
     float gamma;
     float lmbda;
 } refil_dims;

@@ -55,6 +55,7 @@ class Cfg:
     agent_ff: bool = False         # entity_attend_ff agents (entity_ff_agent.py) instead of the recurrent ones
     mixer_lin: bool = False        # lin_flex_qmix (flex_qmix.py:124-172) instead of flex_qmix
     mixer_vdn: bool = False        # VDNMixer (modules/mixers/vdn.py:9-10): q_tot = sum of the agents' Qs, no parameters
+    mixer_none: bool = False       # args.mixer = None (q_learner.py:19-21,131): per-agent TD loss, no mixing network
     gt_obs_mask: bool = False      # entity_ff_agent.py:34-35
     pooling_type: Optional[str] = None   # 'mean' / 'max': EntityPoolingLayer instead of attention (default.yaml:43)
     train_gt_factors: bool = False       # q_learner.py:88: imagined groups = ground-truth factors (batch["gt_mask"])
@@ -109,7 +110,7 @@ def mixer_param_shapes(cfg: Cfg) -> Dict[str, Tuple[int, ...]]:
     """state_dict layout of FlexQMixer (flex_qmix.py:28-38,69-73)."""
     h, M, E = cfg.hypernet_embed, cfg.mixing_embed_dim, cfg.in_dim
     out = {}
-    if cfg.mixer_vdn:
+    if cfg.mixer_vdn or cfg.mixer_none:
         return out
     for net in (LIN_HYPERNETS if cfg.mixer_lin else HYPERNETS):
         out[f"{net}.fc1.weight"] = (h, E)
@@ -355,6 +356,9 @@ def mixer_forward(cfg: Cfg, p: Dict[str, Tensor], agent_qs: Tensor, xe: Tensor, 
     B, T, ne, E = xe.shape
     na, M = cfg.n_agents, cfg.mixing_embed_dim
     R = B * T
+    if cfg.mixer_none:                                                                     # q_learner.py:131 not taken
+        assert agent_qs_imagine is None, "mixer=None: caq_imagine [B,T,2na] does not broadcast against targets [B,T,na]"
+        return agent_qs
     if cfg.mixer_vdn:                                                                      # vdn.py:9-10
         q_tot = agent_qs.sum(dim=2, keepdim=True)
         return q_tot if agent_qs_imagine is None else (q_tot, agent_qs_imagine.sum(dim=2, keepdim=True))
@@ -452,6 +456,7 @@ def learner_forward(cfg: Cfg, agent_p, mixer_p, tgt_agent_p, tgt_mixer_p, batch:
         q_tot = mixer_forward(cfg, mixer_p, chosen[0], xe[:, :-1], batch["entity_mask"][:, :-1])
         q_tot_im = None
     targets = rewards + cfg.gamma * (1 - terminated) * tq_tot                           # :157
+    mask = mask.expand_as(q_tot)                                                        # :161 (a no-op with a mixer: [B,T,1])
     td = (q_tot - targets.detach()) * mask
     msum = mask.sum()
     q_loss = (td ** 2).sum() / msum                                                     # :160-165

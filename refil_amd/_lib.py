@@ -24,7 +24,7 @@ MASK_OBS_RGTW, MASK_OBS_RGTI, MASK_RGTW, MASK_RGTI = 10, 11, 12, 13
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "B", "T1", "ne", "na", "ed", "A", "d", "heads", "H", "hyp", "M", "entity_last_action", "imagine",
-        "softmax_mixing_weights", "mixer_tanh", "double_q", "agent_ff", "mixer_lin", "mixer_vdn", "gt_factors", "gt_obs_mask", "pooling")] + [("gamma", C.c_float), ("lmbda", C.c_float)]
+        "softmax_mixing_weights", "mixer_tanh", "double_q", "agent_ff", "mixer_lin", "mixer_vdn", "gt_factors", "gt_obs_mask", "pooling", "mixer_none")] + [("gamma", C.c_float), ("lmbda", C.c_float)]
 
 
 class ParamLayout(C.Structure):

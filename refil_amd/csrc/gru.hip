@@ -25,10 +25,9 @@
 
 namespace refil {
 
-constexpr int GH = 64;        // hidden size (rnn_hidden_dim of every shipped config)
+// Hidden size GH (rnn_hidden_dim) is a template parameter: 32, 64 (every shipped config) or 128; a workgroup has GH/16 waves.
 constexpr int GROWS = 16;     // rows per workgroup
-constexpr int HP = GH + 4;    // LDS pitch of the h tile (HP/4 odd: conflict-free 16-byte fragment reads)
-constexpr int GP = 3 * GH + 4;  // LDS pitch of the dgh tile (GP/4 odd)
+// LDS pitches: h tile GH + 4, dgh tile 3 GH + 4 (pitch/4 odd: conflict-free 16-byte fragment reads)
 
 struct GruK {
     const float* gi; float* hsx; const float* w_hh; const float* b_hh;
@@ -50,8 +49,9 @@ __device__ inline int tile_steps(const GruK& p, int r0) {
     return min(tend, p.T1);
 }
 
-template <bool SAVE>
-__global__ __launch_bounds__(256) void gru_fwd_kernel(GruK2 p2) {
+template <bool SAVE, int GH>
+__global__ __launch_bounds__(4 * GH) void gru_fwd_kernel(GruK2 p2) {
+    constexpr int HP = GH + 4, KQ = GH / 4;                // KQ: reduction indices per lane group
     __shared__ __attribute__((aligned(16))) float hbuf[2][GROWS * HP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, c16 = lane & 15;
@@ -62,14 +62,14 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruK2 p2) {
     const int tend = tile_steps(p, r0);
     const bool save = SAVE && p.save_r != nullptr;
 
-    // W_hh fragments: bw[g][s] = W_hh[g*64 + c][16q + s]. (The MFMA k order is a free permutation as long as both
-    // operands agree: giving lane group q the CONTIGUOUS k range [16q, 16q+16) turns the 16 scalar LDS reads of the
-    // h fragment into 4 ds_read_b128.)
-    float bw[3][16];
+    // W_hh fragments: bw[g][s] = W_hh[g*GH + c][KQ q + s]. (The MFMA k order is a free permutation as long as both
+    // operands agree: giving lane group q the CONTIGUOUS k range [KQ q, KQ q + KQ) turns the scalar LDS reads of the
+    // h fragment into ds_read_b128.)
+    float bw[3][KQ];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) bw[g][s] = p.w_hh[(long)(g * GH + c) * GH + 16 * q + s];
+        for (int s = 0; s < KQ; ++s) bw[g][s] = p.w_hh[(long)(g * GH + c) * GH + KQ * q + s];
     const float bhr = p.b_hh[c], bhz = p.b_hh[GH + c], bhn = p.b_hh[2 * GH + c];
 
     long gi_base[4], hs_base[4];
@@ -103,15 +103,15 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruK2 p2) {
                 for (int g = 0; g < 3; ++g)
                     gnext[reg][g] = valid[reg] ? p.gi[(gi_base[reg] + (long)(t + 1) * p.na) * (3 * GH) + g * GH + c] : 0.f;
         }
-        float a[16];
+        float a[KQ];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const float4 v = *reinterpret_cast<const float4*>(hb + c16 * HP + 16 * q + 4 * s4);
+        for (int s4 = 0; s4 < KQ / 4; ++s4) {
+            const float4 v = *reinterpret_cast<const float4*>(hb + c16 * HP + KQ * q + 4 * s4);
             a[4 * s4] = v.x; a[4 * s4 + 1] = v.y; a[4 * s4 + 2] = v.z; a[4 * s4 + 3] = v.w;
         }
         f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, an = ar;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < KQ; ++s) {
             ar = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[0][s], ar, 0, 0, 0);
             az = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[1][s], az, 0, 0, 0);
             an = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[2][s], an, 0, 0, 0);
@@ -156,7 +156,9 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruK2 p2) {
 //   dn_pre = dn (1-n^2);  dr = dn_pre ghn;  dgh_n = dn_pre r
 //   dr_pre = dr r (1-r);  dz_pre = dz z (1-z)
 //   dgi[t] = (dr_pre, dz_pre, dn_pre);  dgh[t] = (dr_pre, dz_pre, dgh_n);  carry' += dgh[t] W_hh
-__global__ __launch_bounds__(256) void gru_bwd_kernel(GruK p) {
+template <int GH>
+__global__ __launch_bounds__(4 * GH) void gru_bwd_kernel(GruK p) {
+    constexpr int GP = 3 * GH + 4, KQ = 3 * GH / 4, NW = GH / 16;
     __shared__ __attribute__((aligned(16))) float gbuf[2][GROWS * GP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, c16 = lane & 15;
@@ -164,10 +166,10 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruK p) {
     const int r0 = blockIdx.x * GROWS;
     const int tend = tile_steps(p, r0);
 
-    // W_hh^T fragments: carry[row][c] += sum_k dgh[row][k] W_hh[k][c];  bw[s] = W_hh[48q+s][c]  (contiguous k range per lane group, see the forward kernel)
-    float bw[48];
+    // W_hh^T fragments: carry[row][c] += sum_k dgh[row][k] W_hh[k][c];  bw[s] = W_hh[KQ q + s][c]  (contiguous k range per lane group, see the forward kernel)
+    float bw[KQ];
 #pragma unroll
-    for (int s = 0; s < 48; ++s) bw[s] = p.w_hh[(long)(48 * q + s) * GH + c];
+    for (int s = 0; s < KQ; ++s) bw[s] = p.w_hh[(long)(KQ * q + s) * GH + c];
 
     long gi_base[4], hs_base[4];
     bool valid[4];
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruK p) {
         }
     };
     // steps the episode's loss cannot reach (t >= tend): exact zeros, what the full recurrence would have produced
-    for (int t = tend + (tid >> 6); t < p.T1; t += 4) {
+    for (int t = tend + (tid >> 6); t < p.T1; t += NW) {
         for (int idx = lane; idx < GROWS * (3 * GH / 4); idx += 64) {
             const int row = idx / (3 * GH / 4), c4 = idx % (3 * GH / 4);
             const int rr = r0 + row;
@@ -238,10 +240,10 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruK p) {
         __syncthreads();
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
 #pragma unroll
-        for (int s = 0; s < 48; s += 12) {
-            const float4 v0 = *reinterpret_cast<const float4*>(gb_w + c16 * GP + 48 * q + s);
-            const float4 v1 = *reinterpret_cast<const float4*>(gb_w + c16 * GP + 48 * q + s + 4);
-            const float4 v2 = *reinterpret_cast<const float4*>(gb_w + c16 * GP + 48 * q + s + 8);
+        for (int s = 0; s < KQ; s += 12) {
+            const float4 v0 = *reinterpret_cast<const float4*>(gb_w + c16 * GP + KQ * q + s);
+            const float4 v1 = *reinterpret_cast<const float4*>(gb_w + c16 * GP + KQ * q + s + 4);
+            const float4 v2 = *reinterpret_cast<const float4*>(gb_w + c16 * GP + KQ * q + s + 8);
             a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0.x, bw[s], a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0.y, bw[s + 1], a1, 0, 0, 0);
             a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(v0.z, bw[s + 2], a2, 0, 0, 0);
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruK p) {
 }
 
 static int gru_check_fwd(const refil_gru_desc& d) {
-    REFIL_CHECK(d.H == GH, "refil_gru: rnn_hidden_dim must be %d (got %d)", GH, d.H);
+    REFIL_CHECK(d.H == 32 || d.H == 64 || d.H == 128, "refil_gru: rnn_hidden_dim must be 32, 64 or 128 (got %d)", d.H);
     REFIL_CHECK(d.gi && d.hsx && d.w_hh && d.b_hh, "refil_gru_forward: null pointer");
     REFIL_CHECK(d.NR > 0 && d.T1 > 0 && d.na > 0, "refil_gru_forward: bad sizes");
     REFIL_CHECK(!d.save_r || (d.save_z && d.save_n && d.save_ghn), "refil_gru_forward: all four save buffers or none");
@@ -291,7 +293,11 @@ static GruK gru_k(const refil_gru_desc& d) {
 // `second` (may be NULL): another, independent recurrence run by the same launch
 int gru_forward_launch2(const refil_gru_desc& d, const refil_gru_desc* second, hipStream_t st) {
     if (int e = gru_check_fwd(d)) return e;
-    if (second) if (int e = gru_check_fwd(*second)) return e;
+    if (second) {
+        if (int e = gru_check_fwd(*second)) return e;
+        REFIL_CHECK(second->H == d.H, "refil_gru: the two recurrences of one launch need the same hidden size");
+    }
+    const int GH = d.H;
     GruK2 k;
     k.a = gru_k(d); k.b = second ? gru_k(*second) : k.a;
     k.nblk0 = cdiv(d.NR, GROWS);
@@ -300,22 +306,27 @@ int gru_forward_launch2(const refil_gru_desc& d, const refil_gru_desc* second, h
     dim3 grid(k.nblk0 + (second ? cdiv(second->NR, GROWS) : 0));
     ProfScope prof(save ? "gru_fwd_kernel<true>" : "gru_fwd_kernel<false>", 2.0 * rows_t * GH * 3 * GH,
                    4.0 * rows_t * GH * (save ? 8.0 : 4.0), st);
-    if (save) hipLaunchKernelGGL(gru_fwd_kernel<true>, grid, dim3(256), 0, st, k);
-    else hipLaunchKernelGGL(gru_fwd_kernel<false>, grid, dim3(256), 0, st, k);
+#define GRU_FWD(HH) do { if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, HH>), grid, dim3(4 * HH), 0, st, k); \
+                        else hipLaunchKernelGGL((gru_fwd_kernel<false, HH>), grid, dim3(4 * HH), 0, st, k); } while (0)
+    if (GH == 32) GRU_FWD(32); else if (GH == 64) GRU_FWD(64); else GRU_FWD(128);
+#undef GRU_FWD
     REFIL_LAUNCH_CHECK();
     return 0;
 }
 int gru_forward_launch(const refil_gru_desc& d, hipStream_t st) { return gru_forward_launch2(d, nullptr, st); }
 
 int gru_backward_launch(const refil_gru_desc& d, hipStream_t st) {
-    REFIL_CHECK(d.H == GH, "refil_gru: rnn_hidden_dim must be %d (got %d)", GH, d.H);
+    REFIL_CHECK(d.H == 32 || d.H == 64 || d.H == 128, "refil_gru: rnn_hidden_dim must be 32, 64 or 128 (got %d)", d.H);
+    const int GH = d.H;
     REFIL_CHECK(d.hsx && d.w_hh && d.save_r && d.save_z && d.save_n && d.save_ghn && d.dhs && d.dgi && d.dgh,
                 "refil_gru_backward: null pointer");
     REFIL_CHECK(d.NR > 0 && d.T1 > 0 && d.na > 0, "refil_gru_backward: bad sizes");
     REFIL_CHECK(!d.t_last || d.B > 0, "refil_gru: t_last needs B");
     GruK k = gru_k(d);
     ProfScope prof("gru_bwd_kernel", 2.0 * d.NR * d.T1 * GH * 3 * GH, 4.0 * d.NR * d.T1 * GH * 12.0, st);
-    hipLaunchKernelGGL(gru_bwd_kernel, dim3(cdiv(d.NR, GROWS)), dim3(256), 0, st, k);
+    if (GH == 32) hipLaunchKernelGGL(gru_bwd_kernel<32>, dim3(cdiv(d.NR, GROWS)), dim3(128), 0, st, k);
+    else if (GH == 64) hipLaunchKernelGGL(gru_bwd_kernel<64>, dim3(cdiv(d.NR, GROWS)), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL(gru_bwd_kernel<128>, dim3(cdiv(d.NR, GROWS)), dim3(512), 0, st, k);
     REFIL_LAUNCH_CHECK();
     return 0;
 }

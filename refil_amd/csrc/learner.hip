@@ -38,10 +38,12 @@ static int check_dims(const refil_dims& d) {
     REFIL_CHECK(d.ed > 0 && d.A > 0, "refil: entity_shape and n_actions must be > 0");
     REFIL_CHECK(d.heads > 0 && d.d % d.heads == 0 && d.hyp % d.heads == 0, "refil: embed dims must be divisible by attn_n_heads");
     REFIL_CHECK((d.d / d.heads) % 4 == 0 && (d.hyp / d.heads) % 4 == 0, "refil: head dim must be a multiple of 4");
-    REFIL_CHECK(d.agent_ff || d.H == 64, "refil: rnn_hidden_dim must be 64 (got %d)", d.H);
+    REFIL_CHECK(d.agent_ff || d.H == 32 || d.H == 64 || d.H == 128, "refil: rnn_hidden_dim must be 32, 64 or 128 (got %d)", d.H);
     REFIL_CHECK(!d.mixer_lin || 2 * d.na <= 64, "refil: LinearFlexQMixer supports n_agents <= 32");
     REFIL_CHECK(d.M >= 1 && d.M <= 64, "refil: mixing_embed_dim must be in [1,64]");
     REFIL_CHECK(d.pooling >= 0 && d.pooling <= 2, "refil: pooling must be 0 (attention), 1 (mean) or 2 (max)");
+    REFIL_CHECK(!d.mixer_none || !d.imagine, "refil: mixer=None cannot train an imagine agent (caq_imagine [B,T,2*n_agents] vs targets [B,T,n_agents], q_learner.py:96,169)");
+    REFIL_CHECK(!d.mixer_none || (!d.mixer_lin && !d.mixer_vdn), "refil: mixer_none excludes mixer_lin / mixer_vdn");
     return 0;
 }
 
@@ -67,7 +69,7 @@ static void param_layout(const refil_dims& d, refil_param_layout& L) {
         L.ag_fc3_w = take(A * H); L.ag_fc3_b = take(A);
     }
     L.agent_total = o;
-    const long nn = d.mixer_vdn ? 0 : (d.mixer_lin ? 2 : 4);       // hypernets: none (VDN), (hyper_w_1, V) or (hyper_w_1, hyper_w_final, hyper_b_1, V)
+    const long nn = (d.mixer_vdn || d.mixer_none) ? 0 : (d.mixer_lin ? 2 : 4);       // hypernets: none (VDN), (hyper_w_1, V) or (hyper_w_1, hyper_w_final, hyper_b_1, V)
     L.mix_fc1_w_stride = h * E; L.mix_fc1_w = take(nn * h * E);
     L.mix_fc1_b_stride = h; L.mix_fc1_b = take(nn * h);
     L.mix_in_w_stride = 3 * h * h; L.mix_in_w = take(nn * 3 * h * h);
@@ -132,7 +134,7 @@ struct Sizes {
 static Sizes sizes_of(const refil_dims& d) {
     Sizes s;
     s.R = (long)d.B * d.T1; s.NE = s.R * d.ne; s.NA = s.R * d.na;
-    s.G = d.imagine ? 3 : 1; s.nv0 = s.G; s.nets = d.mixer_vdn ? 0 : (d.mixer_lin ? 2 : 4); s.NV = s.nets ? s.nv0 + s.nets - 1 : 0;
+    s.G = d.imagine ? 3 : 1; s.nv0 = s.G; s.nets = (d.mixer_vdn || d.mixer_none) ? 0 : (d.mixer_lin ? 2 : 4); s.NV = s.nets ? s.nv0 + s.nets - 1 : 0;
     s.E = in_dim(d); s.Ep = (int)rup(s.E, 4);
     s.NEa = s.NE + 8; s.NAa = s.NA + 8;
     return s;
@@ -190,7 +192,7 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     w.chosen = a.take<float>((long)s.G * BT * d.na);
     w.tmax = a.take<float>(BT * d.na);
     w.q_tot = a.take<float>(BT); w.q_tot_im = a.take<float>(BT); w.tq_tot = a.take<float>(BT);
-    w.gc_real = a.take<float>(BT); w.gc_im = a.take<float>(BT); w.targets = a.take<float>(BT); w.ingroup = a.take<float>(BT);
+    w.gc_real = a.take<float>(BT); w.gc_im = a.take<float>(BT); w.targets = a.take<float>(BT * (d.mixer_none ? d.na : 1)); w.ingroup = a.take<float>(BT);
     w.dx3h = a.take<float>(((long)s.NV * s.NA + 8) * d.M);
     w.dchosen = a.take<float>((long)s.G * BT * d.na);
     w.dx2h = a.take<float>((long)s.NV * s.NA * d.hyp);
@@ -795,7 +797,7 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
     param_layout(c.d, c.L);
     const char* pe = getenv("REFIL_PRESUM");          // read per call: tests compare both paths in one process
     const bool presum_on = !(pe && pe[0] == '0');
-    c.presum = presum_on && !dims->mixer_lin && !dims->mixer_vdn && !dims->pooling &&
+    c.presum = presum_on && !dims->mixer_lin && !dims->mixer_vdn && !dims->mixer_none && !dims->pooling &&
                attn_mfma_supported(dims->ne, dims->na, dims->hyp / dims->heads);
     c.compose_agent = presum_on && !dims->agent_ff && !dims->pooling && attn_mfma_supported(dims->ne, dims->na, dims->d / dims->heads);
     {
@@ -805,10 +807,10 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
         // every listed GEMM must take the weight-resident / streaming-dW kernels (gemm_wres_eligible): whole 32-column
         // tiles, reductions <= 128 (<= 256 through the ReLU), 16-byte aligned rows, enough rows for a split reduction
         const bool shapes = E % 4 == 0 && E <= 128 && d.d % 32 == 0 && d.d <= 128 && d.hyp % 32 == 0 && d.hyp <= 128 &&
-                            c.s.NE >= 2048 && c.s.NA >= 512;
+                            d.H == 64 && c.s.NE >= 2048 && c.s.NA >= 512;     // (rnn_hidden_dim 32 / 128: dense schedule)
         c.lists = mode == CARVE_LEARNER && !(de && de[0] == '1') && shapes && c.presum && c.compose_agent;
         const char* me = getenv("REFIL_MASKWORDS");
-        c.mwords = mode == CARVE_LEARNER && !(me && me[0] == '0') && !d.pooling && !d.mixer_vdn &&
+        c.mwords = mode == CARVE_LEARNER && !(me && me[0] == '0') && !d.pooling && !d.mixer_vdn && !d.mixer_none &&
                    attn_mfma_supported(d.ne, d.na, d.d / d.heads) && attn_mfma_supported(d.ne, d.na, d.hyp / d.heads);
     }
     REFIL_CHECK(batch->entities && batch->entity_mask, "refil: batch.entities / entity_mask missing");
@@ -938,7 +940,8 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     }
     RUN(stream_after(sd, c.st, ch.st));                    // fork: inputs assembled
     RUN(stream_after(sd, c.st, ct.st));
-    if (!d.mixer_vdn) {
+    const bool hypernets = !d.mixer_vdn && !d.mixer_none;
+    if (hypernets) {
         RUN(hyper_forward(ch, params_live, w.lh, nv0));                           // live mixer hypernets
         RUN(hyper_forward(ch, params_target, w.th, 1));                           // target mixer hypernets
     }
@@ -971,17 +974,23 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     MixArgs ml = mix_args(c, w.lh, nv0, w.chosen, G, 0, T);
     ml.q_tot = w.q_tot; ml.q_tot_im = w.q_tot_im;
     ml.ingroup_rows = (d.mixer_lin && d.imagine) ? w.ingroup : nullptr;
-    RUN(mix_forward_launch(ml, c.st));                                            // :134-152
     MixArgs mt = mix_args(c, w.th, 1, w.tmax, 1, 1, T);
     mt.q_tot = w.tq_tot; mt.q_tot_im = nullptr;
-    RUN(mix_forward_launch(mt, c.st));                                            // :154
+    if (!d.mixer_none) {
+        RUN(mix_forward_launch(ml, c.st));                                        // :134-152
+        RUN(mix_forward_launch(mt, c.st));                                        // :154
+    }
     {
         TdArgs t;
         t.q_tot = w.q_tot; t.q_tot_im = w.q_tot_im; t.tq_tot = w.tq_tot;
+        t.nq = 1;
+        if (d.mixer_none) {     // :131 `if self.mixer is not None` not taken: the per-agent values enter the loss directly
+            t.q_tot = w.chosen; t.q_tot_im = nullptr; t.tq_tot = w.tmax; t.nq = d.na;
+        }
         t.reward = c.b.reward; t.rw_sB = c.b.rw_sB; t.rw_sT = c.b.rw_sT;
         t.terminated = c.b.terminated; t.tm_sB = c.b.tm_sB; t.tm_sT = c.b.tm_sT;
         t.filled = c.b.filled; t.fl_sB = c.b.fl_sB; t.fl_sT = c.b.fl_sT;
-        t.gc_real = w.gc_real; t.gc_im = w.gc_im; t.targets = w.targets; t.stats = stats;
+        t.gc_real = d.mixer_none ? w.dchosen : w.gc_real; t.gc_im = w.gc_im; t.targets = w.targets; t.stats = stats;
         t.t_last = c.lists ? w.t_last : nullptr;
         t.ingroup_rows = ml.ingroup_rows;
         t.B = d.B; t.T = T; t.imagine = d.imagine; t.gamma = d.gamma; t.lmbda = d.lmbda;
@@ -991,10 +1000,12 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         RUN(copy_out(debug->q, w.la.qv, (long)G * s.NA * d.A, c.st));
         RUN(copy_out(debug->chosen_q, w.chosen, (long)G * BT * d.na, c.st));
         RUN(copy_out(debug->target_max_q, w.tmax, BT * d.na, c.st));
-        RUN(copy_out(debug->q_tot, w.q_tot, BT, c.st));
-        if (d.imagine) RUN(copy_out(debug->q_tot_imagine, w.q_tot_im, BT, c.st));
-        RUN(copy_out(debug->target_q_tot, w.tq_tot, BT, c.st));
-        RUN(copy_out(debug->targets, w.targets, BT, c.st));
+        if (!d.mixer_none) {          // (mixer=None: chosen_q / target_max_q ARE the values the loss is taken on)
+            RUN(copy_out(debug->q_tot, w.q_tot, BT, c.st));
+            if (d.imagine) RUN(copy_out(debug->q_tot_imagine, w.q_tot_im, BT, c.st));
+            RUN(copy_out(debug->target_q_tot, w.tq_tot, BT, c.st));
+            RUN(copy_out(debug->targets, w.targets, BT, c.st));
+        }
     }
 
     // ---------------- backward (q_learner.py:176, hand-scheduled) ----------------
@@ -1010,13 +1021,13 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         ml.dx_v = w.dx3h + (long)(nv0 + 2) * s.NA * M;
     }
     ml.dqs = w.dchosen;
-    RUN(mix_backward_launch(ml, c.st));
+    if (!d.mixer_none) RUN(mix_backward_launch(ml, c.st));
     if (overlap) {                                                                 // fork: agent backward chain
         REFIL_HIP(hipEventRecord(sd->ev[2], c.st));
         REFIL_HIP(hipStreamWaitEvent(sd->s, sd->ev[2], 0));
     }
     // (the hypernet chain -- the critical path -- is enqueued first, on the side stream)
-    if (!d.mixer_vdn) {
+    if (hypernets) {
     if (c.presum) {
         // composed tails (x3 = mask(a W_c^T + b_c)): G_c = g3^T a, g_c = colsum(g3) (weighted by n_act on the summed rows),
         // d(attention output) = g3 W_c straight into daoh; compose_backward turns (G_c, g_c) into the four parameter gradients
@@ -1251,6 +1262,7 @@ extern "C" int refil_mixer_forward(const refil_dims* dims, const refil_batch* ba
                                    size_t workspace_bytes_, void* stream) {
     Ctx c;
     if (int e = make_ctx(c, dims, batch, workspace, workspace_bytes_, CARVE_MIXER_FWD, stream)) return e;
+    REFIL_CHECK(!dims->mixer_none, "refil_mixer_forward: dims.mixer_none has no mixing network");
     REFIL_CHECK((params || dims->mixer_vdn) && agent_qs && q_tot, "refil_mixer_forward: null pointer");
     REFIL_CHECK(t0 >= 0 && T > 0 && t0 + T <= dims->T1, "refil_mixer_forward: step range [%d,%d) outside the batch", t0, t0 + T);
     const bool im = agent_qs_imagine != nullptr;

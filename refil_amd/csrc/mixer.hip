@@ -662,9 +662,11 @@ int mix_backward_launch(const MixArgs& a, hipStream_t st) {
 __global__ __launch_bounds__(1024) void td_loss_kernel(TdArgs a) {
     __shared__ float red[7][16];
     float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int total = a.B * a.T;
+    const int nq = a.nq > 1 ? a.nq : 1;
+    const int total = a.B * a.T * nq;
     for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-        const int b = idx / a.T, t = idx % a.T;
+        const int bt = idx / nq;
+        const int b = bt / a.T, t = bt % a.T;
         float mask = (float)a.filled[b * a.fl_sB + t * a.fl_sT];
         if (t > 0) mask *= 1.0f - (float)a.terminated[b * a.tm_sB + (t - 1) * a.tm_sT];
         const float term = (float)a.terminated[b * a.tm_sB + t * a.tm_sT];
@@ -684,7 +686,7 @@ __global__ __launch_bounds__(1024) void td_loss_kernel(TdArgs a) {
             s[2] += tdi * tdi;
         }
         if (a.targets) a.targets[idx] = target;
-        if (a.ingroup_rows) s[6] += a.ingroup_rows[idx];
+        if (a.ingroup_rows) s[6] += a.ingroup_rows[idx];       // (only with a mixing network: nq == 1)
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll

@@ -24,6 +24,7 @@ def dims_from_args(args, B: int, T1: int) -> Dims:
         agent_ff=int(args.agent.endswith("_ff")), mixer_lin=int(getattr(args, "mixer", None) == "lin_flex_qmix"),
         mixer_vdn=int(getattr(args, "mixer", None) == "vdn"), gt_factors=0, gt_obs_mask=int(bool(getattr(args, "gt_obs_mask", False))),
         pooling={None: 0, "mean": 1, "max": 2}[getattr(args, "pooling_type", None)],
+        mixer_none=int(getattr(args, "mixer", None) is None),
         gamma=float(args.gamma), lmbda=float(getattr(args, "lmbda", 0.0)))
 
 

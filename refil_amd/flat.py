@@ -68,7 +68,7 @@ def views(flat: torch.Tensor, dims: _lib.Dims) -> Tuple[Dict[str, torch.Tensor],
             put(agent, "attn.in_trans.bias", L.ag_in_w + c["d"] * c["d"], (c["d"],))
             continue
         put(agent, key, getattr(L, fld), shp(c))
-    for ni, net in enumerate(() if dims.mixer_vdn else (LIN_HYPERNETS if dims.mixer_lin else HYPERNETS)):
+    for ni, net in enumerate(() if (dims.mixer_vdn or dims.mixer_none) else (LIN_HYPERNETS if dims.mixer_lin else HYPERNETS)):
         for key, fld, shp in _MIXER:
             o = getattr(L, fld) + ni * getattr(L, fld + "_stride")
             if key == "attn.in_trans.weight" and dims.pooling:

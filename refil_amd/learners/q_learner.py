@@ -34,10 +34,13 @@ class QLearner:
                 raise NotImplementedError(f"mixer {args.mixer} is outside the REFIL hot path built so far (SURVEY.md 8f4)")
             else:
                 raise ValueError("Mixer {} not recognised.".format(args.mixer))
-        else:
-            raise NotImplementedError("mixer-less learning is outside the REFIL hot path")
-        self.params = list(mac.parameters()) + list(self.mixer.parameters())      # q_learner.py:16,34 order
-        self.target_mixer = copy.deepcopy(self.mixer)
+        # args.mixer = None (q_learner.py:19-21): no mixing network, `learner.mixer is None` like the reference. The flat
+        # parameter buffer then has an empty mixer section, carried by a parameter-less holder.
+        self._mix = self.mixer if self.mixer is not None else VDNMixer()
+        self.params = list(mac.parameters()) + list(self._mix.parameters())       # q_learner.py:16,34 order
+        if self.mixer is not None:
+            self.target_mixer = copy.deepcopy(self.mixer)
+        self._tmix = self.target_mixer if self.mixer is not None else VDNMixer()
         self.target_mac = copy.deepcopy(mac)
         self.log_stats_t = -self.args.learner_log_interval - 1
         self._step_count = 0
@@ -60,13 +63,13 @@ class QLearner:
         self.square_avg = th.zeros(self._n, dtype=th.float32, device=dev)
         self.grads = th.zeros(self._n + _lib.REFIL_NSTAT, dtype=th.float32, device=dev)
         self.mac.agent.adopt(self.flat_live[:self._na])
-        self.mixer.adopt(self.flat_live[self._na:])
+        self._mix.adopt(self.flat_live[self._na:])
         self.target_mac.agent.adopt(self.flat_target[:self._na])
-        self.target_mixer.adopt(self.flat_target[self._na:])
-        self.params = list(self.mac.parameters()) + list(self.mixer.parameters())
+        self._tmix.adopt(self.flat_target[self._na:])
+        self.params = list(self.mac.parameters()) + list(self._mix.parameters())
         g_agent = self.grads[:self._na]
         g_mixer = self.grads[self._na:self._n]
-        for mod, g in ((self.mac.agent, g_agent), (self.mixer, g_mixer)):      # expose .grad as views of the flat grads
+        for mod, g in ((self.mac.agent, g_agent), (self._mix, g_mixer)):      # expose .grad as views of the flat grads
             named = dict(mod.named_parameters())
             for name, off, shape in mod._fields():
                 n = 1
@@ -81,8 +84,8 @@ class QLearner:
         if not self._flat_ready:
             self._setup_flat()
             return
-        for mod, st in ((self.mac.agent, self.flat_live[:self._na]), (self.mixer, self.flat_live[self._na:]),
-                        (self.target_mac.agent, self.flat_target[:self._na]), (self.target_mixer, self.flat_target[self._na:])):
+        for mod, st in ((self.mac.agent, self.flat_live[:self._na]), (self._mix, self.flat_live[self._na:]),
+                        (self.target_mac.agent, self.flat_target[:self._na]), (self._tmix, self.flat_target[self._na:])):
             if getattr(mod, "_flat", None) is None or mod._flat.data_ptr() != st.data_ptr() or not mod._is_flat():
                 mod.adopt(st)
 
@@ -208,8 +211,9 @@ class QLearner:
     def cuda(self):
         self.mac.cuda()
         self.target_mac.cuda()
-        self.mixer.cuda()
-        self.target_mixer.cuda()
+        if self.mixer is not None:                      # q_learner.py:212-214
+            self.mixer.cuda()
+            self.target_mixer.cuda()
         self._flat_ready = False
 
     # -- checkpoints in the reference's format (agent.th / mixer.th / opt.th) -------------------
@@ -217,7 +221,7 @@ class QLearner:
         self._check_flat()
         state = {}
         idx = 0
-        for mod, base in ((self.mac.agent, 0), (self.mixer, self._na)):
+        for mod, base in ((self.mac.agent, 0), (self._mix, self._na)):
             offs = {name: (off, shape) for name, off, shape in mod._fields()}
             for name, _ in mod.named_parameters():
                 off, shape = offs[name]
@@ -234,7 +238,7 @@ class QLearner:
     def _load_opt_state_dict(self, sd):
         self._check_flat()
         idx = 0
-        for mod, base in ((self.mac.agent, 0), (self.mixer, self._na)):
+        for mod, base in ((self.mac.agent, 0), (self._mix, self._na)):
             offs = {name: (off, shape) for name, off, shape in mod._fields()}
             for name, _ in mod.named_parameters():
                 off, shape = offs[name]
@@ -250,12 +254,14 @@ class QLearner:
 
     def save_models(self, path):
         self.mac.save_models(path)
-        th.save(self.mixer.state_dict(), "{}/mixer.th".format(path))
+        if self.mixer is not None:                      # q_learner.py:218-219
+            th.save(self.mixer.state_dict(), "{}/mixer.th".format(path))
         th.save(self._opt_state_dict(), "{}/opt.th".format(path))
 
     def load_models(self, path, evaluate=False):
         self.mac.load_models(path)
         self.target_mac.load_models(path)       # like the reference: targets are not checkpointed (:224-225)
         if not evaluate:
-            self.mixer.load_state_dict(th.load("{}/mixer.th".format(path), map_location=lambda storage, loc: storage))
+            if self.mixer is not None:                  # q_learner.py:226-227
+                self.mixer.load_state_dict(th.load("{}/mixer.th".format(path), map_location=lambda storage, loc: storage))
             self._load_opt_state_dict(th.load("{}/opt.th".format(path), map_location=lambda storage, loc: storage))

@@ -9,7 +9,7 @@ from oracle import refil_oracle as orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["refil_tiny", "qmix_atten_tiny", "refil_abs_masked", "refil_odd", "refil_mid", "refil_vdn_tiny",
-         "refil_tanh", "refil_tanh_abs", "refil_d128"]
+         "refil_tanh", "refil_tanh_abs", "refil_d128", "refil_rnn32", "refil_rnn128"]
 TRAJ_CASES = ["refil_traj5"]      # consecutive train() calls: RMSprop state, weight decay, target syncs, checkpoint
 POOL_CASES = ["refil_pool_mean", "refil_pool_max"]     # pooling_type = mean / max (EntityPoolingLayer)
 GM_CASES = ["gm_refil_ff_lin"]       # BASELINE.json configs[0]: group_matching + FF agent + lin_flex_qmix
@@ -27,6 +27,7 @@ def cfg_of(case):
         double_q=case.get("double_q", True), lmbda=case.get("lmbda", 0.5),
         grad_norm_clip=case.get("grad_norm_clip", 10),
         agent_ff=case.get("kind") == "gm", mixer_lin=case.get("kind") == "gm", mixer_vdn=case.get("mixer") == "vdn",
+        mixer_none="mixer" in case and case["mixer"] is None,
         pooling_type=case.get("pooling_type"),
         train_gt_factors=bool(case.get("train_gt_factors", False)),
         train_rand_gt_factors=bool(case.get("train_rand_gt_factors", False)),

@@ -20,7 +20,8 @@ def make_args(cfg, imagine=None, **over):
     kind = "ff" if cfg.agent_ff else "rnn"
     a = types.SimpleNamespace(
         agent=("imagine_entity_attend_" if imagine else "entity_attend_") + kind,
-        mac="entity_mac", learner="q_learner", mixer="vdn" if cfg.mixer_vdn else ("lin_flex_qmix" if cfg.mixer_lin else "flex_qmix"), agent_output_type="q",
+        mac="entity_mac", learner="q_learner", mixer=None if cfg.mixer_none else ("vdn" if cfg.mixer_vdn else ("lin_flex_qmix" if cfg.mixer_lin else "flex_qmix")),
+        agent_output_type="q",
         train_gt_factors=False, train_rand_gt_factors=False, test_gt_factors=False, gt_obs_mask=cfg.gt_obs_mask,
         action_selector="epsilon_greedy", epsilon_start=1.0, epsilon_finish=0.05, epsilon_anneal_time=500000,
         n_agents=cfg.n_agents, n_actions=cfg.n_actions, n_entities=cfg.n_entities, entity_shape=cfg.entity_shape,

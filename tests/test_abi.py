@@ -67,7 +67,7 @@ def test_param_layout_counts(L):
 
 def test_bad_dims_are_rejected_with_message(L):
     from refil_amd import _lib
-    d = _lib.make_dims(B=1, T1=2, ne=32, na=16, ed=62, A=22, d=128, heads=4, H=32, hyp=128, M=32)
+    d = _lib.make_dims(B=1, T1=2, ne=32, na=16, ed=62, A=22, d=128, heads=4, H=48, hyp=128, M=32)
     out = _lib.ParamLayout()
     rc = L.refil_get_param_layout(C.byref(d), C.byref(out))
     assert rc != 0 and b"rnn_hidden_dim" in L.refil_last_error()

@@ -320,12 +320,12 @@ def test_pool_forward_backward(mode, B, T1, ne, na, w, codes):
 # ------------------------------------------------------------------------------------------------
 # persistent GRU
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("GB,T1,na", [(6, 9, 16), (5, 4, 3), (2, 1, 8), (3, 21, 5)])
-def test_gru_forward_backward(GB, T1, na):
+@pytest.mark.parametrize("GB,T1,na,H", [(6, 9, 16, 64), (5, 4, 3, 64), (2, 1, 8, 64), (3, 21, 5, 64),
+                                        (5, 6, 7, 32), (2, 1, 8, 32), (4, 7, 6, 128), (3, 5, 16, 128)])
+def test_gru_forward_backward(GB, T1, na, H):
     import hip_ops
     from oracle.refil_oracle import gru_cell
     torch.manual_seed(GB * 7 + T1)
-    H = 64
     NR = GB * na
     w_ih = (torch.randn(3 * H, H) / 8).requires_grad_(True)
     w_hh = (torch.randn(3 * H, H) / 8).requires_grad_(True)
@@ -347,12 +347,12 @@ def test_gru_forward_backward(GB, T1, na):
     hsx[:, 0] = h0.to(DEV)
     saves = [torch.full((GB * T1 * na, H), float("nan"), device=DEV) for _ in range(4)]
     whh, bhh = w_hh.detach().to(DEV), b_hh.detach().to(DEV)
-    d = hip_ops.gru_desc(gi, hsx, whh, bhh, NR, T1, na, saves=saves)
+    d = hip_ops.gru_desc(gi, hsx, whh, bhh, NR, T1, na, H=H, saves=saves)
     hip_ops.gru_forward(d)
     _close(hsx[:, 1:], hs, what="gru hs")
     dgi = torch.full((GB * T1 * na, 3 * H), float("nan"), device=DEV)
     dgh = torch.full((GB * T1 * na, 3 * H), float("nan"), device=DEV)
-    d = hip_ops.gru_desc(gi, hsx, whh, bhh, NR, T1, na, saves=saves, dhs=dhs.to(DEV), dgi=dgi, dgh=dgh)
+    d = hip_ops.gru_desc(gi, hsx, whh, bhh, NR, T1, na, H=H, saves=saves, dhs=dhs.to(DEV), dgi=dgi, dgh=dgh)
     hip_ops.gru_backward(d)
     dgi_c, dgh_c = dgi.cpu(), dgh.cpu()
     _close(dgi_c.sum(0), b_ih.grad, tol=1e-4, what="db_ih")
@@ -364,7 +364,7 @@ def test_gru_forward_backward(GB, T1, na):
     # inference variant (no saves) gives the same hidden states
     hsx2 = torch.zeros_like(hsx)
     hsx2[:, 0] = h0.to(DEV)
-    hip_ops.gru_forward(hip_ops.gru_desc(gi, hsx2, whh, bhh, NR, T1, na))
+    hip_ops.gru_forward(hip_ops.gru_desc(gi, hsx2, whh, bhh, NR, T1, na, H=H))
     assert torch.equal(hsx2[:, 1:], hsx[:, 1:])
 
 
@@ -530,7 +530,7 @@ def test_gru_time_bounds():
     for skip in (False, True):
         hsx = torch.full((GB, T1 + 1, na, H), 9.0, device=DEV); hsx[:, 0] = h0
         saves = [torch.full((GB * T1 * na, H), 9.0, device=DEV) for _ in range(4)]
-        d = hip_ops.gru_desc(gi, hsx, whh, bhh, NR, T1, na, saves=saves)
+        d = hip_ops.gru_desc(gi, hsx, whh, bhh, NR, T1, na, H=H, saves=saves)
         if skip:
             hip_ops.gru_skip(d, t_last.to(DEV), B)
         hip_ops.gru_forward(d)

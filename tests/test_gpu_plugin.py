@@ -33,7 +33,7 @@ def _build(name, **over):
 
 
 @pytest.mark.parametrize("name", ["refil_tiny", "qmix_atten_tiny", "refil_abs_masked", "refil_odd", "refil_vdn_tiny",
-                                  "refil_pool_mean", "refil_pool_max"])
+                                  "refil_pool_mean", "refil_pool_max", "refil_rnn32", "refil_rnn128"])
 def test_qlearner_train_matches_reference(name):
     g, args, batch, mac, learner, logger = _build(name)
     z, case = g["z"], g["case"]
@@ -217,6 +217,45 @@ def test_reference_written_checkpoint_loads_and_continues(tmp_path):
     for k in ("loss", "grad_norm"):
         assert abs(logger.stats[k] - g["stats"][ck][k]) < 2e-4 * abs(g["stats"][ck][k]), k
     _assert_state(g0, ck + 1, mac, learner, 5e-6)
+
+
+def test_qlearner_without_mixer(tmp_path):
+    """args.mixer = None (q_learner.py:19-21): `learner.mixer is None`, cuda() / save_models() / load_models() skip the mixer
+    like the reference's guards (:212-214,218-219,226-227); train() takes the TD loss per agent, as the code below :131 does
+    when no mixer is configured (mask expanded to [B,T,n_agents], :161). The reference's own train() raises at :81
+    (`self.mixer.train()`), so this mode is pinned by the oracle restatement only."""
+    import dataclasses
+    from refil_amd.controllers import REGISTRY as mac_REGISTRY
+    from refil_amd.learners import REGISTRY as le_REGISTRY
+    g = load("qmix_atten_tiny")
+    cfg = dataclasses.replace(g["cfg"], mixer_none=True)
+    args = make_args(cfg)
+    assert args.mixer is None
+    batch, groups = make_episode_batch(cfg, g["batch"])
+    mac = mac_REGISTRY[args.mac](batch.scheme, groups, args)
+    logger = RecLogger()
+    learner = le_REGISTRY[args.learner](mac, batch.scheme, logger, args)
+    learner.cuda()
+    batch.to("cuda")
+    assert learner.mixer is None and not hasattr(learner, "target_mixer")
+    z = g["z"]
+    agent = {k[len("agent0."):]: th.from_numpy(z[k]) for k in z.files if k.startswith("agent0.")}
+    tagent = {k[len("tagent."):]: th.from_numpy(z[k]) for k in z.files if k.startswith("tagent.")}
+    mac.agent.load_state_dict(agent)
+    learner.target_mac.agent.load_state_dict(tagent)
+    learner.train(batch, t_env=0, episode_num=0)
+    th.cuda.synchronize()
+    a2 = {k: v.clone() for k, v in agent.items()}
+    out, grads, gnorm = orc.train_step(cfg, a2, {}, tagent, {}, g["batch"], None)
+    assert abs(logger.stats["loss"] - out.loss.item()) < 2e-4 * out.loss.item()
+    assert abs(logger.stats["grad_norm"] - gnorm) < 2e-4 * gnorm
+    for k in ("td_error_abs", "q_taken_mean", "target_mean"):
+        assert abs(logger.stats[k] - out.stats[k]) < 2e-4 * max(abs(out.stats[k]), 1e-3), k
+    for k, v in mac.agent.state_dict().items():
+        assert (v.cpu() - a2[k]).abs().max().item() < 5e-6, k
+    learner.save_models(str(tmp_path))
+    assert sorted(os.listdir(tmp_path)) == ["agent.th", "opt.th"]        # no mixer.th (q_learner.py:218-219)
+    learner.load_models(str(tmp_path))
 
 
 def test_target_update_copies_flat_buffer():

@@ -102,8 +102,9 @@ def run_case(name, case, out_dir):
     logger = _Logger()
     learner = le_REGISTRY[args.learner](mac, batch.scheme, logger, args)
     # make the target nets differ from the live nets so the target path is really exercised
+    has_mixer = learner.mixer is not None          # args.mixer = None: q_learner.py:19-21
     with th.no_grad():
-        for p in list(learner.target_mac.parameters()) + list(learner.target_mixer.parameters()):
+        for p in list(learner.target_mac.parameters()) + (list(learner.target_mixer.parameters()) if has_mixer else []):
             p.add_(0.05 * th.randn_like(p))
 
     rec = {}
@@ -111,18 +112,20 @@ def run_case(name, case, out_dir):
         rec["in." + k] = v.numpy()
     for k, v in mac.agent.state_dict().items():
         rec["agent0." + k] = v.numpy().copy()
-    for k, v in learner.mixer.state_dict().items():
-        rec["mixer0." + k] = v.numpy().copy()
     for k, v in learner.target_mac.agent.state_dict().items():
         rec["tagent." + k] = v.numpy().copy()
-    for k, v in learner.target_mixer.state_dict().items():
-        rec["tmixer." + k] = v.numpy().copy()
+    if has_mixer:
+        for k, v in learner.mixer.state_dict().items():
+            rec["mixer0." + k] = v.numpy().copy()
+        for k, v in learner.target_mixer.state_dict().items():
+            rec["tmixer." + k] = v.numpy().copy()
 
     cap = {"mixer_calls": []}
     mac.agent.register_forward_hook(lambda m, i, o: cap.__setitem__("agent_out", o))
     learner.target_mac.agent.register_forward_hook(lambda m, i, o: cap.__setitem__("tagent_out", o))
-    learner.mixer.register_forward_hook(lambda m, i, o: cap["mixer_calls"].append((i, o)))
-    learner.target_mixer.register_forward_hook(lambda m, i, o: cap.__setitem__("tmixer", (i, o)))
+    if has_mixer:
+        learner.mixer.register_forward_hook(lambda m, i, o: cap["mixer_calls"].append((i, o)))
+        learner.target_mixer.register_forward_hook(lambda m, i, o: cap.__setitem__("tmixer", (i, o)))
 
     # the partition draw = the first two calls on the default CPU generator inside train()
     # (entity_rnn_agent.py:94-96); reproduce them from the same seed to store the bits.
@@ -146,15 +149,16 @@ def run_case(name, case, out_dir):
         rec["Wmask_noobs"] = Wm.numpy()
         rec["Imask_noobs"] = cap["agent_out"][2][1][:, 0].numpy()
     rec["tq"] = cap["tagent_out"][0].detach().numpy()
-    (i0, o0) = cap["mixer_calls"][0]
-    rec["chosen_q_real"] = i0[0].detach().numpy()
-    rec["q_tot"] = o0.detach().numpy()
-    if case["imagine"]:
-        (i1, o1) = cap["mixer_calls"][1]
-        rec["chosen_q_imagine"] = i1[0].detach().numpy()
-        rec["q_tot_imagine"] = o1.detach().numpy()
-    rec["target_max_q"] = cap["tmixer"][0][0].detach().numpy()
-    rec["target_q_tot"] = cap["tmixer"][1].detach().numpy()
+    if has_mixer:
+        (i0, o0) = cap["mixer_calls"][0]
+        rec["chosen_q_real"] = i0[0].detach().numpy()
+        rec["q_tot"] = o0.detach().numpy()
+        if case["imagine"]:
+            (i1, o1) = cap["mixer_calls"][1]
+            rec["chosen_q_imagine"] = i1[0].detach().numpy()
+            rec["q_tot_imagine"] = o1.detach().numpy()
+        rec["target_max_q"] = cap["tmixer"][0][0].detach().numpy()
+        rec["target_q_tot"] = cap["tmixer"][1].detach().numpy()
     for k, v in logger.stats.items():
         rec["stat." + k] = np.float64(v)
     gn = logger.stats["grad_norm"]
@@ -162,7 +166,7 @@ def run_case(name, case, out_dir):
     rec["clip_coef"] = np.float64(coef)
     full = case.get("store_grads", True)
     names = [("agent", k, p) for k, p in mac.agent.named_parameters()] + \
-            [("mixer", k, p) for k, p in learner.mixer.named_parameters()]
+            ([("mixer", k, p) for k, p in learner.mixer.named_parameters()] if has_mixer else [])
     for which, k, p in names:
         g = p.grad.detach() / coef          # p.grad was scaled in place by clip_grad_norm_
         if full:
@@ -431,6 +435,14 @@ CASES = {
 
 # consecutive train() calls: non-zero RMSprop state, weight decay, target sync after calls 2 and 4 (episode_num 2, 4),
 # checkpoint contents before the last call
+CASES.update({
+    # rnn_hidden_dim is a free flag (default.yaml:47): 32 and 128 next to the shipped 64
+    "refil_rnn32": dict(imagine=True, B=3, T=5, ne=6, na=3, A=5, ed=9, d=16, heads=4, H=32, h=16, M=32, seed=51),
+    "refil_rnn128": dict(imagine=True, B=3, T=4, ne=8, na=4, A=6, ed=11, d=32, heads=4, H=128, h=32, M=32, seed=52),
+    # (args.mixer = None cannot be pinned this way: the reference's own train() raises AttributeError at
+    #  q_learner.py:81 `self.mixer.train()`; the has_mixer guards in run_case only cover construction)
+})
+
 TRAJ_CASES = {
     "refil_traj5": dict(imagine=True, B=3, T=5, ne=6, na=3, A=5, ed=9, d=16, heads=4, H=64, h=16, M=32, seed=41,
                         n_steps=5, checkpoint_after=4, weight_decay=1e-4, target_update_interval=2),
