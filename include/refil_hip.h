@@ -108,6 +108,14 @@ typedef struct refil_batch {
     const uint8_t* group_bits;    /* [B,ne] the random 2-way entity split (entity_rnn_agent.py:94-96);
                                      drawn by the host so that seeds reproduce the reference's masks.
                                      Ignored when dims.imagine == 0. */
+    /* refil_mixer_forward only: the imagined groups as explicit masks -- what FlexQMixer.forward receives as
+     * imagine_groups = (Wmask, Imask) (flex_qmix.py:85-94) -- packed per (b,t) row as 64-bit key words in the layout
+     * of refil_attn_desc.mask_words with 3 variants: [B*T1][3][16*ceil(na/16)], variant 0 = the entity mask, 1 = Wmask,
+     * 2 = Imask rows of the agents (bit j set = key entity j masked; bits >= ne and padded agents all ones), and
+     * mask_row_bits [B*T1][3] = (0, 0, word of inactive entities). Replaces group_bits / gt factors when non-NULL.
+     * Needs a shape the MFMA attention kernels take and attention (not pooling) hypernets. */
+    const uint64_t* mask_words;
+    const uint64_t* mask_row_bits;
 } refil_batch;
 
 /* Scalars produced by a step, as a device array of REFIL_NSTAT floats (sums over this rank's shard,

@@ -49,6 +49,7 @@ class Batch(C.Structure):
         ("filled", C.c_void_p), ("fl_sB", C.c_int64), ("fl_sT", C.c_int64),
         ("gt_mask", C.c_void_p), ("gt_sB", C.c_int64), ("gt_sT", C.c_int64),
         ("group_bits", C.c_void_p),
+        ("mask_words", C.c_void_p), ("mask_row_bits", C.c_void_p),
     ]
 
 
@@ -230,7 +231,7 @@ def _field_dtypes():
     return _FIELD_DTYPES
 
 
-def make_batch(fields: dict, group_bits=None, device=None) -> Batch:
+def make_batch(fields: dict, group_bits=None, device=None, mask_words=None, mask_row_bits=None) -> Batch:
     """fields: name -> DEVICE tensor [B,T1,...] (any batch/time strides, inner dims contiguous).
 
     The kernels reinterpret raw pointers, so every field is checked here: a host tensor is an error (the library has no
@@ -275,5 +276,10 @@ def make_batch(fields: dict, group_bits=None, device=None) -> Batch:
             group_bits = group_bits.to(torch.uint8).contiguous()
         keep.append(group_bits)
         b.group_bits = group_bits.data_ptr()
+    if mask_words is not None:
+        assert mask_words.is_cuda and mask_words.dtype == torch.int64 and mask_words.is_contiguous()
+        assert mask_row_bits is not None and mask_row_bits.dtype == torch.int64 and mask_row_bits.is_contiguous()
+        keep += [mask_words, mask_row_bits]
+        b.mask_words, b.mask_row_bits = mask_words.data_ptr(), mask_row_bits.data_ptr()
     b._keep = keep
     return b

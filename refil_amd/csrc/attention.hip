@@ -333,6 +333,7 @@ int attn_forward_launch(const refil_attn_desc& d, hipStream_t st) {
         const int rc = attn_mfma_launch(d, false, st);
         if (rc >= 0) return rc;
     }
+    REFIL_CHECK(!d.mask_words, "refil_attn_forward: precomputed mask words need a shape the MFMA kernels take");
     const size_t smem = attn_smem_bytes(d.ne, d.na, d.hd, false);
     const double unit = (double)d.R * d.heads * d.na * d.ne * d.hd;
     ProfScope prof("attn_fwd_kernel", unit * (2.0 + 2.0 * d.nvar),
@@ -349,6 +350,7 @@ int attn_backward_launch(const refil_attn_desc& d, hipStream_t st) {
         const int rc = attn_mfma_launch(d, true, st);
         if (rc >= 0) return rc;
     }
+    REFIL_CHECK(!d.mask_words, "refil_attn_backward: precomputed mask words need a shape the MFMA kernels take");
     const size_t smem = attn_smem_bytes(d.ne, d.na, d.hd, true);
     REFIL_CHECK(smem <= 160 * 1024, "refil_attn_backward: LDS need %zu B exceeds 160 KiB", smem);
     if (smem > 64 * 1024) {

@@ -1267,8 +1267,19 @@ extern "C" int refil_mixer_forward(const refil_dims* dims, const refil_batch* ba
     REFIL_CHECK(t0 >= 0 && T > 0 && t0 + T <= dims->T1, "refil_mixer_forward: step range [%d,%d) outside the batch", t0, t0 + T);
     const bool im = agent_qs_imagine != nullptr;
     REFIL_CHECK(dims->gt_factors >= 0 && dims->gt_factors <= 2, "refil: gt_factors must be 0, 1 or 2");
-    REFIL_CHECK(!im || ((batch->group_bits || dims->gt_factors == 1) && q_tot_imagine && dims->imagine),
-                "refil_mixer_forward: imagined mix needs imagine=1, group_bits (or gt_factors) and q_tot_imagine");
+    REFIL_CHECK(!im || ((batch->group_bits || dims->gt_factors == 1 || batch->mask_words) && q_tot_imagine && dims->imagine),
+                "refil_mixer_forward: imagined mix needs imagine=1, group_bits (or gt_factors, or explicit mask words) and q_tot_imagine");
+    if (im && batch->mask_words) {
+        // imagine_groups = (Wmask, Imask) tensors (flex_qmix.py:85-94), packed by the caller: the attention kernels read
+        // the words instead of deriving the masks from the partition bits
+        REFIL_CHECK(batch->mask_row_bits, "refil_mixer_forward: mask_words needs mask_row_bits");
+        REFIL_CHECK(!dims->pooling && !dims->mixer_vdn && attn_mfma_supported(dims->ne, dims->na, dims->hyp / dims->heads),
+                    "refil_mixer_forward: explicit mask tensors need attention hypernets of a shape the MFMA kernels take "
+                    "(ne=%d na=%d head dim=%d)", dims->ne, dims->na, dims->hyp / dims->heads);
+        c.mwords = true;
+        c.w.mw_h = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(batch->mask_words));
+        c.w.rb_h = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(batch->mask_row_bits));
+    }
     REFIL_CHECK(!dims->gt_factors || batch->gt_mask, "refil_mixer_forward: gt_factors needs batch.gt_mask");
     RUN(run_prep(c, 1));
     const int nv0 = im ? 3 : 1;

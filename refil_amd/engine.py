@@ -127,10 +127,10 @@ class LearnerEngine:
     # -- flex_qmix.py:79-121 -------------------------------------------------------------------
     def mixer_forward(self, dims: Dims, fields: Dict[str, torch.Tensor], group_bits, params: torch.Tensor,
                       agent_qs: torch.Tensor, agent_qs_imagine: Optional[torch.Tensor], t0: int, T: int,
-                      params_ptr: Optional[int] = None, want_ingroup: bool = False):
+                      params_ptr: Optional[int] = None, want_ingroup: bool = False, mask_words=None, mask_row_bits=None):
         nbytes = lib().refil_mixer_workspace_bytes(C.byref(dims))
         wp, wsz = self.ws.ptr_size(nbytes)
-        b = _lib.make_batch(fields, group_bits)
+        b = _lib.make_batch(fields, group_bits, mask_words=mask_words, mask_row_bits=mask_row_bits)
         q_tot = torch.empty(dims.B, T, dtype=torch.float32, device=self.device)
         q_im = torch.empty(dims.B, T, dtype=torch.float32, device=self.device) if agent_qs_imagine is not None else None
         ing = torch.zeros(1, dtype=torch.float32, device=self.device) if want_ingroup else None

@@ -28,6 +28,31 @@ class AttentionHyperNet(nn.Module):
         self.fc2 = nn.Linear(h, args.mixing_embed_dim)
 
 
+def pack_mask_words(Wmask, Imask, entity_mask, n_agents):
+    """(Wmask, Imask) as the imagine agents return them ([bs, T or 1, ne, ne], nonzero = masked) -> the 64-bit key
+    words refil_batch.mask_words documents: [bs*T, 3, 16*ceil(na/16)] (variant 0: the hypernets' default entity mask
+    1 - active_i active_j, attention.py / flex_qmix.py:43-46) and the per-row words [bs*T, 3]. Glue on small integer
+    tensors, off the learner's hot path (QLearner.train hands the partition bits to the kernels instead)."""
+    bs, T, ne = entity_mask.shape
+    na_pad = 16 * ((n_agents + 15) // 16)
+    dev = entity_mask.device
+    em = entity_mask.reshape(bs, T, ne).bool()
+    shifts = th.arange(ne, device=dev, dtype=th.int64)
+    pad_keys = th.tensor(-1 << ne if ne < 64 else 0, dtype=th.int64, device=dev)        # bits >= ne set
+
+    def words(m):                                   # m [bs,T,na,ne] bool -> [bs,T,na] int64 (bit j = key j masked)
+        return (m.to(th.int64) << shifts).sum(-1) | pad_keys      # (distinct bits: the sum is a bitwise OR)
+
+    ent = em[:, :, :n_agents, None] | em[:, :, None, :]
+    var = [ent] + [g.bool().expand(bs, T, ne, ne)[:, :, :n_agents, :] for g in (Wmask.to(dev), Imask.to(dev))]
+    mw = th.full((bs, T, 3, na_pad), -1, dtype=th.int64, device=dev)                     # padded agents: all ones
+    for v, m in enumerate(var):
+        mw[:, :, v, :n_agents] = words(m)
+    rb = th.zeros(bs, T, 3, dtype=th.int64, device=dev)
+    rb[:, :, 2] = (em.to(th.int64) << shifts).sum(-1)
+    return mw.reshape(bs * T, 3, na_pad).contiguous(), rb.reshape(bs * T, 3).contiguous()
+
+
 class FlexQMixer(FlatParamModule):
     def __init__(self, args):
         super().__init__()
@@ -86,7 +111,7 @@ class FlexQMixer(FlatParamModule):
         dims = self._dims(bs, T)
         dims.ed, dims.entity_last_action = E, 0          # entities already carry the one-hots
         fields = {"entities": entities.contiguous(), "entity_mask": entity_mask.contiguous()}
-        gb = qs_im = None
+        gb = qs_im = mw = rb = None
         dims.imagine = dims.gt_factors = 0
         if imagine_groups is not None:
             if isinstance(imagine_groups, ImagineGroups):
@@ -98,7 +123,8 @@ class FlexQMixer(FlatParamModule):
                 else:
                     gb = imagine_groups.bits
             elif isinstance(imagine_groups, (tuple, list)):
-                raise NotImplementedError("pass the agent's ImagineGroups (or the [bs, ne] partition bits), not bare mask tensors")
+                # the reference's own calling convention (flex_qmix.py:85-94): (Wmask, Imask) [bs, T or 1, ne, ne]
+                mw, rb = pack_mask_words(imagine_groups[0], imagine_groups[1], entity_mask, self.n_agents)
             else:
                 gb = imagine_groups
             if gb is not None:
@@ -112,7 +138,7 @@ class FlexQMixer(FlatParamModule):
         # the library indexes the mixer tensors at absolute offsets of the combined [agent|mixer] buffer
         base_ptr = self.flat().data_ptr() - 4 * int(L.agent_total)
         out = self.engine().mixer_forward(dims, fields, gb, None, real, qs_im, 0, T, params_ptr=base_ptr,
-                                          want_ingroup=want_ingroup)
+                                          want_ingroup=want_ingroup, mask_words=mw, mask_row_bits=rb)
         q = (out[1] if qs_im is not None else out[0]).reshape(bs, T, 1)
         if want_ingroup:
             return q, out[2][0] / (bs * T)

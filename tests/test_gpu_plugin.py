@@ -100,6 +100,26 @@ def test_mixer_module_forward():
     assert rel_err(q.cpu(), z["q_tot"]) < 1e-4
     qi = learner.mixer(th.from_numpy(z["chosen_q_imagine"]).cuda(), (xe[:, :-1], em[:, :-1]), imagine_groups=g["bits"].cuda())
     assert rel_err(qi.cpu(), z["q_tot_imagine"]) < 1e-4
+    # the reference's own calling convention: imagine_groups = (Wmask, Imask) mask tensors (flex_qmix.py:85-94), as the
+    # imagine agent returns them (entity_rnn_agent.py:130) and QLearner slices them (q_learner.py:137)
+    T = xe.shape[1] - 1
+    Wm = th.from_numpy(z["Wmask_noobs"]).cuda()[:, None].repeat(1, T, 1, 1)
+    Im = th.from_numpy(z["Imask_noobs"]).cuda()[:, None].repeat(1, T, 1, 1)
+    qi2 = learner.mixer(th.from_numpy(z["chosen_q_imagine"]).cuda(), (xe[:, :-1], em[:, :-1]), imagine_groups=(Wm, Im))
+    assert rel_err(qi2.cpu(), z["q_tot_imagine"]) < 1e-4
+    assert th.equal(qi2, qi)                       # same kernels, same mask words: bit-identical
+    qi3 = learner.mixer(th.from_numpy(z["chosen_q_imagine"]).cuda(), (xe[:, :-1], em[:, :-1]), imagine_groups=[Wm[:, :1], Im[:, :1]])
+    assert th.equal(qi3, qi)
+    # arbitrary masks (not derivable from a 2-way split) against the oracle's mixer
+    gen = th.Generator().manual_seed(5)
+    Wr = (th.rand(Wm.shape, generator=gen) < 0.4)
+    Ir = (th.rand(Wm.shape, generator=gen) < 0.4)
+    mixer_p = {k[len("mixer0."):]: th.from_numpy(z[k]) for k in z.files if k.startswith("mixer0.")}
+    caq = th.from_numpy(z["chosen_q_imagine"])
+    _, ref_im = orc.mixer_forward(cfg, mixer_p, th.from_numpy(z["chosen_q_real"]), xe[:, :-1].cpu(), g["batch"]["entity_mask"][:, :-1],
+                                  caq, (Wr[:, :, :cfg.n_agents], Ir[:, :, :cfg.n_agents]))     # (the oracle takes the agents' rows)
+    qi4 = learner.mixer(caq.cuda(), (xe[:, :-1], em[:, :-1]), imagine_groups=(Wr.cuda(), Ir.cuda()))
+    assert rel_err(qi4.cpu(), ref_im) < 1e-4
     tq = learner.target_mixer(th.from_numpy(z["target_max_q"]).cuda(), (xe[:, 1:], em[:, 1:]))
     assert rel_err(tq.cpu(), z["target_q_tot"]) < 1e-4
 
