@@ -66,6 +66,15 @@ def algorithmic_flops(B, T, ne, na, E, A, d, h, H, M, G):
     return la_f + la_b + ta_f + sum(f + b for f, b in lm) + sum(f for f, _ in tm)
 
 
+def workload_dims(W):
+    """Network / environment sizes of a CONFIGS entry (the SC2 shape law of refil_amd.synthetic for its entity count)."""
+    from refil_amd.synthetic import sc2_shape_law
+    W = dict(W, **COMMON)
+    law = sc2_shape_law(W["ne"])
+    return dict(ne=W["ne"], na=law["n_agents"], A=law["n_actions"], ed=law["entity_shape"], d=W["d"], h=W["h"],
+                heads=W["heads"], H=W["H"], M=W["M"])
+
+
 def make_args(dims, imagine):
     return types.SimpleNamespace(
         agent="imagine_entity_attend_rnn" if imagine else "entity_attend_rnn", mac="entity_mac", learner="q_learner", mixer="flex_qmix",
@@ -216,13 +225,10 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     from refil_amd import _lib
-    from refil_amd.synthetic import sc2_shape_law
     W = dict(CONFIGS[a.config], **COMMON)
     if a.batch > 0:
         W["B"] = a.batch
-    law = sc2_shape_law(W["ne"])
-    dims = dict(ne=W["ne"], na=law["n_agents"], A=law["n_actions"], ed=law["entity_shape"], d=W["d"], h=W["h"],
-                heads=W["heads"], H=W["H"], M=W["M"])
+    dims = workload_dims(W)
     T = W["T"]
     if a.scaling == "strong":
         assert a.global_batch % world == 0, "--global-batch must be a multiple of the number of GPUs"

@@ -1,14 +1,13 @@
 """Soak test on the GPU: a few hundred QLearner.train steps on one synthetic batch (bench shapes, smaller B/T). Checks
 that parameters and statistics stay finite and that the loss goes down (usage: python tools/soak_test.py [steps])."""
 import sys, os, math
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 import bench
-from refil_amd.synthetic import sc2_shape_law
-W = bench.WORKLOAD
-law = sc2_shape_law(W["ne"])
-dims = dict(ne=W["ne"], na=law["n_agents"], A=law["n_actions"], ed=law["entity_shape"], d=W["d"], h=W["h"], heads=W["heads"], H=W["H"], M=W["M"])
-args, batch, learner, data = bench.build(dims, 16, 40, seed=3, device=torch.device("cuda", 0))
+W = bench.CONFIGS["cfgT"]
+dims = bench.workload_dims(W)
+args, batch, learner, data = bench.build(dims, W["imagine"], 16, 40, seed=3, device=torch.device("cuda", 0))
 from plugin_util import RecLogger
 learner.logger = RecLogger()
 learner.args.learner_log_interval = 1
