@@ -140,6 +140,12 @@ struct TdArgs {
     int nq;                           // values per (b,t): 1 (mixed q_tot) or n_agents (args.mixer = None: per-agent TD, q_learner.py:131,161)
 };
 int td_loss_launch(const TdArgs& a, hipStream_t st);
+// FlexQMixer learner step in one launch per (b,t) row: live mix, target mix (the step after), TD error and the live mix's
+// backward (q_learner.py:134-172 and its gradient). live: forward + backward pointers, t_off 0; targ: forward pointers,
+// t_off 1; td: the batch scalars and the outputs q_tot / q_tot_im / tq_tot / targets / gc_real / gc_im (kept for parity
+// checks). row_stats [B*T][8]: per-row terms of the stat sums, folded into td.stats by td_stats_launch.
+int mix_train_launch(const MixArgs& live, const MixArgs& targ, const TdArgs& td, float* row_stats, hipStream_t st);
+int td_stats_launch(const float* row_stats, int rows, float* stats, hipStream_t st);
 
 int sum_launch(const float* x, long n, float* out, hipStream_t st);   // out[0] = sum(x)
 

@@ -109,6 +109,7 @@ struct Work {
     AgentBufs la, ta;
     HyperBufs lh, th;
     float *chosen, *tmax, *q_tot, *q_tot_im, *tq_tot, *gc_real, *gc_im, *targets, *ingroup;
+    float* row_stats;  // [B*T][8] per-row terms of the stat sums (fused mixing kernel)
     float* actf;       // [R*na] 1 / 0 for active / inactive agents
     float* nact;       // [R] active agents per (b,t): weight of the bias terms of the agent-summed hypernet tails
     // backward
@@ -193,6 +194,7 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     w.tmax = a.take<float>(BT * d.na);
     w.q_tot = a.take<float>(BT); w.q_tot_im = a.take<float>(BT); w.tq_tot = a.take<float>(BT);
     w.gc_real = a.take<float>(BT); w.gc_im = a.take<float>(BT); w.targets = a.take<float>(BT * (d.mixer_none ? d.na : 1)); w.ingroup = a.take<float>(BT);
+    w.row_stats = a.take<float>(BT * 8);
     w.dx3h = a.take<float>(((long)s.NV * s.NA + 8) * d.M);
     w.dchosen = a.take<float>((long)s.G * BT * d.na);
     w.dx2h = a.take<float>((long)s.NV * s.NA * d.hyp);
@@ -976,24 +978,42 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     ml.ingroup_rows = (d.mixer_lin && d.imagine) ? w.ingroup : nullptr;
     MixArgs mt = mix_args(c, w.th, 1, w.tmax, 1, 1, T);
     mt.q_tot = w.tq_tot; mt.q_tot_im = nullptr;
-    if (!d.mixer_none) {
-        RUN(mix_forward_launch(ml, c.st));                                        // :134-152
-        RUN(mix_forward_launch(mt, c.st));                                        // :154
+    // gradient targets of the live mix (the backward, q_learner.py:176, is hand-scheduled)
+    ml.gc_real = w.gc_real; ml.gc_im = w.gc_im;
+    ml.dx_w1 = w.dx3h;
+    if (d.mixer_vdn) {
+        // nothing flows to hypernets
+    } else if (d.mixer_lin) {
+        ml.dx_v = w.dx3h + (long)(nv0 + 0) * s.NA * M;
+    } else {
+        ml.dx_wf = w.dx3h + (long)(nv0 + 0) * s.NA * M;
+        ml.dx_b1 = w.dx3h + (long)(nv0 + 1) * s.NA * M;
+        ml.dx_v = w.dx3h + (long)(nv0 + 2) * s.NA * M;
     }
-    {
-        TdArgs t;
-        t.q_tot = w.q_tot; t.q_tot_im = w.q_tot_im; t.tq_tot = w.tq_tot;
-        t.nq = 1;
-        if (d.mixer_none) {     // :131 `if self.mixer is not None` not taken: the per-agent values enter the loss directly
-            t.q_tot = w.chosen; t.q_tot_im = nullptr; t.tq_tot = w.tmax; t.nq = d.na;
+    ml.dqs = w.dchosen;
+    TdArgs t;
+    t.q_tot = w.q_tot; t.q_tot_im = w.q_tot_im; t.tq_tot = w.tq_tot;
+    t.nq = 1;
+    if (d.mixer_none) {     // :131 `if self.mixer is not None` not taken: the per-agent values enter the loss directly
+        t.q_tot = w.chosen; t.q_tot_im = nullptr; t.tq_tot = w.tmax; t.nq = d.na;
+    }
+    t.reward = c.b.reward; t.rw_sB = c.b.rw_sB; t.rw_sT = c.b.rw_sT;
+    t.terminated = c.b.terminated; t.tm_sB = c.b.tm_sB; t.tm_sT = c.b.tm_sT;
+    t.filled = c.b.filled; t.fl_sB = c.b.fl_sB; t.fl_sT = c.b.fl_sT;
+    t.gc_real = d.mixer_none ? w.dchosen : w.gc_real; t.gc_im = w.gc_im; t.targets = w.targets; t.stats = stats;
+    t.t_last = c.lists ? w.t_last : nullptr;
+    t.ingroup_rows = ml.ingroup_rows;
+    t.B = d.B; t.T = T; t.imagine = d.imagine; t.gamma = d.gamma; t.lmbda = d.lmbda;
+    // FlexQMixer: live mix, target mix, TD error and the live mix's backward in one launch (REFIL_MIX_FUSED=0: four launches)
+    static const bool fused_env = [] { const char* e = getenv("REFIL_MIX_FUSED"); return !(e && e[0] == '0'); }();
+    const bool mix_fused = fused_env && hypernets && !d.mixer_lin;
+    if (mix_fused) {
+        RUN(mix_train_launch(ml, mt, t, w.row_stats, c.st));                      // :134-172 + backward of the mix
+    } else {
+        if (!d.mixer_none) {
+            RUN(mix_forward_launch(ml, c.st));                                    // :134-152
+            RUN(mix_forward_launch(mt, c.st));                                    // :154
         }
-        t.reward = c.b.reward; t.rw_sB = c.b.rw_sB; t.rw_sT = c.b.rw_sT;
-        t.terminated = c.b.terminated; t.tm_sB = c.b.tm_sB; t.tm_sT = c.b.tm_sT;
-        t.filled = c.b.filled; t.fl_sB = c.b.fl_sB; t.fl_sT = c.b.fl_sT;
-        t.gc_real = d.mixer_none ? w.dchosen : w.gc_real; t.gc_im = w.gc_im; t.targets = w.targets; t.stats = stats;
-        t.t_last = c.lists ? w.t_last : nullptr;
-        t.ingroup_rows = ml.ingroup_rows;
-        t.B = d.B; t.T = T; t.imagine = d.imagine; t.gamma = d.gamma; t.lmbda = d.lmbda;
         RUN(td_loss_launch(t, c.st));                                             // :157-172
     }
     if (debug) {
@@ -1009,19 +1029,14 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     }
 
     // ---------------- backward (q_learner.py:176, hand-scheduled) ----------------
-    ml.gc_real = w.gc_real; ml.gc_im = w.gc_im;
-    ml.dx_w1 = w.dx3h;
-    if (d.mixer_vdn) {
-        // nothing flows to hypernets
-    } else if (d.mixer_lin) {
-        ml.dx_v = w.dx3h + (long)(nv0 + 0) * s.NA * M;
-    } else {
-        ml.dx_wf = w.dx3h + (long)(nv0 + 0) * s.NA * M;
-        ml.dx_b1 = w.dx3h + (long)(nv0 + 1) * s.NA * M;
-        ml.dx_v = w.dx3h + (long)(nv0 + 2) * s.NA * M;
+    if (mix_fused) {
+        // the stat sums leave the critical path: folded on the hypernet chain's weight-gradient stream (joined before the
+        // optimiser; the data-parallel hook hands that stream to the all-reduce)
+        RUN(stream_after(sd, c.st, ch.gst));
+        RUN(td_stats_launch(w.row_stats, (int)BT, stats, ch.gst));
+    } else if (!d.mixer_none) {
+        RUN(mix_backward_launch(ml, c.st));
     }
-    ml.dqs = w.dchosen;
-    if (!d.mixer_none) RUN(mix_backward_launch(ml, c.st));
     if (overlap) {                                                                 // fork: agent backward chain
         REFIL_HIP(hipEventRecord(sd->ev[2], c.st));
         REFIL_HIP(hipStreamWaitEvent(sd->s, sd->ev[2], 0));

@@ -498,6 +498,147 @@ __global__ __launch_bounds__(64 * MIXW) void mix_bwd_kernel(MixArgs a) {
     }
 }
 
+// Learner step of FlexQMixer in ONE launch (these kernels sit at the join of the two chains, on the critical path: four
+// dependent launches -- live mix, target mix, TD, backward -- become one). Workgroup r = (b,tt): live mix of step tt,
+// target mix of step tt+1, TD error of (b,tt), then the backward of the live mix with that row's own loss gradient.
+// Same arithmetic, in the same order, as mix_fwd_kernel / td_loss_kernel / mix_bwd_kernel.
+struct MixTrainArgs { MixArgs live, targ; TdArgs td; float* row_stats; };
+
+__global__ __launch_bounds__(64 * MIXW) void mix_train_kernel(MixTrainArgs p) {
+    __shared__ float red[MIXW][5][64];
+    const MixArgs& a = p.live;
+    const TdArgs& d = p.td;
+    const int r = blockIdx.x;
+    const int b = r / a.T1, tt = r % a.T1;
+    const int m = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool act = m < a.M;
+    const long base = (long)r * a.na * a.M;
+    const int nvar = a.imagine ? 3 : 1;
+    const bool skipped = a.t_last && tt > a.t_last[b];
+    const int bt = b * a.T + tt;
+    if (tt >= a.T || skipped) {                            // no loss term: exact-zero gradients (see mix_bwd_kernel)
+        if (tt < a.T) {
+            if (m == 0)
+                for (int i = wave; i < a.na; i += MIXW)
+                    for (int v = 0; v < nvar; ++v) a.dqs[(long)v * a.B * a.T * a.na + (long)bt * a.na + i] = 0.f;
+            if (threadIdx.x == 0) {
+                a.q_tot[bt] = 0.f;
+                if (a.imagine) a.q_tot_im[bt] = 0.f;
+                p.targ.q_tot[bt] = 0.f;
+                d.gc_real[bt] = 0.f;
+                if (a.imagine) d.gc_im[bt] = 0.f;
+                if (d.targets) d.targets[bt] = d.reward[b * d.rw_sB + tt * d.rw_sT];
+            }
+            if (threadIdx.x < 8) p.row_stats[(long)bt * 8 + threadIdx.x] = 0.f;
+        }
+        if (act) {
+            for (int i = wave; i < a.na; i += MIXW) {
+                const long o = base + (long)i * a.M + m;
+                for (int v = 0; v < nvar; ++v) a.dx_w1[v * a.s_var + o] = 0.f;
+                if (!a.presum) { a.dx_wf[o] = 0.f; a.dx_b1[o] = 0.f; a.dx_v[o] = 0.f; }
+            }
+            if (a.presum && wave == 0) { const long o = (long)r * a.M + m; a.dx_wf[o] = 0.f; a.dx_b1[o] = 0.f; a.dx_v[o] = 0.f; }
+        }
+        return;
+    }
+    const long qbase = (long)bt * a.na;
+    const long BTn = (long)a.B * a.T * a.na;
+    const MixRow o = mix_row_forward(a, base, qbase, m, act, wave, red);
+    const float qt = wave_sum(act ? o.hid_r * o.wf : 0.f) + o.v;
+    const float qi = a.imagine ? wave_sum(act ? o.hid_i * o.wf : 0.f) + o.v : 0.f;
+    // target mixer on step tt+1 (q_learner.py:154); a step nothing upstream computed enters as 0 (it has mask 0)
+    float tq = 0.f;
+    if (!(a.t_last && tt + 1 > a.t_last[b])) {             // (uniform)
+        __syncthreads();                                   // `red` is reused
+        const MixRow ot = mix_row_forward(p.targ, base + (long)a.na * a.M, qbase, m, act, wave, red);
+        tq = wave_sum(act ? ot.hid_r * ot.wf : 0.f) + ot.v;
+    }
+    // TD error of (b,tt) (q_learner.py:68-72,157-172)
+    float mask = (float)d.filled[b * d.fl_sB + tt * d.fl_sT];
+    if (tt > 0) mask *= 1.0f - (float)d.terminated[b * d.tm_sB + (tt - 1) * d.tm_sT];
+    const float term = (float)d.terminated[b * d.tm_sB + tt * d.tm_sT];
+    const float target = d.reward[b * d.rw_sB + tt * d.rw_sT] + d.gamma * (1.0f - term) * tq;
+    const float td = (qt - target) * mask;
+    const float wr = a.imagine ? 1.0f - d.lmbda : 1.0f;
+    const float g_r = 2.0f * wr * td * mask;
+    const float tdi = a.imagine ? (qi - target) * mask : 0.f;
+    const float g_i = a.imagine ? 2.0f * d.lmbda * tdi * mask : 0.f;
+    if (threadIdx.x == 0) {
+        a.q_tot[bt] = qt;
+        if (a.imagine) a.q_tot_im[bt] = qi;
+        p.targ.q_tot[bt] = tq;
+        d.gc_real[bt] = g_r;
+        if (a.imagine) d.gc_im[bt] = g_i;
+        if (d.targets) d.targets[bt] = target;
+        float* rs = p.row_stats + (long)bt * 8;
+        rs[0] = mask; rs[1] = td * td; rs[2] = tdi * tdi; rs[3] = fabsf(td); rs[4] = qt * mask; rs[5] = target * mask;
+        rs[6] = 0.f; rs[7] = 0.f;
+    }
+    // backward of the live mix (mix_bwd_kernel)
+    const float dv = (g_r + g_i) / (float)(a.na * a.M);
+    const float dwf = g_r * o.hid_r + g_i * o.hid_i;
+    float dwf_raw;
+    if (a.softmax_w) {
+        const float dot = wave_sum(act ? o.wf * dwf : 0.f);
+        dwf_raw = o.wf * (dwf - dot);
+    } else {
+        dwf_raw = sgn(o.wf_raw) * dwf;
+    }
+    dwf_raw /= (float)a.na;
+    const float dpre_r = g_r * o.wf * nonlin_grad(o.pre_r, o.hid_r, a.tanh_nl);
+    const float dpre_i = g_i * o.wf * nonlin_grad(o.pre_i, o.hid_i, a.tanh_nl);
+    const float db1 = (dpre_r + dpre_i) / (float)a.na;
+    for (int i = wave; i < a.na; i += MIXW) {
+        const long oo = base + (long)i * a.M + m;
+        const bool dead = a.amask[(long)r * a.na + i];
+        for (int v = 0; v < nvar; ++v) {
+            const float x = act ? a.x_w1[v * a.s_var + oo] : 0.f;
+            const float w = mix_weight(x, act, a.softmax_w);
+            const float dpre = v == 0 ? dpre_r : dpre_i;
+            const float q = a.qs[v * a.s_qs_g + qbase + i];
+            const float dq = wave_sum(act ? dpre * w : 0.f);
+            if (m == 0) a.dqs[(long)v * BTn + qbase + i] = dq;
+            const float dw = q * dpre;
+            const float dx = a.softmax_w ? w * (dw - q * dq) : sgn(x) * dw;
+            if (act) a.dx_w1[v * a.s_var + oo] = dead ? 0.f : dx;
+        }
+        if (act && !a.presum) {
+            a.dx_wf[oo] = dead ? 0.f : dwf_raw;
+            a.dx_b1[oo] = dead ? 0.f : db1;
+            a.dx_v[oo] = dead ? 0.f : dv;
+        }
+    }
+    if (a.presum && act && wave == 0) {
+        const long oo = (long)r * a.M + m;
+        a.dx_wf[oo] = dwf_raw; a.dx_b1[oo] = db1; a.dx_v[oo] = dv;
+    }
+}
+
+// stats[k] = sum over the rows of row_stats[row][k] (fixed order: deterministic)
+__global__ __launch_bounds__(1024) void td_stats_kernel(const float* row_stats, int rows, float* stats) {
+    __shared__ float red[6][16];
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int idx = threadIdx.x; idx < rows; idx += blockDim.x) {
+        const float4 v0 = *reinterpret_cast<const float4*>(row_stats + (long)idx * 8);
+        const float2 v1 = *reinterpret_cast<const float2*>(row_stats + (long)idx * 8 + 4);
+        s[0] += v0.x; s[1] += v0.y; s[2] += v0.z; s[3] += v0.w; s[4] += v1.x; s[5] += v1.y;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float v = wave_sum(s[k]);
+        if (lane == 0) red[k][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += red[threadIdx.x][w];
+        stats[threadIdx.x] = v;
+    }
+    if (threadIdx.x == 6) stats[REFIL_STAT_INGROUP_SUM] = 0.f;
+    if (threadIdx.x == 7) stats[REFIL_STAT_GRAD_NORM] = 0.f;
+}
+
 // ------------------------------------------------------------------------------------------------
 // LinearFlexQMixer (flex_qmix.py:136-172). One wave per (b,t); lane l owns mixing weight l:
 //   real:     w = softmax_na / abs ( mean_M hyper_w_1[default mask] ),          q_tot = sum_i q_i w_i + v
@@ -651,6 +792,24 @@ int mix_backward_launch(const MixArgs& a, hipStream_t st) {
     ProfScope prof_mix_bwd_kernel(a.lin ? "mix_lin_bwd_kernel" : "mix_bwd_kernel", 0.0, 0.0, st);
     if (a.lin) hipLaunchKernelGGL(mix_lin_bwd_kernel, dim3(a.B * a.T1), dim3(64), 0, st, a);
     else hipLaunchKernelGGL(mix_bwd_kernel, dim3(a.B * a.T1), dim3(64 * MIXW), 0, st, a);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
+int mix_train_launch(const MixArgs& live, const MixArgs& targ, const TdArgs& td, float* row_stats, hipStream_t st) {
+    if (int e = mix_check(live)) return e;
+    if (int e = mix_check(targ)) return e;
+    REFIL_CHECK(live.lin == 0 && targ.lin == 0 && row_stats && live.t_off == 0 && targ.t_off == 1, "refil mix_train: FlexQMixer learner step only");
+    MixTrainArgs p;
+    p.live = live; p.targ = targ; p.td = td; p.row_stats = row_stats;
+    ProfScope prof("mix_train_kernel", 0.0, 0.0, st);
+    hipLaunchKernelGGL(mix_train_kernel, dim3(live.B * live.T1), dim3(64 * MIXW), 0, st, p);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+int td_stats_launch(const float* row_stats, int rows, float* stats, hipStream_t st) {
+    ProfScope prof("td_stats_kernel", 0.0, 0.0, st);
+    hipLaunchKernelGGL(td_stats_kernel, dim3(1), dim3(1024), 0, st, row_stats, rows, stats);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
