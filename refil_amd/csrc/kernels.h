@@ -103,6 +103,9 @@ struct QSelBwdArgs {
     const uint8_t* amask;  // [B*T1*na]
     float* dq;             // [G, B*T1*na, A]
     int G, B, T1, na, A;
+    // optional: also d(hidden state) = dq W3 (W3 [A,H] row-major: fc3.weight). dq has one non-zero per row, so the product
+    // is a scaled row of W3 -- written here instead of by a [rows x A] x [A x H] GEMM on the critical path
+    const float* w3; float* dhs; int H;
 };
 int qselect_bwd_launch(const QSelBwdArgs& a, hipStream_t st);
 

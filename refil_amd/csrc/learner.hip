@@ -1115,6 +1115,8 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         QSelBwdArgs q;
         q.dchosen = w.dchosen; q.actions = c.b.actions; q.ac_sB = c.b.ac_sB; q.ac_sT = c.b.ac_sT; q.amask = w.amask;
         q.dq = w.dqva; q.G = G; q.B = d.B; q.T1 = d.T1; q.na = d.na; q.A = d.A;
+        q.w3 = nullptr; q.dhs = nullptr; q.H = 0;
+        if (!d.agent_ff) { q.w3 = params_live + L.ag_fc3_w; q.dhs = w.dhs; q.H = H; }     // recurrent agent: + d(hidden) = dq W3
         RUN(qselect_bwd_launch(q, ca.st));
         const long rows = (long)G * s.NA;
         if (d.agent_ff) {
@@ -1127,7 +1129,6 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
             refil_gemm_desc gw = linear_dw(w.dqva, d.A, w.la.hsx, H, grads + L.ag_fc3_w, H, grads + L.ag_fc3_b, rows, d.A, H, ca.w.partial, 1);
             gw.b_map = hs_rows(c, d.na);
             RUN(launch_dw(ca, with_rows(gw, ca, rows_t(ca, G))));
-            RUN(gemm_launch(linear_dx(w.dqva, d.A, params_live + L.ag_fc3_w, H, w.dhs, H, rows, d.A, H, 0), ca.st));
             // BPTT
             refil_gru_desc g;
             memset(&g, 0, sizeof(g));

@@ -326,7 +326,45 @@ __global__ void qselect_bwd_kernel(QSelBwdArgs a) {
         a.dq[idx] = v;
     }
 }
+// the same, plus dhs[row] = dq[row] W3 = dchosen * W3[action] (one thread per (row, 4 hidden columns))
+__global__ __launch_bounds__(256) void qselect_bwd_hs_kernel(QSelBwdArgs a) {
+    const int T = a.T1 - 1, H4 = a.H >> 2;
+    const long NA = (long)a.B * a.T1 * a.na;
+    const long total = (long)a.G * NA * H4;
+    const long BTn = (long)a.B * T * a.na;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = idx % H4;
+        const long grow = idx / H4;
+        const int g = grow / NA;
+        const long row = grow % NA;
+        const int i = row % a.na;
+        const long r = row / a.na;
+        const int b = r / a.T1, t = r % a.T1;
+        float v = 0.f;
+        int act = -1;
+        if (t < T && !a.amask[row]) {
+            act = (int)a.actions[b * a.ac_sB + t * a.ac_sT + i];
+            v = a.dchosen[(long)g * BTn + ((long)b * T + t) * a.na + i];
+        }
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act >= 0) {
+            const float4 w = *reinterpret_cast<const float4*>(a.w3 + (long)act * a.H + 4 * c4);
+            o = make_float4(v * w.x, v * w.y, v * w.z, v * w.w);
+        }
+        *reinterpret_cast<float4*>(a.dhs + grow * a.H + 4 * c4) = o;
+        for (int k = 4 * c4; k < 4 * c4 + 4 && k < a.A; ++k) a.dq[grow * a.A + k] = k == act ? v : 0.f;
+        if (c4 == H4 - 1) for (int k = a.H; k < a.A; ++k) a.dq[grow * a.A + k] = k == act ? v : 0.f;    // (n_actions > rnn_hidden_dim)
+    }
+}
 int qselect_bwd_launch(const QSelBwdArgs& a, hipStream_t st) {
+    if (a.dhs) {
+        REFIL_CHECK(a.w3 && a.H > 0 && a.H % 4 == 0, "refil qselect_bwd: dhs needs fc3.weight and a hidden size that is a multiple of 4");
+        const long total = (long)a.G * a.B * a.T1 * a.na * (a.H / 4);
+        ProfScope prof("qselect_bwd_hs_kernel", 0.0, 0.0, st);
+        hipLaunchKernelGGL(qselect_bwd_hs_kernel, dim3((int)min((long)8192, cdivl(total, 256))), dim3(256), 0, st, a);
+        REFIL_LAUNCH_CHECK();
+        return 0;
+    }
     const long total = (long)a.G * a.B * a.T1 * a.na * a.A;
     ProfScope prof_qselect_bwd_kernel("qselect_bwd_kernel", 0.0, 0.0, st);
     hipLaunchKernelGGL(qselect_bwd_kernel, dim3((int)min((long)4096, cdivl(total, 256))), dim3(256), 0, st, a);
