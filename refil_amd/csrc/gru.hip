@@ -184,22 +184,26 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd_kernel(GruK p) {
         carry[reg] = 0.f;
     }
     // per-step inputs: 0 dhs, 1 r, 2 z, 3 n, 4 ghn, 5 h_{t-1}
-    float cur[4][6], nxt[4][6] = {};
-    auto fetch = [&](float (&dst)[4][6], int t) {
+    float cur[4][6];
+    // (rows past the end read row r0's values instead of branching around the loads: nothing of theirs is stored, and a
+    // row's recurrence depends on nothing but that row)
+    long go[4], ho[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        go[reg] = (valid[reg] ? gi_base[reg] : gi_base[0]) * GH + c;
+        ho[reg] = (valid[reg] ? hs_base[reg] : hs_base[0]) * GH + c;
+    }
+    const long row_step = (long)p.na * GH;
+    auto fetch = [&](float (&dst)[4][6], int t) __attribute__((always_inline)) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            if (valid[reg]) {
-                const long o = (gi_base[reg] + (long)t * p.na) * GH + c;
-                dst[reg][0] = p.dhs[o];
-                dst[reg][1] = p.save_r[o];
-                dst[reg][2] = p.save_z[o];
-                dst[reg][3] = p.save_n[o];
-                dst[reg][4] = p.save_ghn[o];
-                dst[reg][5] = p.hsx[(hs_base[reg] + (long)t * p.na) * GH + c];
-            } else {
-#pragma unroll
-                for (int k = 0; k < 6; ++k) dst[reg][k] = 0.f;
-            }
+            const long o = go[reg] + t * row_step;
+            dst[reg][0] = p.dhs[o];
+            dst[reg][1] = p.save_r[o];
+            dst[reg][2] = p.save_z[o];
+            dst[reg][3] = p.save_n[o];
+            dst[reg][4] = p.save_ghn[o];
+            dst[reg][5] = p.hsx[ho[reg] + t * row_step];
         }
     };
     // steps the episode's loss cannot reach (t >= tend): exact zeros, what the full recurrence would have produced
@@ -215,11 +219,16 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd_kernel(GruK p) {
         }
     }
     if (tend <= 0) return;
+    // The per-step inputs come from HBM: their latency (> 1 us under load) exceeds a step's compute, so they are fetched TWO
+    // steps ahead into two alternating register sets (the loop is unrolled by two: no moves of in-flight registers).
+    float pa[4][6], pb[4][6] = {};
     fetch(cur, tend - 1);
+    fetch(pa, max(tend - 2, 0));
     int it = 0;
-    for (int t = tend - 1; t >= 0; --t, ++it) {
+    auto step = [&](int t, float (&issue)[4][6], float (&next)[4][6]) __attribute__((always_inline)) {
         float* gb_w = gbuf[it & 1];
-        if (t > 0) fetch(nxt, t - 1);
+        ++it;
+        fetch(issue, max(t - 2, 0));                       // (unconditional: a branch here costs register copies and waits)
         float dhz[4], sv[4][4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -263,8 +272,8 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd_kernel(GruK p) {
             carry[reg] = dhz[reg] + (a0[reg] + a1[reg] + a2[reg]);
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                asm volatile("" : "+v"(nxt[reg][k]));
-                cur[reg][k] = nxt[reg][k];
+                asm volatile("" : "+v"(next[reg][k]));
+                cur[reg][k] = next[reg][k];
             }
         }
 #pragma unroll
@@ -275,6 +284,10 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd_kernel(GruK p) {
                 p.dgh[o] = sv[reg][0]; p.dgh[o + GH] = sv[reg][1]; p.dgh[o + 2 * GH] = sv[reg][3];
             }
         }
+    };
+    for (int t = tend - 1; t >= 0; t -= 2) {
+        step(t, pb, pa);                       // pa holds step t-1 (in flight), pb receives step t-2
+        if (t >= 1) step(t - 1, pa, pb);       // pb holds step t-2, pa receives step t-3
     }
 }
 
