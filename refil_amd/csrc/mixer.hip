@@ -8,14 +8,21 @@
 
 namespace refil {
 
+// Wave-wide all-reduce. The 16 lanes of a DPP row are folded with four DPP-modified VALU ops (quad_perm [1,0,3,2],
+// quad_perm [2,3,0,1], row_half_mirror, row_mirror: no LDS crossbar round trip), the four rows with two ds_bpermute
+// exchanges -- the mixing kernels are chains of ~60 dependent reductions per row on the step's critical path.
+template <int CTRL>
+__device__ inline float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ inline float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    v = fmaxf(v, dpp_mov<0xB1>(v)); v = fmaxf(v, dpp_mov<0x4E>(v)); v = fmaxf(v, dpp_mov<0x141>(v)); v = fmaxf(v, dpp_mov<0x140>(v));
+    v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
 
