@@ -409,18 +409,24 @@ __device__ inline float nonlin_grad(float pre, float hid, int tanh_nl) {
 // two streams, i.e. directly on the critical path). Partial sums are combined through LDS.
 constexpr int MIXW = 4;
 
+// wkeep (optional, LDS [na][3][64]): the mixing weights, wkeep[(i * 3 + v) * 64 + m] for agent i and mask variant v -- the
+// backward pass of the same row reuses them instead of repeating the softmax reductions (written and read by the same lane)
 __device__ inline MixRow mix_row_forward(const MixArgs& a, long base, long qbase, int m, bool act, int wave,
-                                         float (*red)[5][64]) {
+                                         float (*red)[5][64], float* wkeep = nullptr) {
     float acc_r = 0.f, acc_i = 0.f, b1 = 0.f, wfr = 0.f, vs = 0.f;
     for (int i = wave; i < a.na; i += MIXW) {
         const long o_im = base + (long)i * a.M + m;
         const float x0 = act ? a.x_w1[o_im] : 0.f;
-        acc_r = fmaf(a.qs[qbase + i], mix_weight(x0, act, a.softmax_w), acc_r);
+        const float w0 = mix_weight(x0, act, a.softmax_w);
+        if (wkeep) wkeep[(i * 3 + 0) * 64 + m] = w0;
+        acc_r = fmaf(a.qs[qbase + i], w0, acc_r);
         if (a.imagine) {
             const float xw = act ? a.x_w1[a.s_var + o_im] : 0.f;
             const float xi = act ? a.x_w1[2 * a.s_var + o_im] : 0.f;
-            acc_i = fmaf(a.qs[a.s_qs_g + qbase + i], mix_weight(xw, act, a.softmax_w), acc_i);
-            acc_i = fmaf(a.qs[2 * a.s_qs_g + qbase + i], mix_weight(xi, act, a.softmax_w), acc_i);
+            const float ww = mix_weight(xw, act, a.softmax_w), wi = mix_weight(xi, act, a.softmax_w);
+            if (wkeep) { wkeep[(i * 3 + 1) * 64 + m] = ww; wkeep[(i * 3 + 2) * 64 + m] = wi; }
+            acc_i = fmaf(a.qs[a.s_qs_g + qbase + i], ww, acc_i);
+            acc_i = fmaf(a.qs[2 * a.s_qs_g + qbase + i], wi, acc_i);
         }
         if (act && !a.presum) { b1 += a.x_b1[o_im]; wfr += a.x_wf[o_im]; vs += a.x_v[o_im]; }
     }
@@ -551,6 +557,7 @@ struct MixTrainArgs { MixArgs live, targ; TdArgs td; float* row_stats; };
 
 __global__ __launch_bounds__(64 * MIXW) void mix_train_kernel(MixTrainArgs p) {
     __shared__ float red[MIXW][5][64];
+    extern __shared__ float wk[];                          // [na][3][64] mixing weights of the live mix
     const MixArgs& a = p.live;
     const TdArgs& d = p.td;
     const int r = blockIdx.x;
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(64 * MIXW) void mix_train_kernel(MixTrainArgs p) {
     }
     const long qbase = (long)bt * a.na;
     const long BTn = (long)a.B * a.T * a.na;
-    const MixRow o = mix_row_forward(a, base, qbase, m, act, wave, red);
+    const MixRow o = mix_row_forward(a, base, qbase, m, act, wave, red, wk);
     const float qt = wave_sum(act ? o.hid_r * o.wf : 0.f) + o.v;
     const float qi = a.imagine ? wave_sum(act ? o.hid_i * o.wf : 0.f) + o.v : 0.f;
     // target mixer on step tt+1 (q_learner.py:154); a step nothing upstream computed enters as 0 (it has mask 0)
@@ -637,8 +644,8 @@ __global__ __launch_bounds__(64 * MIXW) void mix_train_kernel(MixTrainArgs p) {
         const long oo = base + (long)i * a.M + m;
         const bool dead = a.amask[(long)r * a.na + i];
         for (int v = 0; v < nvar; ++v) {
-            const float x = act ? a.x_w1[v * a.s_var + oo] : 0.f;
-            const float w = mix_weight(x, act, a.softmax_w);
+            const float x = (act && !a.softmax_w) ? a.x_w1[v * a.s_var + oo] : 0.f;      // (abs weights: the sign of x)
+            const float w = wk[(i * 3 + v) * 64 + m];
             const float dpre = v == 0 ? dpre_r : dpre_i;
             const float q = a.qs[v * a.s_qs_g + qbase + i];
             const float dq = wave_sum(act ? dpre * w : 0.f);
@@ -848,7 +855,7 @@ int mix_train_launch(const MixArgs& live, const MixArgs& targ, const TdArgs& td,
     MixTrainArgs p;
     p.live = live; p.targ = targ; p.td = td; p.row_stats = row_stats;
     ProfScope prof("mix_train_kernel", 0.0, 0.0, st);
-    hipLaunchKernelGGL(mix_train_kernel, dim3(live.B * live.T1), dim3(64 * MIXW), 0, st, p);
+    hipLaunchKernelGGL(mix_train_kernel, dim3(live.B * live.T1), dim3(64 * MIXW), (size_t)live.na * 3 * 64 * sizeof(float), st, p);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
