@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--global-batch", type=int, default=64, help="episodes of the whole job under --scaling strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--top", type=int, default=10, help="kernels listed in the `kernels` array (by isolated time per step)")
     ap.add_argument("--batch", type=int, default=0, help="episodes per GPU instead of the config's")
     ap.add_argument("--serial", action="store_true", help="serialise the two chains on one stream for the whole run "
                     "(kernel-quality profiling: in-situ == isolated); the default overlaps them")
@@ -299,7 +300,7 @@ def main():
         _lib.lib().refil_set_overlap(0 if a.serial else -1)
         ents.sort(key=lambda e: -(iso.get(e["name"], e)["total_ms"]))       # by the kernel's own (isolated) cost
         kernels = []
-        for e in ents[:10]:
+        for e in ents[:max(a.top, 1)]:
             k = {"name": e["name"], "launches_per_step": e["launches"] // nprof, "ms_per_step": round(e["total_ms"] / nprof, 4),
                  "avg_us": round(1e3 * e["total_ms"] / e["launches"], 2),
                  "tflops": round(e["flops"] / (e["total_ms"] * 1e-3) / 1e12, 2) if e["flops"] > 0 else None}

@@ -49,6 +49,15 @@ __device__ inline int tile_steps(const GruK& p, int r0) {
     return min(tend, p.T1);
 }
 
+// Global accesses of the step loops: scalar (SGPR) base + 32-bit byte offset per lane -- one instruction per access
+// instead of a 64-bit multiply-add chain in front of each (the launchers check that the tensors stay below 4 GiB).
+__device__ inline float ldg32(const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ inline void stg32(float* base, unsigned byte_off, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
 template <bool SAVE, int GH>
 __global__ __launch_bounds__(4 * GH) void gru_fwd_kernel(GruK2 p2) {
     constexpr int HP = GH + 4, KQ = GH / 4;                // KQ: reduction indices per lane group
@@ -85,24 +94,36 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd_kernel(GruK2 p2) {
         hold[reg] = valid[reg] ? p.hsx[hs_base[reg] * GH + c] : 0.f;
         hbuf[0][(4 * q + reg) * HP + c] = hold[reg];
     }
-    float gcur[4][3], gnext[4][3] = {};
+    // byte offsets of this lane's four rows at step 0: gi [.., 3 GH], the saved gates [.., GH], hsx [.., GH] (slot t+1);
+    // rows past the end alias row 0 of the tensor (loaded, never stored: a row's recurrence depends on that row only)
+    unsigned go[4], so[4], ho[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        go[reg] = (unsigned)((gi_base[reg] * (3 * GH) + c) * sizeof(float));
+        so[reg] = (unsigned)((gi_base[reg] * GH + c) * sizeof(float));
+        ho[reg] = (unsigned)(((hs_base[reg] + p.na) * GH + c) * sizeof(float));
+    }
+    const unsigned gi_step = (unsigned)(p.na * 3 * GH * sizeof(float)), row_step = (unsigned)(p.na * GH * sizeof(float));
+    float gcur[4][3], gnext[4][3];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
-            gcur[reg][g] = valid[reg] ? p.gi[gi_base[reg] * (3 * GH) + g * GH + c] : 0.f;
+        for (int g = 0; g < 3; ++g) gcur[reg][g] = ldg32(p.gi, go[reg] + g * GH * (unsigned)sizeof(float));
     __syncthreads();
 
     for (int t = 0; t < tend; ++t) {
         const float* hb = hbuf[t & 1];
         float* hn = hbuf[(t + 1) & 1];
-        if (t + 1 < tend) {
+        {   // next step's gi (the last step re-reads its own: no branch around the loads)
+            const unsigned adv = t + 1 < tend ? gi_step : 0u;
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
+            for (int reg = 0; reg < 4; ++reg) {
+                go[reg] += adv;
 #pragma unroll
-                for (int g = 0; g < 3; ++g)
-                    gnext[reg][g] = valid[reg] ? p.gi[(gi_base[reg] + (long)(t + 1) * p.na) * (3 * GH) + g * GH + c] : 0.f;
+                for (int g = 0; g < 3; ++g) gnext[reg][g] = ldg32(p.gi, go[reg] + g * GH * (unsigned)sizeof(float));
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);                 // the loads are ISSUED here: they need the whole step to arrive
         float a[KQ];
 #pragma unroll
         for (int s4 = 0; s4 < KQ / 4; ++s4) {
@@ -140,12 +161,13 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd_kernel(GruK2 p2) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             if (valid[reg]) {
-                p.hsx[(hs_base[reg] + (long)(t + 1) * p.na) * GH + c] = hold[reg];
+                stg32(p.hsx, ho[reg], hold[reg]);
                 if (save) {
-                    const long o = (gi_base[reg] + (long)t * p.na) * GH + c;
-                    p.save_r[o] = rgv[reg]; p.save_z[o] = zgv[reg]; p.save_n[o] = ngv[reg]; p.save_ghn[o] = ghv[reg];
+                    stg32(p.save_r, so[reg], rgv[reg]); stg32(p.save_z, so[reg], zgv[reg]);
+                    stg32(p.save_n, so[reg], ngv[reg]); stg32(p.save_ghn, so[reg], ghv[reg]);
                 }
             }
+            ho[reg] += row_step; so[reg] += row_step;
         }
         __syncthreads();
     }
@@ -187,23 +209,24 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd_kernel(GruK p) {
     float cur[4][6];
     // (rows past the end read row r0's values instead of branching around the loads: nothing of theirs is stored, and a
     // row's recurrence depends on nothing but that row)
-    long go[4], ho[4];
+    unsigned go[4], ho[4], so[4];      // byte offsets at step 0: [.., GH] tensors, hsx (slot t), dgi / dgh [.., 3 GH]
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-        go[reg] = (valid[reg] ? gi_base[reg] : gi_base[0]) * GH + c;
-        ho[reg] = (valid[reg] ? hs_base[reg] : hs_base[0]) * GH + c;
+        go[reg] = (unsigned)((gi_base[reg] * GH + c) * sizeof(float));
+        ho[reg] = (unsigned)((hs_base[reg] * GH + c) * sizeof(float));
+        so[reg] = (unsigned)((gi_base[reg] * (3 * GH) + c) * sizeof(float));
     }
-    const long row_step = (long)p.na * GH;
+    const unsigned row_step = (unsigned)(p.na * GH * sizeof(float));
     auto fetch = [&](float (&dst)[4][6], int t) __attribute__((always_inline)) {
+        const unsigned adv = (unsigned)t * row_step;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const long o = go[reg] + t * row_step;
-            dst[reg][0] = p.dhs[o];
-            dst[reg][1] = p.save_r[o];
-            dst[reg][2] = p.save_z[o];
-            dst[reg][3] = p.save_n[o];
-            dst[reg][4] = p.save_ghn[o];
-            dst[reg][5] = p.hsx[ho[reg] + t * row_step];
+            dst[reg][0] = ldg32(p.dhs, go[reg] + adv);
+            dst[reg][1] = ldg32(p.save_r, go[reg] + adv);
+            dst[reg][2] = ldg32(p.save_z, go[reg] + adv);
+            dst[reg][3] = ldg32(p.save_n, go[reg] + adv);
+            dst[reg][4] = ldg32(p.save_ghn, go[reg] + adv);
+            dst[reg][5] = ldg32(p.hsx, ho[reg] + adv);
         }
     };
     // steps the episode's loss cannot reach (t >= tend): exact zeros, what the full recurrence would have produced
@@ -229,6 +252,7 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd_kernel(GruK p) {
         float* gb_w = gbuf[it & 1];
         ++it;
         fetch(issue, max(t - 2, 0));                       // (unconditional: a branch here costs register copies and waits)
+        __builtin_amdgcn_sched_barrier(0);                 // the loads are ISSUED here, ahead of the step's arithmetic
         float dhz[4], sv[4][4];
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
@@ -279,9 +303,10 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd_kernel(GruK p) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             if (valid[reg]) {
-                const long o = (gi_base[reg] + (long)t * p.na) * (3 * GH) + c;
-                p.dgi[o] = sv[reg][0]; p.dgi[o + GH] = sv[reg][1]; p.dgi[o + 2 * GH] = sv[reg][2];
-                p.dgh[o] = sv[reg][0]; p.dgh[o + GH] = sv[reg][1]; p.dgh[o + 2 * GH] = sv[reg][3];
+                constexpr unsigned G1 = GH * sizeof(float);
+                const unsigned o = so[reg] + 3u * (unsigned)t * row_step;
+                stg32(p.dgi, o, sv[reg][0]); stg32(p.dgi, o + G1, sv[reg][1]); stg32(p.dgi, o + 2 * G1, sv[reg][2]);
+                stg32(p.dgh, o, sv[reg][0]); stg32(p.dgh, o + G1, sv[reg][1]); stg32(p.dgh, o + 2 * G1, sv[reg][3]);
             }
         }
     };
@@ -311,6 +336,8 @@ int gru_forward_launch2(const refil_gru_desc& d, const refil_gru_desc* second, h
         REFIL_CHECK(second->H == d.H, "refil_gru: the two recurrences of one launch need the same hidden size");
     }
     const int GH = d.H;
+    REFIL_CHECK((double)d.NR * (d.T1 + 1) * 3 * GH * sizeof(float) < 4.0e9 && (!second || (double)second->NR * (second->T1 + 1) * 3 * GH * sizeof(float) < 4.0e9),
+                "refil_gru: NR * T1 too large for the 32-bit offsets of the recurrence kernels (split the batch)");
     GruK2 k;
     k.a = gru_k(d); k.b = second ? gru_k(*second) : k.a;
     k.nblk0 = cdiv(d.NR, GROWS);
@@ -331,6 +358,7 @@ int gru_forward_launch(const refil_gru_desc& d, hipStream_t st) { return gru_for
 int gru_backward_launch(const refil_gru_desc& d, hipStream_t st) {
     REFIL_CHECK(d.H == 32 || d.H == 64 || d.H == 128, "refil_gru: rnn_hidden_dim must be 32, 64 or 128 (got %d)", d.H);
     const int GH = d.H;
+    REFIL_CHECK((double)d.NR * (d.T1 + 1) * 3 * GH * sizeof(float) < 4.0e9, "refil_gru: NR * T1 too large for the 32-bit offsets of the recurrence kernels (split the batch)");
     REFIL_CHECK(d.hsx && d.w_hh && d.save_r && d.save_z && d.save_n && d.save_ghn && d.dhs && d.dgi && d.dgh,
                 "refil_gru_backward: null pointer");
     REFIL_CHECK(d.NR > 0 && d.T1 > 0 && d.na > 0, "refil_gru_backward: bad sizes");
