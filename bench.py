@@ -13,9 +13,14 @@ summed over all GPUs); --scaling strong fixes the GLOBAL batch (--global-batch, 
 Prints ONE JSON line (rank 0). Extra objects:
   roofline     -- the kernel symbol with the largest isolated GPU time per step, timed with HIP events on the launch
                   stream by the library's profiler right after the timed region (events are kept out of the timed
-                  region itself so they cannot perturb `value`); achieved = FLOPs the kernel executes per launch
-                  (the rows that can influence the loss: the library skips the others) / mean launch duration;
-                  peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).
+                  region itself so they cannot perturb `value`). bound = "hbm" for the attention cores / recurrences /
+                  mixing kernels (below the 19.7 FLOP/B ridge): achieved = algorithmic bytes per launch (operands read
+                  once, results written once, rows of live steps) / mean launch duration against 8 TB/s; bound = "mfma"
+                  for the projections: achieved = FLOPs the kernel executes per launch (the rows that can influence the
+                  loss: the library skips the others) / mean launch duration against 157.3 TFLOP/s (fp32 MFMA,
+                  MI355X_MICROARCH.md). traffic = HBM bytes per launch from a rocprofv3 PMC pass of THIS build handed in
+                  with --traffic-json (tools/collect_profiles.sh), else null. heaviest_gemm = the same for the GEMM
+                  kernel with the largest isolated time (the matrix-core evidence when the dominant kernel is HBM-bound).
   cpu_baseline -- oracle/refil_oracle.py (a fixture-pinned CPU port of the reference learner) timed on this box's host
                   cores on a bounded sample of the same workload (N=1, rank 0 only).
 """
