@@ -310,7 +310,7 @@ struct SideStream {
     // reductions) of each chain are forked onto their own stream as soon as their operands exist instead of sitting
     // in the chain's launch order in front of the dX GEMMs that ARE on the critical path.
     hipStream_t g[2] = {nullptr, nullptr};
-    hipEvent_t pool[32] = {};
+    hipEvent_t pool[128] = {};
     int next_ev = 0;
     bool ok = false;
 };
@@ -354,7 +354,7 @@ static void side_stream_rejoin(SideStream* sd, hipStream_t main) {
 static int stream_after(SideStream* sd, hipStream_t from, hipStream_t to) {
     if (from == to || !sd) return 0;
     hipEvent_t e = sd->pool[sd->next_ev];
-    sd->next_ev = (sd->next_ev + 1) % 32;
+    sd->next_ev = (sd->next_ev + 1) % 128;
     REFIL_HIP(hipEventRecord(e, from));
     REFIL_HIP(hipStreamWaitEvent(to, e, 0));
     return 0;
@@ -1187,10 +1187,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     if (overlap) {                                                                 // join: hypernet chain, both weight-gradient streams
         REFIL_HIP(hipEventRecord(sd->ev[3], sd->s));
         REFIL_HIP(hipStreamWaitEvent(c.st, sd->ev[3], 0));
-        for (int i = 0; i < 2; ++i) {
-            REFIL_HIP(hipEventRecord(sd->pool[i], sd->g[i]));
-            REFIL_HIP(hipStreamWaitEvent(c.st, sd->pool[i], 0));
-        }
+        for (int i = 0; i < 2; ++i) RUN(stream_after(sd, sd->g[i], c.st));
     }
     return 0;
 }

@@ -77,6 +77,8 @@ class QLearner:
                     n *= s
                 named[name].grad = g[off:off + n].view(*shape)
         self._bits_host = None
+        self._bits_dev = None
+        self._graphs = {}
         self._buckets = None
         self._flat_ready = True
 
@@ -108,9 +110,13 @@ class QLearner:
         self._bits_slot = (self._bits_slot + 1) % len(self._bits_host)
         ev.synchronize()                       # no-op unless the copy issued 16 steps ago is still pending
         host.copy_(bits)
-        dev = host.to(device, non_blocking=True)
+        # one device buffer per shape, reused by every step (stream order protects it): a fixed address, so that a
+        # captured step (REFIL_HIPGRAPH=1) finds the partition where it was at capture time
+        if self._bits_dev is None or self._bits_dev.shape != bits.shape or self._bits_dev.device != th.device(device):
+            self._bits_dev = th.empty(bits.shape, dtype=th.uint8, device=device)
+        self._bits_dev.copy_(host, non_blocking=True)
         ev.record()
-        return dev
+        return self._bits_dev
 
     def _fields(self, batch):
         names = ["entities", "obs_mask", "entity_mask", "actions", "avail_actions", "reward", "terminated", "filled"]
@@ -155,11 +161,13 @@ class QLearner:
             with self._buckets:
                 self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads)
             self._buckets.finish()
+            self._optimiser_step()
+        elif os.environ.get("REFIL_HIPGRAPH") == "1" and group_bits is None:
+            self._graphed_step(dims, fields, bits)
         else:
             self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads)
             dp.allreduce_sum_(self.grads)
-        self._engine.clip_rmsprop(self.flat_live, self.grads, self.square_avg, self._n, args.lr, args.optim_alpha,
-                                  args.optim_eps, args.weight_decay, args.grad_norm_clip)
+            self._optimiser_step()
         self._step_count += 1
 
         if (episode_num - self.last_target_update_episode) / args.target_update_interval >= 1.0:
@@ -185,6 +193,47 @@ class QLearner:
             self.logger.log_stat("q_taken_mean", st[_lib.STAT_QTOT_SUM] / (msum * args.n_agents), t_env)    # :194 quirk kept
             self.logger.log_stat("target_mean", st[_lib.STAT_TARGET_SUM] / (msum * args.n_agents), t_env)
             self.log_stats_t = t_env
+
+    def _optimiser_step(self):
+        a = self.args
+        self._engine.clip_rmsprop(self.flat_live, self.grads, self.square_avg, self._n, a.lr, a.optim_alpha, a.optim_eps,
+                                  a.weight_decay, a.grad_norm_clip)
+
+    def _graphed_step(self, dims, fields, bits):
+        """REFIL_HIPGRAPH=1: the ~95 launches of a step (four streams, fork / join by events, no allocation, no host
+        sync) are captured into a hipGraph the second time a (shapes, buffer addresses) combination is seen and replayed
+        afterwards -- one launch per step. Single process: forward + backward + optimiser in one graph; data parallel:
+        forward + backward only (the all-reduce and the optimiser stay eager). The batch tensors must keep their
+        addresses (ReplayBuffer's device staging batch does); the kernels' grid sizes are frozen at the row counts of the
+        captured step, which is safe (they loop over the device-side counts) but tuned for that batch."""
+        if os.environ.get("REFIL_GRADSTREAM") != "0":
+            # measured on ROCm 7.2: ending the capture of the four-stream schedule (weight-gradient streams that also carry
+            # the forward's mask-word kernels) crashes inside hipStreamEndCapture; the two-stream schedule captures fine
+            raise RuntimeError("REFIL_HIPGRAPH=1 needs REFIL_GRADSTREAM=0 (two-stream schedule) on this ROCm release")
+        key = (bytes(dims), tuple((k, v.data_ptr(), v.stride(0), v.stride(1)) for k, v in sorted(fields.items())),
+               0 if bits is None else bits.data_ptr(), dp.world())
+        ent = self._graphs.get(key)
+        fused = dp.world() == 1
+
+        def body():
+            self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads)
+            if fused:
+                self._optimiser_step()
+
+        if ent is None:                         # first sight: eager (lazy initialisation inside the library happens here)
+            self._graphs[key] = ent = {"graph": None}
+            body()
+        elif ent["graph"] is None:
+            g = th.cuda.CUDAGraph()
+            with th.cuda.graph(g):
+                body()
+            ent["graph"] = g
+            g.replay()
+        else:
+            ent["graph"].replay()
+        if not fused:
+            dp.allreduce_sum_(self.grads)
+            self._optimiser_step()
 
     def _gt_ingroup_prop(self, dims, fields, B, T1):
         """Log-step-only diagnostic of refil_group_matching (q_learner.py:98-105,143-147): imagine with the
