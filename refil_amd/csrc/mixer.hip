@@ -25,6 +25,21 @@ __device__ inline float wave_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
+// the same over each 32-lane half of the wave separately (HALF) or over the whole wave
+template <bool HALF>
+__device__ inline float grp_sum(float v) {
+    v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+    v += __shfl_xor(v, 16, 64);
+    if (!HALF) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+template <bool HALF>
+__device__ inline float grp_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v)); v = fmaxf(v, dpp_mov<0x4E>(v)); v = fmaxf(v, dpp_mov<0x141>(v)); v = fmaxf(v, dpp_mov<0x140>(v));
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    if (!HALF) v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
 
 // ------------------------------------------------------------------------------------------------
 // prep: entities || one-hot(previous action)  (entity_controller.py:13-27 == q_learner.py:50-60)
@@ -389,11 +404,12 @@ struct MixRow {
     float b1, wf, wf_raw, v, pre_r, hid_r, pre_i, hid_i;
 };
 
+template <bool HALF = false>
 __device__ inline float mix_weight(float x, bool act, int softmax_w) {
     if (softmax_w) {
-        const float mx = wave_max(act ? x : -INFINITY);
+        const float mx = grp_max<HALF>(act ? x : -INFINITY);
         const float e = act ? expf(x - mx) : 0.f;
-        const float s = wave_sum(e);
+        const float s = grp_sum<HALF>(e);
         return e / s;
     }
     return act ? fabsf(x) : 0.f;
@@ -409,43 +425,51 @@ __device__ inline float nonlin_grad(float pre, float hid, int tanh_nl) {
 // two streams, i.e. directly on the critical path). Partial sums are combined through LDS.
 constexpr int MIXW = 4;
 
-// wkeep (optional, LDS [na][3][64]): the mixing weights, wkeep[(i * 3 + v) * 64 + m] for agent i and mask variant v -- the
-// backward pass of the same row reuses them instead of repeating the softmax reductions (written and read by the same lane)
-__device__ inline MixRow mix_row_forward(const MixArgs& a, long base, long qbase, int m, bool act, int wave,
+// wkeep (optional, LDS [na][3][64]): the mixing weights, wkeep[(i * 3 + v) * 64 + lane] for agent i and mask variant v -- the
+// backward pass of the same row reuses them instead of repeating the softmax reductions (written and read by the same lane).
+// HALF (mixing_embed_dim <= 32): the two 32-lane halves of a wave take different agents (lane = 32 half + m), so the chain of
+// dependent per-agent reductions is half as long; every lane still ends up with the row's totals of its unit m.
+template <bool HALF = false>
+__device__ inline MixRow mix_row_forward(const MixArgs& a, long base, long qbase, int lane, int wave,
                                          float (*red)[5][64], float* wkeep = nullptr) {
+    const int m = HALF ? (lane & 31) : lane, half = HALF ? (lane >> 5) : 0;
+    const bool act = m < a.M;
     float acc_r = 0.f, acc_i = 0.f, b1 = 0.f, wfr = 0.f, vs = 0.f;
-    for (int i = wave; i < a.na; i += MIXW) {
+    for (int i = HALF ? 2 * wave + half : wave; i < a.na; i += HALF ? 2 * MIXW : MIXW) {
         const long o_im = base + (long)i * a.M + m;
         const float x0 = act ? a.x_w1[o_im] : 0.f;
-        const float w0 = mix_weight(x0, act, a.softmax_w);
-        if (wkeep) wkeep[(i * 3 + 0) * 64 + m] = w0;
+        const float w0 = mix_weight<HALF>(x0, act, a.softmax_w);
+        if (wkeep) wkeep[(i * 3 + 0) * 64 + lane] = w0;
         acc_r = fmaf(a.qs[qbase + i], w0, acc_r);
         if (a.imagine) {
             const float xw = act ? a.x_w1[a.s_var + o_im] : 0.f;
             const float xi = act ? a.x_w1[2 * a.s_var + o_im] : 0.f;
-            const float ww = mix_weight(xw, act, a.softmax_w), wi = mix_weight(xi, act, a.softmax_w);
-            if (wkeep) { wkeep[(i * 3 + 1) * 64 + m] = ww; wkeep[(i * 3 + 2) * 64 + m] = wi; }
+            const float ww = mix_weight<HALF>(xw, act, a.softmax_w), wi = mix_weight<HALF>(xi, act, a.softmax_w);
+            if (wkeep) { wkeep[(i * 3 + 1) * 64 + lane] = ww; wkeep[(i * 3 + 2) * 64 + lane] = wi; }
             acc_i = fmaf(a.qs[a.s_qs_g + qbase + i], ww, acc_i);
             acc_i = fmaf(a.qs[2 * a.s_qs_g + qbase + i], wi, acc_i);
         }
         if (act && !a.presum) { b1 += a.x_b1[o_im]; wfr += a.x_wf[o_im]; vs += a.x_v[o_im]; }
     }
-    if (a.presum && act && wave == 0) {          // already summed over the active agents: row rr of [R, M]
+    if (a.presum && act && wave == 0 && half == 0) {          // already summed over the active agents: row rr of [R, M]
         const long o_m = base / a.na + m;
         b1 = a.x_b1[o_m]; wfr = a.x_wf[o_m]; vs = a.x_v[o_m];
     }
-    red[wave][0][m] = acc_r; red[wave][1][m] = acc_i; red[wave][2][m] = b1; red[wave][3][m] = wfr; red[wave][4][m] = vs;
+    red[wave][0][lane] = acc_r; red[wave][1][lane] = acc_i; red[wave][2][lane] = b1; red[wave][3][lane] = wfr; red[wave][4][lane] = vs;
     __syncthreads();
     acc_r = acc_i = b1 = wfr = vs = 0.f;
 #pragma unroll
     for (int w = 0; w < MIXW; ++w) {
         acc_r += red[w][0][m]; acc_i += red[w][1][m]; b1 += red[w][2][m]; wfr += red[w][3][m]; vs += red[w][4][m];
+        if (HALF) {
+            acc_r += red[w][0][m + 32]; acc_i += red[w][1][m + 32]; b1 += red[w][2][m + 32]; wfr += red[w][3][m + 32]; vs += red[w][4][m + 32];
+        }
     }
     MixRow o;
     o.b1 = b1 / (float)a.na;
     o.wf_raw = wfr / (float)a.na;
-    o.wf = mix_weight(o.wf_raw, act, a.softmax_w);
-    o.v = wave_sum(vs) / (float)(a.na * a.M);
+    o.wf = mix_weight<HALF>(o.wf_raw, act, a.softmax_w);
+    o.v = grp_sum<HALF>(vs) / (float)(a.na * a.M);
     o.pre_r = acc_r + o.b1;
     o.hid_r = nonlin(o.pre_r, a.tanh_nl);
     o.pre_i = acc_i + o.b1;
@@ -466,7 +490,7 @@ __global__ __launch_bounds__(64 * MIXW) void mix_fwd_kernel(MixArgs a) {
     }
     const long base = rr * a.na * a.M;
     const long qbase = (long)bt * a.na;
-    const MixRow o = mix_row_forward(a, base, qbase, m, act, wave, red);
+    const MixRow o = mix_row_forward(a, base, qbase, m, wave, red);
     if (wave != 0) return;
     const float qt = wave_sum(act ? o.hid_r * o.wf : 0.f) + o.v;
     if (m == 0) a.q_tot[bt] = qt;
@@ -506,7 +530,7 @@ __global__ __launch_bounds__(64 * MIXW) void mix_bwd_kernel(MixArgs a) {
     const int bt = b * a.T + t;
     const long qbase = (long)bt * a.na;
     const long BTn = (long)a.B * a.T * a.na;
-    const MixRow o = mix_row_forward(a, base, qbase, m, act, wave, red);
+    const MixRow o = mix_row_forward(a, base, qbase, m, wave, red);
     const float g_r = a.gc_real[bt];
     const float g_i = a.imagine ? a.gc_im[bt] : 0.f;
     // q_tot = sum_m hid*wf + v
@@ -555,6 +579,7 @@ __global__ __launch_bounds__(64 * MIXW) void mix_bwd_kernel(MixArgs a) {
 // Same arithmetic, in the same order, as mix_fwd_kernel / td_loss_kernel / mix_bwd_kernel.
 struct MixTrainArgs { MixArgs live, targ; TdArgs td; float* row_stats; };
 
+template <bool HALF>
 __global__ __launch_bounds__(64 * MIXW) void mix_train_kernel(MixTrainArgs p) {
     __shared__ float red[MIXW][5][64];
     extern __shared__ float wk[];                          // [na][3][64] mixing weights of the live mix
@@ -562,8 +587,10 @@ __global__ __launch_bounds__(64 * MIXW) void mix_train_kernel(MixTrainArgs p) {
     const TdArgs& d = p.td;
     const int r = blockIdx.x;
     const int b = r / a.T1, tt = r % a.T1;
-    const int m = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = HALF ? (lane & 31) : lane, half = HALF ? (lane >> 5) : 0;     // HALF: see mix_row_forward
     const bool act = m < a.M;
+    const int i0 = HALF ? 2 * wave + half : wave, istep = HALF ? 2 * MIXW : MIXW;   // this lane group's agents
     const long base = (long)r * a.na * a.M;
     const int nvar = a.imagine ? 3 : 1;
     const bool skipped = a.t_last && tt > a.t_last[b];
@@ -571,7 +598,7 @@ __global__ __launch_bounds__(64 * MIXW) void mix_train_kernel(MixTrainArgs p) {
     if (tt >= a.T || skipped) {                            // no loss term: exact-zero gradients (see mix_bwd_kernel)
         if (tt < a.T) {
             if (m == 0)
-                for (int i = wave; i < a.na; i += MIXW)
+                for (int i = i0; i < a.na; i += istep)
                     for (int v = 0; v < nvar; ++v) a.dqs[(long)v * a.B * a.T * a.na + (long)bt * a.na + i] = 0.f;
             if (threadIdx.x == 0) {
                 a.q_tot[bt] = 0.f;
@@ -584,26 +611,26 @@ __global__ __launch_bounds__(64 * MIXW) void mix_train_kernel(MixTrainArgs p) {
             if (threadIdx.x < 8) p.row_stats[(long)bt * 8 + threadIdx.x] = 0.f;
         }
         if (act) {
-            for (int i = wave; i < a.na; i += MIXW) {
+            for (int i = i0; i < a.na; i += istep) {
                 const long o = base + (long)i * a.M + m;
                 for (int v = 0; v < nvar; ++v) a.dx_w1[v * a.s_var + o] = 0.f;
                 if (!a.presum) { a.dx_wf[o] = 0.f; a.dx_b1[o] = 0.f; a.dx_v[o] = 0.f; }
             }
-            if (a.presum && wave == 0) { const long o = (long)r * a.M + m; a.dx_wf[o] = 0.f; a.dx_b1[o] = 0.f; a.dx_v[o] = 0.f; }
+            if (a.presum && wave == 0 && half == 0) { const long o = (long)r * a.M + m; a.dx_wf[o] = 0.f; a.dx_b1[o] = 0.f; a.dx_v[o] = 0.f; }
         }
         return;
     }
     const long qbase = (long)bt * a.na;
     const long BTn = (long)a.B * a.T * a.na;
-    const MixRow o = mix_row_forward(a, base, qbase, m, act, wave, red, wk);
-    const float qt = wave_sum(act ? o.hid_r * o.wf : 0.f) + o.v;
-    const float qi = a.imagine ? wave_sum(act ? o.hid_i * o.wf : 0.f) + o.v : 0.f;
+    const MixRow o = mix_row_forward<HALF>(a, base, qbase, lane, wave, red, wk);
+    const float qt = grp_sum<HALF>(act ? o.hid_r * o.wf : 0.f) + o.v;
+    const float qi = a.imagine ? grp_sum<HALF>(act ? o.hid_i * o.wf : 0.f) + o.v : 0.f;
     // target mixer on step tt+1 (q_learner.py:154); a step nothing upstream computed enters as 0 (it has mask 0)
     float tq = 0.f;
     if (!(a.t_last && tt + 1 > a.t_last[b])) {             // (uniform)
         __syncthreads();                                   // `red` is reused
-        const MixRow ot = mix_row_forward(p.targ, base + (long)a.na * a.M, qbase, m, act, wave, red);
-        tq = wave_sum(act ? ot.hid_r * ot.wf : 0.f) + ot.v;
+        const MixRow ot = mix_row_forward<HALF>(p.targ, base + (long)a.na * a.M, qbase, lane, wave, red);
+        tq = grp_sum<HALF>(act ? ot.hid_r * ot.wf : 0.f) + ot.v;
     }
     // TD error of (b,tt) (q_learner.py:68-72,157-172)
     float mask = (float)d.filled[b * d.fl_sB + tt * d.fl_sT];
@@ -631,7 +658,7 @@ __global__ __launch_bounds__(64 * MIXW) void mix_train_kernel(MixTrainArgs p) {
     const float dwf = g_r * o.hid_r + g_i * o.hid_i;
     float dwf_raw;
     if (a.softmax_w) {
-        const float dot = wave_sum(act ? o.wf * dwf : 0.f);
+        const float dot = grp_sum<HALF>(act ? o.wf * dwf : 0.f);
         dwf_raw = o.wf * (dwf - dot);
     } else {
         dwf_raw = sgn(o.wf_raw) * dwf;
@@ -640,15 +667,15 @@ __global__ __launch_bounds__(64 * MIXW) void mix_train_kernel(MixTrainArgs p) {
     const float dpre_r = g_r * o.wf * nonlin_grad(o.pre_r, o.hid_r, a.tanh_nl);
     const float dpre_i = g_i * o.wf * nonlin_grad(o.pre_i, o.hid_i, a.tanh_nl);
     const float db1 = (dpre_r + dpre_i) / (float)a.na;
-    for (int i = wave; i < a.na; i += MIXW) {
+    for (int i = i0; i < a.na; i += istep) {
         const long oo = base + (long)i * a.M + m;
         const bool dead = a.amask[(long)r * a.na + i];
         for (int v = 0; v < nvar; ++v) {
             const float x = (act && !a.softmax_w) ? a.x_w1[v * a.s_var + oo] : 0.f;      // (abs weights: the sign of x)
-            const float w = wk[(i * 3 + v) * 64 + m];
+            const float w = wk[(i * 3 + v) * 64 + lane];
             const float dpre = v == 0 ? dpre_r : dpre_i;
             const float q = a.qs[v * a.s_qs_g + qbase + i];
-            const float dq = wave_sum(act ? dpre * w : 0.f);
+            const float dq = grp_sum<HALF>(act ? dpre * w : 0.f);
             if (m == 0) a.dqs[(long)v * BTn + qbase + i] = dq;
             const float dw = q * dpre;
             const float dx = a.softmax_w ? w * (dw - q * dq) : sgn(x) * dw;
@@ -660,7 +687,7 @@ __global__ __launch_bounds__(64 * MIXW) void mix_train_kernel(MixTrainArgs p) {
             a.dx_v[oo] = dead ? 0.f : dv;
         }
     }
-    if (a.presum && act && wave == 0) {
+    if (a.presum && act && wave == 0 && half == 0) {
         const long oo = (long)r * a.M + m;
         a.dx_wf[oo] = dwf_raw; a.dx_b1[oo] = db1; a.dx_v[oo] = dv;
     }
@@ -855,7 +882,9 @@ int mix_train_launch(const MixArgs& live, const MixArgs& targ, const TdArgs& td,
     MixTrainArgs p;
     p.live = live; p.targ = targ; p.td = td; p.row_stats = row_stats;
     ProfScope prof("mix_train_kernel", 0.0, 0.0, st);
-    hipLaunchKernelGGL(mix_train_kernel, dim3(live.B * live.T1), dim3(64 * MIXW), (size_t)live.na * 3 * 64 * sizeof(float), st, p);
+    const size_t smem = (size_t)live.na * 3 * 64 * sizeof(float);
+    if (live.M <= 32) hipLaunchKernelGGL(mix_train_kernel<true>, dim3(live.B * live.T1), dim3(64 * MIXW), smem, st, p);
+    else hipLaunchKernelGGL(mix_train_kernel<false>, dim3(live.B * live.T1), dim3(64 * MIXW), smem, st, p);
     REFIL_LAUNCH_CHECK();
     return 0;
 }

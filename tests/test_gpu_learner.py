@@ -374,7 +374,7 @@ def test_gt_factor_diagnostics_match_reference(name):
     assert abs(ing2.item() / (B * T) - float(z["stat.ingroup_prop"])) < 1e-5
 
 
-@pytest.mark.parametrize("what", ["ff_lin_noimagine", "tanh_abs", "ne48_cfg5", "long_T150", "vdn_atten", "rnn32", "rnn128", "nomixer"])
+@pytest.mark.parametrize("what", ["ff_lin_noimagine", "tanh_abs", "ne48_cfg5", "long_T150", "vdn_atten", "rnn32", "rnn128", "nomixer", "mix64"])
 def test_config_matrix_matches_oracle(what):
     """The remaining shipped alg/shape combinations (src/config/algs/*.yaml, BASELINE.json configs[3..4]):
     qmix_atten_group_matching (FF agent + linear mixer, no imagination), tanh/abs mixing, the 48-entity MMM shape,
@@ -394,6 +394,8 @@ def test_config_matrix_matches_oracle(what):
         cfgkw = dict(mixer_vdn=True, imagine=False)
     elif what in ("rnn32", "rnn128"):
         cfgkw = dict(rnn_hidden_dim=int(what[3:]))
+    elif what == "mix64":       # mixing_embed_dim > 32: one agent per wave in the fused mixing kernel
+        cfgkw = dict(mixing_embed_dim=64)
     elif what == "nomixer":     # args.mixer = None: per-agent TD loss (q_learner.py:131 not taken; oracle-pinned only, the
         cfgkw = dict(mixer_none=True, imagine=False)      # reference's own train() raises at :81 without a mixer)
     law = sc2_shape_law(kw["ne"])
