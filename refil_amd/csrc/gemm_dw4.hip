@@ -275,7 +275,7 @@ bool gemm_dw4_eligible(const refil_gemm_desc& d) {
     // Measured on MI355X (cfg-T shapes): the big wave tiles win when the output is large enough to give every CU a
     // workgroup with a long row range (the four hypernets' in_trans / fc1 gradients: 181 -> 119, 70 -> 52, 96 -> 70 us);
     // small outputs (agent nets, GRU, thin tails) are faster on the 2 x 2-tile streaming kernel / the LDS-tiled one.
-    static const long min_out = [] { const char* e = getenv("REFIL_DW4_MIN_OUT"); return e ? atol(e) : 40000L; }();
+    static const long min_out = [] { const char* e = getenv("REFIL_DW4_MIN_OUT"); return e ? atol(e) : 30000L; }();
     if ((long)d.batch * d.M * d.N < min_out) return false;
     int ti, tj, wmt;
     dw4_shape(d.M, d.N, ti, tj, wmt);
@@ -301,7 +301,8 @@ int gemm_dw4_splits(int M, int N, int batch, long R) {
     int ti, tj, wmt;
     dw4_shape(M, N, ti, tj, wmt);
     const long tiles = (long)cdiv(M, 32 * ti * wmt) * cdiv(N, 32 * tj) * batch;
-    static const long target = [] { const char* e = getenv("REFIL_DW4_TARGET"); return e ? atol(e) : 256L; }();
+    // (swept with the step's four streams running, tools/sweep.sh: 128 workgroups beat one per CU by 1 % of the step, 64 lose 5 %)
+    static const long target = [] { const char* e = getenv("REFIL_DW4_TARGET"); return e ? atol(e) : 128L; }();
     long splits = max(2L, target / tiles);
     splits = min(splits, max(2L, R / 512));          // >= 512 rows per workgroup: the LDS reduction + partial tile are amortised
     return (int)splits;

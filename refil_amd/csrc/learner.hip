@@ -278,7 +278,10 @@ static refil_gemm_desc linear_dw(const float* dy, int lddy, const float* x, int 
     }
     const int bn = K > 64 ? 128 : (K > 32 ? 64 : 32);
     const long tiles = (long)cdiv(N, 128) * cdiv(K, bn) * batch;
-    static const long target = [] { const char* e = getenv("REFIL_DW_TARGET"); return e ? atol(e) : 1024L; }();
+    // workgroups a streamed weight-gradient launch aims for. Swept on one box with the step's four streams running
+    // (tools/sweep.sh): 512 beats 1024 and 256 -- these launches share the GPU with three other streams, and fewer splits
+    // mean less partial traffic and a shorter reduction
+    static const long target = [] { const char* e = getenv("REFIL_DW_TARGET"); return e ? atol(e) : 512L; }();
     long splits = target / tiles;
     splits = min(splits, cdivl(R, N <= 64 ? 128 : 256));      // thin layers run narrow tiles: more, shorter splits
     splits = max(splits, 1L);
