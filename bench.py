@@ -297,11 +297,15 @@ def main():
         # second pass with the two streams serialised: every kernel alone on the GPU (kernel quality). These
         # are the durations rocprofv3 --kernel-trace reports for the same steps (and for a whole `--serial` run)
         _lib.lib().refil_set_overlap(0)
-        _lib.profile_enable(True)
-        for i in range(nprof):
-            step(a.warmup + a.steps + nprof + i)
-        iso = {e["name"]: e for e in _lib.profile_collect()}
-        _lib.profile_enable(False)
+        iso = {}
+        for rep in range(2):          # two passes, the faster one per kernel: a one-off stall (seen once: 4 ms inside one launch
+            _lib.profile_enable(True)   # of ten) must not decide which kernel is "dominant"
+            for i in range(nprof):
+                step(a.warmup + a.steps + (1 + rep) * nprof + i)
+            for e in _lib.profile_collect():
+                if e["name"] not in iso or e["total_ms"] < iso[e["name"]]["total_ms"]:
+                    iso[e["name"]] = e
+            _lib.profile_enable(False)
         _lib.lib().refil_set_overlap(0 if a.serial else -1)
         ents.sort(key=lambda e: -(iso.get(e["name"], e)["total_ms"]))       # by the kernel's own (isolated) cost
         kernels = []

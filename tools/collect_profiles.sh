@@ -29,6 +29,11 @@ rm -rf $OUT/${TAG}_stats $OUT/${TAG}_stats_serial $OUT/${TAG}_pmc_FETCH_SIZE $OU
 python bench.py --traffic-json $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_bench_cfgT.json 2> $OUT/${TAG}_bench_cfgT.err
 for c in cfg2 cfg3 cfg4 cfg5; do
     python bench.py --config $c > $OUT/${TAG}_bench_$c.json 2> $OUT/${TAG}_bench_$c.err
+    # per-config rocprofv3 summary with the chains serialised (each kernel alone on the GPU: the kernel's own duration)
+    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_$c -o p -- \
+        python $ROOT/bench.py --config $c --no-cpu-baseline --serial --steps 20 --warmup 5 > /dev/null 2>&1)
+    cp $(find $OUT/${TAG}_stats_$c -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${c}_kernel_stats_serial.csv
+    rm -rf $OUT/${TAG}_stats_$c
 done
 python bench.py --serial --no-cpu-baseline > $OUT/${TAG}_bench_cfgT_serial.json 2>/dev/null
 ls -la $OUT | grep ${TAG}_
