@@ -20,7 +20,8 @@ Prints ONE JSON line (rank 0). Extra objects:
                   loss: the library skips the others) / mean launch duration against 157.3 TFLOP/s (fp32 MFMA,
                   MI355X_MICROARCH.md). traffic = HBM bytes per launch from a rocprofv3 PMC pass of THIS build handed in
                   with --traffic-json (tools/collect_profiles.sh), else null. heaviest_gemm = the same for the GEMM
-                  kernel with the largest isolated time (the matrix-core evidence when the dominant kernel is HBM-bound).
+                  kernel that executes the most FLOPs per step (the matrix-core evidence when the dominant kernel is
+                  HBM-bound); every kernel's own rate is in kernels[] (tflops_isolated).
   cpu_baseline -- oracle/refil_oracle.py (a fixture-pinned CPU port of the reference learner) timed on this box's host
                   cores on a bounded sample of the same workload (N=1, rank 0 only).
 """
@@ -341,7 +342,8 @@ def main():
             ach_iso = dom_iso["flops"] / (dom_iso["total_ms"] * 1e-3) / 1e12
             ach_situ = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
             peak, unit = PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
-        gemm = next((e for e in ents if e["name"].startswith("gemm_") and e["flops"] > 0), None)     # the heaviest projection kernel as well
+        # the projection kernel that executes the most FLOPs per step as well (matrix-core evidence when the dominant kernel is HBM-bound)
+        gemm = max((e for e in ents if e["name"].startswith("gemm_") and e["flops"] > 0), key=lambda e: iso.get(e["name"], e)["flops"], default=None)
         gemm_iso = iso.get(gemm["name"], gemm) if gemm else None
         roofline = {"kernel": dom["name"], "bound": "hbm" if hbm_bound else "mfma", "achieved": round(ach_iso, 2), "peak": peak,
                     "unit": unit, "frac": round(ach_iso / peak, 4), "traffic": traffic,
