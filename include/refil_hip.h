@@ -355,6 +355,8 @@ typedef struct refil_gru_desc {
     /* optional: t_last[b] for b = gb % B -- the recurrence of episode b stops after step t_last[b] (forward: later
      * hsx / save slots are left untouched; backward: starts there and writes zeros to dgi / dgh of the later steps). */
     const int32_t* t_last; int32_t B;
+    int32_t zero_h0;         /* forward: 1 = the initial hidden state is zero (BasicMAC.init_hidden, basic_controller.py:41-42):
+                              * the kernel writes slot 0 of hsx itself instead of reading it                           */
 } refil_gru_desc;
 
 int refil_gru_forward(const refil_gru_desc* desc, void* stream);

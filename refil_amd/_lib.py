@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librefil_hip.so")
+# REFIL_LIB_PATH: load another build of the library (A/B runs of two builds on one GPU box, tools/ab.sh)
+LIB_PATH = os.environ.get("REFIL_LIB_PATH") or os.path.join(_HERE, "librefil_hip.so")
 
 REFIL_NSTAT = 8
 STAT_MASK_SUM, STAT_TD_SQ, STAT_IM_TD_SQ, STAT_TD_ABS, STAT_QTOT_SUM, STAT_TARGET_SUM, STAT_GRAD_NORM, STAT_INGROUP_SUM = range(8)
@@ -98,7 +99,7 @@ class GruDesc(C.Structure):
         ("save_r", C.c_void_p), ("save_z", C.c_void_p), ("save_n", C.c_void_p), ("save_ghn", C.c_void_p),
         ("dhs", C.c_void_p), ("dgi", C.c_void_p), ("dgh", C.c_void_p),
         ("NR", C.c_int32), ("T1", C.c_int32), ("na", C.c_int32), ("H", C.c_int32),
-        ("t_last", C.c_void_p), ("B", C.c_int32),
+        ("t_last", C.c_void_p), ("B", C.c_int32), ("zero_h0", C.c_int32),
     ]
 
 

@@ -35,6 +35,7 @@ struct GruK {
     const float* dhs; float* dgi; float* dgh;
     int NR, T1, na;
     const int* t_last; int B;     // optional: episode b = gb % B only needs steps t <= t_last[b]
+    int zero_h0;                  // forward: h_0 = 0, slot 0 of hsx is written here (no separate fill launch)
 };
 // two independent recurrences (the live and the target agent's) in ONE launch: the first nblk0 workgroups run `a`,
 // the others `b` -- the two 100 us latency chains overlap instead of queueing behind each other
@@ -91,7 +92,8 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd_kernel(GruK2 p2) {
         const int gb = valid[reg] ? rr / p.na : 0, i = valid[reg] ? rr % p.na : 0;
         gi_base[reg] = (long)gb * p.T1 * p.na + i;
         hs_base[reg] = (long)gb * (p.T1 + 1) * p.na + i;
-        hold[reg] = valid[reg] ? p.hsx[hs_base[reg] * GH + c] : 0.f;
+        hold[reg] = (valid[reg] && !p.zero_h0) ? p.hsx[hs_base[reg] * GH + c] : 0.f;
+        if (valid[reg] && p.zero_h0) p.hsx[hs_base[reg] * GH + c] = 0.f;      // (the backward and the weight gradients read h_{-1} from slot 0)
         hbuf[0][(4 * q + reg) * HP + c] = hold[reg];
     }
     // byte offsets of this lane's four rows at step 0: gi [.., 3 GH], the saved gates [.., GH], hsx [.., GH] (slot t+1);
@@ -325,7 +327,7 @@ static int gru_check_fwd(const refil_gru_desc& d) {
     return 0;
 }
 static GruK gru_k(const refil_gru_desc& d) {
-    return GruK{d.gi, d.hsx, d.w_hh, d.b_hh, d.save_r, d.save_z, d.save_n, d.save_ghn, d.dhs, d.dgi, d.dgh, d.NR, d.T1, d.na, d.t_last, d.B};
+    return GruK{d.gi, d.hsx, d.w_hh, d.b_hh, d.save_r, d.save_z, d.save_n, d.save_ghn, d.dhs, d.dgi, d.dgh, d.NR, d.T1, d.na, d.t_last, d.B, d.zero_h0};
 }
 
 // `second` (may be NULL): another, independent recurrence run by the same launch

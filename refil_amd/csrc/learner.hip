@@ -470,7 +470,7 @@ static refil_attn_desc attn_base(const Ctx& c, int w) {
 // ------------------------------------------------------------------------------------------------
 enum { AG_PRE = 1, AG_GRU = 2, AG_POST = 4, AG_ALL = 7 };
 
-static refil_gru_desc agent_gru_desc(const Ctx& c, const float* P, const AgentBufs& b, int G) {
+static refil_gru_desc agent_gru_desc(const Ctx& c, const float* P, const AgentBufs& b, int G, bool zero_h0 = false) {
     const refil_dims& d = c.d;
     refil_gru_desc g;
     memset(&g, 0, sizeof(g));
@@ -478,6 +478,7 @@ static refil_gru_desc agent_gru_desc(const Ctx& c, const float* P, const AgentBu
     g.save_r = b.sr; g.save_z = b.sz; g.save_n = b.sn; g.save_ghn = b.sg;
     g.NR = G * d.B * d.na; g.T1 = d.T1; g.na = d.na; g.H = d.H;
     if (c.lists) { g.t_last = c.w.t_last; g.B = d.B; }
+    g.zero_h0 = zero_h0 ? 1 : 0;
     return g;
 }
 
@@ -557,10 +558,10 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
         if (c.compose_agent) g = with_rows(g, c, rows_t(c, G));       // (x3 exists on the listed rows only)
         RUN(gemm_launch(g, c.st));
     }
-    RUN(set_h0_launch(b.hsx, h0, G * d.B, d.T1, d.na, H, c.st));
+    if (h0 || d.agent_ff) RUN(set_h0_launch(b.hsx, h0, G * d.B, d.T1, d.na, H, c.st));      // (h0 = NULL: the recurrence kernel zero-fills slot 0)
     }   // AG_PRE
     if (d.agent_ff) return 0;
-    if (phases & AG_GRU) RUN(gru_forward_launch(agent_gru_desc(c, P, b, G), c.st));
+    if (phases & AG_GRU) RUN(gru_forward_launch(agent_gru_desc(c, P, b, G, h0 == nullptr), c.st));
     // q = fc3(h), zero for inactive agents                            :57-60
     if (phases & AG_POST) {
         refil_gemm_desc g = linear(b.hsx, H, P + L.ag_fc3_w, H, P + L.ag_fc3_b, b.qv, d.A, (long)G * s.NA, d.A, H, 0);
@@ -960,7 +961,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         // one stream: the two recurrences share one launch
         RUN(agent_forward(ca, params_live, w.la, G, nullptr, AG_PRE));
         RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_PRE));
-        const refil_gru_desc gl = agent_gru_desc(ca, params_live, w.la, G), gt = agent_gru_desc(ca, params_target, w.ta, 1);
+        const refil_gru_desc gl = agent_gru_desc(ca, params_live, w.la, G, true), gt = agent_gru_desc(ca, params_target, w.ta, 1, true);
         RUN(gru_forward_launch2(gl, &gt, ca.st));
         RUN(agent_forward(ca, params_live, w.la, G, nullptr, AG_POST));
         RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_POST));
