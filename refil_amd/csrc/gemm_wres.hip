@@ -42,7 +42,11 @@ struct WresK {
                                             // padded to whole 32-row tiles with the index of a scratch row
 };
 
-constexpr int WR_WAVES = 8;
+// waves per workgroup. Swept with the step's four streams running (tools/sweep.sh, builds selected with REFIL_LIB_PATH):
+// 4 waves beat 8 by 1.2 % of the step (2: +22 %, 3 / 6: +7 %, 16: +40 %) -- one wave per SIMD keeps the matrix pipe fed
+// because the x rows stream straight into the operand registers, and the smaller epilogue slabs (18 instead of 37 KB of
+// LDS) leave room for an attention workgroup of the other chain on the same CU
+constexpr int WR_WAVES = 4;
 constexpr int WR_SLAB_P = 36;      // floats per row of the 32 x 32 epilogue slab
 
 __device__ inline float4 keep_if(bool in, float4 v) {
