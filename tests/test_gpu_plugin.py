@@ -278,6 +278,38 @@ def test_qlearner_without_mixer(tmp_path):
     learner.load_models(str(tmp_path))
 
 
+def test_long_trajectory_tracks_oracle():
+    """40 consecutive train() calls on one batch (RMSprop state carried, hard target syncs every 7 episodes, a fresh
+    partition every call): the HIP learner stays on the oracle's trajectory -- errors of single steps must not
+    accumulate into a different optimisation path (tools/soak_test.py runs the long unattended version)."""
+    g, args, batch, mac, learner, logger = _build("refil_abs_masked", target_update_interval=7)
+    cfg, z = g["cfg"], g["z"]
+    agent = {k[len("agent0."):]: th.from_numpy(z[k]).clone() for k in z.files if k.startswith("agent0.")}
+    mixer = {k[len("mixer0."):]: th.from_numpy(z[k]).clone() for k in z.files if k.startswith("mixer0.")}
+    tagent = {k[len("tagent."):]: th.from_numpy(z[k]).clone() for k in z.files if k.startswith("tagent.")}
+    tmixer = {k[len("tmixer."):]: th.from_numpy(z[k]).clone() for k in z.files if k.startswith("tmixer.")}
+    sq = {}
+    B, ne = g["batch"]["entities"].shape[0], cfg.n_entities
+    gen = th.Generator().manual_seed(77)
+    last_sync = 0
+    for ep in range(40):
+        bits = orc.draw_partition_bits(B, ne, generator=gen)
+        out, _, gnorm = orc.train_step(cfg, agent, mixer, tagent, tmixer, g["batch"], bits, square_avg=sq)
+        learner.train(batch, t_env=ep, episode_num=ep, group_bits=bits)
+        if (ep - last_sync) / 7 >= 1.0:                    # q_learner.py:180-182
+            tagent = {k: v.detach().clone() for k, v in agent.items()}
+            tmixer = {k: v.detach().clone() for k, v in mixer.items()}
+            last_sync = ep
+        if ep % 10 == 9 or ep == 39:
+            th.cuda.synchronize()
+            ref = out.loss.item()
+            assert abs(logger.stats["loss"] - ref) < 2e-3 * max(abs(ref), 1e-3), (ep, logger.stats["loss"], ref)
+            assert abs(logger.stats["grad_norm"] - gnorm) < 5e-3 * gnorm, (ep, logger.stats["grad_norm"], gnorm)
+    sd = mac.agent.state_dict()
+    worst = max((sd[k].cpu() - agent[k]).abs().max().item() for k in agent)
+    assert worst < 2e-4, worst
+
+
 def test_target_update_copies_flat_buffer():
     g, args, batch, mac, learner, logger = _build("refil_tiny", target_update_interval=1)
     th.manual_seed(1)
