@@ -20,7 +20,7 @@ class MultinomialActionSelector:
         self.epsilon = self.schedule.eval(t_env)
         if test_mode and self.test_greedy:
             return policies.max(dim=2)[1]
-        return Categorical(policies).sample().long()
+        return Categorical(policies, validate_args=False).sample().long()     # (same draw; the argument checks cost ~0.1 ms per env step)
 
 
 class EpsilonGreedyActionSelector:
@@ -33,7 +33,7 @@ class EpsilonGreedyActionSelector:
         self.epsilon = 0.0 if test_mode else self.schedule.eval(t_env)
         q = agent_inputs.masked_fill(avail_actions == 0, -float("inf"))      # never pick an unavailable action
         explore = (th.rand_like(agent_inputs[:, :, 0]) < self.epsilon).long()
-        random_actions = Categorical(avail_actions.float()).sample().long()
+        random_actions = Categorical(avail_actions.float(), validate_args=False).sample().long()     # (same draw, no argument checks)
         return explore * random_actions + (1 - explore) * q.max(dim=2)[1]
 
 

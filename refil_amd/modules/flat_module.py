@@ -29,11 +29,16 @@ class FlatParamModule(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = None if k in ("_engine", "_flat") else copy.deepcopy(v, memo)
+            new.__dict__[k] = None if k in ("_engine", "_flat", "_named_cache") else copy.deepcopy(v, memo)
         return new
 
     def _named(self):
-        return dict(self.named_parameters())
+        # (name -> Parameter) is walked once per module instance: the Parameter objects are stable, only their .data moves
+        named = self.__dict__.get("_named_cache")
+        if named is None:
+            named = dict(self.named_parameters())
+            object.__setattr__(self, "_named_cache", named)
+        return named
 
     def _is_flat(self) -> bool:
         flat = getattr(self, "_flat", None)
