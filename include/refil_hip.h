@@ -168,6 +168,24 @@ int refil_learner_forward_backward(const refil_dims* dims, const refil_batch* ba
 typedef void (*refil_grads_hook)(void* user, void* stream);
 int refil_set_mixer_grads_hook(refil_grads_hook hook, void* user);
 
+/* One-shot all-reduce(SUM) over peer memory for the step's small [gradients | stats] message (replaces the ring
+ * all-reduce torch.distributed issues for q_learner.py:176's gradients under data parallelism):
+ * every rank stages its buffer in IPC-exported device memory, signals a flag, and sums all ranks' staged buffers in rank
+ * order (identical results on every rank) -- one hop over the point-to-point xGMI links instead of 2 (N-1).
+ *   create   allocates two staging buffers + a flag word and writes their three IPC handles to handles_out
+ *            [3][REFIL_IPC_HANDLE_BYTES]; the caller exchanges them between the ranks (any side channel);
+ *   connect  takes every rank's handles [world][3][REFIL_IPC_HANDLE_BYTES] (own entry ignored) and maps the peers;
+ *   allreduce  in place on `inout` (n_floats of create), stream-ordered, no host synchronisation; every rank must call it
+ *            the same number of times. A peer that does not arrive within 10 s sets the status word (refil_oneshot_status)
+ *            instead of hanging the GPU.
+ * world <= 16. Needs HSA_ENABLE_IPC_MODE_LEGACY=0 where the driver only supports dmabuf IPC. */
+#define REFIL_IPC_HANDLE_BYTES 64
+int refil_oneshot_create(int32_t world, int32_t rank, int64_t n_floats, uint8_t* handles_out, void** ctx_out);
+int refil_oneshot_connect(void* ctx, const uint8_t* all_handles);
+int refil_oneshot_allreduce(void* ctx, float* inout, void* stream);
+int refil_oneshot_status(void* ctx, int32_t* timed_out);
+int refil_oneshot_destroy(void* ctx);
+
 /* Diagnostics (synchronises the stream): which rows the LAST refil_learner_forward_backward on this workspace / dims
  * actually processed. The step skips rows that cannot influence the loss -- entity rows no query can attend to, query rows
  * of inactive agents, steps after an episode's last loss-carrying step -- through device-side row lists (no host round

@@ -124,7 +124,9 @@ EXPORTS = [
     "refil_attn_backward", "refil_pool_forward", "refil_pool_backward", "refil_gru_forward", "refil_gru_backward", "refil_last_error", "refil_version",
     "refil_profile_enable", "refil_profile_collect", "refil_set_overlap", "refil_release_streams", "refil_replay_gather",
     "refil_learner_row_counts", "refil_attn_mask_words", "refil_set_mixer_grads_hook",
+    "refil_oneshot_create", "refil_oneshot_connect", "refil_oneshot_allreduce", "refil_oneshot_status", "refil_oneshot_destroy",
 ]
+IPC_HANDLE_BYTES = 64
 
 _lib = None
 
@@ -167,6 +169,11 @@ def lib():
     L.refil_gru_backward.argtypes = [C.POINTER(GruDesc), C.c_void_p]
     L.refil_set_overlap.argtypes = [C.c_int]
     L.refil_set_mixer_grads_hook.argtypes = [GRADS_HOOK, C.c_void_p]
+    L.refil_oneshot_create.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.refil_oneshot_connect.argtypes = [C.c_void_p, C.c_void_p]
+    L.refil_oneshot_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.refil_oneshot_status.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    L.refil_oneshot_destroy.argtypes = [C.c_void_p]
     L.refil_learner_row_counts.argtypes = [C.POINTER(Dims), C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.c_void_p]
     L.refil_replay_gather.argtypes = [C.POINTER(GatherField), C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
     L.refil_profile_enable.argtypes = [C.c_int]

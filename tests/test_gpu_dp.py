@@ -119,3 +119,72 @@ def test_bench_two_ranks_control_flow():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 64
     assert out["roofline"]["frac"] > 0 and out["value"] > 0
+
+
+def _oneshot_worker(rank, world, port, q):
+    import numpy as np
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from refil_amd import dp
+    th.cuda.set_device(0)
+    n = 433886                                               # the north-star buffer: 433878 gradients + 8 stat sums
+    ar = dp.OneShotAllReduce(n, th.device("cuda", 0))
+    worst = 0.0
+    for step in range(6):                                    # both staging buffers are reused several times
+        gen = th.Generator().manual_seed(1000 * step + rank)
+        x = th.randn(n, generator=gen)
+        ref = x.clone()
+        dist.all_reduce(ref, op=dist.ReduceOp.SUM)           # gloo, on the host
+        y = x.cuda()
+        ar(y)
+        worst = max(worst, (y.cpu() - ref).abs().max().item())
+        if step == 2:                                        # a straggler: the peers wait for its flag, they do not read early
+            if rank == 1:
+                import time
+                time.sleep(0.3)
+    th.cuda.synchronize()
+    timed_out = ar.timed_out()
+    # the dp entry point picks it up behind the environment switch
+    os.environ["REFIL_ALLREDUCE"] = "oneshot"
+    z = th.full((1000,), float(rank + 1), device="cuda")
+    dp.allreduce_sum_(z)
+    th.cuda.synchronize()
+    q.put((rank, worst, timed_out, z[0].item(), y.cpu().numpy()))
+    dist.barrier()
+    ar.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_oneshot_peer_allreduce_equals_dist_allreduce():
+    """refil_oneshot_* (REFIL_ALLREDUCE=oneshot): IPC handles exchanged once, every rank sums all ranks' staged buffers in
+    rank order. Two processes sharing the test box's one GPU: equals torch.distributed's all-reduce (to fp32 summation
+    order -- exactly, with two ranks), identical bits on both ranks, no timeout, staging buffers reused."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_oneshot_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=280) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r, worst, timed_out, z0, _ in res:
+        assert not timed_out, f"rank {r}: a peer's flag never arrived"
+        assert worst == 0.0, (r, worst)                      # a + b in the same order on both sides
+        assert z0 == 3.0
+    assert (res[0][4] == res[1][4]).all(), "ranks hold different sums"
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_learner_step_with_oneshot_allreduce():
+    """The whole QLearner.train step under REFIL_ALLREDUCE=oneshot: same parameters as with the backend's all-reduce."""
+    ref = _run(2)
+    one = _run(2, env={"REFIL_ALLREDUCE": "oneshot", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert (one[0][0] == one[1][0]).all(), "replicas diverged"
+    assert (one[0][0] == ref[0][0]).all(), "one-shot all-reduce changed the result"
+    for k in ("loss", "grad_norm"):
+        assert one[0][1][k] == ref[0][1][k], k
