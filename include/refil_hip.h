@@ -375,6 +375,8 @@ typedef struct refil_gru_desc {
     const int32_t* t_last; int32_t B;
     int32_t zero_h0;         /* forward: 1 = the initial hidden state is zero (BasicMAC.init_hidden, basic_controller.py:41-42):
                               * the kernel writes slot 0 of hsx itself instead of reading it                           */
+    const uint8_t* ever;     /* optional [B, na] (needs B): 0 = agent i of episode gb % B is never active, nothing downstream
+                              * reads its rows: neither fetched nor written (their hsx / gate / gradient rows stay untouched) */
 } refil_gru_desc;
 
 int refil_gru_forward(const refil_gru_desc* desc, void* stream);

@@ -99,7 +99,7 @@ class GruDesc(C.Structure):
         ("save_r", C.c_void_p), ("save_z", C.c_void_p), ("save_n", C.c_void_p), ("save_ghn", C.c_void_p),
         ("dhs", C.c_void_p), ("dgi", C.c_void_p), ("dgh", C.c_void_p),
         ("NR", C.c_int32), ("T1", C.c_int32), ("na", C.c_int32), ("H", C.c_int32),
-        ("t_last", C.c_void_p), ("B", C.c_int32), ("zero_h0", C.c_int32),
+        ("t_last", C.c_void_p), ("B", C.c_int32), ("zero_h0", C.c_int32), ("ever", C.c_void_p),
     ]
 
 

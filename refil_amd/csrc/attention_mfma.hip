@@ -105,15 +105,16 @@ template <int ROWS_PAD, int C4MAX>
 struct Stage {
     static constexpr int N = ROWS_PAD * C4MAX / 64;
     float4 v[N];
-    __device__ inline void load(const float* src, long row0, int rows, int ld, int col0, int hd, int lane) {
+    // dead: bit r set -> row r is not fetched at all (its producer skipped it; it enters as zeros). The lanes of such rows
+    // issue no load: with row lists more than half of the K / V rows of a step are dead, i.e. more than half of the traffic
+    __device__ inline void load(const float* src, long row0, int rows, int ld, int col0, int hd, int lane, unsigned long long dead = 0ull) {
         const int c4n = hd >> 2;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int idx = lane + 64 * i, r = idx / C4MAX, c4 = idx % C4MAX;
-            const bool ok = r < rows && c4 < c4n;
-            const float* p = src + (row0 + (ok ? r : 0)) * (long)ld + col0 + (ok ? c4 : 0) * 4;
-            const float4 t = *reinterpret_cast<const float4*>(p);
-            v[i] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = r < rows && c4 < c4n && !((dead >> r) & 1ull);
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) v[i] = *reinterpret_cast<const float4*>(src + (row0 + r) * (long)ld + col0 + c4 * 4);
         }
     }
     // dead: bit r set -> row r was not computed by its producer (it cannot influence the result): it enters as zeros,
@@ -334,6 +335,11 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
     // so lane group q takes the CONTIGUOUS channels 4 NCT q .. 4 NCT (q+1) - 1 of "its" K row (key 16 jt + l15) and of
     // "its" Q row (agent 16 at + l15): NCT 16-byte global loads per tile, already in operand layout.
     float4 kf[HDX ? NJT : 1][NCT], qf[HDX ? NAT : 1][NCT];
+    // precomputed mask words: the row's dead-row words are three scalar loads away, so the operand fetch can leave out the
+    // K / V / Q rows nobody computed (more than half of a step's entity rows with row lists) instead of loading and zeroing
+    // them. (In-kernel mask phase: the words are not known yet, everything is fetched.)
+    unsigned long long fk = 0ull, fq = 0ull;
+    if (p.mwords) { fk = p.rbits[3 * (long)r]; fq = p.rbits[3 * (long)r + 1]; }
     auto fetch = [&](int job) {
         const AttnNet& n = p.net[job / p.heads];
         const int head = job % p.heads;
@@ -341,22 +347,30 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt) {
                 const int key = 16 * jt + l15;
-                const float* src = n.K + ((long)r * p.ne + (key < p.ne ? key : 0)) * p.ldkv + head * hd + 4 * NCT * q;
+                const bool ok = key < p.ne && !((fk >> key) & 1ull);
+                const float* src = n.K + ((long)r * p.ne + key) * p.ldkv + head * hd + 4 * NCT * q;
 #pragma unroll
-                for (int u = 0; u < NCT; ++u) kf[HDX ? jt : 0][u] = *reinterpret_cast<const float4*>(src + 4 * u);
+                for (int u = 0; u < NCT; ++u) {
+                    kf[HDX ? jt : 0][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) kf[HDX ? jt : 0][u] = *reinterpret_cast<const float4*>(src + 4 * u);
+                }
             }
 #pragma unroll
             for (int at = 0; at < NAT; ++at) {
                 const int ag = 16 * at + l15;
-                const float* src = n.Q + ((long)r * p.na + (ag < p.na ? ag : 0)) * p.ldq + head * hd + 4 * NCT * q;
+                const bool ok = ag < p.na && !((fq >> ag) & 1ull);
+                const float* src = n.Q + ((long)r * p.na + ag) * p.ldq + head * hd + 4 * NCT * q;
 #pragma unroll
-                for (int u = 0; u < NCT; ++u) qf[HDX ? at : 0][u] = *reinterpret_cast<const float4*>(src + 4 * u);
+                for (int u = 0; u < NCT; ++u) {
+                    qf[HDX ? at : 0][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) qf[HDX ? at : 0][u] = *reinterpret_cast<const float4*>(src + 4 * u);
+                }
             }
         } else {
-            sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * hd, hd, lane);
-            sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane);
+            sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * hd, hd, lane, fq);
+            sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane, fk);
         }
-        sv.load(n.V, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane);
+        sv.load(n.V, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane, fk);
     };
     if (wave < njobs) fetch(wave);                         // the first job's operands are in flight during the mask phase
     const RowMasks rm = p.mwords ? mask_words_of(p, NAT * 16, r) : mask_phase(p, smem, NAT * 16, r, tid);
@@ -470,9 +484,9 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
         {
             Stage<NAT * 16, 4 * NCT> sq;
             Stage<NJT * 16, 4 * NCT> sk, sv;
-            sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * hd, hd, lane);
-            sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane);
-            sv.load(n.V, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane);
+            sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * hd, hd, lane, rm.qdw);       // (dead rows are not fetched)
+            sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane, rm.kdw);
+            sv.load(n.V, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane, rm.kdw);
             sq.store(Qs, hd, pd, lane, rm.qdw); sk.store(Ks, hd, pd, lane, rm.kdw); sv.store(Vs, hd, pd, lane, rm.kdw);
         }
         f32x4 dKt[NCT][NJT], dVt[NCT][NJT];     // [c 16ct+4q+reg][key 16jt+l15]
@@ -497,7 +511,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
             const long drow0 = n.bcast_do ? 0 : (long)r * p.na + 16 * at;
             const int dld = n.bcast_do ? 0 : p.ldo;
             const unsigned long long ddead = n.bcast_do ? 0ull : (rm.qdw >> (16 * at));
-            sd.load(dO0, drow0, na_t, dld, head * hd, hd, lane);
+            sd.load(dO0, drow0, na_t, dld, head * hd, hd, lane, ddead);
             f32x4 sn0[NJT];
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt) sn0[jt] = dot_tile(Qs, 16 * at, Ks, 16 * jt, hd, pd, l15, q);   // S[agent][key]
@@ -506,7 +520,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
             for (int ct = 0; ct < NCT; ++ct) dQt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int v = 0; v < n.nvar; ++v) {
                 sd.store(Ds, hd, pd, lane, ddead);
-                if (v + 1 < n.nvar) sd.load(dO0 + (v + 1) * p.sO, drow0, na_t, dld, head * hd, hd, lane);
+                if (v + 1 < n.nvar) sd.load(dO0 + (v + 1) * p.sO, drow0, na_t, dld, head * hd, hd, lane, ddead);
                 f32x4 pn[NJT];
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt)
@@ -557,7 +571,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const int c = 16 * ct + 4 * q;
-                if (agentT < p.na && c < hd)
+                if (agentT < p.na && c < hd && !((rm.qdw >> agentT) & 1ull))       // (rows of skipped agents: nobody reads them)
                     *reinterpret_cast<float4*>(n.dQ + ((long)r * p.na + agentT) * p.ldq + head * hd + c) =
                         make_float4(dQt[ct][0], dQt[ct][1], dQt[ct][2], dQt[ct][3]);
             }
@@ -567,7 +581,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
 #pragma unroll
             for (int jt = 0; jt < NJT; ++jt) {
                 const int key = 16 * jt + l15, c = 16 * ct + 4 * q;
-                if (key < p.ne && c < hd) {
+                if (key < p.ne && c < hd && !((rm.kdw >> key) & 1ull)) {               // (dead K / V rows: their gradients are exact zeros nobody reads)
                     const long off = ((long)r * p.ne + key) * p.ldkv + head * hd + c;
                     *reinterpret_cast<float4*>(n.dK + off) = make_float4(dKt[ct][jt][0], dKt[ct][jt][1], dKt[ct][jt][2], dKt[ct][jt][3]);
                     *reinterpret_cast<float4*>(n.dV + off) = make_float4(dVt[ct][jt][0], dVt[ct][jt][1], dVt[ct][jt][2], dVt[ct][jt][3]);

@@ -36,6 +36,7 @@ struct GruK {
     int NR, T1, na;
     const int* t_last; int B;     // optional: episode b = gb % B only needs steps t <= t_last[b]
     int zero_h0;                  // forward: h_0 = 0, slot 0 of hsx is written here (no separate fill launch)
+    const uint8_t* ever;          // optional [B, na]: rows of never-active agents move no data (loads alias row 0, no stores)
 };
 // two independent recurrences (the live and the target agent's) in ONE launch: the first nblk0 workgroups run `a`,
 // the others `b` -- the two 100 us latency chains overlap instead of queueing behind each other
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd_kernel(GruK2 p2) {
     for (int reg = 0; reg < 4; ++reg) {
         const int rr = r0 + 4 * q + reg;
         valid[reg] = rr < p.NR;
+        if (valid[reg] && p.ever) valid[reg] = p.ever[((rr / p.na) % p.B) * p.na + rr % p.na] != 0;      // (never-active agent: no traffic)
         const int gb = valid[reg] ? rr / p.na : 0, i = valid[reg] ? rr % p.na : 0;
         gi_base[reg] = (long)gb * p.T1 * p.na + i;
         hs_base[reg] = (long)gb * (p.T1 + 1) * p.na + i;
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd_kernel(GruK p) {
     for (int reg = 0; reg < 4; ++reg) {
         const int rr = r0 + 4 * q + reg;
         valid[reg] = rr < p.NR;
+        if (valid[reg] && p.ever) valid[reg] = p.ever[((rr / p.na) % p.B) * p.na + rr % p.na] != 0;      // (never-active agent: no traffic)
         const int gb = valid[reg] ? rr / p.na : 0, i = valid[reg] ? rr % p.na : 0;
         gi_base[reg] = (long)gb * p.T1 * p.na + i;
         hs_base[reg] = (long)gb * (p.T1 + 1) * p.na + i;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd_kernel(GruK p) {
         for (int idx = lane; idx < GROWS * (3 * GH / 4); idx += 64) {
             const int row = idx / (3 * GH / 4), c4 = idx % (3 * GH / 4);
             const int rr = r0 + row;
-            if (rr < p.NR) {
+            if (rr < p.NR && (!p.ever || p.ever[((rr / p.na) % p.B) * p.na + rr % p.na])) {
                 const long o = (((long)(rr / p.na) * p.T1 + t) * p.na + rr % p.na) * (3 * GH) + 4 * c4;
                 *reinterpret_cast<float4*>(p.dgi + o) = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(p.dgh + o) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -323,11 +326,11 @@ static int gru_check_fwd(const refil_gru_desc& d) {
     REFIL_CHECK(d.gi && d.hsx && d.w_hh && d.b_hh, "refil_gru_forward: null pointer");
     REFIL_CHECK(d.NR > 0 && d.T1 > 0 && d.na > 0, "refil_gru_forward: bad sizes");
     REFIL_CHECK(!d.save_r || (d.save_z && d.save_n && d.save_ghn), "refil_gru_forward: all four save buffers or none");
-    REFIL_CHECK(!d.t_last || d.B > 0, "refil_gru: t_last needs B");
+    REFIL_CHECK((!d.t_last && !d.ever) || d.B > 0, "refil_gru: t_last / ever need B");
     return 0;
 }
 static GruK gru_k(const refil_gru_desc& d) {
-    return GruK{d.gi, d.hsx, d.w_hh, d.b_hh, d.save_r, d.save_z, d.save_n, d.save_ghn, d.dhs, d.dgi, d.dgh, d.NR, d.T1, d.na, d.t_last, d.B, d.zero_h0};
+    return GruK{d.gi, d.hsx, d.w_hh, d.b_hh, d.save_r, d.save_z, d.save_n, d.save_ghn, d.dhs, d.dgi, d.dgh, d.NR, d.T1, d.na, d.t_last, d.B, d.zero_h0, d.ever};
 }
 
 // `second` (may be NULL): another, independent recurrence run by the same launch
@@ -364,7 +367,7 @@ int gru_backward_launch(const refil_gru_desc& d, hipStream_t st) {
     REFIL_CHECK(d.hsx && d.w_hh && d.save_r && d.save_z && d.save_n && d.save_ghn && d.dhs && d.dgi && d.dgh,
                 "refil_gru_backward: null pointer");
     REFIL_CHECK(d.NR > 0 && d.T1 > 0 && d.na > 0, "refil_gru_backward: bad sizes");
-    REFIL_CHECK(!d.t_last || d.B > 0, "refil_gru: t_last needs B");
+    REFIL_CHECK((!d.t_last && !d.ever) || d.B > 0, "refil_gru: t_last / ever need B");
     GruK k = gru_k(d);
     ProfScope prof("gru_bwd_kernel", 2.0 * d.NR * d.T1 * GH * 3 * GH, 4.0 * d.NR * d.T1 * GH * 12.0, st);
     if (GH == 32) hipLaunchKernelGGL(gru_bwd_kernel<32>, dim3(cdiv(d.NR, GROWS)), dim3(128), 0, st, k);

@@ -478,6 +478,7 @@ static refil_gru_desc agent_gru_desc(const Ctx& c, const float* P, const AgentBu
     g.save_r = b.sr; g.save_z = b.sz; g.save_n = b.sn; g.save_ghn = b.sg;
     g.NR = G * d.B * d.na; g.T1 = d.T1; g.na = d.na; g.H = d.H;
     if (c.lists) { g.t_last = c.w.t_last; g.B = d.B; }
+    if (c.lists && c.compose_agent) g.ever = c.w.ever;     // (everything behind the recurrence runs on list_t: ever-active agents only)
     g.zero_h0 = zero_h0 ? 1 : 0;
     return g;
 }
@@ -1143,6 +1144,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
             g.save_r = w.la.sr; g.save_z = w.la.sz; g.save_n = w.la.sn; g.save_ghn = w.la.sg;
             g.dhs = w.dhs; g.dgi = w.dgi; g.dgh = w.dgh; g.NR = G * d.B * d.na; g.T1 = d.T1; g.na = d.na; g.H = H;
             if (c.lists) { g.t_last = w.t_last; g.B = d.B; }
+            if (c.lists && c.compose_agent) g.ever = w.ever;
             RUN(gru_backward_launch(g, ca.st));
             refil_gemm_desc ghh = linear_dw(w.dgh, 3 * H, w.la.hsx, H, grads + L.ag_w_hh, H, grads + L.ag_b_hh, rows, 3 * H, H, ca.w.partial, 1);
             ghh.b_map = hs_rows(c, 0);

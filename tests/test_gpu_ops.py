@@ -475,7 +475,8 @@ def test_gemm_row_list_rejected_by_the_tiled_kernel():
 
 
 def test_attention_row_skipping():
-    """t_last leaves the rows of finished episodes untouched; dead K/V and Q rows enter as zeros whatever they hold."""
+    """t_last leaves the rows of finished episodes untouched; dead K/V and Q rows enter as zeros whatever they hold, are not
+    fetched, and their gradient rows (exact zeros nobody reads) are not written."""
     import hip_ops
     torch.manual_seed(5)
     B, T1, ne, na, heads, hd = 3, 6, 32, 16, 4, 32
@@ -508,7 +509,11 @@ def test_attention_row_skipping():
         live_q = ~em[b, :tl + 1, :na].bool()
         assert torch.equal(O1[b, :tl + 1][live_q], O0[b, :tl + 1][live_q])
         assert torch.equal(dQ1[b, :tl + 1][live_q], dQ0[b, :tl + 1][live_q])
-        assert torch.equal(dK1[b, :tl + 1], dK0[b, :tl + 1])
+        live_k = ~em[b, :tl + 1].bool()
+        assert torch.equal(dK1[b, :tl + 1][live_k], dK0[b, :tl + 1][live_k])
+        assert (dK0[b, :tl + 1][~live_k] == 0).all()                   # what the dense schedule writes there ...
+        assert (dK1[b, :tl + 1][~live_k] == 5.0).all()                 # ... is left unwritten when the rows are declared dead
+        assert (dQ1[b, :tl + 1][~live_q] == 5.0).all()
         assert torch.isfinite(O1[b, :tl + 1]).all() and torch.isfinite(dK1[b, :tl + 1]).all()
         assert (O1[b, tl + 1:] == 5.0).all() and (dK1[b, tl + 1:] == 5.0).all() and (dQ1[b, tl + 1:] == 5.0).all()
 
