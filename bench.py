@@ -332,7 +332,20 @@ def main():
         # bytes of the rows they process; the attention launches skip finished steps: scaled by the live-step fraction.
         hbm_bound = dom["name"].split("<")[0] in ("attn_fwd_mfma", "attn_bwd_mfma", "attn_fwd_kernel", "attn_bwd_kernel", "gru_fwd_kernel",
                                                    "gru_bwd_kernel", "mix_fwd_kernel", "mix_bwd_kernel", "reduce_partials_kernel")
-        live = rows["live_steps"] / max(rows["steps"], 1) if dom["name"].startswith("attn_") else 1.0
+        live = 1.0
+        if dom["name"].startswith("attn_"):
+            # attention launches: the profiler's bytes are the dense (all rows) operand + result sizes. The kernels move data
+            # for the K / V rows and the query rows that can influence the loss only (row lists); one symbol covers the agent
+            # launch (1 net) and the hypernet launch (4 nets): K/V-side bytes scale with the listed entity rows, Q-side bytes
+            # with the active agent rows (fractions of the dense rows, finished steps included)
+            if rows["lists"]:
+                f_e = (rows["entity_rows_agent"] + 4.0 * rows["entity_rows_hyper"]) / (5.0 * max(rows["entity_rows"], 1))
+                f_a = rows["agent_rows"] / max(rows["all_agent_rows"], 1)
+                bwd = "bwd" in dom["name"]
+                w_e, w_a = (4.0 * dims["ne"], 3.0 * dims["na"]) if bwd else (2.0 * dims["ne"], 2.0 * dims["na"])
+                live = (w_e * f_e + w_a * f_a) / (w_e + w_a)
+            else:
+                live = rows["live_steps"] / max(rows["steps"], 1)
         if hbm_bound:
             per_launch = live * dom_iso["bytes"] / dom_iso["launches"]
             ach_iso = per_launch / (1e-3 * dom_iso["total_ms"] / dom_iso["launches"]) / 1e9
