@@ -333,8 +333,9 @@ typedef struct refil_attn_desc {
     const uint8_t* gt_mask;  int64_t gt_sB, gt_sT;    /* [B,T1,na,ne], for the *_GT* variants      */
     /* optional row skipping (all NULL: every row is processed). t_last[b]: rows of episode b with t > t_last[b] are
      * left untouched (forward and backward). kv_dead [R*ne] / q_dead [R*na]: rows of K,V / Q (and dO) whose producer
-     * skipped them; they are read as zeros whatever the buffers hold (a dead key must be masked in every variant, a dead
-     * query's output must be discarded by the caller). */
+     * skipped them; they enter as zeros whatever the buffers hold (with precomputed mask words they are not even fetched)
+     * and the backward leaves their dK / dV / dQ rows unwritten (a dead key must be masked in every variant, a dead
+     * query's output must be discarded by the caller: those gradient rows are exact zeros nobody may read). */
     const int32_t* t_last; const uint8_t* kv_dead; const uint8_t* q_dead;
     /* optional: the mask words of every row built ahead of the launch by refil_attn_mask_words (one 64-bit word per
      * (row, variant, agent), bit j = key j masked; agents padded to a multiple of 16) and three words per row (dead K/V
