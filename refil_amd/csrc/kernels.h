@@ -106,6 +106,7 @@ struct QSelBwdArgs {
     // optional: also d(hidden state) = dq W3 (W3 [A,H] row-major: fc3.weight). dq has one non-zero per row, so the product
     // is a scaled row of W3 -- written here instead of by a [rows x A] x [A x H] GEMM on the critical path
     const float* w3; float* dhs; int H;
+    const uint8_t* ever;   // optional [B, na]: rows of agents that are never active are not written (nothing reads them)
 };
 int qselect_bwd_launch(const QSelBwdArgs& a, hipStream_t st);
 

@@ -1123,8 +1123,9 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         QSelBwdArgs q;
         q.dchosen = w.dchosen; q.actions = c.b.actions; q.ac_sB = c.b.ac_sB; q.ac_sT = c.b.ac_sT; q.amask = w.amask;
         q.dq = w.dqva; q.G = G; q.B = d.B; q.T1 = d.T1; q.na = d.na; q.A = d.A;
-        q.w3 = nullptr; q.dhs = nullptr; q.H = 0;
+        q.w3 = nullptr; q.dhs = nullptr; q.H = 0; q.ever = nullptr;
         if (!d.agent_ff) { q.w3 = params_live + L.ag_fc3_w; q.dhs = w.dhs; q.H = H; }     // recurrent agent: + d(hidden) = dq W3
+        if (!d.agent_ff && c.lists && c.compose_agent) q.ever = w.ever;     // (the recurrence and the fc3 gradient read list_t rows only)
         RUN(qselect_bwd_launch(q, ca.st));
         const long rows = (long)G * s.NA;
         if (d.agent_ff) {

@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256) void qselect_bwd_hs_kernel(QSelBwdArgs a) {
         const int i = row % a.na;
         const long r = row / a.na;
         const int b = r / a.T1, t = r % a.T1;
+        if (a.ever && !a.ever[b * a.na + i]) continue;
         float v = 0.f;
         int act = -1;
         if (t < T && !a.amask[row]) {
