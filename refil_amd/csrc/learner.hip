@@ -468,7 +468,7 @@ static refil_attn_desc attn_base(const Ctx& c, int w) {
 // ------------------------------------------------------------------------------------------------
 // agent forward (entity_rnn_agent.py:31-64 with the G mask variants of :116-124)
 // ------------------------------------------------------------------------------------------------
-enum { AG_PRE = 1, AG_GRU = 2, AG_POST = 4, AG_ALL = 7 };
+enum { AG_PRE = 1, AG_GRU = 2, AG_POST = 4, AG_ALL = 7, AG_NO_ENTITY = 8 };     // AG_NO_ENTITY: fc1 .. attention core already done (agent_entity_dual)
 
 static refil_gru_desc agent_gru_desc(const Ctx& c, const float* P, const AgentBufs& b, int G, bool zero_h0 = false) {
     const refil_dims& d = c.d;
@@ -483,12 +483,55 @@ static refil_gru_desc agent_gru_desc(const Ctx& c, const float* P, const AgentBu
     return g;
 }
 
+// The entity-side layers (fc1, K/V and Q projections, attention core) of the LIVE and the TARGET agent as two-net launches:
+// same rows, same masks, different parameters and buffers (batch strides = pointer differences). Five launches instead of
+// ten on the agent chain, and twice the tiles per projection launch (learner steps on row lists).
+static int agent_entity_dual(const Ctx& c, const float* Pl, const float* Pt, const AgentBufs& bl, const AgentBufs& bt, int G) {
+    const refil_dims& d = c.d; const Sizes& s = c.s; const refil_param_layout& L = c.L;
+    const int dd = d.d;
+    const long dP = Pt - Pl;
+    {
+        refil_gemm_desc g = with_rows(linear(c.w.xe, s.Ep, Pl + L.ag_fc1_w, s.E, Pl + L.ag_fc1_b, bl.x1, dd, s.NE, dd, s.E, REFIL_GEMM_RELU), c, rows_ea(c));
+        g.batch = 2; g.sA = 0; g.sB = dP; g.sBias = dP; g.sC = bt.x1 - bl.x1;
+        RUN(gemm_launch(g, c.st));
+    }
+    {
+        refil_gemm_desc g = with_rows(linear(bl.x1, dd, Pl + L.ag_in_w + (long)dd * dd, dd, nullptr, bl.kv, 2 * dd, s.NE, 2 * dd, dd, 0), c, rows_ea(c));
+        g.batch = 2; g.sA = bt.x1 - bl.x1; g.sB = dP; g.sC = bt.kv - bl.kv;
+        RUN(gemm_launch(g, c.st));
+    }
+    {
+        refil_gemm_desc g = linear(bl.x1, dd, Pl + L.ag_in_w, dd, nullptr, bl.q, dd, s.NA, dd, dd, 0);
+        g.a_map = agent_rows(c);
+        g = with_rows(g, c, rows_a(c));
+        g.batch = 2; g.sA = bt.x1 - bl.x1; g.sB = dP; g.sC = bt.q - bl.q;
+        RUN(gemm_launch(g, c.st));
+    }
+    refil_attn_desc ad[2];
+    AttnNetOpts ao[2] = {AttnNetOpts{0, 0}, AttnNetOpts{0, 0}};
+    for (int n = 0; n < 2; ++n) {
+        const AgentBufs& b = n ? bt : bl;
+        refil_attn_desc a = attn_base(c, dd);
+        a.Q = b.q; a.K = b.kv; a.V = b.kv + dd; a.O = b.ao; a.sO = s.NA * dd;
+        a.nvar = n ? 1 : G; a.var[0] = REFIL_MASK_OBS;
+        a.var[1] = group_code(d, 0, true);
+        a.var[2] = group_code(d, 1, true);
+        attn_rows(c, a, false);
+        ad[n] = a;
+    }
+    RUN(stream_after(c.sd, c.mwst, c.st));
+    const int rc = attn_mfma_launch_multi(ad, ao, 2, false, c.st, nullptr, 1);      // inactive agents -> exact zeros
+    REFIL_CHECK(rc >= 0, "refil: agent attention shape not instantiated");
+    return rc;
+}
+
 // phases: AG_PRE everything up to the GRU input gates, AG_GRU the recurrence, AG_POST fc3 (the learner runs the live and
 // the target agent's recurrences in ONE launch between their PRE and POST parts)
 static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G, const float* h0, int phases = AG_ALL) {
     const refil_dims& d = c.d; const Sizes& s = c.s; const refil_param_layout& L = c.L;
     const int dd = d.d, H = d.H;
     if (phases & AG_PRE) {
+    if (!(phases & AG_NO_ENTITY)) {
     // x1 = relu(fc1(entities))                                       :38
     RUN(gemm_launch(with_rows(linear(c.w.xe, s.Ep, P + L.ag_fc1_w, s.E, P + L.ag_fc1_b, b.x1, dd, s.NE, dd, s.E, REFIL_GEMM_RELU), c, rows_ea(c)), c.st));
     if (d.pooling) {
@@ -523,6 +566,7 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
         } else RUN(attn_forward_launch(a, c.st));
     }
     }
+    }   // !AG_NO_ENTITY
     if (d.agent_ff) {
         // feed-forward agent (entity_ff_agent.py:40-52): x2 = relu(out_trans(attn)) (inactive agents zeroed), q = fc2(x2)
         refil_gemm_desc g = linear(b.ao, dd, P + L.ag_out_w, dd, P + L.ag_out_b, b.x2, dd, (long)G * s.NA, dd, dd, REFIL_GEMM_RELU);
@@ -963,8 +1007,12 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         RUN(stream_after(sd, ct.st, ca.st));
     } else if (!d.agent_ff && (G * d.B * d.na) % 16 == 0) {
         // one stream: the two recurrences share one launch
-        RUN(agent_forward(ca, params_live, w.la, G, nullptr, AG_PRE));
-        RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_PRE));
+        static const bool dual_env = [] { const char* e = getenv("REFIL_AGENT_DUAL"); return !(e && e[0] == '0'); }();
+        const bool dual = dual_env && c.lists && c.compose_agent && !d.pooling && attn_mfma_supported(d.ne, d.na, d.d / d.heads) &&
+                          (params_target - params_live) % 4 == 0;
+        if (dual) RUN(agent_entity_dual(ca, params_live, params_target, w.la, w.ta, G));
+        RUN(agent_forward(ca, params_live, w.la, G, nullptr, AG_PRE | (dual ? AG_NO_ENTITY : 0)));
+        RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_PRE | (dual ? AG_NO_ENTITY : 0)));
         const refil_gru_desc gl = agent_gru_desc(ca, params_live, w.la, G, true), gt = agent_gru_desc(ca, params_target, w.ta, 1, true);
         RUN(gru_forward_launch2(gl, &gt, ca.st));
         RUN(agent_forward(ca, params_live, w.la, G, nullptr, AG_POST));
