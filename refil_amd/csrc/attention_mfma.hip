@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
 }
 
 template <int NJT, int NAT, int NCT, bool HDX>
-__global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_mfma(AttnM p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, q = lane >> 4;
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(AttnM p) {
                 dKt[ct][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 dVt[ct][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-#pragma unroll
+#pragma unroll 1
         for (int at = 0; at < NAT; ++at) {
             const int agentT = 16 * at + l15;        // agent of this lane in the transposed orientation (dQ^T columns)
             const int agentN0 = 16 * at + 4 * q;     // first agent of this lane in the normal orientation
