@@ -520,6 +520,19 @@ static int agent_entity_dual(const Ctx& c, const float* Pl, const float* Pt, con
         ad[n] = a;
     }
     RUN(stream_after(c.sd, c.mwst, c.st));
+    // the two attention cores: one launch up to 16 entities (launch-bound shapes: cfg2 1.4 % faster), one launch per net
+    // above (a second job per wave lengthens every workgroup: cfg-T 1.6 % faster with two launches). REFIL_AGENT_DUAL=2 / 3
+    // force two launches / one
+    static const int dual_mode = [] { const char* e = getenv("REFIL_AGENT_DUAL"); return e ? atoi(e) : 1; }();
+    const bool split_attn = dual_mode == 2 || (dual_mode != 3 && d.ne > 16);
+    if (split_attn) {
+        for (int n = 0; n < 2; ++n) {
+            const int rc1 = attn_mfma_launch_ex(ad[n], false, c.st, 0, nullptr, 0, 1);
+            REFIL_CHECK(rc1 >= 0, "refil: agent attention shape not instantiated");
+            if (rc1) return rc1;
+        }
+        return 0;
+    }
     const int rc = attn_mfma_launch_multi(ad, ao, 2, false, c.st, nullptr, 1);      // inactive agents -> exact zeros
     REFIL_CHECK(rc >= 0, "refil: agent attention shape not instantiated");
     return rc;
