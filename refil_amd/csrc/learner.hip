@@ -949,21 +949,18 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     // so that the latency-bound kernels (the recurrences: <= 128 workgroups) always have GEMM trains of other chains beside them.
     Ctx ca = c;                       // live agent chain: caller's stream
     Ctx ch = c;                       // hypernet chain: side stream + its own split-K scratch
-    Ctx ct = c;                       // target agent (forward only)
     const bool overlap = overlap_enabled();
     ca.gpartial = w.partial; ch.gpartial = w.partial2;
     if (overlap) {
         RUN(side_stream(sd));
         sd->next_ev = 2;                                   // (pool[0..1]: the final joins of the two weight-gradient streams)
-        ch.st = sd->s; ch.gst = sd->s; ca.sd = ch.sd = ct.sd = sd;
+        ch.st = sd->s; ch.gst = sd->s; ca.sd = ch.sd = sd;
         static const bool gstreams = [] { const char* e = getenv("REFIL_GRADSTREAM"); return !(e && e[0] == '0'); }();
         if (gstreams) { ch.gst = sd->g[1]; ca.gst = sd->g[0]; }
-        // REFIL_FWD3=1: the target agent on its own stream (measured slower at cfg-T: 2.42 vs 2.37 ms -- three GEMM trains
-        // thrash each other's L2 more than the lone recurrence at the end of the forward costs)
-        static const bool fwd3 = [] { const char* e = getenv("REFIL_FWD3"); return e && e[0] == '1'; }();
+        // (the target agent on a third stream was measured slower: three GEMM trains thrash each other more than the lone
+        // recurrence at the end of the forward costs)
         static const bool mwside = [] { const char* e = getenv("REFIL_MW_SIDE"); return !(e && e[0] == '0'); }();
-        if (fwd3) ct.st = sd->g[0];
-        if (mwside || fwd3) { ca.mwst = ct.mwst = sd->g[0]; ch.mwst = sd->g[1]; }
+        if (mwside) { ca.mwst = sd->g[0]; ch.mwst = sd->g[1]; }
     }
     if (!c.lists) RUN(run_prep(c, 1, 3));
     else {
@@ -1006,20 +1003,14 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         }
     }
     RUN(stream_after(sd, c.st, ch.st));                    // fork: inputs assembled
-    RUN(stream_after(sd, c.st, ct.st));
     const bool hypernets = !d.mixer_vdn && !d.mixer_none;
     if (hypernets) {
         RUN(hyper_forward(ch, params_live, w.lh, nv0));                           // live mixer hypernets
         RUN(hyper_forward(ch, params_target, w.th, 1));                           // target mixer hypernets
     }
     if (overlap) REFIL_HIP(hipEventRecord(sd->ev[1], sd->s));
-    if (ct.st != ca.st) {
-        // live (q_learner.py:86-89 / 107) and target (:111-113) agents side by side on their own streams
-        RUN(agent_forward(ct, params_target, w.ta, 1, nullptr));
-        RUN(agent_forward(ca, params_live, w.la, G, nullptr));
-        RUN(stream_after(sd, ct.st, ca.st));
-    } else if (!d.agent_ff && (G * d.B * d.na) % 16 == 0) {
-        // one stream: the two recurrences share one launch
+    if (!d.agent_ff && (G * d.B * d.na) % 16 == 0) {
+        // live (q_learner.py:86-89 / 107) and target (:111-113) agents on one stream: their recurrences share one launch
         static const bool dual_env = [] { const char* e = getenv("REFIL_AGENT_DUAL"); return !(e && e[0] == '0'); }();
         const bool dual = dual_env && c.lists && c.compose_agent && !d.pooling && attn_mfma_supported(d.ne, d.na, d.d / d.heads) &&
                           (params_target - params_live) % 4 == 0;
