@@ -119,6 +119,7 @@ struct Work {
     float *dqva, *dhs, *dgi, *dgh, *dx3a, *dx2a, *daoa, *dqa, *dkva, *dx1a;
     float* partial;
     float* partial2;   // split-K scratch of the side (agent-chain) stream
+    float* partial3; float* partial4;   // split-K scratch of the chains' own streams (their last weight gradients)
     // row lists (kernels.h: ListArgs): rows that cannot influence the step are skipped
     int *t_last, *list_ea, *list_eh, *list_a, *counts, *lcnt, *loff;
     int *list_t, *list_t3, *list_h, *list_ht;      // agent-row lists of the layers behind the attention cores (kernels.h: ListArgs)
@@ -217,6 +218,8 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     w.dx1a = a.take<float>(s.NEa * d.d);
     w.partial = a.take<float>(PARTIAL_FLOATS);
     w.partial2 = a.take<float>(PARTIAL_FLOATS);
+    w.partial3 = a.take<float>(PARTIAL_FLOATS);
+    w.partial4 = a.take<float>(PARTIAL_FLOATS);
     w.t_last = a.take<int>(d.B);
     w.list_ea = a.take<int>(s.NE + 256); w.list_eh = a.take<int>(s.NE + 256); w.list_a = a.take<int>(s.NA + 256);
     w.counts = a.take<int>(8); w.lcnt = a.take<int>(4 * s.R); w.loff = a.take<int>(4 * (s.R + 1));
@@ -392,6 +395,10 @@ struct Ctx {
     bool mwords;       // the step's mask words are precomputed (learner steps on the matrix-core attention path)
     // weight-gradient stream of this chain (== st when the chains are serialised) and its split-reduction scratch
     hipStream_t gst; float* gpartial; SideStream* sd;
+    // The chain's LAST weight gradients (bit 0: the query projection's, bit 1: fc1's) run on the chain's own stream, which has
+    // nothing else left to do, beside the ones still queued on the weight-gradient stream; bit 2: the composed tail's
+    // parameter gradients are enqueued behind the in_trans gradient instead of in front of it
+    int tail_dw; float* tpartial;
     hipStream_t mwst;  // stream the step's mask words are built on (the chain waits for it right before its first attention launch)
 };
 
@@ -400,6 +407,11 @@ static int launch_dw(const Ctx& c, refil_gemm_desc g) {
     g.partial = c.gpartial;
     if (int e = stream_after(c.sd, c.st, c.gst)) return e;
     return gemm_launch(g, c.gst);
+}
+static int launch_dw_tail(const Ctx& c, refil_gemm_desc g, int bit) {
+    if (!(c.tail_dw & bit)) return launch_dw(c, g);
+    g.partial = c.tpartial;
+    return gemm_launch(g, c.st);
 }
 
 // List lengths of an earlier step, copied back asynchronously into pinned host memory (one slot per device): a HINT
@@ -832,7 +844,7 @@ static int attn_block_backward(const Ctx& c, const AttnBlockBwd& k) {
         refil_gemm_desc q = linear_dw(k.dq, w, k.x1, (int)ldx1, k.Gr + k.in_w, w, nullptr, s.NA, w, w, c.w.partial, k.nets);
         q.b_map = refil_rowmap{d.na, d.ne, 0};
         q.sA = s.NAa * w; q.sB = w; q.sC = k.in_w_stride;
-        RUN(launch_dw(c, with_rows(q, c, rows_a(c))));
+        if (!(c.tail_dw & 1)) RUN(launch_dw(c, with_rows(q, c, rows_a(c))));
     }
     // dx1 = relu'(x1) * (dKV W_kv + scatter(dQ W_q))
     {
@@ -843,6 +855,12 @@ static int attn_block_backward(const Ctx& c, const AttnBlockBwd& k) {
         q.aux = k.x1; q.c_map = refil_rowmap{d.na, d.ne, 0};
         q.batch = k.nets; q.sA = s.NAa * w; q.sB = k.in_w_stride; q.sC = w;
         RUN(gemm_launch(with_rows(q, c, rows_a(c)), c.st));
+    }
+    if (c.tail_dw & 1) {
+        refil_gemm_desc q = linear_dw(k.dq, w, k.x1, (int)ldx1, k.Gr + k.in_w, w, nullptr, s.NA, w, w, c.w.partial, k.nets);
+        q.b_map = refil_rowmap{d.na, d.ne, 0};
+        q.sA = s.NAa * w; q.sB = w; q.sC = k.in_w_stride;
+        RUN(launch_dw_tail(c, with_rows(q, c, rows_a(c)), 1));
     }
     return 0;
 }
@@ -857,7 +875,7 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
     REFIL_CHECK(dims && batch && ws, "refil: null dims/batch/workspace");
     if (int e = check_dims(*dims)) return e;
     c.d = *dims; c.s = sizes_of(*dims); c.b = *batch; c.st = (hipStream_t)stream;
-    c.gst = c.st; c.gpartial = nullptr; c.sd = nullptr; c.mwst = c.st;
+    c.gst = c.st; c.gpartial = nullptr; c.sd = nullptr; c.mwst = c.st; c.tail_dw = 0; c.tpartial = nullptr;
     param_layout(c.d, c.L);
     const char* pe = getenv("REFIL_PRESUM");          // read per call: tests compare both paths in one process
     const bool presum_on = !(pe && pe[0] == '0');
@@ -950,7 +968,13 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     Ctx ca = c;                       // live agent chain: caller's stream
     Ctx ch = c;                       // hypernet chain: side stream + its own split-K scratch
     const bool overlap = overlap_enabled();
-    ca.gpartial = w.partial; ch.gpartial = w.partial2;
+    ca.gpartial = w.partial; ch.gpartial = w.partial2; ca.tpartial = w.partial3; ch.tpartial = w.partial4;
+    // Swept on one box (tools/sweep.sh, all 8 x 3 combinations): agent chain 7 + hypernet chain 2 = 2.014 ms against 2.050 with
+    // every weight gradient on the weight-gradient streams (the agent settings alone lose 0.5 %: they only pay off once the
+    // hypernet chain's stream takes its fc1 gradient and frees the other streams earlier)
+    static const int tail_a = [] { const char* e = getenv("REFIL_TAIL_DW_A"); return e ? atoi(e) : 7; }();
+    static const int tail_h = [] { const char* e = getenv("REFIL_TAIL_DW_H"); return e ? atoi(e) : 2; }();
+    ca.tail_dw = tail_a; ch.tail_dw = tail_h;
     if (overlap) {
         RUN(side_stream(sd));
         sd->next_ev = 2;                                   // (pool[0..1]: the final joins of the two weight-gradient streams)
@@ -1102,6 +1126,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         REFIL_HIP(hipStreamWaitEvent(sd->s, sd->ev[2], 0));
     }
     // (the hypernet chain -- the critical path -- is enqueued first, on the side stream)
+    ComposeArgs hyp_compose;
     if (hypernets) {
     if (c.presum) {
         // composed tails (x3 = mask(a W_c^T + b_c)): G_c = g3^T a, g_c = colsum(g3) (weighted by n_act on the summed rows),
@@ -1127,7 +1152,8 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         ca.Gc = w.gwc; ca.gc = w.gbc;
         ca.dW2 = grads + L.mix_fc2_w; ca.db2 = grads + L.mix_fc2_b; ca.dWo = grads + L.mix_out_w; ca.dbo = grads + L.mix_out_b;
         ca.nets = s.nets; ca.M = M; ca.h = h;
-        RUN(compose_backward_launch(ca, ch.gst));          // (consumes G_c / g_c: stays behind them on the weight-gradient stream)
+        hyp_compose = ca;
+        if (!(ch.tail_dw & 4)) RUN(compose_backward_launch(ca, ch.gst));          // (consumes G_c / g_c: stays behind them on the weight-gradient stream)
     } else {
     // hypernet tails: fc2 (flex_qmix.py:49)
     for (int part = 0; part < 2; ++part) {
@@ -1159,10 +1185,11 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         k.var_first[2] = group_code(d, 1, false);
         k.var_rest = REFIL_MASK_ENTITY;
         RUN(attn_block_backward(ch, k));
+        if (c.presum && (ch.tail_dw & 4)) RUN(compose_backward_launch(hyp_compose, ch.gst));
         // the four hypernet fc1 layers: dW = dx1^T xe (one [4h,E] GEMM), db = colsum(dx1)
         refil_gemm_desc g = linear_dw(w.dx1h, s.nets * h, w.xe, s.Ep, grads + L.mix_fc1_w, s.E, grads + L.mix_fc1_b, s.NE, s.nets * h, s.E,
                                       ch.w.partial, 1);
-        RUN(launch_dw(ch, with_rows(g, ch, rows_eh(ch))));
+        RUN(launch_dw_tail(ch, with_rows(g, ch, rows_eh(ch)), 2));
     }
     }
     // every kernel that writes a mixer gradient (and, earlier, the stat sums) is enqueued: on ch.gst they are complete
@@ -1180,6 +1207,8 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         if (!d.agent_ff && c.lists && c.compose_agent) q.ever = w.ever;     // (the recurrence and the fc3 gradient read list_t rows only)
         RUN(qselect_bwd_launch(q, ca.st));
         const long rows = (long)G * s.NA;
+        ComposeArgs ag_compose;
+        bool ag_compose_pending = false;
         if (d.agent_ff) {
             // feed-forward agent: q = fc2(x2), x2 = relu(masked out_trans)  (entity_ff_agent.py:44-52)
             RUN(launch_dw(ca, linear_dw(w.dqva, d.A, w.la.x2, dd, grads + L.ag_fc2_w, dd, grads + L.ag_fc2_b, rows, d.A, dd, ca.w.partial, 1)));
@@ -1224,7 +1253,8 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
                 cb.Gc = w.gwca; cb.gc = w.gbact; cb.gc_b2 = w.gbca;
                 cb.dW2 = grads + L.ag_fc2_w; cb.db2 = grads + L.ag_fc2_b; cb.dWo = grads + L.ag_out_w; cb.dbo = grads + L.ag_out_b;
                 cb.nets = 1; cb.M = H; cb.h = dd;
-                RUN(compose_backward_launch(cb, ca.gst));
+                ag_compose = cb; ag_compose_pending = (ca.tail_dw & 4) != 0;
+                if (!ag_compose_pending) RUN(compose_backward_launch(cb, ca.gst));
             } else {
             // fc2
             RUN(launch_dw(ca, linear_dw(w.dx3a, H, w.la.x2, dd, grads + L.ag_fc2_w, dd, grads + L.ag_fc2_b, rows, H, dd, ca.w.partial, 1)));
@@ -1244,7 +1274,8 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         k.var_first[2] = group_code(d, 1, true);
         k.var_rest = REFIL_MASK_OBS;
         RUN(attn_block_backward(ca, k));
-        RUN(launch_dw(ca, with_rows(linear_dw(w.dx1a, dd, w.xe, s.Ep, grads + L.ag_fc1_w, s.E, grads + L.ag_fc1_b, s.NE, dd, s.E, ca.w.partial, 1), ca, rows_ea(ca))));
+        if (ag_compose_pending) RUN(compose_backward_launch(ag_compose, ca.gst));
+        RUN(launch_dw_tail(ca, with_rows(linear_dw(w.dx1a, dd, w.xe, s.Ep, grads + L.ag_fc1_w, s.E, grads + L.ag_fc1_b, s.NE, dd, s.E, ca.w.partial, 1), ca, rows_ea(ca)), 2));
     }
     if (overlap) {                                                                 // join: hypernet chain, both weight-gradient streams
         REFIL_HIP(hipEventRecord(sd->ev[3], sd->s));

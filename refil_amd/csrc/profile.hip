@@ -1,5 +1,7 @@
 #include "profile.h"
 
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -11,14 +13,14 @@
 
 namespace refil {
 
-struct Rec { const char* name; double flops, bytes; hipEvent_t e0, e1; const int* rows_dev; double rows_max; };
+struct Rec { const char* name; double flops, bytes; hipEvent_t e0, e1; const int* rows_dev; double rows_max; hipStream_t st; };
 static bool g_on = false;
 static std::vector<Rec> g_recs;
 
 bool prof_enabled() { return g_on; }
 
 void prof_begin(const char* kernel, double flops, double bytes, hipStream_t st, const int* rows_dev, double rows_max) {
-    Rec r{kernel, flops, bytes, nullptr, nullptr, rows_dev, rows_max};
+    Rec r{kernel, flops, bytes, nullptr, nullptr, rows_dev, rows_max, st};
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
     hipEventRecord(r.e0, st);
     g_recs.push_back(r);
@@ -42,6 +44,18 @@ extern "C" int refil_profile_enable(int on) {
 extern "C" int refil_profile_collect(refil_profile_entry* out, int max_entries) {
     REFIL_CHECK(out && max_entries > 0, "refil_profile_collect: bad arguments");
     REFIL_HIP(hipDeviceSynchronize());
+    // REFIL_PROFILE_TIMELINE=<file>: every recorded launch with its stream, start (us after the first record) and duration --
+    // the untraced counterpart of a rocprofv3 kernel trace (tools/probes/timeline.py)
+    if (const char* path = getenv("REFIL_PROFILE_TIMELINE")) {
+        if (FILE* f = fopen(path, "w")) {
+            for (auto& r : g_recs) {
+                float t0 = 0.f, dt = 0.f;
+                if (hipEventElapsedTime(&t0, g_recs[0].e0, r.e0) != hipSuccess || hipEventElapsedTime(&dt, r.e0, r.e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+                fprintf(f, "%p\t%.1f\t%.1f\t%s\n", (void*)r.st, t0 * 1e3, dt * 1e3, r.name);
+            }
+            fclose(f);
+        }
+    }
     std::map<std::string, refil_profile_entry> agg;
     for (auto& r : g_recs) {
         float ms = 0.f;
