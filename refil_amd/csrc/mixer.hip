@@ -85,10 +85,44 @@ __global__ void prep_kernel(PrepArgs a, int phases, const uint8_t* skip_a, const
     }
 }
 
+
+// Phase 2 of the input assembly (xe = entities || one-hot(previous action), zero padded to Ep columns) with one WAVE per entity
+// row: the row's (b, t, e) decomposition is done once per wave in 32-bit arithmetic and the lanes walk the columns, instead of
+// four 64-bit divisions per ELEMENT (the grid-stride form above: 34 us for 29 MB at the flagship shape).
+__global__ __launch_bounds__(256) void prep_rows_kernel(PrepArgs a, const uint8_t* skip_a, const uint8_t* skip_h) {
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned rows = (unsigned)a.B * a.T1 * a.ne;
+    for (unsigned row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        if (skip_a && skip_a[row] && skip_h[row]) continue;
+        const unsigned e = row % (unsigned)a.ne, r = row / (unsigned)a.ne;
+        const unsigned b = r / (unsigned)a.T1, t = r % (unsigned)a.T1;
+        const float* src = a.b.entities + (long)b * a.b.ent_sB + (long)t * a.b.ent_sT + (long)e * a.ed;
+        int act = -1;                                      // column (relative to ed) of the one-hot entry, -1: none
+        if (a.last_action && e < (unsigned)a.na) {
+            const int tp = a.first_step_zero ? (int)t - 1 : (int)t;
+            if (tp >= 0) act = (int)a.b.actions[(long)b * a.b.ac_sB + (long)tp * a.b.ac_sT + e];
+        }
+        float* dst = a.xe + (long)row * a.Ep;
+        for (int c = lane; c < a.Ep; c += 64) {
+            float v = 0.f;
+            if (c < a.ed) v = src[c];
+            else if (c - a.ed == act && c < a.ed + a.A) v = 1.f;
+            dst[c] = v;
+        }
+    }
+}
+
 int prep_launch(const PrepArgs& a, hipStream_t st, int phases, const uint8_t* skip_a, const uint8_t* skip_h) {
     const long total = (phases & 2) ? (long)a.B * a.T1 * a.ne * a.Ep : (long)a.B * a.T1 * a.ne;
     const int blocks = (int)min((long)4096, cdivl(total, 256));
     ProfScope prof_prep_kernel("prep_kernel", 0.0, 0.0, st);
+    const long rows = (long)a.B * a.T1 * a.ne;
+    static const bool by_rows = [] { const char* e = getenv("REFIL_PREP_ROWS"); return !(e && e[0] == '0'); }();
+    if (by_rows && (phases & 2) && rows * a.Ep < (1L << 31)) {
+        hipLaunchKernelGGL(prep_rows_kernel, dim3((int)min((long)16384, cdivl(rows, 4))), dim3(256), 0, st, a, skip_a, skip_h);
+        phases &= ~2;
+        if (!phases) { REFIL_LAUNCH_CHECK(); return 0; }
+    }
     hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, st, a, phases, skip_a, skip_h);
     REFIL_LAUNCH_CHECK();
     return 0;
@@ -121,10 +155,21 @@ __global__ __launch_bounds__(256) void lists_episode_kernel(ListArgs a) {       
     }
     __syncthreads();
     const int tl = tl_s;
-    bool any = false;
-    if (lane < a.na)
-        for (int t = wave; t <= tl; t += 4) any |= a.b.entity_mask[b * a.b.em_sB + t * a.b.em_sT + lane] == 0;
-    if (any) any_s[lane] = 1;                              // (benign race: every writer stores 1)
+    // (t, agent) pairs spread over the 256 threads, four independent loads in flight per thread: a per-wave loop over t is a
+    // chain of ~20 dependent byte loads = most of the list phase's latency
+    const int n = (tl + 1) * a.na;
+    for (int base = 0; base < n; base += 256 * 4) {
+        uint8_t m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 256 + (int)threadIdx.x;
+            m[u] = 1;
+            if (idx < n) m[u] = a.b.entity_mask[b * a.b.em_sB + (idx / a.na) * a.b.em_sT + idx % a.na];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (m[u] == 0) any_s[(base + u * 256 + (int)threadIdx.x) % a.na] = 1;      // (benign race: every writer stores 1)
+    }
     __syncthreads();
     if (threadIdx.x < a.na) a.ever[(long)b * a.na + threadIdx.x] = any_s[threadIdx.x] ? 1 : 0;
 }
