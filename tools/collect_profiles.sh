@@ -3,6 +3,7 @@
 #   1. rocprofv3 --kernel-trace --stats of the default bench, overlapped and --serial      -> gpurun_out/<tag>_stats*/
 #   2. PMC passes FETCH_SIZE / WRITE_SIZE (kernel-trace only, each in its own run)          -> gpurun_out/<tag>_pmc_*/
 #   3. per-dispatch timeline of one step (serial and overlapped)                            -> gpurun_out/<tag>_timeline_*.txt
+#   3b. the same step without a tracer (HIP events of the library profiler)                 -> gpurun_out/<tag>_timeline_untraced.txt
 #   4. the bench line of every BASELINE.json config (cfgT with the CPU baseline and the PMC traffic of step 2)
 # Copy the summaries into profiles/ afterwards (tools/pmc_summarize.py folds step 2).
 TAG=${1:-r02}
@@ -36,4 +37,6 @@ for c in cfg2 cfg3 cfg4 cfg5; do
     rm -rf $OUT/${TAG}_stats_$c
 done
 python bench.py --serial --no-cpu-baseline > $OUT/${TAG}_bench_cfgT_serial.json 2>/dev/null
+# one step WITHOUT a tracer: HIP events around every launch (library profiler), stream + start + duration per launch
+python tools/probes/timeline.py --out $OUT/${TAG}_timeline_untraced.txt > /dev/null 2>&1; rm -f $OUT/${TAG}_timeline_untraced.txt.raw
 ls -la $OUT | grep ${TAG}_

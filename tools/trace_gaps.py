@@ -3,7 +3,7 @@ lone-kernel time. usage: python tools/trace_gaps.py <kernel_trace.csv>"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'prep_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'lists_episode_kernel' in r['Kernel_Name']]
 s, e = idx[-2], idx[-1]
 t0 = int(rows[s]['Start_Timestamp'])
 qs = sorted(set(r['Queue_Id'] for r in rows[s:e]))

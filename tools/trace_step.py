@@ -1,16 +1,14 @@
-"""Timeline of ONE learner step from a rocprofv3 --kernel-trace CSV of bench.py: every dispatch between the last two
-prep_kernel launches with its start offset, duration, queue and (shortened) name.
+"""Timeline of ONE learner step from a rocprofv3 --kernel-trace CSV of bench.py: every dispatch between two
+step starts (lists_episode_kernel / prep kernel) with its start offset, duration, queue and (shortened) name.
 usage: python tools/trace_step.py <kernel_trace.csv> [--sum]"""
 import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'lists_tlast_kernel' in r['Kernel_Name']]
-if len(idx) >= 2:                       # steps with row lists: prep (masks) runs right before the lists
-    idx = [i - 1 for i in idx]
-else:
-    idx = [i for i, r in enumerate(rows) if 'prep_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'lists_episode_kernel' in r['Kernel_Name']]       # first kernel of a step with row lists
+if len(idx) < 2:
+    idx = [i for i, r in enumerate(rows) if 'prep_kernel' in r['Kernel_Name'] or 'prep_rows_kernel' in r['Kernel_Name']]
 # which step: --step K (K-th step start of the run), default the one at 40 % of the run (inside bench.py's timed region;
 # the last steps of a bench run are its serialised profiling passes)
 k = int(sys.argv[sys.argv.index('--step') + 1]) if '--step' in sys.argv else int(0.4 * len(idx))
