@@ -1041,9 +1041,8 @@ __global__ void compose_fwd_kernel(ComposeArgs a) {      // grid (M, nets): W_c[
         }
     }
 }
-__global__ void compose_bwd_w2_kernel(ComposeArgs a) {   // grid (M, nets): dW_2[m][j] = sum_k G[m][k] W_o[j][k] + g[m] b_o[j]; db_2[m] = g[m]
-    extern __shared__ float Gs[];
-    const int n = blockIdx.y, m = blockIdx.x, M = a.M, h = a.h;
+__device__ inline void compose_bwd_w2(const ComposeArgs& a, int m, int n, float* Gs) {   // (m, net): dW_2[m][j] = sum_k G[m][k] W_o[j][k] + g[m] b_o[j]; db_2[m] = g[m]
+    const int M = a.M, h = a.h;
     const float* Wo = a.Wo + n * a.sWo; const float* bo = a.bo + n * a.sbo;
     const float* G = a.Gc + ((long)n * M + m) * h;
     const float gm = a.gc[(long)n * M + m];
@@ -1058,8 +1057,8 @@ __global__ void compose_bwd_w2_kernel(ComposeArgs a) {   // grid (M, nets): dW_2
     }
     if (threadIdx.x == 0) a.db2[n * a.sb2 + m] = a.gc_b2 ? a.gc_b2[(long)n * M + m] : gm;
 }
-__global__ void compose_bwd_wo_kernel(ComposeArgs a) {   // grid (h, nets): dW_o[j][k] = sum_m W_2[m][j] G[m][k]; db_o[j] = sum_m W_2[m][j] g[m]
-    const int n = blockIdx.y, j = blockIdx.x, M = a.M, h = a.h;
+__device__ inline void compose_bwd_wo(const ComposeArgs& a, int j, int n) {   // (j, net): dW_o[j][k] = sum_m W_2[m][j] G[m][k]; db_o[j] = sum_m W_2[m][j] g[m]
+    const int M = a.M, h = a.h;
     const float* W2 = a.W2 + n * a.sW2; const float* G = a.Gc + (long)n * M * h; const float* g = a.gc + (long)n * M;
     for (int k = threadIdx.x; k < h; k += blockDim.x) {
         float s = 0.f;
@@ -1073,6 +1072,13 @@ __global__ void compose_bwd_wo_kernel(ComposeArgs a) {   // grid (h, nets): dW_o
         a.dbo[n * a.sbo + j] = s;
     }
 }
+// both halves in ONE launch (they only share their input G_c): grid (M + h, nets) -- the pair sits at the very end of a
+// chain's weight-gradient queue, where a second dependent launch is pure latency
+__global__ void compose_bwd_kernel(ComposeArgs a) {
+    extern __shared__ float Gs[];
+    if ((int)blockIdx.x < a.M) compose_bwd_w2(a, blockIdx.x, blockIdx.y, Gs);
+    else compose_bwd_wo(a, blockIdx.x - a.M, blockIdx.y);
+}
 int compose_forward_launch(const ComposeArgs& a, hipStream_t st) {
     ProfScope prof("compose_fwd_kernel", 2.0 * a.nets * a.M * a.h * a.h, 0.0, st);
     hipLaunchKernelGGL(compose_fwd_kernel, dim3(a.M, a.nets), dim3(128), a.h * sizeof(float), st, a);
@@ -1080,13 +1086,8 @@ int compose_forward_launch(const ComposeArgs& a, hipStream_t st) {
     return 0;
 }
 int compose_backward_launch(const ComposeArgs& a, hipStream_t st) {
-    {
-        ProfScope prof("compose_bwd_w2_kernel", 2.0 * a.nets * a.M * a.h * a.h, 0.0, st);
-        hipLaunchKernelGGL(compose_bwd_w2_kernel, dim3(a.M, a.nets), dim3(128), a.h * sizeof(float), st, a);
-        REFIL_LAUNCH_CHECK();
-    }
-    ProfScope prof("compose_bwd_wo_kernel", 2.0 * a.nets * a.M * a.h * a.h, 0.0, st);
-    hipLaunchKernelGGL(compose_bwd_wo_kernel, dim3(a.h, a.nets), dim3(128), 0, st, a);
+    ProfScope prof("compose_bwd_kernel", 4.0 * a.nets * a.M * a.h * a.h, 0.0, st);
+    hipLaunchKernelGGL(compose_bwd_kernel, dim3(a.M + a.h, a.nets), dim3(128), a.h * sizeof(float), st, a);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
