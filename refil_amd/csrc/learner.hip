@@ -972,8 +972,9 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     // Swept on one box (tools/sweep.sh, all 8 x 3 combinations): agent chain 7 + hypernet chain 2 = 2.014 ms against 2.050 with
     // every weight gradient on the weight-gradient streams (the agent settings alone lose 0.5 %: they only pay off once the
     // hypernet chain's stream takes its fc1 gradient and frees the other streams earlier)
-    static const int tail_a = [] { const char* e = getenv("REFIL_TAIL_DW_A"); return e ? atoi(e) : 7; }();
-    static const int tail_h = [] { const char* e = getenv("REFIL_TAIL_DW_H"); return e ? atoi(e) : 2; }();
+    // (read per call: tests/test_gpu_learner.py compares the two placements in one process)
+    const char* tail_ea = getenv("REFIL_TAIL_DW_A"); const char* tail_eh = getenv("REFIL_TAIL_DW_H");
+    const int tail_a = tail_ea ? atoi(tail_ea) : 7, tail_h = tail_eh ? atoi(tail_eh) : 2;
     ca.tail_dw = tail_a; ch.tail_dw = tail_h;
     if (overlap) {
         RUN(side_stream(sd));

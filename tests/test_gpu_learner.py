@@ -254,6 +254,30 @@ def test_trajectory_matches_reference_golden(name):
                 assert rel_err(v.cpu(), ref_sq) < 2e-3 or ref_sq.abs().max() < 1e-12, (s, which, k)
 
 
+@pytest.mark.parametrize("B,T,ne,d,imagine", [(8, 20, 32, 128, True), (6, 30, 16, 128, False)])
+def test_tail_gradient_placement_is_bit_identical(B, T, ne, d, imagine):
+    """The chains' last weight gradients run on the chains' own streams with their own split-K scratch (learner.hip:
+    Ctx::tail_dw). Same launches, same splits, same reduction order as on the weight-gradient streams: every output and
+    every gradient is bit-identical to the placement REFIL_TAIL_DW_A=0 / REFIL_TAIL_DW_H=0."""
+    import os
+    cfg, batch, bits, agent, mixer, tagent, tmixer = _oracle_case(B, T, ne, seed=78, imagine=imagine, d=d, h=d)
+    res = {}
+    for flag in ("default", "0"):
+        if flag == "0":
+            os.environ["REFIL_TAIL_DW_A"] = os.environ["REFIL_TAIL_DW_H"] = "0"
+        try:
+            res[flag] = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer)
+        finally:
+            os.environ.pop("REFIL_TAIL_DW_A", None)
+            os.environ.pop("REFIL_TAIL_DW_H", None)
+    a, b = res["default"], res["0"]
+    for k, gv in b["grads"].items():
+        assert torch.equal(a["grads"][k], gv), k
+        assert torch.equal(a["post"][k], b["post"][k]), k
+    assert torch.equal(a["stats"], b["stats"])
+    assert a["grad_norm"] == b["grad_norm"]
+
+
 @pytest.mark.parametrize("B,T,ne,d,imagine", [(8, 20, 32, 128, True), (16, 40, 16, 64, True), (6, 30, 16, 128, False)])
 def test_row_skipping_equals_dense_schedule(B, T, ne, d, imagine):
     """Rows that cannot influence the loss (padded entities, steps after an episode's end) are skipped (row lists,
