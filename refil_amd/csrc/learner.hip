@@ -892,10 +892,10 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
                             d.H == 64 && c.s.NE >= 2048 && c.s.NA >= 512;     // (rnn_hidden_dim 32 / 128: dense schedule)
         c.lists = mode == CARVE_LEARNER && !(de && de[0] == '1') && shapes && c.presum && c.compose_agent;
         const char* me = getenv("REFIL_MASKWORDS");
-        // (16 entities or fewer: building the words in the attention kernels' own mask phase is cheaper than a separate
-        // pass -- A/B: cfg2 1.10 vs 1.13 ms without, cfg4 equal; 32 / 48 entities: 3.6 % / 4.7 % faster with the words.
-        // REFIL_MASKWORDS=1 forces them on)
-        c.mwords = mode == CARVE_LEARNER && !(me && me[0] == '0') && (d.ne > 16 || (me && me[0] == '1')) && !d.pooling && !d.mixer_vdn && !d.mixer_none &&
+        // (A/B with the words against the attention kernels' own mask phase: 32 / 48 entities 3.6 % / 4.7 % faster; 16 entities
+        // 1.8 % (cfg2) / 2.1 % (cfg4) faster since the kernels use the row words to leave dead K / V / Q rows unfetched --
+        // before that the separate pass cost more than it saved there. REFIL_MASKWORDS=0 switches them off)
+        c.mwords = mode == CARVE_LEARNER && !(me && me[0] == '0') && !d.pooling && !d.mixer_vdn && !d.mixer_none &&
                    attn_mfma_supported(d.ne, d.na, d.d / d.heads) && attn_mfma_supported(d.ne, d.na, d.hyp / d.heads);
     }
     REFIL_CHECK(batch->entities && batch->entity_mask, "refil: batch.entities / entity_mask missing");
