@@ -126,14 +126,44 @@ def _oracle_case(B, T, ne, seed, imagine=True, d=64, h=64, heads=4, H=64):
 @pytest.mark.parametrize("B,T,ne,imagine,d", [(4, 10, 16, True, 64), (3, 7, 32, True, 128), (4, 9, 16, False, 128)])
 def test_learner_step_matches_oracle(B, T, ne, imagine, d):
     cfg, batch, bits, agent, mixer, tagent, tmixer = _oracle_case(B, T, ne, seed=100 + B, imagine=imagine, d=d, h=d)
+    _assert_step_matches_oracle(cfg, batch, bits, agent, mixer, tagent, tmixer, imagine)
+
+
+@pytest.mark.parametrize("B,T,ne,d", [(5, 9, 16, 64), (8, 20, 32, 128)])
+def test_degenerate_episodes_match_oracle(B, T, ne, d):
+    """Edge cases of the episode structure in one batch: an episode that never started (filled == 0 everywhere: no loss
+    weight, its rows are skipped), one that terminates at its first step (a single transition), one with a single active
+    agent and no other entity (every other attention key masked, fully masked rows for the padded agents), and one that
+    runs to the last slot without terminating. Small shape: LDS-tiled kernels; (8, 20, 32, 128): the row-list schedule."""
+    cfg, batch, bits, agent, mixer, tagent, tmixer = _oracle_case(B, T, ne, seed=321, imagine=True, d=d, h=d)
+    batch = {k: v.clone() for k, v in batch.items()}
+    batch["filled"][1] = 0                                   # never started
+    batch["terminated"][1] = 0
+    batch["filled"][2] = 0                                   # one transition, terminated at once
+    batch["filled"][2, :2] = 1
+    batch["terminated"][2] = 0
+    batch["terminated"][2, 0] = 1
+    batch["entity_mask"][3, :, 1:] = 1                       # a lone agent
+    batch["entity_mask"][3, :, 0] = 0
+    batch["obs_mask"][3] = 1
+    batch["obs_mask"][3, :, 0, 0] = 0
+    batch["filled"][4] = 1                                   # full length, never terminated
+    batch["terminated"][4] = 0
+    _assert_step_matches_oracle(cfg, batch, bits, agent, mixer, tagent, tmixer, True)
+
+
+def _assert_step_matches_oracle(cfg, batch, bits, agent, mixer, tagent, tmixer, imagine):
     r = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer)
     a2, m2 = dict(agent), dict(mixer)
     out, grads, gnorm = orc.train_step(cfg, a2, m2, tagent, tmixer, batch, bits)
     o, st = r["out"], r["stats"]
-    assert rel_err(o["q"], out.q.detach()) < TOL_FWD
-    assert rel_err(o["chosen_q"], out.chosen_q.detach()) < TOL_FWD
-    assert rel_err(o["q_tot"], out.q_tot.detach()[..., 0]) < TOL_FWD
-    assert rel_err(o["targets"], out.targets[..., 0]) < TOL_FWD
+    # (row-list schedule: steps after an episode's last contributing step are skipped, their outputs are unspecified)
+    live = live_steps(batch)
+    lt, lt1 = live[:, :-1], live[:, 1:]
+    assert rel_err(o["q"] * live[None, :, :, None, None], out.q.detach() * live[None, :, :, None, None]) < TOL_FWD
+    assert rel_err(o["chosen_q"] * lt[None, :, :, None], out.chosen_q.detach() * lt[None, :, :, None]) < TOL_FWD
+    assert rel_err(o["q_tot"] * lt, out.q_tot.detach()[..., 0] * lt) < TOL_FWD
+    assert rel_err(o["targets"] * lt1, out.targets[..., 0] * lt1) < TOL_FWD
     msum = st[0].item()
     assert abs(msum - out.mask.sum().item()) < 1e-6
     assert abs(st[1].item() / msum - out.q_loss.item()) < TOL_FWD * out.q_loss.item()
