@@ -123,7 +123,9 @@ def _oracle_case(B, T, ne, seed, imagine=True, d=64, h=64, heads=4, H=64):
     return cfg, batch, bits, agent, mixer, tagent, tmixer
 
 
-@pytest.mark.parametrize("B,T,ne,imagine,d", [(4, 10, 16, True, 64), (3, 7, 32, True, 128), (4, 9, 16, False, 128)])
+# (2, 5, 64, ...) / (6, 12, 64, ...): the largest entity count the 64-bit mask words hold (32 agents, 148 input features)
+@pytest.mark.parametrize("B,T,ne,imagine,d", [(4, 10, 16, True, 64), (3, 7, 32, True, 128), (4, 9, 16, False, 128), (2, 5, 64, True, 128),
+                                              (6, 12, 64, True, 128)])
 def test_learner_step_matches_oracle(B, T, ne, imagine, d):
     cfg, batch, bits, agent, mixer, tagent, tmixer = _oracle_case(B, T, ne, seed=100 + B, imagine=imagine, d=d, h=d)
     _assert_step_matches_oracle(cfg, batch, bits, agent, mixer, tagent, tmixer, imagine)
