@@ -80,3 +80,25 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
         _lib.lib()
+
+
+@pytest.mark.parametrize("bad,needle", [
+    (dict(ne=65), b"n_entities <= 64"),                      # the 64-bit mask words' limit
+    (dict(na=33, ne=32), b"n_agents <= n_entities"),
+    (dict(B=0), b"B and T1"),
+    (dict(heads=3), b"divisible by attn_n_heads"),
+    (dict(d=24, heads=4), b"head dim"),
+    (dict(M=65), b"mixing_embed_dim"),
+    (dict(pooling=3), b"pooling"),
+    (dict(mixer_none=1, imagine=1), b"mixer=None"),
+])
+def test_every_dims_limit_is_reported(L, bad, needle):
+    """check_dims (learner.hip): every limit of the path is rejected with a message naming it, through each sizing / layout entry."""
+    from refil_amd import _lib
+    kw = dict(B=2, T1=3, ne=32, na=16, ed=62, A=22, d=128, heads=4, H=64, hyp=128, M=32)
+    kw.update(bad)
+    d = _lib.make_dims(**kw)
+    out = _lib.ParamLayout()
+    assert L.refil_get_param_layout(C.byref(d), C.byref(out)) != 0
+    assert needle in L.refil_last_error(), L.refil_last_error()
+    assert L.refil_learner_workspace_bytes(C.byref(d)) == 0
