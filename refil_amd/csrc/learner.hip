@@ -646,9 +646,14 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
 // the four attention hypernets up to the masked fc2 output (flex_qmix.py:41-50)
 // variant order in ao/x2/x3: hyper_w_1 under nv0 masks, then hyper_w_final, hyper_b_1, V
 // ------------------------------------------------------------------------------------------------
-static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int nv0) {
+enum { HY_PRE = 1, HY_ATTN = 2, HY_POST = 4, HY_ALL = 7 };
+// phases: HY_PRE fc1 + K/V/Q projections, HY_ATTN the attention cores, HY_POST the tails. `second` (HY_ATTN only): another set
+// of hypernets under the SAME masks (the target mixer's, single-variant) whose attention cores join this launch -- 8 nets, one
+// launch: a launch's fixed per-row cost (mask words, first operand fetch, ramp) is paid once
+static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int nv0, int phases = HY_ALL, const HyperBufs* second = nullptr) {
     const refil_dims& d = c.d; const Sizes& s = c.s; const refil_param_layout& L = c.L;
     const int h = d.hyp, M = d.M, nets = s.nets;
+    if (phases & HY_PRE) {
     RUN(gemm_launch(with_rows(linear(c.w.xe, s.Ep, P + L.mix_fc1_w, s.E, P + L.mix_fc1_b, b.x1, nets * h, s.NE, nets * h, s.E, REFIL_GEMM_RELU), c, rows_eh(c)), c.st));
     if (d.pooling) {
         refil_gemm_desc g = linear(b.x1, nets * h, P + L.mix_in_w, h, P + L.mix_in_w + (long)h * h, b.kv, 2 * h, s.NE, h, h, 0);
@@ -663,36 +668,44 @@ static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int n
         q.batch = nets; q.sA = h; q.sB = L.mix_in_w_stride; q.sC = s.NAa * h;
         RUN(gemm_launch(with_rows(q, c, rows_a(c)), c.st));
     }
-    {
+    }   // HY_PRE
+    if (phases & HY_ATTN) {
         // the hypernets' attention cores: ONE launch when the matrix-core kernel covers the shape (shared mask words, jobs
         // of a row pipelined), else one launch per net
-        refil_attn_desc ad[4];
-        AttnNetOpts ao[4];
-        for (int n = 0; n < nets; ++n) {
-            refil_attn_desc a = attn_base(c, h);
-            attn_rows(c, a, true);
-            a.Q = b.q + (long)n * s.NAa * h; a.K = b.kv + (long)n * s.NEa * 2 * h; a.V = a.K + h;
-            a.O = b.ao + (long)(n == 0 ? 0 : nv0 + n - 1) * s.NA * h; a.sO = s.NA * h;
-            a.nvar = n == 0 ? nv0 : 1;
-            a.var[0] = REFIL_MASK_ENTITY;
-            a.var[1] = group_code(d, 0, false);
-            a.var[2] = group_code(d, 1, false);
-            ad[n] = a;
-            ao[n] = AttnNetOpts{(c.presum && n > 0) ? 1 : 0, 0};
+        refil_attn_desc ad[8];
+        AttnNetOpts ao[8];
+        const int nsets = second ? 2 : 1;
+        REFIL_CHECK(nsets * nets <= 8, "refil: too many hypernets for one attention launch");
+        for (int set = 0; set < nsets; ++set) {
+            const HyperBufs& bb = set == 0 ? b : *second;
+            const int nv = set == 0 ? nv0 : 1;
+            for (int n = 0; n < nets; ++n) {
+                refil_attn_desc a = attn_base(c, h);
+                attn_rows(c, a, true);
+                a.Q = bb.q + (long)n * s.NAa * h; a.K = bb.kv + (long)n * s.NEa * 2 * h; a.V = a.K + h;
+                a.O = bb.ao + (long)(n == 0 ? 0 : nv + n - 1) * s.NA * h; a.sO = s.NA * h;
+                a.nvar = n == 0 ? nv : 1;
+                a.var[0] = REFIL_MASK_ENTITY;
+                a.var[1] = group_code(d, 0, false);
+                a.var[2] = group_code(d, 1, false);
+                ad[set * nets + n] = a;
+                ao[set * nets + n] = AttnNetOpts{(c.presum && n > 0) ? 1 : 0, 0};
+            }
         }
         int rc = -1;
         RUN(stream_after(c.sd, c.mwst, c.st));
         if (!d.pooling && attn_mfma_supported(d.ne, d.na, h / d.heads))
-            rc = attn_mfma_launch_multi(ad, ao, nets, false, c.st, c.presum ? c.w.nact : nullptr, 0);
+            rc = attn_mfma_launch_multi(ad, ao, nsets * nets, false, c.st, c.presum ? c.w.nact : nullptr, 0);
         if (rc > 0) return rc;
         if (rc < 0) {
             REFIL_CHECK(!c.presum, "refil: agent-sum attention shape not instantiated");
-            for (int n = 0; n < nets; ++n) {
+            for (int n = 0; n < nsets * nets; ++n) {
                 if (d.pooling) RUN(pool_launch(ad[n], d.pooling, false, c.st));
                 else RUN(attn_forward_launch(ad[n], c.st));
             }
         }
     }
+    if (!(phases & HY_POST)) return 0;
     if (c.presum) {
         // out_trans o fc2 is one linear map per hypernet: x3 = mask(a W_c^T + b_c), W_c = W_2 W_o (kernels.h: ComposeArgs).
         // x2 is never formed. hyper_w_1 (matrix mode) per agent row; the other nets on the agent-summed rows.
@@ -1030,8 +1043,22 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     RUN(stream_after(sd, c.st, ch.st));                    // fork: inputs assembled
     const bool hypernets = !d.mixer_vdn && !d.mixer_none;
     if (hypernets) {
+        // A/B on one box: with imagined copies (live net 0 under three mask variants) the merged launch LOSES 1.1 % (cfg-T) to
+        // 3.5 % (cfg2) -- the projections of both mixers in front of it no longer interleave with an attention launch of the
+        // other chain; without them (qmix_atten: two symmetric light launches) it wins 2.5 % (cfg4). REFIL_HYPER_MERGE=0/1 forces it
+        static const int hy_env = [] { const char* e = getenv("REFIL_HYPER_MERGE"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+        const bool hy_merge = hy_env >= 0 ? hy_env == 1 : nv0 == 1;
+        if (hy_merge && 2 * s.nets <= 8 && !d.pooling && attn_mfma_supported(d.ne, d.na, d.hyp / d.heads)) {
+            // live and target mixers' hypernets: projections of both, then ONE attention launch for all eight nets, then the tails
+            RUN(hyper_forward(ch, params_live, w.lh, nv0, HY_PRE));
+            RUN(hyper_forward(ch, params_target, w.th, 1, HY_PRE));
+            RUN(hyper_forward(ch, params_live, w.lh, nv0, HY_ATTN, &w.th));
+            RUN(hyper_forward(ch, params_live, w.lh, nv0, HY_POST));
+            RUN(hyper_forward(ch, params_target, w.th, 1, HY_POST));
+        } else {
         RUN(hyper_forward(ch, params_live, w.lh, nv0));                           // live mixer hypernets
         RUN(hyper_forward(ch, params_target, w.th, 1));                           // target mixer hypernets
+        }
     }
     if (overlap) REFIL_HIP(hipEventRecord(sd->ev[1], sd->s));
     if (!d.agent_ff && (G * d.B * d.na) % 16 == 0) {
