@@ -1056,8 +1056,12 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
             RUN(hyper_forward(ch, params_live, w.lh, nv0, HY_POST));
             RUN(hyper_forward(ch, params_target, w.th, 1, HY_POST));
         } else {
-        RUN(hyper_forward(ch, params_live, w.lh, nv0));                           // live mixer hypernets
+        // the target mixer's hypernets first: A/B on one box -0.2 % (cfg-T) .. -0.7 % (cfg3, cfg5) against live-first -- the live
+        // mixer's heavier attention launch (three mask variants) then runs beside the recurrence instead of the agents' GEMMs
+        static const bool live_first = [] { const char* e = getenv("REFIL_HYPER_ORDER"); return e && e[0] == '0'; }();
+        if (live_first) RUN(hyper_forward(ch, params_live, w.lh, nv0));
         RUN(hyper_forward(ch, params_target, w.th, 1));                           // target mixer hypernets
+        if (!live_first) RUN(hyper_forward(ch, params_live, w.lh, nv0));          // live mixer hypernets
         }
     }
     if (overlap) REFIL_HIP(hipEventRecord(sd->ev[1], sd->s));
