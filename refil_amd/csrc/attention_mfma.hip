@@ -16,6 +16,7 @@
 // Backward needs products contracted over agents as well (dV, dK), for which the logits are
 // recomputed in the other orientation S[agent,key] too -- MFMA work is free here, the kernel is
 // bound by its HBM traffic.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -591,6 +592,550 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_mfma(AttnM p) {
     }
 }
 
+// ================================================================================================
+// Second generation: PERSISTENT workgroups with a software-pipelined operand fetch (attn_fwd_pipe / attn_bwd_pipe).
+//
+// What bounded the kernels above was neither HBM bandwidth (0.24-0.33 of the roof by the PMC counters) nor the matrix
+// cores (0.30): every wave walked load -> wait -> LDS -> compute -> store once per job, its operand fetch was a chain
+// of dependent round trips (net pointers looked up with per-lane loads, one conditional load per operand tile, each
+// behind its own s_waitcnt), and a workgroup lived for ONE row. Here
+//   * a launch is (CUs x resident workgroups) workgroups; each walks the LIVE rows (b,t <= t_last[b]) it owns -- the
+//     live-row ordinals are mapped to rows through a prefix sum of the episodes' live steps built in LDS once per
+//     workgroup -- and each of its 4 waves walks its own stream of (row, net, head) jobs;
+//   * the operands of job k+1 (Q, K, V, every variant's dO, the mask words) are fetched into REGISTERS while job k is
+//     computed from wave-private LDS; the row words of the row after next are fetched one stage earlier still;
+//   * every global access is a buffer instruction on a wave-uniform resource: rows nobody computed (dead K / V / Q rows,
+//     padded tiles, the variants a net does not have, the jobs past the end) get an out-of-range offset -- the hardware
+//     returns zeros / drops the store, moves no data and needs no branch, so the fetch is straight-line code whose
+//     s_waitcnt bookkeeping the compiler can count exactly;
+//   * nothing is loaded inside the compute phase (vmcnt is in order: a load waited for there would wait for the
+//     prefetch issued before it).
+// Same math as above (reference: src/modules/layers/attention.py:48-64).
+// ================================================================================================
+typedef unsigned int u32x4 __attribute__((vector_size(16)));
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr int BUF_OOB = 0x7ffffff0;          // >= every num_records used here: the access is dropped by the range check
+constexpr int BUF_MAX = 0x7fffffe0;
+
+__device__ inline rsrc_t mk_rsrc(const void* base, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(bytes > BUF_MAX ? BUF_MAX : bytes), 0x00020000);
+}
+__device__ inline float4 buf_ld4(rsrc_t rs, int off) {
+    // (the whole vector is bit-cast at once: __builtin_bit_cast of ONE element of a vector reads element 0 in this clang)
+    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ inline unsigned long long buf_ld_u64(rsrc_t rs, int off) {
+    return __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+}
+__device__ inline void buf_st4(rsrc_t rs, int off, f32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, off, 0, 0); }
+
+// ROWS x (4 C4) floats of a row-major matrix on their way global -> registers -> wave-private LDS (pitch pd)
+template <int ROWS, int C4>
+struct Tile {
+    static constexpr int N = ROWS * C4 / 64;
+    float4 v[N];
+    // rows >= `rows`, columns >= hd and rows whose `dead` bit is set are not fetched: they enter as zeros
+    __device__ inline void load(rsrc_t rs, int rows, int ld, int col0, int hd, int lane, unsigned long long dead) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int idx = lane + 64 * i, r = idx / C4, c4 = idx % C4;
+            const bool ok = r < rows && 4 * c4 < hd && !((dead >> r) & 1ull);
+            v[i] = buf_ld4(rs, ok ? (r * ld + col0 + 4 * c4) * 4 : BUF_OOB);
+        }
+    }
+    __device__ inline void store(float* dst, int pd, int lane) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int idx = lane + 64 * i, r = idx / C4, c4 = idx % C4;
+            float2* d = reinterpret_cast<float2*>(dst + r * pd + c4 * 4);
+            d[0] = make_float2(v[i].x, v[i].y);
+            d[1] = make_float2(v[i].z, v[i].w);
+        }
+    }
+};
+
+// The rows a persistent workgroup owns: live row ordinals blockIdx.x, blockIdx.x + G, ... (a row (b,t) is live when
+// t <= t_last[b]); ordinal -> row through a prefix sum of the episodes' live steps, built once per workgroup in LDS
+// scratch (the wave regions, not yet in use) and resolved into the workgroup's own row table rows[slot].
+struct Walk { int nslots; const int* rows; };
+
+__device__ inline Walk walk_setup(const AttnM& p, int* pref, int* rows, int tid) {
+    const int G = gridDim.x, bid = blockIdx.x, nB = p.R / p.T1;
+    Walk w;
+    w.rows = rows;
+    int nlive = p.R;
+    if (p.t_last) {
+        if (tid < 64) {
+            int carry = 0;
+            if (tid == 0) pref[0] = 0;
+            for (int base = 0; base < nB; base += 64) {
+                const int j = base + tid;
+                int c = 0;
+                if (j < nB) { c = p.t_last[j] + 1; c = c < 0 ? 0 : (c > p.T1 ? p.T1 : c); }
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(c, d, 64); if (tid >= d) c += o; }
+                if (j < nB) pref[j + 1] = carry + c;
+                carry += __shfl(c, 63, 64);
+            }
+        }
+        __syncthreads();
+        nlive = pref[nB];
+    }
+    w.nslots = bid < nlive ? (nlive - bid + G - 1) / G : 0;
+    for (int s = tid; s < w.nslots; s += 256) {
+        const int i = bid + s * G;
+        int r = i;
+        if (p.t_last) {                       // b = number of j in [1, nB] with pref[j] <= i
+            int lo = 0, hi = nB;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (pref[mid + 1] <= i) lo = mid + 1; else hi = mid; }
+            r = lo * p.T1 + (i - pref[lo]);
+        }
+        rows[s] = r;
+    }
+    __syncthreads();                          // (the row table is complete; the prefix scratch may be overwritten)
+    return w;
+}
+
+struct RowInfo { int r; unsigned long long kdw, qdw, emtw; };      // wave-uniform
+
+// the mask state of a row straight from the mask bytes (launches without precomputed words: the acting path, op-level calls)
+struct RowBytes { unsigned long long emtw, em0w, gbw; };
+__device__ inline RowBytes row_bytes(const AttnM& p, int r, int lane) {
+    const int b = r / p.T1;
+    const bool in = lane < p.ne;
+    const bool e = in && p.ent_mask && p.ent_mask[(long)r * p.ne + lane];
+    const bool e0 = in && p.ent_mask0 && p.ent_mask0[(long)b * p.ne + lane];
+    const bool g = in && p.group_bits && p.group_bits[(long)b * p.ne + lane];
+    RowBytes x; x.emtw = __ballot(e); x.em0w = __ballot(e0); x.gbw = __ballot(g);
+    return x;
+}
+// bit j of the result: logit (agent i, key j) is masked under variant `code`; padded agents / keys are set (lane = key)
+__device__ inline unsigned long long mask_word(const AttnM& p, int code, int r, int i, int lane, const RowBytes& rb) {
+    bool masked = true;
+    if (i < p.na && lane < p.ne) {
+        const int b = r / p.T1, t = r % p.T1;
+        const bool in0 = ((rb.em0w >> i) | (rb.em0w >> lane)) & 1ull;
+        const bool same = !in0 && !(((rb.gbw >> i) ^ (rb.gbw >> lane)) & 1ull);
+        const bool om = mask_uses_obs(code) && p.obs_mask[b * p.om_sB + t * p.om_sT + i * p.ne + lane];
+        const bool gt = mask_uses_gt(code) && p.gt_mask[b * p.gt_sB + t * p.gt_sT + i * p.ne + lane];
+        switch (code) {
+            case REFIL_MASK_OBS: masked = om; break;
+            case REFIL_MASK_OBS_WITHIN: masked = !same || om; break;
+            case REFIL_MASK_OBS_INTERACT: masked = same || om; break;
+            case REFIL_MASK_ENTITY: masked = ((rb.emtw >> i) | (rb.emtw >> lane)) & 1ull; break;
+            case REFIL_MASK_WITHIN: masked = !same; break;
+            case REFIL_MASK_INTERACT: masked = same || in0; break;
+            case REFIL_MASK_OBS_GTW: masked = gt || om; break;
+            case REFIL_MASK_OBS_GTI: masked = !gt || om; break;
+            case REFIL_MASK_GTW: masked = gt || in0; break;
+            case REFIL_MASK_GTI: masked = !gt || in0; break;
+            case REFIL_MASK_OBS_RGTW: masked = !same || gt || om; break;
+            case REFIL_MASK_OBS_RGTI: masked = (same && !gt) || om; break;
+            case REFIL_MASK_RGTW: masked = !same || gt; break;
+            default: masked = (same && !gt) || in0; break;       // REFIL_MASK_RGTI
+        }
+    }
+    return __ballot(masked);
+}
+
+// The row words of a row are fetched one job ahead of the row's first operand fetch and stay in a VECTOR register
+// until then (lane l holds word l % 3: a scalar destination would have to be waited for where the load is issued).
+struct RowNext { int r; unsigned long long w; };
+__device__ inline unsigned long long readlane64(unsigned long long v, int l) {
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l), hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <bool PRE>
+__device__ inline RowNext row_next(const AttnM& p, const Walk& w, int slot, int lane) {
+    RowNext x;
+    x.r = __builtin_amdgcn_readfirstlane(w.rows[slot]);
+    x.w = PRE ? p.rbits[3 * (long)x.r + lane % 3] : 0ull;
+    return x;
+}
+template <bool PRE>
+__device__ inline RowInfo row_take(const AttnM& p, const RowNext& nx, int lane) {
+    RowInfo x;
+    x.r = nx.r;
+    if (PRE) {
+        x.kdw = readlane64(nx.w, 0); x.qdw = readlane64(nx.w, 1); x.emtw = readlane64(nx.w, 2);
+    } else {
+        x.kdw = __ballot(p.kv_dead && lane < p.ne && p.kv_dead[(long)x.r * p.ne + (lane < p.ne ? lane : 0)]);
+        x.qdw = __ballot(p.q_dead && lane < p.na && p.q_dead[(long)x.r * p.na + (lane < p.na ? lane : 0)]);
+        x.emtw = __ballot(p.ent_mask && lane < p.ne && p.ent_mask[(long)x.r * p.ne + (lane < p.ne ? lane : 0)]);
+    }
+    return x;
+}
+
+// LDS floats per wave / workgroup of the two kernels (launcher and kernels agree through these)
+template <int NJT, int NAT, int NCT> struct PipeShape {
+    static constexpr int KP = NJT * 16, AP = NAT * 16, CP = NCT * 16, C4 = CP / 4, PD = CP + 2, TP = KP + 4;
+    static constexpr int FWD_WF = KP * PD;
+    static constexpr int BWD_WF = (AP + 2 * KP + 3 * AP) * PD + 16 * TP + 3 * AP * 2;
+};
+
+template <int NJT, int NAT, int NCT, bool PRE>
+__global__ __launch_bounds__(256) void attn_fwd_pipe(AttnM p) {
+    using S = PipeShape<NJT, NAT, NCT>;
+    constexpr int KP = S::KP, AP = S::AP, C4 = S::C4, pd = S::PD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q = lane >> 4;
+    float* Vs = smem + wave * S::FWD_WF;
+    const Walk W = walk_setup(p, reinterpret_cast<int*>(smem), reinterpret_cast<int*>(smem + 4 * S::FWD_WF), tid);
+    if (W.nslots == 0) return;
+    const int hd = p.hd;
+    const int njobs = p.nnets * p.heads, jpw = (njobs + 3) >> 2;
+    const int total = W.nslots * jpw;
+    const float inv_scale = 1.0f / sqrtf((float)hd);
+    const unsigned long long na_bits = (p.na >= 64) ? ~0ull : ((1ull << p.na) - 1ull);
+
+    float4 kf[NJT][NCT], qf[NAT][NCT];          // operands of S^T = K Q^T in MFMA layout straight from global memory
+    Tile<KP, C4> tv;
+    unsigned long long nw[3][NAT];              // PRE: mask words of (variant, this lane's agent of tile at) in flight
+    auto fetch = [&](const RowInfo& ri, int job, bool valid) {
+        const int net = job / p.heads, head = job - net * p.heads;
+        const AttnNet& n = p.net[valid ? net : 0];
+        const int col0 = head * hd;
+        const rsrc_t rk = mk_rsrc(n.K + (long)ri.r * p.ne * p.ldkv, valid ? (long)p.ne * p.ldkv * 4 : 0);
+        const rsrc_t rq = mk_rsrc(n.Q + (long)ri.r * p.na * p.ldq, valid ? (long)p.na * p.ldq * 4 : 0);
+        const rsrc_t rv = mk_rsrc(n.V + (long)ri.r * p.ne * p.ldkv, valid ? (long)p.ne * p.ldkv * 4 : 0);
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            const int key = 16 * jt + l15;
+            const bool ok = key < p.ne && !((ri.kdw >> key) & 1ull);
+#pragma unroll
+            for (int u = 0; u < NCT; ++u) {
+                const int c = 4 * NCT * q + 4 * u;
+                kf[jt][u] = buf_ld4(rk, ok && c < hd ? (key * p.ldkv + col0 + c) * 4 : BUF_OOB);
+            }
+        }
+#pragma unroll
+        for (int at = 0; at < NAT; ++at) {
+            const int ag = 16 * at + l15;
+            const bool ok = ag < p.na && !((ri.qdw >> ag) & 1ull);
+#pragma unroll
+            for (int u = 0; u < NCT; ++u) {
+                const int c = 4 * NCT * q + 4 * u;
+                qf[at][u] = buf_ld4(rq, ok && c < hd ? (ag * p.ldq + col0 + c) * 4 : BUF_OOB);
+            }
+        }
+        tv.load(rv, p.ne, p.ldkv, col0, hd, lane, ri.kdw);
+        if (PRE) {
+            const rsrc_t rw = mk_rsrc(p.mwords + (long)ri.r * p.mw_nvar * AP, valid ? (long)p.mw_nvar * AP * 8 : 0);
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+#pragma unroll
+                for (int at = 0; at < NAT; ++at) nw[v][at] = buf_ld_u64(rw, v < p.nvar ? (v * AP + 16 * at + l15) * 8 : BUF_OOB);
+        }
+    };
+
+    // fetch cursor (one job ahead of the compute cursor) and the row after its row
+    int f_slot = 0, f_jj = 0;
+    RowNext nx = row_next<PRE>(p, W, 0, lane);
+    RowInfo frow = row_take<PRE>(p, nx, lane);
+    nx = row_next<PRE>(p, W, min(1, W.nslots - 1), lane);
+    fetch(frow, wave, wave < njobs);
+    {   // as many (dropped) stores behind the first fetch as every job issues behind the fetch of its successor: the operand
+        // wait at the top of the loop is then the same count on both ways into the loop
+        const rsrc_t none = mk_rsrc(p.net[0].O, 0);
+#pragma unroll
+        for (int i = 0; i < NAT * 3 * NCT + NCT + 1; ++i) buf_st4(none, BUF_OOB - 16 * i, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    for (int k = 0; k < total; ++k) {
+        const RowInfo crow = frow;
+        const int job = wave + 4 * f_jj;
+        const bool cvalid = job < njobs;
+        const int net = job / p.heads, head = job - net * p.heads;
+        const AttnNet& n = p.net[cvalid ? net : 0];
+        const int r = crow.r;
+        // ---- operands of job k: S^T tiles from the operand registers, V and the words to their compute-phase homes
+        f32x4 stt[NAT][NJT];
+#pragma unroll
+        for (int at = 0; at < NAT; ++at)
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < NCT; ++u) {
+                    const float4 kv = kf[jt][u], qv = qf[at][u];
+                    acc = MFMA16(kv.x, qv.x, acc);
+                    acc = MFMA16(kv.y, qv.y, acc);
+                    acc = MFMA16(kv.z, qv.z, acc);
+                    acc = MFMA16(kv.w, qv.w, acc);
+                }
+                stt[at][jt] = acc;
+            }
+        tv.store(Vs, pd, lane);
+        unsigned long long cw[3][NAT];
+        if (PRE) {
+#pragma unroll
+            for (int v = 0; v < 3; ++v)
+#pragma unroll
+                for (int at = 0; at < NAT; ++at) cw[v][at] = nw[v][at];
+        } else {
+            const RowBytes rb = row_bytes(p, r, lane);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+#pragma unroll
+                for (int at = 0; at < NAT; ++at) cw[v][at] = ~0ull;
+                if (v < p.nvar)
+                    for (int i = 0; i < p.na; ++i) {
+                        const unsigned long long w = mask_word(p, p.var[v], r, i, lane, rb);
+#pragma unroll
+                        for (int at = 0; at < NAT; ++at)
+                            if (i == 16 * at + l15) cw[v][at] = w;
+                    }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- advance the fetch cursor; the operands of job k+1 are in flight during the compute phase below
+        const bool adv = f_jj + 1 == jpw;
+        f_jj = adv ? 0 : f_jj + 1;
+        f_slot += adv;
+        if (adv) frow = row_take<PRE>(p, nx, lane);
+        nx = row_next<PRE>(p, W, min(f_slot + 1, W.nslots - 1), lane);    // (every job: no branch around a load in flight)
+        fetch(frow, wave + 4 * f_jj, k + 1 < total && wave + 4 * f_jj < njobs);
+        // (nact[r] by lane 0 of the row's first job; a buffer store like the others: no divergent branch, a fixed store count)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)__popcll(~crow.emtw & na_bits)),
+                                              mk_rsrc(p.nact + r, p.nact && job == 0 ? 4 : 0), lane == 0 ? 0 : BUF_OOB, 0, 0);
+        // ---- compute. Every job issues the SAME number of stores (the ones it does not have are out of range): the
+        // s_waitcnt for the operands of the next job can then be counted past them instead of waiting for them
+        f32x4 osum[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) osum[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int at = 0; at < NAT; ++at) {
+            const int agent = 16 * at + l15;
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                f32x4 o[NCT];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const bool on = cvalid && v < n.nvar;
+                if (on) {
+                    f32x4 pt[NJT];
+#pragma unroll
+                    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) pt[jt][reg] = stt[at][jt][reg] * inv_scale;   // attention.py:54
+                    softmax_T<NJT>(pt, cw[v][at], q);
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        // O^T[c][agent] = sum_key V[key][c] P^T[key][agent]; virtual k (jt,reg | q) <-> key 16jt+4q+reg
+#pragma unroll
+                        for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg)
+                                o[ct] = MFMA16(Vs[(16 * jt + 4 * q + reg) * pd + 16 * ct + l15], pt[jt][reg], o[ct]);
+                        if (n.sum_agents) {      // padded / inactive agents have P = 0, hence o = 0: plain sum over the 16 lanes
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) osum[ct][e] += group16_sum(o[ct][e]);
+                        } else if (p.zero_dead && ((crow.emtw >> agent) & 1ull)) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                const rsrc_t ro = mk_rsrc(n.O + v * p.sO + (long)r * p.na * p.ldo, on && !n.sum_agents ? (long)p.na * p.ldo * 4 : 0);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const int c = 16 * ct + 4 * q;
+                    buf_st4(ro, agent < p.na && c < hd ? (agent * p.ldo + head * hd + c) * 4 : BUF_OOB, o[ct]);
+                }
+            }
+        }
+        {
+            const rsrc_t ro = mk_rsrc(n.O + (long)r * p.ldo, cvalid && n.sum_agents ? (long)p.ldo * 4 : 0);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int c = 16 * ct + 4 * q;
+                buf_st4(ro, l15 == 0 && c < hd ? (head * hd + c) * 4 : BUF_OOB, osum[ct]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                   // (the next job's V tile overwrites the wave's LDS region)
+    }
+}
+
+template <int NJT, int NAT, int NCT, bool PRE>
+__global__ __launch_bounds__(256, (NJT <= 2 && NAT == 1) ? 2 : 1) void attn_bwd_pipe(AttnM p) {
+    using S = PipeShape<NJT, NAT, NCT>;
+    constexpr int KP = S::KP, AP = S::AP, C4 = S::C4, pd = S::PD, TP = S::TP;
+    constexpr int NW = (3 * AP + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q = lane >> 4;
+    float* Qs = smem + wave * S::BWD_WF;
+    float* Ks = Qs + AP * pd;
+    float* Vs = Ks + KP * pd;
+    float* Ds = Vs + KP * pd;                 // dO of every variant: [3][AP] rows
+    float* Ts = Ds + 3 * AP * pd;             // dS transposition tile (16 agents x keys)
+    unsigned long long* MW = reinterpret_cast<unsigned long long*>(Ts + 16 * TP);      // mask words [3][AP]
+    const Walk W = walk_setup(p, reinterpret_cast<int*>(smem), reinterpret_cast<int*>(smem + 4 * S::BWD_WF), tid);
+    if (W.nslots == 0) return;
+    const int hd = p.hd;
+    const int njobs = p.nnets * p.heads, jpw = (njobs + 3) >> 2;
+    const int total = W.nslots * jpw;
+    const float inv_scale = 1.0f / sqrtf((float)hd);
+
+    Tile<AP, C4> tq, td[3];
+    Tile<KP, C4> tk, tv;
+    unsigned long long tw[NW];
+    auto fetch = [&](const RowInfo& ri, int job, bool valid) {
+        const int net = job / p.heads, head = job - net * p.heads;
+        const AttnNet& n = p.net[valid ? net : 0];
+        const int col0 = head * hd;
+        const long qrow = (long)ri.r * p.na, krow = (long)ri.r * p.ne;
+        tq.load(mk_rsrc(n.Q + qrow * p.ldq, valid ? (long)p.na * p.ldq * 4 : 0), p.na, p.ldq, col0, hd, lane, ri.qdw);
+        tk.load(mk_rsrc(n.K + krow * p.ldkv, valid ? (long)p.ne * p.ldkv * 4 : 0), p.ne, p.ldkv, col0, hd, lane, ri.kdw);
+        tv.load(mk_rsrc(n.V + krow * p.ldkv, valid ? (long)p.ne * p.ldkv * 4 : 0), p.ne, p.ldkv, col0, hd, lane, ri.kdw);
+        // (bcast_do: one dO row per (b,t), shared by its agents -- leading dimension 0 re-reads the same row)
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const bool on = valid && v < n.nvar, bc = n.bcast_do != 0;
+            td[v].load(mk_rsrc(n.dO + v * p.sO + (bc ? (long)ri.r : qrow) * p.ldo, on ? (long)(bc ? 1 : p.na) * p.ldo * 4 : 0), p.na, bc ? 0 : p.ldo,
+                       col0, hd, lane, bc ? 0ull : ri.qdw);
+        }
+        if (PRE) {
+            const rsrc_t rw = mk_rsrc(p.mwords + (long)ri.r * p.mw_nvar * AP, valid ? (long)p.mw_nvar * AP * 8 : 0);
+#pragma unroll
+            for (int i = 0; i < NW; ++i) tw[i] = buf_ld_u64(rw, lane + 64 * i < p.nvar * AP ? (lane + 64 * i) * 8 : BUF_OOB);
+        }
+    };
+
+    int f_slot = 0, f_jj = 0;
+    RowNext nx = row_next<PRE>(p, W, 0, lane);
+    RowInfo frow = row_take<PRE>(p, nx, lane);
+    nx = row_next<PRE>(p, W, min(1, W.nslots - 1), lane);
+    fetch(frow, wave, wave < njobs);
+    {   // as many (dropped) stores behind the first fetch as every job issues behind the fetch of its successor: the operand
+        // wait at the top of the loop is then the same count on both ways into the loop
+        const rsrc_t none = mk_rsrc(p.net[0].dQ, 0);
+#pragma unroll
+        for (int i = 0; i < NAT * NCT + 2 * NCT * NJT; ++i) buf_st4(none, BUF_OOB - 16 * i, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    for (int k = 0; k < total; ++k) {
+        const RowInfo crow = frow;
+        const int job = wave + 4 * f_jj;
+        const bool cvalid = job < njobs;
+        const int net = job / p.heads, head = job - net * p.heads;
+        const AttnNet& n = p.net[cvalid ? net : 0];
+        const int r = crow.r, nvar = cvalid ? n.nvar : 0;
+        // ---- operands of job k: registers -> wave-private LDS
+        tq.store(Qs, pd, lane); tk.store(Ks, pd, lane); tv.store(Vs, pd, lane);
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+            if (v < nvar) td[v].store(Ds + v * AP * pd, pd, lane);
+        if (PRE) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+                if (lane + 64 * i < 3 * AP) MW[lane + 64 * i] = tw[i];
+        } else if (cvalid) {
+            const RowBytes rb = row_bytes(p, r, lane);
+            for (int idx = 0; idx < nvar * AP; ++idx) {
+                const unsigned long long w = mask_word(p, p.var[idx / AP], r, idx % AP, lane, rb);
+                if (lane == 0) MW[idx] = w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- advance the fetch cursor; the operands of job k+1 are in flight during the compute phase below
+        const bool adv = f_jj + 1 == jpw;
+        f_jj = adv ? 0 : f_jj + 1;
+        f_slot += adv;
+        if (adv) frow = row_take<PRE>(p, nx, lane);
+        nx = row_next<PRE>(p, W, min(f_slot + 1, W.nslots - 1), lane);    // (every job: no branch around a load in flight)
+        fetch(frow, wave + 4 * f_jj, k + 1 < total && wave + 4 * f_jj < njobs);
+        // ---- compute (a job past the end has no variants and its stores are dropped: every job issues the same number of
+        // stores, so the operand wait of the next job can be counted past them)
+        f32x4 dKt[NCT][NJT], dVt[NCT][NJT];     // [c 16ct+4q+reg][key 16jt+l15]
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                dKt[ct][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dVt[ct][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        const rsrc_t rdq = mk_rsrc(n.dQ + (long)r * p.na * p.ldq, cvalid ? (long)p.na * p.ldq * 4 : 0);
+#pragma unroll
+        for (int at = 0; at < NAT; ++at) {
+            const int agentT = 16 * at + l15;        // agent of this lane in the transposed orientation (dQ^T columns)
+            const int agentN0 = 16 * at + 4 * q;     // first agent of this lane in the normal orientation
+            f32x4 sn0[NJT];
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) sn0[jt] = dot_tile(Qs, 16 * at, Ks, 16 * jt, 16 * NCT, pd, l15, q);   // S[agent][key]
+            f32x4 dQt[NCT];                           // [c][agent 16at+l15]
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) dQt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int v = 0; v < nvar; ++v) {
+                const float* Dv = Ds + (v * AP + 16 * at) * pd;
+                f32x4 pn[NJT];
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) pn[jt][reg] = sn0[jt][reg] * inv_scale;
+                const unsigned long long* mv = MW + v * AP + agentN0;
+                const unsigned long long wn[4] = {mv[0], mv[1], mv[2], mv[3]};
+                softmax_N<NJT>(pn, wn, l15);
+                // dP[agent][key] = dO V^T ; dS = P (dP - sum_key P dP) / scale
+                f32x4 dsn[NJT];
+                float rdN[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    dsn[jt] = dot_tile(Dv, 0, Vs, 16 * jt, 16 * NCT, pd, l15, q);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) rdN[reg] += pn[jt][reg] * dsn[jt][reg];
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) rdN[reg] = group16_sum(rdN[reg]);
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        dsn[jt][reg] = pn[jt][reg] * (dsn[jt][reg] - rdN[reg]) * inv_scale;
+                        Ts[(4 * q + reg) * TP + 16 * jt + l15] = dsn[jt][reg];
+                    }
+                // the transposed copy dS^T[key 16jt+4q+reg][agent l15] (B operand of the contraction over keys)
+                // comes back through wave-private LDS (same-wave LDS operations execute in order)
+                __builtin_amdgcn_wave_barrier();
+                f32x4 dst[NJT];
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) dst[jt] = *reinterpret_cast<const f32x4*>(Ts + l15 * TP + 16 * jt + 4 * q);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+                    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            // contraction over agents: virtual k (reg | q) <-> agent 16at+4q+reg (rows of Dv / Qs)
+                            dVt[ct][jt] = MFMA16(Dv[(4 * q + reg) * pd + 16 * ct + l15], pn[jt][reg], dVt[ct][jt]);
+                            dKt[ct][jt] = MFMA16(Qs[(16 * at + 4 * q + reg) * pd + 16 * ct + l15], dsn[jt][reg], dKt[ct][jt]);
+                            // contraction over keys: virtual k (jt,reg | q) <-> key 16jt+4q+reg
+                            dQt[ct] = MFMA16(Ks[(16 * jt + 4 * q + reg) * pd + 16 * ct + l15], dst[jt][reg], dQt[ct]);
+                        }
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int c = 16 * ct + 4 * q;
+                const bool ok = agentT < p.na && c < hd && !((crow.qdw >> agentT) & 1ull);       // (rows of skipped agents: nobody reads them)
+                buf_st4(rdq, ok ? (agentT * p.ldq + head * hd + c) * 4 : BUF_OOB, dQt[ct]);
+            }
+        }
+        const rsrc_t rdk = mk_rsrc(n.dK + (long)r * p.ne * p.ldkv, cvalid ? (long)p.ne * p.ldkv * 4 : 0);
+        const rsrc_t rdv = mk_rsrc(n.dV + (long)r * p.ne * p.ldkv, cvalid ? (long)p.ne * p.ldkv * 4 : 0);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                const int key = 16 * jt + l15, c = 16 * ct + 4 * q;
+                const bool ok = key < p.ne && c < hd && !((crow.kdw >> key) & 1ull);      // (dead K / V rows: their gradients are exact zeros nobody reads)
+                const int off = ok ? (key * p.ldkv + head * hd + c) * 4 : BUF_OOB;
+                buf_st4(rdk, off, dKt[ct][jt]);
+                buf_st4(rdv, off, dVt[ct][jt]);
+            }
+        __builtin_amdgcn_wave_barrier();                   // (the next job's operands overwrite the wave's LDS tiles)
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // EntityPoolingLayer core (attention.py:114-123): masked mean / max over the entities, same mask variants.
 // One workgroup per row (b,t); the row's in_trans outputs E[ne][w] sit in LDS; the mask words are the
@@ -743,9 +1288,54 @@ static int launch_pair(const AttnM& k, bool bwd, size_t smem, hipStream_t st) {
     return k.hd == 16 * NCT ? launch_pair_x<NJT, NAT, NCT, true>(k, bwd, smem, st) : launch_pair_x<NJT, NAT, NCT, false>(k, bwd, smem, st);
 }
 
+static int device_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+
+// persistent launch: as many workgroups as the device keeps resident (occupancy query cached per instantiation and LDS size)
+template <int NJT, int NAT, int NCT, bool PRE>
+static int launch_pipe_x(const AttnM& k, bool bwd, hipStream_t st) {
+    using S = PipeShape<NJT, NAT, NCT>;
+    const size_t waves = (size_t)4 * (bwd ? S::BWD_WF : S::FWD_WF) * 4;
+    if (((size_t)(k.R / k.T1) + 1) * 4 > waves) return -1;         // (the live-step prefix sums use the wave regions as scratch)
+    void (*kern)(AttnM) = bwd ? attn_bwd_pipe<NJT, NAT, NCT, PRE> : attn_fwd_pipe<NJT, NAT, NCT, PRE>;
+    static bool raised[2] = {false, false};
+    static int occ[2] = {0, 0};
+    if (!raised[bwd]) {
+        REFIL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised[bwd] = true;
+    }
+    if (!occ[bwd]) {                            // resident workgroups per CU (with room for a row table of a few hundred slots)
+        int n = 0;
+        REFIL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)kern, 256, waves + 1024));
+        occ[bwd] = n > 0 ? n : 1;
+    }
+    static const int occ_cap = [] { const char* e = getenv("REFIL_ATTN_OCC"); return e ? atoi(e) : 0; }();
+    const int per_cu = occ_cap > 0 && occ_cap < occ[bwd] ? occ_cap : occ[bwd];
+    const long resident = (long)device_cus() * per_cu;
+    const int grid = (int)(resident < k.R ? resident : k.R);
+    const size_t smem = waves + ((size_t)(k.R + grid - 1) / grid + 1) * 4;      // + the workgroup's row table
+    if (smem > 160 * 1024) return -1;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, k);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+template <int NJT, int NAT, int NCT>
+static int launch_pipe(const AttnM& k, bool bwd, hipStream_t st) {
+    return k.mwords ? launch_pipe_x<NJT, NAT, NCT, true>(k, bwd, st) : launch_pipe_x<NJT, NAT, NCT, false>(k, bwd, st);
+}
+
+static bool attn_v1() { static const bool v = [] { const char* e = getenv("REFIL_ATTN_V1"); return e && e[0] == '1'; }(); return v; }
+
 bool attn_mfma_supported(int ne, int na, int hd) {
     const int j = tiles16(ne), a = tiles16(na), c = tiles16(hd);
-    return (j == 1 && a == 1 && c <= 2) || (j == 2 && a == 1 && c <= 2) || (a == 2 && c == 2 && j >= 2 && j <= 4);
+    if (attn_v1()) return (j == 1 && a == 1 && c <= 2) || (j == 2 && a == 1 && c <= 2) || (a == 2 && c == 2 && j >= 2 && j <= 4);
+    return hd % 4 == 0 && na <= ne && ((j <= 2 && a == 1 && c <= 2) || (j >= 2 && j <= 4 && a <= 2 && c == 2));
 }
 
 int attn_mfma_launch(const refil_attn_desc& d, bool bwd, hipStream_t st) { return attn_mfma_launch_ex(d, bwd, st, 0, nullptr, 0, 0); }
@@ -812,22 +1402,30 @@ int attn_mfma_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts
     k.mw_nvar = d.mask_words_nvar > 0 ? d.mask_words_nvar : d.nvar;
     REFIL_CHECK(!d.mask_words || (d.row_bits && k.mw_nvar >= d.nvar), "refil_attn: mask_words needs row_bits and >= nvar variants per row");
     REFIL_CHECK(!zero_dead || d.ent_mask || d.mask_words, "refil_attn: zeroing inactive agents needs ent_mask");
-    const int pd = d.hd + 2;
-    // +16 floats of slack: fragment reads of a partial channel tile (hd < 16*nct) run past the last row
-    k.wave_floats = ((nat * 16 + 2 * njt * 16 + (bwd ? 16 : 0)) * pd + 16 + 3) & ~3;
-    if (bwd) k.wave_floats += 16 * (njt * 16 + 4);     // dS transposition tile at the end of the wave region
-    k.mask_floats = (int)(mask_region_bytes(d.ne, d.na) / 4);
-    const size_t smem = (size_t)4 * k.wave_floats * 4 + (size_t)k.mask_floats * 4 + (size_t)3 * nat * 16 * 8;
-    if (smem > 160 * 1024) return -1;
+    REFIL_CHECK(d.T1 > 0 && d.R % d.T1 == 0, "refil_attn: R must be a multiple of T1");
     double flops = 0.0, bytes = 0.0;
     for (int i = 0; i < n; ++i) {
         const double unit = (double)d.R * d.heads * d.na * d.ne * d.hd;
         flops += unit * (bwd ? 2.0 + 8.0 * descs[i].nvar : 2.0 + 2.0 * descs[i].nvar);
         bytes += 4.0 * d.R * d.heads * d.hd * (bwd ? d.na * (2.0 + descs[i].nvar) + 4.0 * d.ne : d.na * (1.0 + descs[i].nvar) + 2.0 * d.ne);
     }
+    if (!attn_mfma_supported(d.ne, d.na, d.hd)) return -1;
     ProfScope prof(bwd ? "attn_bwd_mfma" : "attn_fwd_mfma", flops, bytes, st);
+    if (attn_v1()) {
+        const int pd = d.hd + 2;
+        // +16 floats of slack: fragment reads of a partial channel tile (hd < 16*nct) run past the last row
+        k.wave_floats = ((nat * 16 + 2 * njt * 16 + (bwd ? 16 : 0)) * pd + 16 + 3) & ~3;
+        if (bwd) k.wave_floats += 16 * (njt * 16 + 4);     // dS transposition tile at the end of the wave region
+        k.mask_floats = (int)(mask_region_bytes(d.ne, d.na) / 4);
+        const size_t smem = (size_t)4 * k.wave_floats * 4 + (size_t)k.mask_floats * 4 + (size_t)3 * nat * 16 * 8;
+        if (smem > 160 * 1024) return -1;
 #define CASE(J, A, C) if (njt == J && nat == A && nct == C) return launch_pair<J, A, C>(k, bwd, smem, st)
-    CASE(1, 1, 1); CASE(1, 1, 2); CASE(2, 1, 1); CASE(2, 1, 2); CASE(2, 2, 2); CASE(3, 2, 2); CASE(4, 2, 2);
+        CASE(1, 1, 1); CASE(1, 1, 2); CASE(2, 1, 1); CASE(2, 1, 2); CASE(2, 2, 2); CASE(3, 2, 2); CASE(4, 2, 2);
+#undef CASE
+        return -1;
+    }
+#define CASE(J, A, C) if (njt == J && nat == A && nct == C) return launch_pipe<J, A, C>(k, bwd, st)
+    CASE(1, 1, 1); CASE(1, 1, 2); CASE(2, 1, 1); CASE(2, 1, 2); CASE(2, 2, 2); CASE(3, 1, 2); CASE(3, 2, 2); CASE(4, 1, 2); CASE(4, 2, 2);
 #undef CASE
     return -1;
 }

@@ -103,11 +103,17 @@ def make_batch(B: int, T: int, ne: int, seed: int = 0, na: Optional[int] = None,
     }
 
 
-def make_batch_fast(B: int, T: int, ne: int, seed: int = 0, device="cpu") -> Dict[str, torch.Tensor]:
+def make_batch_fast(B: int, T: int, ne: int, seed: int = 0, device="cpu", na: Optional[int] = None,
+                    A: Optional[int] = None) -> Dict[str, torch.Tensor]:
     """Vectorised generator with the same field distributions for the full bench sizes (the loop
-    version above is O(B*T*ne) Python and is meant for fixture-sized batches)."""
+    version above is O(B*T*ne) Python and is meant for fixture-sized batches). na / A override the shape law's agent and
+    action counts (the real 3-8MMM scenario: ne=16, na=8, A=22 -- medivacs add heal targets, starcraft2custom.py:372-374);
+    the entity width follows the feature layout: ne + (A-2) + 10."""
     law = sc2_shape_law(ne)
-    na, A, ed = law["n_agents"], law["n_actions"], law["entity_shape"]
+    na = law["n_agents"] if na is None else na
+    A = law["n_actions"] if A is None else A
+    ed = ne + (A - 2) + 10
+    assert 1 <= na <= ne and A >= 7
     rng = np.random.default_rng(seed)
     T1 = T + 1
     n_ag = rng.integers(min(3, na), na + 1, size=B)
@@ -160,3 +166,43 @@ def make_batch_fast(B: int, T: int, ne: int, seed: int = 0, device="cpu") -> Dic
         "filled": torch.from_numpy(filled),
     }
     return {k: v.to(device) for k, v in out.items()}
+
+
+def make_batch_group_matching(B: int, T: int, seed: int = 0, ne: int = 8, ed: int = 16, A: int = 3,
+                              n_groups: int = 3) -> Dict[str, torch.Tensor]:
+    """Synthetic replay with the shapes of the reference's GroupMatching env (BASELINE.json configs[0];
+    src/envs/group_matching/group_matching.py: every entity is an agent, one-hot entity features, ground-truth group
+    masks, 3 actions, fixed-length episodes) at the replay sizes of algs/refil_group_matching.yaml (B=8, T=50)."""
+    rng = np.random.default_rng(seed)
+    T1 = T + 1
+    n_act = rng.integers(max(ne // 2, 2), ne + 1, size=B)
+    active = np.arange(ne)[None, :] < n_act[:, None]                                       # [B,ne]
+    ents = np.zeros((B, T1, ne, ed), np.float32)
+    ids = rng.integers(0, ed, size=(B, T1, ne))
+    np.put_along_axis(ents, ids[..., None], 1.0, axis=3)
+    ents *= active[:, None, :, None]
+    grp = rng.integers(0, n_groups, size=(B, ne))
+    same = grp[:, :, None] == grp[:, None, :]
+    inact = ~(active[:, :, None] & active[:, None, :])
+    gt = (~same | inact).astype(np.uint8)                                                    # 1 = different group (or padded)
+    vis = rng.random((B, T1, ne, ne)) < 0.2
+    vis = vis | np.swapaxes(vis, 2, 3)
+    om = vis | inact[:, None]
+    di = np.arange(ne)
+    om[:, :, di, di] = np.broadcast_to((~active)[:, None, :], (B, T1, ne))
+    avail = np.ones((B, T1, ne, A), np.int32)
+    actions = rng.integers(0, A, size=(B, T1, ne, 1)).astype(np.int64)
+    filled = np.ones((B, T1, 1), np.int64)
+    terminated = np.zeros((B, T1, 1), np.uint8)
+    terminated[:, T - 1, 0] = 1
+    return {
+        "entities": torch.from_numpy(ents),
+        "obs_mask": torch.from_numpy(om.astype(np.uint8)),
+        "entity_mask": torch.from_numpy(np.broadcast_to((~active)[:, None, :], (B, T1, ne)).astype(np.uint8).copy()),
+        "gt_mask": torch.from_numpy(np.broadcast_to(gt[:, None], (B, T1, ne, ne)).copy()),
+        "actions": torch.from_numpy(actions),
+        "avail_actions": torch.from_numpy(avail),
+        "reward": torch.from_numpy(rng.uniform(0, 1.0, size=(B, T1, 1)).astype(np.float32)),
+        "terminated": torch.from_numpy(terminated),
+        "filled": torch.from_numpy(filled),
+    }

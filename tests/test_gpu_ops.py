@@ -242,6 +242,10 @@ def _attn_ref(q, k, v, masks, heads):
     (48, 24, 4, 32, [MASK_ENTITY, MASK_WITHIN, MASK_INTERACT]),
     (64, 32, 2, 32, [MASK_OBS]),
     (40, 40, 1, 64, [MASK_ENTITY, MASK_WITHIN]),      # tile shape without a matrix-core instantiation -> VALU fallback
+    (48, 12, 4, 32, [MASK_OBS, MASK_OBS_WITHIN, MASK_OBS_INTERACT]),     # 3 key tiles, one agent tile
+    (64, 16, 2, 32, [MASK_ENTITY, MASK_WITHIN, MASK_INTERACT]),          # 4 key tiles, one agent tile
+    (20, 4, 2, 12, [MASK_OBS, MASK_OBS_INTERACT]),                       # head dim that is not a whole 16-channel tile
+    (30, 20, 4, 24, [MASK_ENTITY]),                                      # two agent tiles, partial second channel tile
 ])
 @pytest.mark.parametrize("force_valu", [False, True])
 def test_attention_forward_backward(ne, na, heads, hd, variants, force_valu, monkeypatch):
@@ -607,3 +611,55 @@ def test_attention_precomputed_mask_words(ne, na, heads, hd, variants):
         res.append((O.cpu(), dQ.cpu(), dKV.cpu()))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,T1,ne,na,heads,hd,pre", [(24, 40, 32, 16, 4, 32, True), (24, 40, 32, 16, 4, 32, False), (40, 30, 16, 8, 4, 16, True),
+                                                       (12, 64, 48, 24, 4, 32, True), (300, 3, 16, 8, 2, 16, True)])
+def test_attention_persistent_walk(B, T1, ne, na, heads, hd, pre):
+    """More live rows than resident workgroups: every workgroup walks several rows and its waves pipeline their jobs
+    across them; ragged episode ends (t_last), dead K/V and Q rows, three variants, against the fp32 torch reference."""
+    import hip_ops
+    torch.manual_seed(B + T1)
+    R, w = B * T1, heads * hd
+    variants = [MASK_OBS, MASK_OBS_WITHIN, MASK_OBS_INTERACT]
+    q = torch.randn(R, na, w, requires_grad=True)
+    kv = torch.randn(R, ne, 2 * w, requires_grad=True)
+    obs = (torch.rand(B, T1, ne, ne) < 0.4).to(torch.uint8)
+    em = torch.zeros(B, T1, ne, dtype=torch.uint8)
+    em[:, :, na - 2:na] = 1; em[:, :, ne - 5:] = 1                   # padded agents / enemies: dead Q and K/V rows
+    em[1::3, T1 // 2:, 0] = 1                                        # an agent dying mid-episode
+    obs = obs | em[:, :, :, None] | em[:, :, None, :]                # (dead entities are never observed)
+    em0 = em[:, 0].contiguous()
+    gb = (torch.rand(B, ne) < 0.5).to(torch.uint8)
+    t_last = torch.randint(-1, T1, (B,), dtype=torch.int32)
+    t_last[0] = T1 - 1; t_last[1] = -1
+    live = (torch.arange(T1)[None, :] <= t_last[:, None]).reshape(R)
+    masks = [_masks(c, obs, em, em0, gb, na).reshape(R, na, ne) for c in variants]
+    qz = q * (1 - em[:, :, :na].reshape(R, na, 1).float())            # dead rows enter as zeros
+    kvz = kv * (1 - em.reshape(R, ne, 1).float())
+    outs = _attn_ref(qz, kvz[:, :, :w], kvz[:, :, w:], masks, heads)
+    dO = torch.randn(3, R, na, w)
+    sum((o * dO[i])[live].sum() for i, o in enumerate(outs)).backward()
+
+    qd, kvd = q.detach().reshape(R * na, w).clone(), kv.detach().reshape(R * ne, 2 * w).clone()
+    qd[em[:, :, :na].reshape(R * na).bool()] = float("nan")           # garbage where the producers skipped
+    kvd[em.reshape(R * ne).bool()] = float("nan")
+    qd, kvd = qd.to(DEV), kvd.to(DEV)
+    d = hip_ops.attn_desc(qd, kvd, kvd[:, w:], w, 2 * w, R, T1, ne, na, heads, hd, variants, obs_mask=obs.to(DEV),
+                          ent_mask=em.reshape(R, ne).to(DEV), ent_mask0=em0.to(DEV), group_bits=gb.to(DEV))
+    hip_ops.attn_skip(d, t_last.to(DEV), em.reshape(R * ne).to(DEV), em[:, :, :na].reshape(R * na).contiguous().to(DEV))
+    if pre:
+        hip_ops.attn_mask_words(d, na)
+    O = torch.full((3, R * na, w), 7.0, device=DEV)
+    hip_ops.attn_forward(d, O, w, R * na * w)
+    dQ = torch.full((R * na, w), 7.0, device=DEV)
+    dKV = torch.full((R * ne, 2 * w), 7.0, device=DEV)
+    hip_ops.attn_backward(d, dO.reshape(3, R * na, w).to(DEV), w, R * na * w, dQ, dKV, dKV[:, w:])
+    lq = (live[:, None] & ~em[:, :, :na].reshape(R, na).bool())
+    lk = (live[:, None] & ~em.reshape(R, ne).bool())
+    O, dQ, dKV = O.cpu().reshape(3, R, na, w), dQ.cpu().reshape(R, na, w), dKV.cpu().reshape(R, ne, 2 * w)
+    for i in range(3):
+        _close(O[i][lq], outs[i].detach()[lq], what=f"walk fwd variant {i}")
+    _close(dQ[lq], q.grad[lq], tol=5e-5, what="walk dQ")
+    _close(dKV[lk], kv.grad[lk], tol=5e-5, what="walk dKV")
+    assert (O[0][~live] == 7.0).all() and (dQ[~lq] == 7.0).all() and (dKV[~lk] == 7.0).all()     # untouched

@@ -448,11 +448,43 @@ TRAJ_CASES = {
                         n_steps=5, checkpoint_after=4, weight_decay=1e-4, target_update_interval=2),
 }
 
+def run_selector_case(name, out_dir):
+    """Exploration parity (src/components/action_selectors.py:10-63): the reference's EpsilonGreedyActionSelector and
+    MultinomialActionSelector under the seeded global CPU generator at several points of the epsilon schedule
+    (t_env = 0: epsilon 1.0, 500: 0.525, 2000: 0.05) and in test mode. Stored: inputs, seeds, picked actions."""
+    import_reference()
+    from components.action_selectors import REGISTRY as sel_REGISTRY
+    args = types.SimpleNamespace(epsilon_start=1.0, epsilon_finish=0.05, epsilon_anneal_time=1000, test_greedy=True)
+    g = th.Generator().manual_seed(77)
+    bs, na, A = 6, 5, 9
+    q = th.randn(bs, na, A, generator=g)
+    avail = (th.rand(bs, na, A, generator=g) < 0.6).int()
+    avail[:, :, 0] = 1                                     # (at least one available action per agent)
+    pol = th.softmax(q, dim=2) * avail
+    out = {"q": q.numpy(), "avail": avail.numpy(), "policy": pol.numpy(),
+           "args": np.array(repr(dict(epsilon_start=1.0, epsilon_finish=0.05, epsilon_anneal_time=1000)))}
+    i = 0
+    for kind, x in (("epsilon_greedy", q), ("multinomial", pol)):
+        sel = sel_REGISTRY[kind](args)
+        for t_env, test_mode in ((0, False), (500, False), (2000, False), (500, True)):
+            seed = 1000 + i
+            th.manual_seed(seed)
+            picked = sel.select_action(x, avail, t_env, test_mode=test_mode)
+            out[f"{kind}.{i}.actions"] = picked.numpy()
+            out[f"{kind}.{i}.meta"] = np.array([seed, t_env, int(test_mode)], dtype=np.int64)
+            out[f"{kind}.{i}.epsilon"] = np.array(float(sel.epsilon))
+            i += 1
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **out)
+    print("wrote", name)
+
+
 if __name__ == "__main__":
     out = os.path.join(REPO, "tests", "golden")
-    only = sys.argv[1:] or (list(CASES) + list(GM_CASES) + list(TRAJ_CASES))
+    only = sys.argv[1:] or (list(CASES) + list(GM_CASES) + list(TRAJ_CASES) + ["action_selectors"])
     for nm in only:
-        if nm in GM_CASES:
+        if nm == "action_selectors":
+            run_selector_case(nm, out)
+        elif nm in GM_CASES:
             run_gm_case(nm, GM_CASES[nm], out)
         elif nm in TRAJ_CASES:
             run_traj_case(nm, TRAJ_CASES[nm], out)
