@@ -101,8 +101,20 @@ class _Logger:
         pass
 
 
-def build(dims, imagine, B, T, seed, device, shard=None):
-    """shard = (rank, world): strong scaling -- generate the GLOBAL batch of B episodes and keep this rank's slice."""
+def densify(data):
+    """--dense-data: every entity active and observed for the whole (full-length, unterminated) episode."""
+    d = {k: v.clone() for k, v in data.items()}
+    d["entity_mask"].zero_()
+    d["obs_mask"].zero_()
+    d["filled"].fill_(1)
+    d["terminated"].zero_()
+    d["avail_actions"].fill_(1)
+    return d
+
+
+def build(dims, imagine, B, T, seed, device, shard=None, dense=False, fresh=0):
+    """shard = (rank, world): strong scaling -- generate the GLOBAL batch of B episodes and keep this rank's slice.
+    fresh = K > 0: additionally a device ReplayBuffer holding K*B episodes (K independently seeded batches)."""
     from refil_amd.components.episode_buffer import EpisodeBatch
     from refil_amd.components.transforms import OneHot
     from refil_amd.controllers import REGISTRY as mac_REGISTRY
@@ -110,6 +122,8 @@ def build(dims, imagine, B, T, seed, device, shard=None):
     from refil_amd.synthetic import make_batch_fast
     args = make_args(dims, imagine)
     data = make_batch_fast(B, T, dims["ne"], seed=seed)
+    if dense:
+        data = densify(data)
     if shard is not None:
         r, n = shard
         per = B // n
@@ -132,8 +146,20 @@ def build(dims, imagine, B, T, seed, device, shard=None):
     mac = mac_REGISTRY[args.mac](batch.scheme, groups, args)
     learner = le_REGISTRY[args.learner](mac, batch.scheme, _Logger(), args)
     learner.cuda()
-    learner.generator = torch.Generator().manual_seed(1234 + seed)
-    return args, batch, learner, data
+    learner.generator = torch.Generator().manual_seed(1234)     # the SAME stream on every rank: train() draws the global partition and slices it
+    buffer = None
+    if fresh > 0:
+        from refil_amd.components.episode_buffer import ReplayBuffer
+        buffer = ReplayBuffer(scheme, groups, fresh * B, T + 1, preprocess={"actions": ("actions_onehot", [OneHot(dims["A"])])}, device=device)
+        for k in range(fresh):
+            dk = data if k == 0 else make_batch_fast(B, T, dims["ne"], seed=seed + 1000 * k)
+            if dense and k:
+                dk = densify(dk)
+            eb = EpisodeBatch(scheme, groups, B, T + 1, preprocess={"actions": ("actions_onehot", [OneHot(dims["A"])])}, device=device)
+            eb.update({kk: v for kk, v in dk.items() if kk != "filled"}, mark_filled=False)
+            eb.data.transition_data["filled"].copy_(dk["filled"])
+            buffer.insert_episode_batch(eb)
+    return args, batch, learner, data, buffer
 
 
 def cpu_model():
@@ -191,6 +217,54 @@ def cpu_baseline(dims, imagine, data_full, target_seconds=20.0):
                       f"d={dims['d']}), fp32 torch CPU, {threads} threads (fastest of {cands})", "ms_per_step": round(best * 1e3, 1)}
 
 
+def collect_traffic(argv_cfg, timeout_s=240):
+    """HBM bytes per launch and per step from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, kernel-trace +
+    pmc only) of a short serialised run of THIS bench configuration, folded exactly like tools/pmc_summarize.py:
+    bytes = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes; the factor 2 is gfx950's FETCH_SIZE under-report for wide coalesced reads,
+    MI355X_MICROARCH.md). Returns None when rocprofv3 is not on PATH or a pass fails (the bench line then says traffic: null)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summarize as ps
+    steps_prof = 5
+    tmp = tempfile.mkdtemp(prefix="refil_pmc_")
+    env = dict(os.environ, TMPDIR=tmp)
+    dirs = {}
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, c)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-profile", "--serial",
+                   "--no-traffic"] + argv_cfg
+            r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            dirs[c] = d
+        F, Wr = ps.fold(dirs["FETCH_SIZE"]), ps.fold(dirs["WRITE_SIZE"])
+        total = 0.0
+        import csv
+        import glob
+        skip = ("FillFunctor", "copyBuffer", "fillBuffer")        # the one-time zero fill of the arena and torch's set-up copies
+        for c, mul in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            for f in glob.glob(os.path.join(dirs[c], "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if not any(x in row["Kernel_Name"] for x in skip):
+                        total += mul * float(row["Counter_Value"]) * 1024.0
+        per = {}
+        for k in set(F) | set(Wr):
+            f = F[k][0] / max(F[k][1], 1) if k in F else 0.0
+            w = Wr[k][0] / max(Wr[k][1], 1) if k in Wr else 0.0
+            per[k] = round(2 * f + w)
+        return {"per_launch": per, "hbm_bytes_per_step": total / steps_prof}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,6 +281,12 @@ def main():
                     "(kernel-quality profiling: in-situ == isolated); the default overlaps them")
     ap.add_argument("--traffic-json", default=None, help="rocprofv3 PMC summary (tools/pmc_summarize.py) of THIS build to quote "
                     "roofline.traffic from; without it traffic is null (never a stale file)")
+    ap.add_argument("--no-traffic", action="store_true", help="do not collect roofline.traffic / hbm_gb_per_step with rocprofv3 PMC passes")
+    ap.add_argument("--fresh-batches", type=int, default=0, help="K > 0: a device replay buffer of K*B episodes is filled once and every step "
+                    "trains on a FRESH ReplayBuffer.sample(B) drawn INSIDE the timed region (the gather launch and stale row-count hints "
+                    "are part of the step); default: one resident batch")
+    ap.add_argument("--dense-data", action="store_true", help="synthetic data without padding: every entity alive, full-length episodes "
+                    "(nothing for the row lists to skip: the dense-equivalent FLOPs are the executed FLOPs)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -240,18 +320,25 @@ def main():
     if a.scaling == "strong":
         assert a.global_batch % world == 0, "--global-batch must be a multiple of the number of GPUs"
         B = a.global_batch // world                        # per rank
-        args, batch, learner, data = build(dims, W["imagine"], a.global_batch, T, seed=100, device=device, shard=(rank, world))
+        args, batch, learner, data, buffer = build(dims, W["imagine"], a.global_batch, T, seed=100, device=device, shard=(rank, world),
+                                                    dense=a.dense_data, fresh=a.fresh_batches)
         global_B = a.global_batch
     else:
         B = W["B"]
-        args, batch, learner, data = build(dims, W["imagine"], B, T, seed=100 + rank, device=device)
+        args, batch, learner, data, buffer = build(dims, W["imagine"], B, T, seed=100 + rank, device=device, dense=a.dense_data, fresh=a.fresh_batches)
         global_B = B * world
 
     if a.serial:
         _lib.lib().refil_set_overlap(0)
 
+    import numpy as np
+    np.random.seed(7 + rank)            # (ReplayBuffer.sample draws the episode ids with numpy's global generator, like the reference)
+
     def step(i):
-        learner.train(batch, t_env=0, episode_num=i)
+        if buffer is not None:          # a fresh minibatch per step: one gather launch over every scheme field, inside the timed region
+            learner.train(buffer.sample(B), t_env=0, episode_num=i)
+        else:
+            learner.train(batch, t_env=0, episode_num=i)
 
     def barrier():
         if world > 1:
@@ -324,9 +411,20 @@ def main():
         iso_total = sum(x["total_ms"] for x in iso.values()) / nprof
         dom = next((e for e in ents if e["flops"] > 0), ents[0])            # dominant kernel (largest isolated time per step)
         dom_iso = iso.get(dom["name"], dom)
-        traffic = None
+        traffic, hbm_step, traffic_src = None, None, "not collected in this run"
         if a.traffic_json:
-            traffic = json.load(open(a.traffic_json))["kernels"].get(dom["name"], {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(a.traffic_json))
+            traffic = tj["kernels"].get(dom["name"], {}).get("hbm_bytes_per_launch")
+            hbm_step, traffic_src = tj.get("hbm_bytes_per_step_all_kernels"), "--traffic-json"
+        elif not a.no_traffic and world == 1 and rank == 0:
+            cfg_argv = ["--config", a.config] + (["--batch", str(a.batch)] if a.batch else []) + (["--dense-data"] if a.dense_data else [])
+            tr = collect_traffic(cfg_argv)
+            if tr:
+                traffic, hbm_step, traffic_src = tr["per_launch"].get(dom["name"]), tr["hbm_bytes_per_step"], "rocprofv3 PMC passes run by bench.py"
+        # what the launches of one step execute: the GEMM scopes report the listed rows (device counts); the attention scopes
+        # report every (b,t) row and skip the finished steps inside the kernel -- scaled by the live-step fraction here
+        live_frac = rows["live_steps"] / max(rows["steps"], 1) if rows["lists"] else 1.0
+        executed_flops = sum(x["flops"] * (live_frac if n.startswith("attn_") else 1.0) for n, x in iso.items()) / nprof
         # which roof bounds it: the projections are matrix-core work; the attention cores / recurrences / mixing kernels move
         # far more bytes per FLOP than the 157 TFLOP/s : 8 TB/s ridge (19.7 FLOP/B) -- HBM. Row-list GEMMs report the FLOPs /
         # bytes of the rows they process; the attention launches skip finished steps: scaled by the live-step fraction.
@@ -360,7 +458,12 @@ def main():
         gemm_iso = iso.get(gemm["name"], gemm) if gemm else None
         roofline = {"kernel": dom["name"], "bound": "hbm" if hbm_bound else "mfma", "achieved": round(ach_iso, 2), "peak": peak,
                     "unit": unit, "frac": round(ach_iso / peak, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE via --traffic-json; null: not collected in this run)",
+                    "traffic_unit": f"HBM bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE, {traffic_src})",
+                    "hbm_gb_per_step": None if hbm_step is None else round(hbm_step / 1e9, 3),
+                    "hbm_gb_per_s_over_step": None if hbm_step is None else round(hbm_step / (ms_per_step * 1e-3) / 1e9, 1),
+                    "executed_gflop_per_step": round(executed_flops / 1e9, 2),
+                    "step_frac_executed": round(executed_flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "mfma_floor_ms_executed": round(executed_flops / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3, 3),
                     "algorithmic_bytes_per_launch": round(live * dom_iso["bytes"] / dom_iso["launches"]),
                     "achieved_in_situ": round(ach_situ, 2), "frac_in_situ": round(ach_situ / peak, 4),
                     "heaviest_gemm": None if not gemm else {
@@ -375,14 +478,16 @@ def main():
                     "share_of_gpu_time": round(dom_iso["total_ms"] / (iso_total * nprof), 3),
                     "gpu_ms_per_step_all_kernels_in_situ": round(tot / nprof, 3),
                     "gpu_ms_per_step_all_kernels": round(iso_total, 3),
-                    "step_frac_of_mfma_roofline": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "step_frac_dense_equivalent": round(flops_step / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                     "streams": "serialised (--serial)" if a.serial else "agent and hypernet chains overlap on two streams",
                     "measured": f"HIP events on the launch streams, {nprof} steps right after the timed region. `achieved` / `avg_launch_us`: "
                                 "the streams serialised, each kernel alone on the GPU = the duration rocprofv3 --kernel-trace reports for it "
                                 "(profiles/README.md); FLOPs = what the launch executes (row-list launches: the listed rows, read back "
                                 "from the device). `*_in_situ`: both chains overlapping as in the timed region -- a launch shares the GPU "
-                                "with the other stream's kernels, a lower bound on kernel quality. `step_frac_of_mfma_roofline` = the DENSE "
-                                "algorithmic FLOPs of SURVEY.md section 8d / step time / peak (row skipping makes it exceed the kernels' own fractions)"}
+                                "with the other stream's kernels, a lower bound on kernel quality. `step_frac_executed` = FLOPs the step's launches "
+                                "EXECUTE (profiler, listed rows) / step time / peak -- the honest step-level fraction; `step_frac_dense_equivalent` = the "
+                                "DENSE algorithmic FLOPs of SURVEY.md section 8d / step time / peak (work the row lists and the algebra of DESIGN.md "
+                                "section 5 remove still counts there: a speed-up figure against the dense schedule, not a utilisation)"}
     if world > 1:
         dist.barrier()
 
@@ -403,7 +508,10 @@ def main():
                                    f"({'imagine agent' if W['imagine'] else 'entity_attend_rnn agent'} + flex_qmix), {W['what']}",
                        "global_batch": global_B, "seq_len": T, "parallelism": f"dp{world}",
                        "world_size": dist.get_world_size() if world > 1 else 1, "backend": backend,
-                       "algorithmic_gflop_per_step_per_gpu": round(flops_step / 1e9, 2)},
+                       "algorithmic_gflop_per_step_per_gpu": round(flops_step / 1e9, 2),
+                       "batches": f"{a.fresh_batches} x B episodes in a device ReplayBuffer, a fresh sample(B) per step inside the timed region" if a.fresh_batches
+                                  else "one resident minibatch (every step trains on the same episodes)",
+                       "padding": "none (--dense-data: every entity alive, full-length episodes)" if a.dense_data else "SC2-law padding / deaths / ragged episode ends"},
             "rows": {"lists_active": bool(rows["lists"]), "live_step_frac": round(rows["live_steps"] / max(rows["steps"], 1), 4),
                      "entity_rows_frac_agent_nets": round(rows["entity_rows_agent"] / max(nE, 1), 4),
                      "entity_rows_frac_hypernets": round(rows["entity_rows_hyper"] / max(nE, 1), 4),

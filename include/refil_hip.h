@@ -176,8 +176,10 @@ int refil_set_mixer_grads_hook(refil_grads_hook hook, void* user);
  *            [3][REFIL_IPC_HANDLE_BYTES]; the caller exchanges them between the ranks (any side channel);
  *   connect  takes every rank's handles [world][3][REFIL_IPC_HANDLE_BYTES] (own entry ignored) and maps the peers;
  *   allreduce  in place on `inout` (n_floats of create), stream-ordered, no host synchronisation; every rank must call it
- *            the same number of times. A peer that does not arrive within 10 s sets the status word (refil_oneshot_status)
- *            instead of hanging the GPU.
+ *            the same number of times. A peer that does not arrive within REFIL_ONESHOT_TIMEOUT_S (default 120 s) makes
+ *            the reduction write NaN over `inout` (nothing behind it can use rank-local gradients unnoticed) and record
+ *            the call number in a host-mapped status word instead of hanging the GPU: refil_oneshot_status reads it
+ *            without synchronising, and every later refil_oneshot_allreduce fails with that message.
  * world <= 16. Needs HSA_ENABLE_IPC_MODE_LEGACY=0 where the driver only supports dmabuf IPC. */
 #define REFIL_IPC_HANDLE_BYTES 64
 int refil_oneshot_create(int32_t world, int32_t rank, int64_t n_floats, uint8_t* handles_out, void** ctx_out);
@@ -185,6 +187,13 @@ int refil_oneshot_connect(void* ctx, const uint8_t* all_handles);
 int refil_oneshot_allreduce(void* ctx, float* inout, void* stream);
 int refil_oneshot_status(void* ctx, int32_t* timed_out);
 int refil_oneshot_destroy(void* ctx);
+
+/* The step's ONE collective for a non-Python host (the reference has none: src/ holds no torch.distributed call; SURVEY.md
+ * section 8e is the specification): in-place all-reduce(SUM) of the flat fp32 buffer [gradients | stat sums]
+ * (refil_learner_forward_backward's `grads`, n_floats = total + REFIL_NSTAT) on the caller's RCCL communicator
+ * (ncclComm_t), enqueued on `stream`; the global sum(mask) normaliser arrives in the same message and is applied by
+ * refil_clip_rmsprop_step. librccl.so is resolved at the first call (REFIL_RCCL_LIB overrides the name). */
+int refil_allreduce_flat(float* buf, int64_t n_floats, void* comm, void* stream);
 
 /* Diagnostics (synchronises the stream): which rows the LAST refil_learner_forward_backward on this workspace / dims
  * actually processed. The step skips rows that cannot influence the loss -- entity rows no query can attend to, query rows

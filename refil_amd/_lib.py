@@ -125,6 +125,7 @@ EXPORTS = [
     "refil_profile_enable", "refil_profile_collect", "refil_set_overlap", "refil_release_streams", "refil_replay_gather",
     "refil_learner_row_counts", "refil_attn_mask_words", "refil_set_mixer_grads_hook",
     "refil_oneshot_create", "refil_oneshot_connect", "refil_oneshot_allreduce", "refil_oneshot_status", "refil_oneshot_destroy",
+    "refil_allreduce_flat",
 ]
 IPC_HANDLE_BYTES = 64
 

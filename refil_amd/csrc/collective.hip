@@ -18,6 +18,8 @@
 // Validation status: exercised by two processes sharing ONE GPU (tests/test_gpu_dp.py: IPC handles, flag protocol,
 // double buffering, equality with torch.distributed.all_reduce). No multi-GPU box was available: cross-device
 // visibility of the staged data relies on the kernel-end release of the copy and on cache-bypassing peer loads.
+#include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -34,16 +36,20 @@ struct OneShot {
     unsigned* peer_flag[16];
     unsigned epoch;
     bool connected;
+    unsigned* status_host;         // pinned, device-mapped word: the reduce kernel sets it when a peer did not arrive
+    unsigned* status_dev;          // its device address
+    unsigned long long timeout_ticks;   // 100 MHz wall-clock ticks a rank waits for its peers
 };
 
 struct ReduceArgs {
     const float* src[16];
     const unsigned* flag[16];
-    unsigned* status;              // [1]: set to 1 on timeout
+    unsigned* status;              // [1] host-mapped: set to the epoch that timed out
     float* out;
     long n;
     int world;
     unsigned epoch;
+    unsigned long long timeout_ticks;
 };
 
 __global__ void oneshot_signal_kernel(unsigned* flag, unsigned epoch) {
@@ -58,15 +64,20 @@ __global__ __launch_bounds__(256) void oneshot_reduce_kernel(ReduceArgs a) {
         const unsigned long long t0 = wall_clock64();                 // 100 MHz
         for (int r = 0; r < a.world && ok; ++r) {
             while ((int)(__hip_atomic_load(a.flag[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - a.epoch) < 0) {
-                if (wall_clock64() - t0 > 1000000000ull) { ok = 0; break; }        // 10 s: a peer died
+                if (wall_clock64() - t0 > a.timeout_ticks) { ok = 0; break; }      // a peer died (REFIL_ONESHOT_TIMEOUT_S, default 120 s)
                 __builtin_amdgcn_s_sleep(32);
             }
         }
-        if (!ok) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!ok) __hip_atomic_store(a.status, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         ok_s = ok;
     }
     __syncthreads();
-    if (!ok_s) return;
+    if (!ok_s) {
+        // nothing was reduced: poison the buffer so that an optimiser step behind this launch cannot silently use rank-local
+        // gradients (the host sees the status word at its next call and raises)
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a.n; i += (long)gridDim.x * blockDim.x) a.out[i] = __builtin_nanf("");
+        return;
+    }
     __threadfence_system();
     const long n4 = a.n >> 2;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -103,6 +114,12 @@ extern "C" int refil_oneshot_create(int32_t world, int32_t rank, int64_t n_float
     }
     REFIL_HIP(hipMalloc((void**)&o->flag, 256));
     REFIL_HIP(hipMemset(o->flag, 0, 256));
+    REFIL_HIP(hipHostMalloc((void**)&o->status_host, 64, hipHostMallocMapped));
+    *o->status_host = 0;
+    REFIL_HIP(hipHostGetDevicePointer((void**)&o->status_dev, o->status_host, 0));
+    const char* te = getenv("REFIL_ONESHOT_TIMEOUT_S");
+    const double tsec = te && atof(te) > 0 ? atof(te) : 120.0;
+    o->timeout_ticks = (unsigned long long)(tsec * 1.0e8);
     hipIpcMemHandle_t h;
     for (int k = 0; k < 3; ++k) {
         REFIL_HIP(hipIpcGetMemHandle(&h, k < 2 ? (void*)o->in[k] : (void*)o->flag));
@@ -137,6 +154,11 @@ extern "C" int refil_oneshot_connect(void* ctx, const uint8_t* all_handles) {
 extern "C" int refil_oneshot_allreduce(void* ctx, float* inout, void* stream) {
     OneShot* o = static_cast<OneShot*>(ctx);
     REFIL_CHECK(o && o->connected && inout, "refil_oneshot_allreduce: not connected");
+    // a peer that did not arrive in an EARLIER call leaves NaNs in that call's buffer and its epoch here: fatal, the replicas
+    // can no longer be trusted to hold the same parameters (and the double-buffer argument above no longer holds)
+    REFIL_CHECK(*static_cast<volatile unsigned*>(o->status_host) == 0,
+                "refil_oneshot_allreduce: a peer did not arrive within the timeout in call %u (REFIL_ONESHOT_TIMEOUT_S); the buffer of that call was "
+                "poisoned with NaN -- restart the job or use the backend's all-reduce", *static_cast<volatile unsigned*>(o->status_host));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const unsigned e = ++o->epoch;
     float* stage = o->in[e & 1];
@@ -145,7 +167,7 @@ extern "C" int refil_oneshot_allreduce(void* ctx, float* inout, void* stream) {
     ReduceArgs a;
     memset(&a, 0, sizeof(a));
     for (int r = 0; r < o->world; ++r) { a.src[r] = o->peer_in[r][e & 1]; a.flag[r] = o->peer_flag[r]; }
-    a.status = o->flag + 1; a.out = inout; a.n = o->n; a.world = o->world; a.epoch = e;
+    a.status = o->status_dev; a.out = inout; a.n = o->n; a.world = o->world; a.epoch = e; a.timeout_ticks = o->timeout_ticks;
     const int blocks = (int)min((long)64, cdivl(o->n, 4 * 256));
     hipLaunchKernelGGL(oneshot_reduce_kernel, dim3(max(blocks, 1)), dim3(256), 0, st, a);
     REFIL_LAUNCH_CHECK();
@@ -155,9 +177,7 @@ extern "C" int refil_oneshot_allreduce(void* ctx, float* inout, void* stream) {
 extern "C" int refil_oneshot_status(void* ctx, int32_t* timed_out) {
     OneShot* o = static_cast<OneShot*>(ctx);
     REFIL_CHECK(o && timed_out, "refil_oneshot_status: bad arguments");
-    unsigned s = 0;
-    REFIL_HIP(hipMemcpy(&s, o->flag + 1, sizeof(s), hipMemcpyDeviceToHost));     // (synchronises: diagnostics only)
-    *timed_out = (int32_t)s;
+    *timed_out = (int32_t)*static_cast<volatile unsigned*>(o->status_host);      // (host-mapped word: no synchronisation; 0 or the call that timed out)
     return 0;
 }
 
@@ -172,7 +192,46 @@ extern "C" int refil_oneshot_destroy(void* ctx) {
     }
     for (int k = 0; k < 2; ++k) if (o->in[k]) (void)hipFree(o->in[k]);
     if (o->flag) (void)hipFree(o->flag);
+    if (o->status_host) (void)hipHostFree(o->status_host);
     (void)hipGetLastError();
     delete o;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// refil_allreduce_flat: the step's ONE collective for a host that is not Python: all-reduce(SUM)
+// of the flat fp32 buffer [gradients | stat sums] on the CALLER's RCCL communicator, enqueued on the caller's stream --
+// what refil_amd/dp.py gets from torch.distributed (backend "nccl" = RCCL). librccl is resolved at the first call
+// (dlopen: the library itself does not link against RCCL, a single-GPU host never loads it).
+// ------------------------------------------------------------------------------------------------
+namespace {
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef const char* (*nccl_errstr_fn)(int);
+struct Rccl { void* h; nccl_allreduce_fn allreduce; nccl_errstr_fn errstr; };
+Rccl* rccl() {
+    static Rccl r = [] {
+        Rccl x{nullptr, nullptr, nullptr};
+        const char* names[] = {getenv("REFIL_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : names) {
+            if (!n || !n[0]) continue;
+            x.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (x.h) break;
+        }
+        if (x.h) {
+            x.allreduce = reinterpret_cast<nccl_allreduce_fn>(dlsym(x.h, "ncclAllReduce"));
+            x.errstr = reinterpret_cast<nccl_errstr_fn>(dlsym(x.h, "ncclGetErrorString"));
+        }
+        return x;
+    }();
+    return &r;
+}
+}  // namespace
+
+extern "C" int refil_allreduce_flat(float* buf, int64_t n_floats, void* comm, void* stream) {
+    REFIL_CHECK(buf && n_floats > 0 && comm, "refil_allreduce_flat: null buffer / communicator");
+    Rccl* r = rccl();
+    REFIL_CHECK(r->h && r->allreduce, "refil_allreduce_flat: librccl.so not found (set REFIL_RCCL_LIB)");
+    const int rc = r->allreduce(buf, buf, (size_t)n_floats, /*ncclFloat32*/ 7, /*ncclSum*/ 0, comm, static_cast<hipStream_t>(stream));
+    REFIL_CHECK(rc == 0, "refil_allreduce_flat: ncclAllReduce failed: %s", r->errstr ? r->errstr(rc) : "?");
     return 0;
 }

@@ -110,6 +110,33 @@ struct QSelBwdArgs {
 };
 int qselect_bwd_launch(const QSelBwdArgs& a, hipStream_t st);
 
+// Q head + selection of the recurrent agents in ONE launch at the join of the two chains (entity_rnn_agent.py:57-60 and
+// q_learner.py:91,109,115-128): workgroup (b,t) computes q = fc3(h) of the live agents' G copies at step t and of the live
+// (copy 0) and target agents at step t+1 straight from the hidden states, zeroes inactive agents, and writes the chosen-action
+// Qs and the (double-Q) target values -- instead of two thin GEMMs over all rows + a gather kernel.
+struct QHeadArgs {
+    const float* hs; const float* ths;         // hidden states [G*B, T1+1, na, H] / [B, T1+1, na, H] (slot t+1 = h_t)
+    const float* w3; const float* b3; const float* tw3; const float* tb3;     // fc3 of the live / target agent: [A,H], [A]
+    const uint8_t* amask;                      // [B*T1*na] 1 = inactive agent
+    const int64_t* actions; long ac_sB, ac_sT;
+    const int32_t* avail; long av_sB, av_sT;
+    const int* t_last;                         // optional [B]
+    float* chosen; float* tmax;                // [G,B,T,na], [B,T,na]
+    float* q_out;                              // optional [G, B*T1*na, A]: the live agents' Q values (debug copies)
+    int G, B, T1, na, A, H, double_q;
+};
+bool qhead_eligible(const QHeadArgs& a);
+int qhead_launch(const QHeadArgs& a, hipStream_t st);
+
+// what the fused mixing kernel (mix_train_launch) needs to also write the Q head's backward (q_learner.py:91's gather and
+// fc3's input gradient): dq [G, B*T1*na, A] = one-hot(action) * d(chosen), dhs [G, B*T1*na, H] = d(chosen) * fc3.weight[action]
+struct QHeadBwd {
+    float* dq; float* dhs; const float* w3;    // dhs == NULL: off
+    const int64_t* actions; long ac_sB, ac_sT;
+    const uint8_t* ever;                       // optional [B, na]: rows of never-active agents are not written
+    int A, H;
+};
+
 // FlexQMixer monotonic mixing on top of the hypernet outputs (flex_qmix.py:96-121)
 struct MixArgs {
     const float* x_w1; long s_var;   // [nvar][R*na, M] masked fc2 outputs of hyper_w_1 (variant stride)
@@ -148,7 +175,7 @@ int td_loss_launch(const TdArgs& a, hipStream_t st);
 // backward (q_learner.py:134-172 and its gradient). live: forward + backward pointers, t_off 0; targ: forward pointers,
 // t_off 1; td: the batch scalars and the outputs q_tot / q_tot_im / tq_tot / targets / gc_real / gc_im (kept for parity
 // checks). row_stats [B*T][8]: per-row terms of the stat sums, folded into td.stats by td_stats_launch.
-int mix_train_launch(const MixArgs& live, const MixArgs& targ, const TdArgs& td, float* row_stats, hipStream_t st);
+int mix_train_launch(const MixArgs& live, const MixArgs& targ, const TdArgs& td, float* row_stats, hipStream_t st, const QHeadBwd* qb = nullptr);
 int td_stats_launch(const float* row_stats, int rows, float* stats, hipStream_t st);
 
 int sum_launch(const float* x, long n, float* out, hipStream_t st);   // out[0] = sum(x)

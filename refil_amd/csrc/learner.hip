@@ -17,6 +17,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unordered_map>
 
 #include "kernels.h"
 
@@ -917,6 +918,26 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
     Arena a{(char*)ws, ws_bytes, 0, false};
     carve(a, c.d, c.w, mode);
     REFIL_CHECK(!a.overflow && a.off <= ws_bytes, "refil: workspace too small (%zu < %zu bytes)", ws_bytes, a.off);
+    // Skipped rows are never written and what they hold only ever meets exact zeros -- it has to be FINITE. The caller zeroes
+    // the arena once; afterwards the only bit patterns of a learner carve that read as NaN are t_last (-1) and the mask words
+    // (all ones). When the layout on this workspace changes (another T1 / B, another entry point) float regions of the new
+    // carve may overlay them: clear those regions of the previous carve first (a few MB, stream-ordered, only on a change).
+    {
+        struct Prev { refil_dims d; int mode; };
+        static std::unordered_map<void*, Prev> prev;
+        auto it = prev.find(ws);
+        if (it != prev.end() && it->second.mode == CARVE_LEARNER && (mode != CARVE_LEARNER || memcmp(&it->second.d, dims, sizeof(refil_dims)) != 0)) {
+            Arena ao{(char*)ws, ws_bytes, 0, false};
+            Work wo;
+            carve(ao, it->second.d, wo, CARVE_LEARNER);
+            const Sizes so = sizes_of(it->second.d);
+            if (!ao.overflow) {
+                REFIL_HIP(hipMemsetAsync(wo.t_last, 0, (size_t)it->second.d.B * sizeof(int), c.st));
+                REFIL_HIP(hipMemsetAsync(wo.mw_a, 0, (size_t)(reinterpret_cast<char*>(wo.rb_h + so.R * 3) - reinterpret_cast<char*>(wo.mw_a)), c.st));
+            }
+        }
+        prev[ws] = Prev{*dims, (int)mode};
+    }
     return 0;
 }
 
@@ -1065,6 +1086,26 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         }
     }
     if (overlap) REFIL_HIP(hipEventRecord(sd->ev[1], sd->s));
+    // The join of the two chains. Opt-in (REFIL_JOIN_FUSED, bit 0 / bit 1): fc3 live + fc3 target + Q selection as ONE launch
+    // per (b,t) row (qhead_kernel), and the Q head's backward as the epilogue of the mixing kernel -- five dependent launches
+    // become two. Measured (one box, 3 interleaved rounds): cfg-T 1.863 ms off / 1.872 (bit 0) / 1.868 (bit 1) / 1.877 (both),
+    // cfg3 3.236 / 3.253 / 3.248 / 3.272, cfg2 0.948 / 0.943 / 0.951 / 0.945, cfg5 2.794 / 2.792 / 2.755 / 2.757: at the join
+    // the HYPERNET chain is the late one (it ends ~80 us after the recurrence), so shortening the agent chain's tail buys
+    // nothing at the north-star shape, and whatever lengthens the mixing kernel delays the hypernets' backward behind it.
+    static const bool fused_env = [] { const char* e = getenv("REFIL_MIX_FUSED"); return !(e && e[0] == '0'); }();
+    const char* join_e = getenv("REFIL_JOIN_FUSED");        // (read per call: a test compares the paths in one process)
+    const int join_env = join_e ? atoi(join_e) : 0;     // bit 0: qhead_kernel, bit 1: Q-head backward as the mixing kernel's epilogue
+    const bool mix_fused = fused_env && hypernets && !d.mixer_lin;
+    QHeadArgs qh;
+    memset(&qh, 0, sizeof(qh));
+    qh.hs = w.la.hsx; qh.ths = w.ta.hsx;
+    qh.w3 = params_live + L.ag_fc3_w; qh.b3 = params_live + L.ag_fc3_b; qh.tw3 = params_target + L.ag_fc3_w; qh.tb3 = params_target + L.ag_fc3_b;
+    qh.amask = w.amask; qh.actions = c.b.actions; qh.ac_sB = c.b.ac_sB; qh.ac_sT = c.b.ac_sT;
+    qh.avail = c.b.avail_actions; qh.av_sB = c.b.av_sB; qh.av_sT = c.b.av_sT;
+    qh.t_last = c.lists ? w.t_last : nullptr;
+    qh.chosen = w.chosen; qh.tmax = w.tmax; qh.G = G; qh.B = d.B; qh.T1 = d.T1; qh.na = d.na; qh.A = d.A; qh.H = H; qh.double_q = d.double_q;
+    const bool qhead_fused = (join_env & 1) && mix_fused && !d.agent_ff && qhead_eligible(qh);
+    const bool qbwd_fused = (join_env & 2) && mix_fused && !d.agent_ff && H % 4 == 0;
     if (!d.agent_ff && (G * d.B * d.na) % 16 == 0) {
         // live (q_learner.py:86-89 / 107) and target (:111-113) agents on one stream: their recurrences share one launch
         static const bool dual_env = [] { const char* e = getenv("REFIL_AGENT_DUAL"); return !(e && e[0] == '0'); }();
@@ -1075,13 +1116,20 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_PRE | (dual ? AG_NO_ENTITY : 0)));
         const refil_gru_desc gl = agent_gru_desc(ca, params_live, w.la, G, true), gt = agent_gru_desc(ca, params_target, w.ta, 1, true);
         RUN(gru_forward_launch2(gl, &gt, ca.st));
-        RUN(agent_forward(ca, params_live, w.la, G, nullptr, AG_POST));
-        RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_POST));
+        if (!qhead_fused) {
+            RUN(agent_forward(ca, params_live, w.la, G, nullptr, AG_POST));
+            RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_POST));
+        }
     } else {
-        RUN(agent_forward(ca, params_live, w.la, G, nullptr));
-        RUN(agent_forward(ca, params_target, w.ta, 1, nullptr));
+        RUN(agent_forward(ca, params_live, w.la, G, nullptr, qhead_fused ? (AG_PRE | AG_GRU) : AG_ALL));
+        RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, qhead_fused ? (AG_PRE | AG_GRU) : AG_ALL));
     }
-    {
+    if (qhead_fused) {
+        // the join of the two chains: Q head (fc3), inactive-agent fill, chosen-action gather and double-Q target selection
+        // in ONE launch per (b,t) row straight from the hidden states (two thin GEMMs over all rows + a gather kernel before)
+        qh.q_out = debug ? w.la.qv : nullptr;
+        RUN(qhead_launch(qh, ca.st));
+    } else {
         QSelArgs q;
         q.q = w.la.qv; q.tq = w.ta.qv; q.actions = c.b.actions; q.ac_sB = c.b.ac_sB; q.ac_sT = c.b.ac_sT;
         q.avail = c.b.avail_actions; q.av_sB = c.b.av_sB; q.av_sT = c.b.av_sT;
@@ -1121,10 +1169,14 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     t.ingroup_rows = ml.ingroup_rows;
     t.B = d.B; t.T = T; t.imagine = d.imagine; t.gamma = d.gamma; t.lmbda = d.lmbda;
     // FlexQMixer: live mix, target mix, TD error and the live mix's backward in one launch (REFIL_MIX_FUSED=0: four launches)
-    static const bool fused_env = [] { const char* e = getenv("REFIL_MIX_FUSED"); return !(e && e[0] == '0'); }();
-    const bool mix_fused = fused_env && hypernets && !d.mixer_lin;
+    QHeadBwd qb;
+    memset(&qb, 0, sizeof(qb));
+    if (qbwd_fused) {
+        qb.dq = w.dqva; qb.dhs = w.dhs; qb.w3 = params_live + L.ag_fc3_w; qb.actions = c.b.actions; qb.ac_sB = c.b.ac_sB; qb.ac_sT = c.b.ac_sT;
+        qb.ever = (c.lists && c.compose_agent) ? w.ever : nullptr; qb.A = d.A; qb.H = H;
+    }
     if (mix_fused) {
-        RUN(mix_train_launch(ml, mt, t, w.row_stats, c.st));                      // :134-172 + backward of the mix
+        RUN(mix_train_launch(ml, mt, t, w.row_stats, c.st, qbwd_fused ? &qb : nullptr));   // :134-172 + backward of the mix (+ of the Q head)
     } else {
         if (!d.mixer_none) {
             RUN(mix_forward_launch(ml, c.st));                                    // :134-152
@@ -1237,7 +1289,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         q.w3 = nullptr; q.dhs = nullptr; q.H = 0; q.ever = nullptr;
         if (!d.agent_ff) { q.w3 = params_live + L.ag_fc3_w; q.dhs = w.dhs; q.H = H; }     // recurrent agent: + d(hidden) = dq W3
         if (!d.agent_ff && c.lists && c.compose_agent) q.ever = w.ever;     // (the recurrence and the fc3 gradient read list_t rows only)
-        RUN(qselect_bwd_launch(q, ca.st));
+        if (!qbwd_fused) RUN(qselect_bwd_launch(q, ca.st));                // (fused: written by the mixing kernel's epilogue)
         const long rows = (long)G * s.NA;
         ComposeArgs ag_compose;
         bool ag_compose_pending = false;

@@ -4,6 +4,7 @@
 // none of them is large enough to matter next to the projections, they exist so that no
 // intermediate ever leaves the GPU or goes through a generic framework op.
 #include "kernels.h"
+#include "bufops.h"
 #include "profile.h"
 
 namespace refil {
@@ -370,6 +371,114 @@ int qselect_launch(const QSelArgs& a, hipStream_t st) {
     return 0;
 }
 
+// Q head + selection in one launch (kernels.h: QHeadArgs). The (G + 2) * na hidden-state rows of the workgroup -- live copies
+// at step t, live copy 0 and target at step t+1 -- go through v_mfma_f32_16x16x4_f32 in 16-row tiles spread over the 4 waves:
+// A = h rows, B = fc3.weight rows, both loaded from global memory straight in operand layout (lane (l15, q) takes the
+// contiguous reduction range [H/4 q, H/4 (q+1)) of "its" row; the k order is a free permutation); the Q values land in LDS
+// (zero for inactive agents, entity_rnn_agent.py:57-60) for the gather / double-Q arg-max of the row.
+template <int GH>
+__global__ __launch_bounds__(256) void qhead_kernel(QHeadArgs a) {
+    constexpr int KQ = GH / 4;
+    extern __shared__ __attribute__((aligned(16))) float Qs[];            // [(G + 2) * na][A]
+    const int T = a.T1 - 1;
+    const int r = blockIdx.x, b = r / a.T1, tt = r % a.T1, tid = threadIdx.x;
+    if (a.t_last && tt > a.t_last[b]) return;
+    const bool need_next = tt < T && !(a.t_last && tt + 1 > a.t_last[b]);      // step t+1 was computed upstream
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, q = lane >> 4;
+    const int nat = (a.na + 15) >> 4, nct = (a.A + 15) >> 4, ntiles = (a.G + 2) * nat;
+    const long NA = (long)a.B * a.T1 * a.na;
+    for (int tile = wave; tile < ntiles; tile += 4) {
+        const int copy = tile / nat, at = tile - copy * nat;
+        const bool next = copy >= a.G, targ = copy == a.G + 1;
+        const int step = next ? tt + 1 : tt, agent = 16 * at + l15;
+        const float* hs = targ ? a.ths : a.hs;
+        const long gb = next ? b : (long)copy * a.B + b;
+        const bool on = !next || need_next;
+        const rsrc_t rh = mk_rsrc(hs + ((gb * (a.T1 + 1) + step + 1) * a.na) * GH, on ? (long)a.na * GH * 4 : 0);
+        const rsrc_t rw = mk_rsrc(targ ? a.tw3 : a.w3, (long)a.A * GH * 4);
+        float av[KQ], bw[4][KQ];
+#pragma unroll
+        for (int u = 0; u < KQ / 4; ++u) {
+            const float4 v = buf_ld4(rh, agent < a.na ? (agent * GH + KQ * q + 4 * u) * 4 : BUF_OOB);
+            av[4 * u] = v.x; av[4 * u + 1] = v.y; av[4 * u + 2] = v.z; av[4 * u + 3] = v.w;
+        }
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int u = 0; u < KQ / 4; ++u) {
+                const int k = 16 * ct + l15;
+                const float4 v = buf_ld4(rw, ct < nct && k < a.A ? (k * GH + KQ * q + 4 * u) * 4 : BUF_OOB);
+                bw[ct][4 * u] = v.x; bw[ct][4 * u + 1] = v.y; bw[ct][4 * u + 2] = v.z; bw[ct][4 * u + 3] = v.w;
+            }
+        const float* bias = targ ? a.tb3 : a.b3;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            if (ct >= nct) break;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < KQ; ++s4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bw[ct][s4], acc, 0, 0, 0);
+            const int k = 16 * ct + l15;                   // D[row 4q+reg][col l15]: agent 16at + 4q + reg, action k
+            if (k < a.A) {
+                const float bk = bias[k];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int i = 16 * at + 4 * q + reg;
+                    if (i < a.na) {
+                        const bool live = step <= T && on && !a.amask[((long)b * a.T1 + step) * a.na + i];
+                        const float v = live ? acc[reg] + bk : 0.f;
+                        Qs[(copy * a.na + i) * a.A + k] = v;
+                        if (a.q_out && !next) a.q_out[((long)copy * NA + ((long)b * a.T1 + tt) * a.na + i) * a.A + k] = v;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tt >= T) return;
+    const int nlive = a.G * a.na;
+    const long BTn = (long)a.B * T * a.na;
+    const long o0 = ((long)b * T + tt) * a.na;
+    for (int idx = tid; idx < nlive; idx += 256) {
+        const int g = idx / a.na, i = idx - g * a.na;
+        const int64_t act = a.actions[b * a.ac_sB + tt * a.ac_sT + i];
+        a.chosen[(long)g * BTn + o0 + i] = Qs[idx * a.A + act];
+    }
+    if (tid < a.na) {
+        const int i = tid;
+        float out = 0.f;
+        if (need_next) {
+            const int32_t* av = a.avail + b * a.av_sB + (tt + 1) * a.av_sT + (long)i * a.A;
+            const float* ql = Qs + (nlive + i) * a.A;               // live copy 0, step t+1
+            const float* tq = Qs + (nlive + a.na + i) * a.A;        // target, step t+1
+            if (a.double_q) {
+                float best = av[0] == 0 ? NEG_UNAVAIL : ql[0];
+                int arg = 0;
+                for (int k = 1; k < a.A; ++k) {
+                    const float v = av[k] == 0 ? NEG_UNAVAIL : ql[k];
+                    if (v > best) { best = v; arg = k; }   // first maximal index on ties
+                }
+                out = av[arg] == 0 ? NEG_UNAVAIL : tq[arg];
+            } else {
+                out = av[0] == 0 ? NEG_UNAVAIL : tq[0];
+                for (int k = 1; k < a.A; ++k) out = fmaxf(out, av[k] == 0 ? NEG_UNAVAIL : tq[k]);
+            }
+        }
+        a.tmax[o0 + i] = out;
+    }
+}
+static size_t qhead_smem(const QHeadArgs& a) { return (size_t)(a.G + 2) * a.na * a.A * sizeof(float); }
+bool qhead_eligible(const QHeadArgs& a) { return (a.H == 32 || a.H == 64 || a.H == 128) && a.A <= 64 && a.na <= 256 && qhead_smem(a) <= 64 * 1024; }
+int qhead_launch(const QHeadArgs& a, hipStream_t st) {
+    REFIL_CHECK(qhead_eligible(a) && a.hs && a.ths && a.chosen && a.tmax, "refil qhead: shape not eligible / null pointer");
+    const size_t smem = qhead_smem(a);
+    ProfScope prof("qhead_kernel", 2.0 * a.B * a.T1 * (a.G + 2.0) * a.na * a.A * a.H, 0.0, st);
+    if (a.H == 32) hipLaunchKernelGGL(qhead_kernel<32>, dim3(a.B * a.T1), dim3(256), smem, st, a);
+    else if (a.H == 64) hipLaunchKernelGGL(qhead_kernel<64>, dim3(a.B * a.T1), dim3(256), smem, st, a);
+    else hipLaunchKernelGGL(qhead_kernel<128>, dim3(a.B * a.T1), dim3(256), smem, st, a);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
 // d(chosen)/d(q): scatter through the gather (q_learner.py:91) and the inactive-agent zero fill
 // (entity_rnn_agent.py:60); dense [G*R*na, A] so that the fc3 dW/dX GEMMs can consume it.
 __global__ void qselect_bwd_kernel(QSelBwdArgs a) {
@@ -623,7 +732,35 @@ __global__ __launch_bounds__(64 * MIXW) void mix_bwd_kernel(MixArgs a) {
 // dependent launches -- live mix, target mix, TD, backward -- become one). Workgroup r = (b,tt): live mix of step tt,
 // target mix of step tt+1, TD error of (b,tt), then the backward of the live mix with that row's own loss gradient.
 // Same arithmetic, in the same order, as mix_fwd_kernel / td_loss_kernel / mix_bwd_kernel.
-struct MixTrainArgs { MixArgs live, targ; TdArgs td; float* row_stats; };
+struct MixTrainArgs { MixArgs live, targ; TdArgs td; float* row_stats; QHeadBwd qb; };
+
+// Q head backward of row (b,tt), written by the whole workgroup once the d(chosen) values dql[v][i] of the row are known:
+// dq rows = one-hot(action) * d(chosen), d(hidden) rows = d(chosen) * fc3.weight[action] (16-byte stores; zero rows for
+// inactive agents and steps without loss; rows of never-active agents are left alone -- nothing reads them).
+// acts[i]: the agent's action, -1 = no gradient (inactive / no loss), -2 = never active. w3s[i][:] = fc3.weight[acts[i]].
+__device__ inline void qhead_bwd_write(const QHeadBwd& qb, const MixArgs& a, int b, int tt, int nvar, const float* dql, const int* acts, const float* w3s) {
+    const long NA = (long)a.B * a.T1 * a.na;
+    const long row0 = ((long)b * a.T1 + tt) * a.na;
+    const int H4 = qb.H >> 2;
+    for (int idx = threadIdx.x; idx < nvar * a.na * H4; idx += 64 * MIXW) {
+        const int c4 = idx % H4, vi = idx / H4, i = vi % a.na, v = vi / a.na;
+        const int ac = acts[i];
+        if (ac == -2) continue;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ac >= 0) {
+            const float g = dql[v * a.na + i];
+            const float4 w = *reinterpret_cast<const float4*>(w3s + i * qb.H + 4 * c4);
+            o = make_float4(g * w.x, g * w.y, g * w.z, g * w.w);
+        }
+        *reinterpret_cast<float4*>(qb.dhs + ((long)v * NA + row0 + i) * qb.H + 4 * c4) = o;
+    }
+    for (int idx = threadIdx.x; idx < nvar * a.na * qb.A; idx += 64 * MIXW) {
+        const int k = idx % qb.A, vi = idx / qb.A, i = vi % a.na, v = vi / a.na;
+        const int ac = acts[i];
+        if (ac == -2) continue;
+        qb.dq[((long)v * NA + row0 + i) * qb.A + k] = k == ac ? dql[v * a.na + i] : 0.f;
+    }
+}
 
 template <bool HALF>
 __global__ __launch_bounds__(64 * MIXW) void mix_train_kernel(MixTrainArgs p) {
@@ -642,6 +779,12 @@ __global__ __launch_bounds__(64 * MIXW) void mix_train_kernel(MixTrainArgs p) {
     const bool skipped = a.t_last && tt > a.t_last[b];
     const int bt = b * a.T + tt;
     if (tt >= a.T || skipped) {                            // no loss term: exact-zero gradients (see mix_bwd_kernel)
+        if (p.qb.dhs) {
+            int* acts = reinterpret_cast<int*>(wk);
+            for (int i = threadIdx.x; i < a.na; i += 64 * MIXW) acts[i] = (p.qb.ever && !p.qb.ever[b * a.na + i]) ? -2 : -1;
+            __syncthreads();
+            qhead_bwd_write(p.qb, a, b, tt, nvar, nullptr, acts, nullptr);
+        }
         if (tt < a.T) {
             if (m == 0)
                 for (int i = i0; i < a.na; i += istep)
@@ -668,6 +811,19 @@ __global__ __launch_bounds__(64 * MIXW) void mix_train_kernel(MixTrainArgs p) {
     }
     const long qbase = (long)bt * a.na;
     const long BTn = (long)a.B * a.T * a.na;
+    // Q head backward (epilogue below): the row's actions and their fc3 rows go to LDS now, underneath the forward mix
+    int* acts = reinterpret_cast<int*>(wk + a.na * 3 * 64);
+    float* dql = wk + a.na * 3 * 64 + ((a.na + 3) & ~3);
+    float* w3s = dql + ((3 * a.na + 3) & ~3);
+    if (p.qb.dhs) {
+        for (int idx = threadIdx.x; idx < a.na * p.qb.H; idx += 64 * MIXW) {
+            const int i = idx / p.qb.H, c = idx - i * p.qb.H;
+            int ac = a.amask[(long)r * a.na + i] ? -1 : (int)p.qb.actions[b * p.qb.ac_sB + tt * p.qb.ac_sT + i];
+            if (p.qb.ever && !p.qb.ever[b * a.na + i]) ac = -2;
+            if (c == 0) acts[i] = ac;
+            w3s[idx] = ac >= 0 ? p.qb.w3[(long)ac * p.qb.H + c] : 0.f;
+        }
+    }
     const MixRow o = mix_row_forward<HALF>(a, base, qbase, lane, wave, red, wk);
     const float qt = grp_sum<HALF>(act ? o.hid_r * o.wf : 0.f) + o.v;
     const float qi = a.imagine ? grp_sum<HALF>(act ? o.hid_i * o.wf : 0.f) + o.v : 0.f;
@@ -723,6 +879,7 @@ __global__ __launch_bounds__(64 * MIXW) void mix_train_kernel(MixTrainArgs p) {
             const float q = a.qs[v * a.s_qs_g + qbase + i];
             const float dq = grp_sum<HALF>(act ? dpre * w : 0.f);
             if (m == 0) a.dqs[(long)v * BTn + qbase + i] = dq;
+            if (m == 0 && p.qb.dhs) dql[v * a.na + i] = dq;
             const float dw = q * dpre;
             const float dx = a.softmax_w ? w * (dw - q * dq) : sgn(x) * dw;
             if (act) a.dx_w1[v * a.s_var + oo] = dead ? 0.f : dx;
@@ -736,6 +893,10 @@ __global__ __launch_bounds__(64 * MIXW) void mix_train_kernel(MixTrainArgs p) {
     if (a.presum && act && wave == 0 && half == 0) {
         const long oo = (long)r * a.M + m;
         a.dx_wf[oo] = dwf_raw; a.dx_b1[oo] = db1; a.dx_v[oo] = dv;
+    }
+    if (p.qb.dhs) {
+        __syncthreads();
+        qhead_bwd_write(p.qb, a, b, tt, nvar, dql, acts, w3s);
     }
 }
 
@@ -921,14 +1082,17 @@ int mix_backward_launch(const MixArgs& a, hipStream_t st) {
     return 0;
 }
 
-int mix_train_launch(const MixArgs& live, const MixArgs& targ, const TdArgs& td, float* row_stats, hipStream_t st) {
+int mix_train_launch(const MixArgs& live, const MixArgs& targ, const TdArgs& td, float* row_stats, hipStream_t st, const QHeadBwd* qb) {
     if (int e = mix_check(live)) return e;
     if (int e = mix_check(targ)) return e;
     REFIL_CHECK(live.lin == 0 && targ.lin == 0 && row_stats && live.t_off == 0 && targ.t_off == 1, "refil mix_train: FlexQMixer learner step only");
     MixTrainArgs p;
     p.live = live; p.targ = targ; p.td = td; p.row_stats = row_stats;
+    p.qb = qb ? *qb : QHeadBwd{};
     ProfScope prof("mix_train_kernel", 0.0, 0.0, st);
-    const size_t smem = (size_t)live.na * 3 * 64 * sizeof(float);
+    const size_t smem = ((size_t)live.na * 3 * 64 + (qb && qb->dhs ? ((live.na + 3) & ~3) + ((3 * live.na + 3) & ~3) + (size_t)live.na * qb->H : 0)) * sizeof(float);
+    REFIL_CHECK(!(qb && qb->dhs) || qb->H % 4 == 0, "refil mix_train: rnn_hidden_dim must be a multiple of 4");
+    REFIL_CHECK(smem <= 60 * 1024, "refil mix_train: n_agents too large for the row's LDS tables");
     if (live.M <= 32) hipLaunchKernelGGL(mix_train_kernel<true>, dim3(live.B * live.T1), dim3(64 * MIXW), smem, st, p);
     else hipLaunchKernelGGL(mix_train_kernel<false>, dim3(live.B * live.T1), dim3(64 * MIXW), smem, st, p);
     REFIL_LAUNCH_CHECK();

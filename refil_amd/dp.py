@@ -47,7 +47,10 @@ class OneShotAllReduce:
     """refil_oneshot_* (include/refil_hip.h): every rank stages its buffer in IPC-exported device memory and sums all
     ranks' staged buffers itself, in rank order -- one hop over xGMI's point-to-point links instead of a ring's
     2 (N-1), bit-identical results on all ranks. The IPC handles are exchanged once through torch.distributed's
-    object all-gather (any backend). Validated with two processes on one GPU (tests/test_gpu_dp.py); opt-in."""
+    object all-gather (any backend). Validated with two processes on one GPU (tests/test_gpu_dp.py); opt-in, and gated by
+    a start-up equality check against the backend's all-reduce. A peer that does not arrive within
+    REFIL_ONESHOT_TIMEOUT_S (default 120 s) is FATAL: that call's buffer is overwritten with NaN and every later call
+    raises (the replicas can no longer be trusted to be identical)."""
 
     def __init__(self, n_floats: int, device):
         import ctypes as C
@@ -65,6 +68,21 @@ class OneShotAllReduce:
             buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
             _lib.check(_lib.lib().refil_oneshot_connect(self.ctx, buf), "refil_oneshot_connect")
         dist.barrier()                           # every rank has mapped every peer before the first reduction
+        self._self_check(device)
+
+    def _self_check(self, device):
+        """Gate: one reduction of a known vector through the peer-memory path must equal the backend's all-reduce before
+        the path is trusted with gradients (cross-device visibility of the staged data is a property of the platform)."""
+        g = torch.Generator().manual_seed(4321 + rank())
+        x = torch.randn(self.n, generator=g).to(device)
+        ref = x.clone()
+        dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+        self(x)
+        torch.cuda.synchronize(device)
+        err = (x - ref).abs().max().item()
+        if not (err <= 1e-5 * max(ref.abs().max().item(), 1.0)) or self.timed_out():
+            raise RuntimeError(f"one-shot peer all-reduce self-check failed on rank {rank()} (max abs diff {err:.3e} against "
+                               "torch.distributed.all_reduce): unset REFIL_ALLREDUCE to use the backend's collective")
 
     def __call__(self, flat: torch.Tensor) -> torch.Tensor:
         assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous() and flat.numel() == self.n

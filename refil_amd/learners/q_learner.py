@@ -99,10 +99,16 @@ class QLearner:
         train() never synchronises the host, so the async H2D copy of step k may still be queued when step k+1
         draws: the pinned staging buffers form a ring, and a slot is rewritten only after the event recorded
         behind its last copy has completed."""
-        p = th.rand(B, 1, 1, generator=self.generator).repeat(1, 1, ne)
+        # data parallel: every rank draws the partition of the GLOBAL batch from an identically seeded generator and keeps
+        # the rows of its shard (episodes [rank*B, (rank+1)*B) of the global batch, dp.shard_episodes), so that the union over
+        # the ranks IS the single-process draw (SURVEY.md section 8e) and the generators stay in step
+        W, R = dp.world(), dp.rank()
+        p = th.rand(B * W, 1, 1, generator=self.generator).repeat(1, 1, ne)
         if not bernoulli:
             return None
-        bits = th.bernoulli(p, generator=self.generator).to(th.uint8).reshape(B, ne)
+        bits = th.bernoulli(p, generator=self.generator).to(th.uint8).reshape(B * W, ne)
+        if W > 1:
+            bits = dp.shard_bits(bits, R, W)
         if self._bits_host is None or self._bits_host[0][0].shape != bits.shape:
             self._bits_host = [(th.empty_like(bits).pin_memory(), th.cuda.Event()) for _ in range(16)]
             self._bits_slot = 0
@@ -210,8 +216,15 @@ class QLearner:
             # measured on ROCm 7.2: ending the capture of the four-stream schedule (weight-gradient streams that also carry
             # the forward's mask-word kernels) crashes inside hipStreamEndCapture; the two-stream schedule captures fine
             raise RuntimeError("REFIL_HIPGRAPH=1 needs REFIL_GRADSTREAM=0 (two-stream schedule) on this ROCm release")
+        # the graph holds raw addresses: the batch fields, the partition bits, the flat parameter / gradient buffers AND the
+        # engine's workspace arena (grow-only: a larger request re-allocates it, and a graph captured against the old arena
+        # would replay into freed memory). The arena is sized for this step BEFORE the key is taken.
+        import ctypes as _C
+        nbytes = _lib.lib().refil_learner_workspace_bytes(_C.byref(dims))
+        self._engine.ws.get(nbytes)
         key = (bytes(dims), tuple((k, v.data_ptr(), v.stride(0), v.stride(1)) for k, v in sorted(fields.items())),
-               0 if bits is None else bits.data_ptr(), dp.world())
+               0 if bits is None else bits.data_ptr(), dp.world(), self._engine.ws.buf.data_ptr(), self.flat_live.data_ptr(),
+               self.flat_target.data_ptr(), self.grads.data_ptr(), self.square_avg.data_ptr())
         ent = self._graphs.get(key)
         fused = dp.world() == 1
 

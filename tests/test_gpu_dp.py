@@ -47,9 +47,16 @@ def _train(rank, world, port, q):
     learner.mixer.load_state_dict({k[len("mixer0."):]: th.from_numpy(z[k]) for k in z.files if k.startswith("mixer0.")})
     learner.target_mac.agent.load_state_dict({k[len("tagent."):]: th.from_numpy(z[k]) for k in z.files if k.startswith("tagent.")})
     learner.target_mixer.load_state_dict({k[len("tmixer."):]: th.from_numpy(z[k]) for k in z.files if k.startswith("tmixer.")})
-    learner.train(batch, 0, 0, group_bits=bits)
+    if os.environ.get("REFIL_TEST_DRAW") == "1":        # the learner draws the partition itself (global draw, sliced per rank)
+        learner.generator = th.Generator().manual_seed(99)
+        learner.train(batch, 0, 0)
+        bits = learner._bits_dev.cpu()
+    else:
+        learner.train(batch, 0, 0, group_bits=bits)
     th.cuda.synchronize()
-    q.put((rank, learner.flat_live.cpu().numpy(), dict(learner.logger.stats)))
+    st = dict(learner.logger.stats)
+    st["bits"] = bits.numpy().tolist()
+    q.put((rank, learner.flat_live.cpu().numpy(), st))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -99,6 +106,22 @@ def test_two_rank_step_equals_single_process_step():
     assert abs(two[0][0] - one[0]).max() < 2e-6
     for k in ("loss", "grad_norm", "td_error_abs"):
         assert abs(two[0][1][k] - one[1][k]) < 1e-4 * max(abs(one[1][k]), 1e-3), k
+
+
+@pytest.mark.timeout(600)
+def test_partition_drawn_once_for_the_global_batch():
+    """Without explicit group_bits every rank draws the partition of the GLOBAL batch from an identically seeded generator
+    and keeps its shard's rows: the union over the ranks equals the single-process draw bit for bit, and the step equals
+    the single-process step."""
+    import numpy as np
+    one = _run(1, env={"REFIL_TEST_DRAW": "1"})[0]
+    two = _run(2, env={"REFIL_TEST_DRAW": "1"})
+    b1 = np.array(one[1]["bits"])
+    b2 = np.concatenate([np.array(two[0][1]["bits"]), np.array(two[1][1]["bits"])])
+    assert b1.shape == b2.shape and (b1 == b2).all(), "union of the ranks' partition bits differs from the single-process draw"
+    assert 0 < b1.sum() < b1.size
+    assert (two[0][0] == two[1][0]).all(), "replicas diverged"
+    assert abs(two[0][0] - one[0]).max() < 2e-6
 
 
 @pytest.mark.timeout(600)
@@ -188,3 +211,41 @@ def test_two_rank_learner_step_with_oneshot_allreduce():
     assert (one[0][0] == ref[0][0]).all(), "one-shot all-reduce changed the result"
     for k in ("loss", "grad_norm"):
         assert one[0][1][k] == ref[0][1][k], k
+
+
+def test_allreduce_flat_on_a_caller_communicator():
+    """refil_allreduce_flat (the step's collective for a non-Python host): ncclAllReduce(SUM) in place on the caller's RCCL
+    communicator and stream. A one-rank communicator created through librccl's own C API: the sum over one rank is the
+    buffer itself; the call must succeed, stay stream-ordered and leave the data intact."""
+    import ctypes as C
+    from refil_amd import _lib
+    rccl = None
+    for name in ("librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", os.path.join(os.path.dirname(th.__file__), "lib", "librccl.so")):
+        try:
+            rccl = C.CDLL(name, mode=C.RTLD_GLOBAL)
+            os.environ["REFIL_RCCL_LIB"] = name
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("librccl.so not loadable on this box")
+    th.cuda.init()
+    x = th.randn(5000, device="cuda")
+    ref = x.clone()
+    uid = (C.c_char * 128)()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+
+    class UID(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    u = UID.from_buffer_copy(bytes(uid))
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, u, 0) == 0
+    L = _lib.lib()
+    L.refil_allreduce_flat.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    _lib.check(L.refil_allreduce_flat(x.data_ptr(), x.numel(), comm, _lib.current_stream_ptr()), "refil_allreduce_flat")
+    th.cuda.synchronize()
+    assert th.equal(x, ref)
+    assert L.refil_allreduce_flat(x.data_ptr(), x.numel(), None, _lib.current_stream_ptr()) != 0      # no communicator: an error, not a crash
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)

@@ -28,7 +28,7 @@ def main():
     W = bench.CONFIGS[a.config]
     dims = bench.workload_dims(W)
     dev = torch.device("cuda", 0)
-    args, batch, learner, _ = bench.build(dims, W["imagine"], a.envs, a.steps, seed=5, device=dev)
+    args, batch, learner, _, _ = bench.build(dims, W["imagine"], a.envs, a.steps, seed=5, device=dev)
     mac = learner.mac
     per_step = []
     for ep in range(a.episodes):

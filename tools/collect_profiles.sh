@@ -6,19 +6,19 @@
 #   3b. the same step without a tracer (HIP events of the library profiler)                 -> gpurun_out/<tag>_timeline_untraced.txt
 #   4. the bench line of every BASELINE.json config (cfgT with the CPU baseline and the PMC traffic of step 2)
 # Copy the summaries into profiles/ afterwards (tools/pmc_summarize.py folds step 2).
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o p -- \
-    python $ROOT/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_n1_under_rocprofv3.json 2> $OUT/${TAG}_stats.log
+    python $ROOT/bench.py --no-cpu-baseline --no-traffic > $OUT/${TAG}_bench_n1_under_rocprofv3.json 2> $OUT/${TAG}_stats.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_serial -o p -- \
-    python $ROOT/bench.py --no-cpu-baseline --serial > $OUT/${TAG}_bench_n1_serial_under_rocprofv3.json 2> $OUT/${TAG}_stats_serial.log
+    python $ROOT/bench.py --no-cpu-baseline --no-traffic --serial > $OUT/${TAG}_bench_n1_serial_under_rocprofv3.json 2> $OUT/${TAG}_stats_serial.log
 for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -o p -- \
-        python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --serial > $OUT/${TAG}_pmc_$c.log 2>&1
+        python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-traffic --serial > $OUT/${TAG}_pmc_$c.log 2>&1
 done
 cd $ROOT
 python tools/trace_step.py $(find $OUT/${TAG}_stats_serial -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_timeline_serial.txt
@@ -28,15 +28,21 @@ cp $(find $OUT/${TAG}_stats_serial -name "*kernel_stats.csv" | head -1) $OUT/${T
 python tools/pmc_summarize.py $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_traffic.json
 rm -rf $OUT/${TAG}_stats $OUT/${TAG}_stats_serial $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE
 python bench.py --traffic-json $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_bench_cfgT.json 2> $OUT/${TAG}_bench_cfgT.err
+# the driver's command line (bench.py collects the PMC traffic itself), a fresh minibatch per step, unpadded data
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_cfgT_driver_cmd.json 2> /dev/null
+python bench.py --fresh-batches 8 --no-cpu-baseline --no-traffic > $OUT/${TAG}_bench_cfgT_fresh.json 2> /dev/null
+python bench.py --dense-data --no-cpu-baseline --no-traffic > $OUT/${TAG}_bench_cfgT_dense.json 2> /dev/null
 for c in cfg2 cfg3 cfg4 cfg5; do
-    python bench.py --config $c > $OUT/${TAG}_bench_$c.json 2> $OUT/${TAG}_bench_$c.err
+    python bench.py --config $c --no-traffic > $OUT/${TAG}_bench_$c.json 2> $OUT/${TAG}_bench_$c.err
     # per-config rocprofv3 summary with the chains serialised (each kernel alone on the GPU: the kernel's own duration)
     (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_$c -o p -- \
-        python $ROOT/bench.py --config $c --no-cpu-baseline --serial --steps 20 --warmup 5 > /dev/null 2>&1)
+        python $ROOT/bench.py --config $c --no-cpu-baseline --no-traffic --serial --steps 20 --warmup 5 > /dev/null 2>&1)
     cp $(find $OUT/${TAG}_stats_$c -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${c}_kernel_stats_serial.csv
     rm -rf $OUT/${TAG}_stats_$c
 done
-python bench.py --serial --no-cpu-baseline > $OUT/${TAG}_bench_cfgT_serial.json 2>/dev/null
+python bench.py --serial --no-cpu-baseline --no-traffic > $OUT/${TAG}_bench_cfgT_serial.json 2>/dev/null
+# calibrated MFMA-busy counters (tools/pmc_mfma.sh: probe at ~99 % of peak under the same counters, then the serialised bench)
+bash tools/pmc_mfma.sh $TAG > $OUT/${TAG}_pmc_mfma.log 2>&1
 # one step WITHOUT a tracer: HIP events around every launch (library profiler), stream + start + duration per launch
 python tools/probes/timeline.py --out $OUT/${TAG}_timeline_untraced.txt > /dev/null 2>&1; rm -f $OUT/${TAG}_timeline_untraced.txt.raw
 ls -la $OUT | grep ${TAG}_

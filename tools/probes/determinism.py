@@ -13,8 +13,8 @@ cfg = sys.argv[2] if len(sys.argv) > 2 else "cfgT"
 W = dict(bench.CONFIGS[cfg])
 dims = bench.workload_dims(W)
 dev = torch.device("cuda", 0)
-_, batch, la, _ = bench.build(dims, W["imagine"], W["B"], W["T"], seed=100, device=dev)
-_, _, lb, _ = bench.build(dims, W["imagine"], W["B"], W["T"], seed=100, device=dev)
+_, batch, la, _, _ = bench.build(dims, W["imagine"], W["B"], W["T"], seed=100, device=dev)
+_, _, lb, _, _ = bench.build(dims, W["imagine"], W["B"], W["T"], seed=100, device=dev)
 la._check_flat(); lb._check_flat()
 assert torch.equal(la.flat_live, lb.flat_live)
 for i in range(N):

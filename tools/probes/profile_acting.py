@@ -2,7 +2,7 @@ import cProfile, pstats, sys, os, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch, bench
 W = bench.CONFIGS["cfgT"]; dims = bench.workload_dims(W)
-args, batch, learner, _ = bench.build(dims, W["imagine"], 8, 80, seed=5, device=torch.device("cuda", 0))
+args, batch, learner, _, _ = bench.build(dims, W["imagine"], 8, 80, seed=5, device=torch.device("cuda", 0))
 mac = learner.mac
 def run(n):
     mac.init_hidden(8)

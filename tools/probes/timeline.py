@@ -20,7 +20,7 @@ from refil_amd import _lib  # noqa: E402
 
 W = dict(bench.CONFIGS[a.config])
 dims = bench.workload_dims(W)
-args, batch, learner, data = bench.build(dims, W["imagine"], W["B"], W["T"], seed=100, device=torch.device("cuda:0"))
+args, batch, learner, data, _ = bench.build(dims, W["imagine"], W["B"], W["T"], seed=100, device=torch.device("cuda:0"))
 for i in range(8):
     learner.train(batch, t_env=0, episode_num=i)
 torch.cuda.synchronize()

@@ -7,7 +7,7 @@ import torch
 import bench
 W = bench.CONFIGS["cfgT"]
 dims = bench.workload_dims(W)
-args, batch, learner, data = bench.build(dims, W["imagine"], 16, 40, seed=3, device=torch.device("cuda", 0))
+args, batch, learner, data, _ = bench.build(dims, W["imagine"], 16, 40, seed=3, device=torch.device("cuda", 0))
 from plugin_util import RecLogger
 learner.logger = RecLogger()
 learner.args.learner_log_interval = 1
