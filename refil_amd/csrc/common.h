@@ -63,6 +63,14 @@ inline RowMap make_rowmap(int grp, int gstride, int off) {
 }
 inline bool rowmap_exact(int grp, long rows) { return !grp || ((long)grp <= (1L << 20) && rows * (long)grp < (1L << 40)); }
 
+// Workgroup barrier that orders LDS traffic only. __syncthreads() is a workgroup-scope release/acquire FENCE around the
+// barrier: on gfx9 the compiler implements it with s_waitcnt vmcnt(0), i.e. every global load AND store in flight is
+// drained at every barrier -- in a recurrence step loop that puts the write-acknowledge latency of the step's own stores
+// (and the prefetch distance of its loads) on the per-step critical path. Here only the LDS operations are completed
+// (lgkmcnt) before the barrier; the "memory" clobber keeps the compiler from moving memory operations across it. Use it
+// where the data exchanged between the waves lives in LDS and global memory is private to a lane.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // hardware-rate versions for the per-step GRU gate math (v_exp_f32 + v_rcp_f32, ~1 ulp each; both saturate
 // correctly: exp2 -> inf gives 0 resp. +-1). expf / tanhf / IEEE division cost ~10x the instructions, and the

@@ -4,21 +4,19 @@
 // src/modules/agents/entity_rnn_agent.py:49-55): T1 dependent GRUCell steps on [G*B*na, H] rows.
 // The reference issues 81 cell launches forward (+81 backward); here ONE kernel walks all steps:
 //
-//  * rows are independent, so a workgroup (4 waves) owns a tile of 16 rows for the whole episode --
-//    no grid sync. The input projection x_t W_ih^T + b_ih for ALL steps is one big GEMM done
-//    beforehand (refil_gemm); only the recurrent h W_hh^T stays in the loop.
-//  * per step each wave computes a 16x16 block of each gate with v_mfma_f32_16x16x4_f32: wave w owns
-//    hidden columns [16w,16w+16) of r, z and n, so the gate math for a column is lane-local.
-//    Its 3x16 B-fragments of W_hh (48 VGPRs) are loaded ONCE and stay in registers for all T1 steps;
-//    backward keeps the 48 fragments of W_hh^T the same way.
-//  * the new hidden tile is exchanged between the 4 waves through a double-buffered 16x64 LDS tile
-//    (pitch 66 floats: the strided ds_read_b32 A-fragment reads are conflict-free) -- one barrier
-//    per step.
-//  * gi (forward) / saved gates (backward) of step t+1 are prefetched into registers while step t
-//    is in the matrix pipe.
-//
-// MFMA fragment maps (v_mfma_f32_16x16x4_f32): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
-// D[row=4*(l>>4)+reg][col=l&15]. The k order is permuted (k = 4s + (l>>4)) identically for A and B.
+//  * rows are independent, so a workgroup owns a tile of FOUR rows for the whole episode -- no grid sync. The input
+//    projection x_t W_ih^T + b_ih for ALL steps is one big GEMM done beforehand; only the recurrent h W_hh^T stays in the loop;
+//  * the recurrent product runs on v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 outer products per instruction): the chain
+//    of T1 dependent steps is bound by the time of ONE step on ONE CU, and a 4-row tile needs a quarter of the matrix-core
+//    cycles per step of the 16-row tile v_mfma_f32_16x16x4_f32 would force (details at the kernels below);
+//  * W_hh fragments (3 x H/4 VGPRs per lane) are loaded ONCE and stay in registers for all steps; backward keeps the
+//    fragments of W_hh^T the same way;
+//  * the new hidden tile is exchanged between the waves through a double-buffered LDS tile, one LDS-only barrier per step
+//    (common.h: lds_barrier -- __syncthreads() would drain the step's global stores at every step);
+//  * the per-step inputs (forward: input gates; backward: six saved tensors) are fetched REFIL_GRU_PD steps ahead into a
+//    ring of registers.
+#include <stdlib.h>
+
 #include "common.h"
 #include "profile.h"
 #include "../../include/refil_hip.h"
@@ -26,7 +24,6 @@
 namespace refil {
 
 // Hidden size GH (rnn_hidden_dim) is a template parameter: 32, 64 (every shipped config) or 128; a workgroup has GH/16 waves.
-constexpr int GROWS = 16;     // rows per workgroup
 // LDS pitches: h tile GH + 4, dgh tile 3 GH + 4 (pitch/4 odd: conflict-free 16-byte fragment reads)
 
 struct GruK {
@@ -42,15 +39,6 @@ struct GruK {
 // the others `b` -- the two 100 us latency chains overlap instead of queueing behind each other
 struct GruK2 { GruK a, b; int nblk0; };
 
-// number of steps the rows [r0, r0 + GROWS) need: 1 + max over their episodes of t_last (all T1 without a bound)
-__device__ inline int tile_steps(const GruK& p, int r0) {
-    if (!p.t_last) return p.T1;
-    int tend = 0;
-    const int rl = min(r0 + GROWS, p.NR) - 1;
-    for (int gb = r0 / p.na; gb <= rl / p.na; ++gb) tend = max(tend, p.t_last[gb % p.B] + 1);
-    return min(tend, p.T1);
-}
-
 // Global accesses of the step loops: scalar (SGPR) base + 32-bit byte offset per lane -- one instruction per access
 // instead of a 64-bit multiply-add chain in front of each (the launchers check that the tensors stay below 4 GiB).
 __device__ inline float ldg32(const float* base, unsigned byte_off) {
@@ -60,8 +48,283 @@ __device__ inline void stg32(float* base, unsigned byte_off, float v) {
     *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
+// ================================================================================================
+// 4-row tiles on v_mfma_f32_4x4x1_16b_f32.
+//
+// A recurrence is a chain of T1 dependent steps per row tile; what bounds it is the time of ONE step on ONE CU, not
+// throughput (128 sixteen-row tiles leave half of the 256 CUs idle). With v_mfma_f32_16x16x4_f32 a tile cannot have fewer
+// than 16 rows, i.e. 48 MFMAs (1536 cycles) per step and SIMD. v_mfma_f32_4x4x1_16b_f32 computes 16 independent 4x4 outer
+// products per instruction at the same FLOP rate (8 cycles; tools/probes/mfma4_probe.hip: layout and rate), so a tile of FOUR
+// rows works: block (cg, ks) = lane / 4 of wave w multiplies the 4 rows (A: lane % 4 = row) by the 4 hidden columns
+// 16 w + 4 cg + (lane % 4) over the k slice ks (a quarter of the reduction: the k order is free), 3 gates x H/4 instructions
+// = 384 cycles per step instead of 1536, on four times as many workgroups (every CU gets two). The four k-slice partials of
+// an element sit in the four quads of a DPP row: two row_ror adds. Afterwards lane (cg, ks, j) OWNS element (row ks, column
+// 16 w + 4 cg + j): a quarter of the gate arithmetic, of the per-step loads and of the stores of the 16-row kernels per lane.
+// ================================================================================================
+constexpr int GR4 = 4;
+#ifndef REFIL_GRU_PD
+#define REFIL_GRU_PD 4      // prefetch distance (steps) of the 4-row recurrence kernels = unroll factor of their step loops
+#endif
+// a tile whose four rows all belong to agents that are never active in their episode has nothing to do: its rows are neither
+// read nor written by anyone (ListArgs::ever); with 16-row tiles (all agents of an episode copy) this never happened
+__device__ inline bool tile_never_active(const GruK& p, int r0) {
+    if (!p.ever) return false;
+    bool any = false;
+    for (int k = 0; k < GR4; ++k) {
+        const int rr = r0 + k;
+        if (rr < p.NR) any |= p.ever[((rr / p.na) % p.B) * p.na + rr % p.na] != 0;
+    }
+    return !any;
+}
+
+__device__ inline int tile_steps4(const GruK& p, int r0) {
+    if (!p.t_last) return p.T1;
+    int tend = 0;
+    const int rl = min(r0 + GR4, p.NR) - 1;
+    for (int gb = r0 / p.na; gb <= rl / p.na; ++gb) tend = max(tend, p.t_last[gb % p.B] + 1);
+    return min(tend, p.T1);
+}
+template <int CTRL>
+__device__ inline float dpp_rot(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the four quads of each 16-lane row (the four k slices of a block column), in every lane
+__device__ inline float quad4_sum(float v) { v += dpp_rot<0x124>(v); v += dpp_rot<0x128>(v); return v; }   // row_ror:4, row_ror:8
+__device__ inline float pick4(const f32x4& v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3])); }
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+
 template <bool SAVE, int GH>
-__global__ __launch_bounds__(4 * GH) void gru_fwd_kernel(GruK2 p2) {
+__global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
+    constexpr int HP = GH + 4, KS = GH / 4;                // KS: reduction indices per k slice
+    __shared__ __attribute__((aligned(16))) float hbuf[2][GR4 * HP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 3, ks = (lane >> 2) & 3, cg = lane >> 4;
+    const int c = wave * 16 + 4 * cg + j;                  // hidden column of this lane (B operand / result column)
+    const bool second = (int)blockIdx.x >= p2.nblk0;
+    const GruK& p = second ? p2.b : p2.a;
+    const int r0 = (second ? blockIdx.x - p2.nblk0 : blockIdx.x) * GR4;
+    if (tile_never_active(p, r0)) return;                 // (uniform)
+    const int tend = tile_steps4(p, r0);
+    const bool save = SAVE && p.save_r != nullptr;
+
+    // W_hh fragments of this lane's column over its k slice: bw[g][s] = W_hh[g GH + c][KS ks + s]
+    float bw[3][KS];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int s4 = 0; s4 < KS / 4; ++s4) {
+            const float4 v = *reinterpret_cast<const float4*>(p.w_hh + (long)(g * GH + c) * GH + KS * ks + 4 * s4);
+            bw[g][4 * s4] = v.x; bw[g][4 * s4 + 1] = v.y; bw[g][4 * s4 + 2] = v.z; bw[g][4 * s4 + 3] = v.w;
+        }
+    const float bhr = p.b_hh[c], bhz = p.b_hh[GH + c], bhn = p.b_hh[2 * GH + c];
+
+    // the element this lane owns: row r0 + ks, column c
+    const int rr = r0 + ks;
+    bool valid = rr < p.NR;
+    if (valid && p.ever) valid = p.ever[((rr / p.na) % p.B) * p.na + rr % p.na] != 0;      // (never-active agent: no traffic)
+    const int gb = valid ? rr / p.na : 0, ia = valid ? rr % p.na : 0;
+    const long gi_base = (long)gb * p.T1 * p.na + ia, hs_base = (long)gb * (p.T1 + 1) * p.na + ia;
+    float hold = (valid && !p.zero_h0) ? p.hsx[hs_base * GH + c] : 0.f;
+    if (valid && p.zero_h0) p.hsx[hs_base * GH + c] = 0.f;       // (the backward and the weight gradients read h_{-1} from slot 0)
+    hbuf[0][ks * HP + c] = hold;
+    // byte offsets at step 0 (rows past the end / never-active rows alias row 0: loaded, never stored)
+    const unsigned go = (unsigned)((gi_base * (3 * GH) + c) * sizeof(float));
+    unsigned so = (unsigned)((gi_base * GH + c) * sizeof(float));
+    unsigned ho = (unsigned)(((hs_base + p.na) * GH + c) * sizeof(float));
+    const unsigned gi_step = (unsigned)(p.na * 3 * GH * sizeof(float)), row_step = (unsigned)(p.na * GH * sizeof(float));
+    // The per-step inputs are fetched PD steps ahead into a ring of registers (the loop is unrolled by PD: static ring
+    // indices, no moves of in-flight registers). gfx9 retires loads and stores through ONE in-order counter: awaiting the
+    // load of step t + PD also awaits every store issued before it, so the distance is what gives the step's own stores
+    // (and the HBM latency under load, > 1 us) PD steps to complete instead of one.
+    constexpr int PD = REFIL_GRU_PD;
+    float gq[PD][3];
+    const int tlast = max(tend - 1, 0);
+#pragma unroll
+    for (int u = 0; u < PD; ++u) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gq[u][g] = ldg32(p.gi, go + (unsigned)min(u, tlast) * gi_step + g * GH * (unsigned)sizeof(float));
+        __builtin_amdgcn_sched_barrier(0);     // (issue order = ring order: slot u has the later slots' loads behind it on the way into the loop too)
+    }
+    __syncthreads();
+
+    for (int t0 = 0; t0 < tend; t0 += PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            const int t = t0 + u;
+            if (t >= tend) return;                         // (uniform; `return`, not `break`: a path from here back to the loop head would make the compiler wait for the youngest loads there)
+            const float* hb = hbuf[t & 1];
+            float* hn = hbuf[(t + 1) & 1];
+            float gcur[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) { asm volatile("" : "+v"(gq[u][g])); gcur[g] = gq[u][g]; }
+            {   // refill the slot with step t + PD (past the end: the last step again -- no branch around the loads)
+                const unsigned o = go + (unsigned)min(t + PD, tlast) * gi_step;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) gq[u][g] = ldg32(p.gi, o + g * GH * (unsigned)sizeof(float));
+            }
+            __builtin_amdgcn_sched_barrier(0);             // the loads are ISSUED here
+            float a[KS];                                   // A operand: row j of the h tile over this lane's k slice
+#pragma unroll
+            for (int s4 = 0; s4 < KS / 4; ++s4) {
+                const float4 v = *reinterpret_cast<const float4*>(hb + j * HP + KS * ks + 4 * s4);
+                a[4 * s4] = v.x; a[4 * s4 + 1] = v.y; a[4 * s4 + 2] = v.z; a[4 * s4 + 3] = v.w;
+            }
+            f32x4 acc[3][2];                               // two accumulators per gate: dependent chains half as long
+#pragma unroll
+            for (int g = 0; g < 3; ++g) { acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = acc[g][0]; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g][s & 1] = MFMA4(a[s], bw[g][s], acc[g][s & 1]);
+            float pre[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                f32x4 v = acc[g][0] + acc[g][1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = quad4_sum(v[i]);
+                pre[g] = pick4(v, ks);                     // (row ks, column c): the element this lane owns
+            }
+            const float rg = fast_sigmoid(gcur[0] + pre[0] + bhr);
+            const float zg = fast_sigmoid(gcur[1] + pre[1] + bhz);
+            const float gh = pre[2] + bhn;
+            const float ng = fast_tanh(gcur[2] + rg * gh);
+            hold = (1.0f - zg) * ng + zg * hold;
+            hn[ks * HP + c] = hold;
+            if (valid) {
+                stg32(p.hsx, ho, hold);
+                if (save) { stg32(p.save_r, so, rg); stg32(p.save_z, so, zg); stg32(p.save_n, so, ng); stg32(p.save_ghn, so, gh); }
+            }
+            ho += row_step; so += row_step;
+            lds_barrier();                                 // (not __syncthreads(): its fence would drain the step's stores -- common.h)
+        }
+    }
+}
+
+// BPTT on 4-row tiles: lane (cg, ks, j) owns element (row ks, column c) of the tile. For t = T1-1 .. 0:
+//   dh = carry + dhs[t];  dn = dh (1-z);  dz = dh (h_{t-1} - n);  carry' = dh z
+//   dn_pre = dn (1-n^2);  dr = dn_pre ghn;  dgh_n = dn_pre r
+//   dr_pre = dr r (1-r);  dz_pre = dz z (1-z)
+//   dgi[t] = (dr_pre, dz_pre, dn_pre);  dgh[t] = (dr_pre, dz_pre, dgh_n);  carry' += dgh[t] W_hh
+template <int GH>
+__global__ __launch_bounds__(4 * GH) void gru_bwd4_kernel(GruK p) {
+    constexpr int GP = 3 * GH + 4, KS = 3 * GH / 4, NW = GH / 16;
+    __shared__ __attribute__((aligned(16))) float gbuf[2][GR4 * GP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 3, ks = (lane >> 2) & 3, cg = lane >> 4;
+    const int c = wave * 16 + 4 * cg + j;
+    const int r0 = blockIdx.x * GR4;
+    if (tile_never_active(p, r0)) return;                 // (uniform)
+    const int tend = tile_steps4(p, r0);
+
+    // carry[row][c] += sum_k dgh[row][k] W_hh[k][c]: bw[s] = W_hh[KS ks + s][c]
+    float bw[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) bw[s] = p.w_hh[(long)(KS * ks + s) * GH + c];
+
+    const int rr = r0 + ks;
+    bool valid = rr < p.NR;
+    if (valid && p.ever) valid = p.ever[((rr / p.na) % p.B) * p.na + rr % p.na] != 0;
+    const int gb = valid ? rr / p.na : 0, ia = valid ? rr % p.na : 0;
+    const long gi_base = (long)gb * p.T1 * p.na + ia, hs_base = (long)gb * (p.T1 + 1) * p.na + ia;
+    const unsigned go = (unsigned)((gi_base * GH + c) * sizeof(float));
+    const unsigned ho = (unsigned)((hs_base * GH + c) * sizeof(float));
+    const unsigned so = (unsigned)((gi_base * (3 * GH) + c) * sizeof(float));
+    const unsigned row_step = (unsigned)(p.na * GH * sizeof(float));
+    // per-step inputs of the own element: 0 dhs, 1 r, 2 z, 3 n, 4 ghn, 5 h_{t-1}
+    auto fetch = [&](float (&dst)[6], int t) __attribute__((always_inline)) {
+        const unsigned adv = (unsigned)t * row_step;
+        dst[0] = ldg32(p.dhs, go + adv); dst[1] = ldg32(p.save_r, go + adv); dst[2] = ldg32(p.save_z, go + adv);
+        dst[3] = ldg32(p.save_n, go + adv); dst[4] = ldg32(p.save_ghn, go + adv); dst[5] = ldg32(p.hsx, ho + adv);
+    };
+    // steps the episode's loss cannot reach (t >= tend): exact zeros, what the full recurrence would have produced
+    for (int t = tend + wave; t < p.T1; t += NW) {
+        for (int idx = lane; idx < GR4 * (3 * GH / 4); idx += 64) {
+            const int row = idx / (3 * GH / 4), c4 = idx % (3 * GH / 4);
+            const int r2 = r0 + row;
+            if (r2 < p.NR && (!p.ever || p.ever[((r2 / p.na) % p.B) * p.na + r2 % p.na])) {
+                const long o = (((long)(r2 / p.na) * p.T1 + t) * p.na + r2 % p.na) * (3 * GH) + 4 * c4;
+                *reinterpret_cast<float4*>(p.dgi + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(p.dgh + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    if (tend <= 0) return;
+    // inputs fetched PD steps ahead into a ring of register sets (loop unrolled by PD: static indices; see the forward kernel)
+    constexpr int PD = REFIL_GRU_PD;
+    float ring[PD][6];
+    float carry = 0.f;
+#pragma unroll
+    for (int u = 0; u < PD; ++u) { fetch(ring[u], max(tend - 1 - u, 0)); __builtin_amdgcn_sched_barrier(0); }     // (issue order = ring order)
+    int it = 0;
+    for (int tb = tend - 1; tb >= 0; tb -= PD) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            const int t = tb - u;
+            if (t < 0) return;                             // (uniform; see the forward kernel)
+            float* gw = gbuf[it & 1];
+            ++it;
+            float cur[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { asm volatile("" : "+v"(ring[u][k])); cur[k] = ring[u][k]; }
+            fetch(ring[u], max(t - PD, 0));                // (unconditional: a branch here costs register copies and waits)
+            __builtin_amdgcn_sched_barrier(0);             // the loads are ISSUED here, ahead of the step's arithmetic
+            const float dh = carry + cur[0];
+            const float rg = cur[1], zg = cur[2], ng = cur[3], ghn = cur[4], hp = cur[5];
+            const float dn = dh * (1.0f - zg);
+            const float dz = dh * (hp - ng);
+            const float dhz = dh * zg;
+            const float dn_pre = dn * (1.0f - ng * ng);
+            const float dr = dn_pre * ghn;
+            const float dghn = dn_pre * rg;
+            const float dr_pre = dr * rg * (1.0f - rg);
+            const float dz_pre = dz * zg * (1.0f - zg);
+            float* row = gw + ks * GP;
+            row[c] = dr_pre; row[GH + c] = dz_pre; row[2 * GH + c] = dghn;
+            lds_barrier();                                 // (not __syncthreads(): its fence would drain the step's loads and stores)
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+#pragma unroll
+            for (int s = 0; s < KS; s += 12) {
+                const float4 v0 = *reinterpret_cast<const float4*>(gw + j * GP + KS * ks + s);
+                const float4 v1 = *reinterpret_cast<const float4*>(gw + j * GP + KS * ks + s + 4);
+                const float4 v2 = *reinterpret_cast<const float4*>(gw + j * GP + KS * ks + s + 8);
+                a0 = MFMA4(v0.x, bw[s], a0); a1 = MFMA4(v0.y, bw[s + 1], a1); a2 = MFMA4(v0.z, bw[s + 2], a2);
+                a0 = MFMA4(v0.w, bw[s + 3], a0); a1 = MFMA4(v1.x, bw[s + 4], a1); a2 = MFMA4(v1.y, bw[s + 5], a2);
+                a0 = MFMA4(v1.z, bw[s + 6], a0); a1 = MFMA4(v1.w, bw[s + 7], a1); a2 = MFMA4(v2.x, bw[s + 8], a2);
+                a0 = MFMA4(v2.y, bw[s + 9], a0); a1 = MFMA4(v2.z, bw[s + 10], a1); a2 = MFMA4(v2.w, bw[s + 11], a2);
+            }
+            f32x4 v = a0 + a1 + a2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = quad4_sum(v[i]);
+            carry = dhz + pick4(v, ks);
+            if (valid) {
+                constexpr unsigned G1 = GH * sizeof(float);
+                const unsigned o = so + 3u * (unsigned)t * row_step;
+                stg32(p.dgi, o, dr_pre); stg32(p.dgi, o + G1, dz_pre); stg32(p.dgi, o + 2 * G1, dn_pre);
+                stg32(p.dgh, o, dr_pre); stg32(p.dgh, o + G1, dz_pre); stg32(p.dgh, o + 2 * G1, dghn);
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// 16-row tiles on v_mfma_f32_16x16x4_f32: the variant for LARGE batches. From three 4-row tiles per CU on (B = 64 at the
+// north-star shape: three to four per CU) a CU works on 16 rows per step either way, and one 16-row workgroup does
+// it with a quarter of the waves, barriers and k-slice reductions (measured at cfg3: 3.245 ms against 3.326 with 4-row tiles;
+// cfg2 / cfg4 / cfg-T: 4-row tiles win by 12 / 7 / 1 %). Wave w owns hidden columns [16w, 16w+16) of r, z and n for all 16
+// rows; fragment maps: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[row=4*(l>>4)+reg][col=l&15].
+// ================================================================================================
+constexpr int GROWS = 16;     // rows per workgroup
+// number of steps the rows [r0, r0 + GROWS) need: 1 + max over their episodes of t_last (all T1 without a bound)
+__device__ inline int tile_steps16(const GruK& p, int r0) {
+    if (!p.t_last) return p.T1;
+    int tend = 0;
+    const int rl = min(r0 + GROWS, p.NR) - 1;
+    for (int gb = r0 / p.na; gb <= rl / p.na; ++gb) tend = max(tend, p.t_last[gb % p.B] + 1);
+    return min(tend, p.T1);
+}
+
+template <bool SAVE, int GH>
+__global__ __launch_bounds__(4 * GH) void gru_fwd16_kernel(GruK2 p2) {
     constexpr int HP = GH + 4, KQ = GH / 4;                // KQ: reduction indices per lane group
     __shared__ __attribute__((aligned(16))) float hbuf[2][GROWS * HP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,7 +333,7 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd_kernel(GruK2 p2) {
     const bool second = (int)blockIdx.x >= p2.nblk0;
     const GruK& p = second ? p2.b : p2.a;
     const int r0 = (second ? blockIdx.x - p2.nblk0 : blockIdx.x) * GROWS;
-    const int tend = tile_steps(p, r0);
+    const int tend = tile_steps16(p, r0);
     const bool save = SAVE && p.save_r != nullptr;
 
     // W_hh fragments: bw[g][s] = W_hh[g*GH + c][KQ q + s]. (The MFMA k order is a free permutation as long as both
@@ -173,7 +436,7 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd_kernel(GruK2 p2) {
             }
             ho[reg] += row_step; so[reg] += row_step;
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -183,14 +446,14 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd_kernel(GruK2 p2) {
 //   dr_pre = dr r (1-r);  dz_pre = dz z (1-z)
 //   dgi[t] = (dr_pre, dz_pre, dn_pre);  dgh[t] = (dr_pre, dz_pre, dgh_n);  carry' += dgh[t] W_hh
 template <int GH>
-__global__ __launch_bounds__(4 * GH) void gru_bwd_kernel(GruK p) {
+__global__ __launch_bounds__(4 * GH) void gru_bwd16_kernel(GruK p) {
     constexpr int GP = 3 * GH + 4, KQ = 3 * GH / 4, NW = GH / 16;
     __shared__ __attribute__((aligned(16))) float gbuf[2][GROWS * GP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, c16 = lane & 15;
     const int c = wave * 16 + c16;
     const int r0 = blockIdx.x * GROWS;
-    const int tend = tile_steps(p, r0);
+    const int tend = tile_steps16(p, r0);
 
     // W_hh^T fragments: carry[row][c] += sum_k dgh[row][k] W_hh[k][c];  bw[s] = W_hh[KQ q + s][c]  (contiguous k range per lane group, see the forward kernel)
     float bw[KQ];
@@ -275,7 +538,7 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd_kernel(GruK p) {
             row[c] = dr_pre; row[GH + c] = dz_pre; row[2 * GH + c] = dghn;
             sv[reg][0] = dr_pre; sv[reg][1] = dz_pre; sv[reg][2] = dn_pre; sv[reg][3] = dghn;
         }
-        __syncthreads();
+        lds_barrier();
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
 #pragma unroll
         for (int s = 0; s < KQ; s += 12) {
@@ -321,6 +584,19 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd_kernel(GruK p) {
     }
 }
 
+// rows per workgroup: 4-row tiles while there are fewer than three per CU (REFIL_GRU_ROWS=4 / 16 forces one). Measured: cfg3's
+// backward (768 tiles on 256 CUs) 38 us faster on 16-row tiles, its forward (1024) 45 us; cfg5 (768 / 576) 20 us faster on 4-row tiles
+static int gru_rows_per_wg(long rows) {
+    static const int forced = [] { const char* e = getenv("REFIL_GRU_ROWS"); return e ? atoi(e) : 0; }();
+    if (forced == 4 || forced == 16) return forced;
+    static const int cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return cdivl(rows, GR4) >= 3L * cus ? GROWS : GR4;
+}
+
 static int gru_check_fwd(const refil_gru_desc& d) {
     REFIL_CHECK(d.H == 32 || d.H == 64 || d.H == 128, "refil_gru: rnn_hidden_dim must be 32, 64 or 128 (got %d)", d.H);
     REFIL_CHECK(d.gi && d.hsx && d.w_hh && d.b_hh, "refil_gru_forward: null pointer");
@@ -345,14 +621,17 @@ int gru_forward_launch2(const refil_gru_desc& d, const refil_gru_desc* second, h
                 "refil_gru: NR * T1 too large for the 32-bit offsets of the recurrence kernels (split the batch)");
     GruK2 k;
     k.a = gru_k(d); k.b = second ? gru_k(*second) : k.a;
-    k.nblk0 = cdiv(d.NR, GROWS);
+    const int rows_wg = gru_rows_per_wg(d.NR + (second ? second->NR : 0));
+    k.nblk0 = cdiv(d.NR, rows_wg);
     const bool save = d.save_r != nullptr || (second && second->save_r != nullptr);
     const long rows_t = (long)d.NR * d.T1 + (second ? (long)second->NR * second->T1 : 0);
-    dim3 grid(k.nblk0 + (second ? cdiv(second->NR, GROWS) : 0));
+    dim3 grid(k.nblk0 + (second ? cdiv(second->NR, rows_wg) : 0));
     ProfScope prof(save ? "gru_fwd_kernel<true>" : "gru_fwd_kernel<false>", 2.0 * rows_t * GH * 3 * GH,
                    4.0 * rows_t * GH * (save ? 8.0 : 4.0), st);
-#define GRU_FWD(HH) do { if (save) hipLaunchKernelGGL((gru_fwd_kernel<true, HH>), grid, dim3(4 * HH), 0, st, k); \
-                        else hipLaunchKernelGGL((gru_fwd_kernel<false, HH>), grid, dim3(4 * HH), 0, st, k); } while (0)
+#define GRU_FWD(HH) do { if (rows_wg == GROWS) { if (save) hipLaunchKernelGGL((gru_fwd16_kernel<true, HH>), grid, dim3(4 * HH), 0, st, k); \
+                                                  else hipLaunchKernelGGL((gru_fwd16_kernel<false, HH>), grid, dim3(4 * HH), 0, st, k); } \
+                        else { if (save) hipLaunchKernelGGL((gru_fwd4_kernel<true, HH>), grid, dim3(4 * HH), 0, st, k); \
+                               else hipLaunchKernelGGL((gru_fwd4_kernel<false, HH>), grid, dim3(4 * HH), 0, st, k); } } while (0)
     if (GH == 32) GRU_FWD(32); else if (GH == 64) GRU_FWD(64); else GRU_FWD(128);
 #undef GRU_FWD
     REFIL_LAUNCH_CHECK();
@@ -370,9 +649,15 @@ int gru_backward_launch(const refil_gru_desc& d, hipStream_t st) {
     REFIL_CHECK((!d.t_last && !d.ever) || d.B > 0, "refil_gru: t_last / ever need B");
     GruK k = gru_k(d);
     ProfScope prof("gru_bwd_kernel", 2.0 * d.NR * d.T1 * GH * 3 * GH, 4.0 * d.NR * d.T1 * GH * 12.0, st);
-    if (GH == 32) hipLaunchKernelGGL(gru_bwd_kernel<32>, dim3(cdiv(d.NR, GROWS)), dim3(128), 0, st, k);
-    else if (GH == 64) hipLaunchKernelGGL(gru_bwd_kernel<64>, dim3(cdiv(d.NR, GROWS)), dim3(256), 0, st, k);
-    else hipLaunchKernelGGL(gru_bwd_kernel<128>, dim3(cdiv(d.NR, GROWS)), dim3(512), 0, st, k);
+    if (gru_rows_per_wg(d.NR) == GROWS) {
+        if (GH == 32) hipLaunchKernelGGL(gru_bwd16_kernel<32>, dim3(cdiv(d.NR, GROWS)), dim3(128), 0, st, k);
+        else if (GH == 64) hipLaunchKernelGGL(gru_bwd16_kernel<64>, dim3(cdiv(d.NR, GROWS)), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL(gru_bwd16_kernel<128>, dim3(cdiv(d.NR, GROWS)), dim3(512), 0, st, k);
+    } else {
+        if (GH == 32) hipLaunchKernelGGL(gru_bwd4_kernel<32>, dim3(cdiv(d.NR, GR4)), dim3(128), 0, st, k);
+        else if (GH == 64) hipLaunchKernelGGL(gru_bwd4_kernel<64>, dim3(cdiv(d.NR, GR4)), dim3(256), 0, st, k);
+        else hipLaunchKernelGGL(gru_bwd4_kernel<128>, dim3(cdiv(d.NR, GR4)), dim3(512), 0, st, k);
+    }
     REFIL_LAUNCH_CHECK();
     return 0;
 }

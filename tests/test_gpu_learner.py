@@ -576,9 +576,11 @@ def test_fused_join_equals_separate_launches(mode, monkeypatch):
     assert ("qselect_bwd_hs_kernel" in got["kernels"]) == (mode == "1")
     live = live_steps(batch)
     lt = live[:, :-1]
+    lt1 = live[:, 1:]                  # (quantities of step t+1: the target side)
     for k in ("chosen_q", "q_tot", "targets", "target_max_q"):
         a, b = got["out"][k], ref["out"][k]
-        m = lt[None, :, :, None] if a.dim() == 4 else (lt[:, :, None] if a.dim() == 3 else lt)
+        l = lt1 if k in ("targets", "target_max_q") else lt
+        m = l[None, :, :, None] if a.dim() == 4 else (l[:, :, None] if a.dim() == 3 else l)
         assert rel_err(a * m, b * m) < 1e-6, k
     assert rel_err(got["out"]["q"] * live[None, :, :, None, None], ref["out"]["q"] * live[None, :, :, None, None]) < 1e-6
     gmax = max(v.abs().max().item() for v in ref["grads"].values())
