@@ -246,7 +246,14 @@ int refil_mixer_forward(const refil_dims* dims, const refil_batch* batch, int32_
 typedef struct refil_gather_field {
     const void* src; void* dst;
     int64_t src_episode_bytes, dst_episode_bytes, copy_bytes;
+    /* unpack_width > 0: the field is stored BIT-PACKED in the buffer (refil_pack_mask_bits: one uint64 per row of
+     * unpack_width <= 64 mask bytes, e.g. obs_mask[b,t,i,:] -- episode_buffer.py keeps the bytes) and the gather expands it:
+     * dst byte (row, j) = bit j of src word `row`. src_episode_bytes = 8 * rows, copy_bytes counts DESTINATION bytes. */
+    int32_t unpack_width, reserved;
 } refil_gather_field;
+/* dst[r] = sum_j (src[r * width + j] != 0) << j for `rows` rows of `width` <= 64 mask bytes (the storage format of byte masks
+ * in the device replay buffer: 8 bytes per row instead of `width`). */
+int refil_pack_mask_bits(const uint8_t* src, uint64_t* dst, int64_t rows, int32_t width, void* stream);
 int refil_replay_gather(const refil_gather_field* fields, int32_t n_fields, const int64_t* episode_ids,
                         int32_t B, int64_t capacity, void* stream);
 

@@ -105,7 +105,10 @@ class GruDesc(C.Structure):
 
 class GatherField(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_episode_bytes", C.c_int64), ("dst_episode_bytes", C.c_int64),
-                ("copy_bytes", C.c_int64)]
+                ("copy_bytes", C.c_int64), ("unpack_width", C.c_int32), ("reserved", C.c_int32)]
+
+
+MAX_GATHER_FIELDS = 24      # refil_amd/csrc/replay.hip
 
 
 GRADS_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
@@ -125,7 +128,7 @@ EXPORTS = [
     "refil_profile_enable", "refil_profile_collect", "refil_set_overlap", "refil_release_streams", "refil_replay_gather",
     "refil_learner_row_counts", "refil_attn_mask_words", "refil_set_mixer_grads_hook",
     "refil_oneshot_create", "refil_oneshot_connect", "refil_oneshot_allreduce", "refil_oneshot_status", "refil_oneshot_destroy",
-    "refil_allreduce_flat",
+    "refil_allreduce_flat", "refil_pack_mask_bits",
 ]
 IPC_HANDLE_BYTES = 64
 
@@ -177,6 +180,7 @@ def lib():
     L.refil_oneshot_destroy.argtypes = [C.c_void_p]
     L.refil_learner_row_counts.argtypes = [C.POINTER(Dims), C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.c_void_p]
     L.refil_replay_gather.argtypes = [C.POINTER(GatherField), C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]
+    L.refil_pack_mask_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     L.refil_profile_enable.argtypes = [C.c_int]
     L.refil_profile_collect.argtypes = [C.POINTER(ProfileEntry), C.c_int]
     _lib = L

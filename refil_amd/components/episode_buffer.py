@@ -149,11 +149,81 @@ class EpisodeBatch:
 
 
 class ReplayBuffer(EpisodeBatch):
-    def __init__(self, scheme, groups, buffer_size, max_seq_length, preprocess=None, device="cpu"):
+    """Ring of episodes with the reference's API (episode_buffer.py:206-246).
+
+    Device buffers keep byte masks whose rows are at most 64 wide (`obs_mask`, `gt_mask`: uint8 [.., ne, ne]) BIT-PACKED --
+    one int64 word per row (bit j = mask[.., i, j]), 8 bytes instead of ne: `insert_episode_batch`
+    packs (refil_pack_mask_bits), `sample` expands the sampled episodes into the staging minibatch inside the one gather
+    launch, and `buffer["obs_mask"]` / `buffer[ids]` expand on demand with torch ops (API compatibility, not a hot path).
+    pack_masks=False keeps the bytes."""
+
+    PACKABLE = ("obs_mask", "gt_mask")
+
+    def __init__(self, scheme, groups, buffer_size, max_seq_length, preprocess=None, device="cpu", pack_masks=None):
         super().__init__(scheme, groups, buffer_size, max_seq_length, preprocess=preprocess, device=device)
         self.buffer_size = buffer_size
         self.buffer_index = 0
         self.episodes_in_buffer = 0
+        self._packed = {}            # key -> int64 [N, T1, rows] words; the byte tensor of the key is dropped
+        on_gpu = th.device(device).type == "cuda"
+        if pack_masks is None:
+            pack_masks = on_gpu
+        if pack_masks and on_gpu:
+            for k in self.PACKABLE:
+                v = self.data.transition_data.get(k)
+                if v is not None and v.dtype == th.uint8 and v.dim() == 4 and v.shape[-1] <= 64:
+                    self._packed[k] = th.zeros(v.shape[:-1], dtype=th.int64, device=self.device)
+                    self._packed_width = getattr(self, "_packed_width", {})
+                    self._packed_width[k] = v.shape[-1]
+                    del self.data.transition_data[k]
+
+    # -- packed byte masks ----------------------------------------------------------------------
+    def _pack(self, key, v):
+        """uint8 [..., rows, width] (device) -> int64 [..., rows] through refil_pack_mask_bits"""
+        import ctypes as C
+        from .. import _lib
+        v = v.to(device=self.device, dtype=th.uint8).contiguous()
+        out = th.empty(v.shape[:-1], dtype=th.int64, device=self.device)
+        _lib.check(_lib.lib().refil_pack_mask_bits(_lib.ptr(v), _lib.ptr(out), C.c_int64(out.numel()), C.c_int32(v.shape[-1]),
+                                                   _lib.current_stream_ptr()), "refil_pack_mask_bits")
+        return out
+
+    def _unpack(self, key, words):
+        w = self._packed_width[key]
+        sh = th.arange(w, device=words.device, dtype=th.int64)
+        return ((words[..., None] >> sh) & 1).to(th.uint8)
+
+    def update(self, data, bs=slice(None), ts=slice(None), mark_filled=True):
+        packed = {k: v for k, v in data.items() if k in self._packed}
+        if packed:
+            sl = self._parse_slices((bs, ts))
+            for k, v in packed.items():
+                dest = self._packed[k][sl]
+                self._packed[k][sl] = self._pack(k, v if isinstance(v, th.Tensor) else th.as_tensor(v)).view_as(dest)
+            data = {k: v for k, v in data.items() if k not in self._packed}
+            if not data:
+                return
+        super().update(data, bs, ts, mark_filled)
+
+    def __getitem__(self, item):
+        if not self._packed:
+            return super().__getitem__(item)
+        if isinstance(item, str):
+            if item in self._packed:
+                return self._unpack(item, self._packed[item])
+            return super().__getitem__(item)
+        if isinstance(item, tuple) and all(isinstance(it, str) for it in item):
+            out = super().__getitem__(tuple(k for k in item if k not in self._packed))
+            for k in item:
+                if k in self._packed:
+                    out.data.transition_data[k] = self._unpack(k, self._packed[k])
+                    out.scheme[k] = self.scheme[k]
+            return out
+        out = super().__getitem__(item)
+        sl = self._parse_slices(item)
+        for k, words in self._packed.items():
+            out.data.transition_data[k] = self._unpack(k, words[sl])
+        return out
 
     def insert_episode_batch(self, ep_batch):
         n = ep_batch.batch_size
@@ -172,13 +242,21 @@ class ReplayBuffer(EpisodeBatch):
     def can_sample(self, batch_size):
         return self.episodes_in_buffer >= batch_size
 
-    def sample(self, batch_size):
+    def sample(self, batch_size, copy=False):
+        """Uniform sample without replacement (episode_buffer.py:233-240). On a device buffer the result is the buffer's
+        STAGING minibatch for this batch size -- fixed addresses, overwritten by the next sample(batch_size); pass copy=True
+        to get an independent batch (the reference always returns a fresh copy) when two samples must be alive at once."""
         assert self.can_sample(batch_size)
         if self.episodes_in_buffer == batch_size:
             return self[:batch_size]
         ep_ids = np.random.choice(self.episodes_in_buffer, batch_size, replace=False)     # uniform, w/o replacement
         if th.device(self.device).type == "cuda":
-            return self._gather(ep_ids)
+            out = self._gather(ep_ids)
+            if copy:
+                out = EpisodeBatch(out.scheme, out.groups, out.batch_size, out.max_seq_length, device=out.device,
+                                   data=SimpleNamespace(transition_data={k: v.clone() for k, v in out.data.transition_data.items()},
+                                                        episode_data={k: v.clone() for k, v in out.data.episode_data.items()}))
+            return out
         return self[ep_ids]
 
     # -- device-resident sampling (SURVEY.md section 8 f2) -----------------------------------------
@@ -190,19 +268,27 @@ class ReplayBuffer(EpisodeBatch):
         import ctypes as C
         from .. import _lib
         n = len(ep_ids)
+        ep_ids = np.ascontiguousarray(ep_ids, dtype=np.int64)
+        if ep_ids.size and (ep_ids.min() < 0 or ep_ids.max() >= self.buffer_size):
+            raise IndexError(f"episode ids must lie in [0, {self.buffer_size})")
+        nfields = len(self.data.transition_data) + len(self.data.episode_data) + len(self._packed)
+        if nfields > _lib.MAX_GATHER_FIELDS:            # (more scheme keys than one gather launch takes: the reference's path)
+            return self[ep_ids]
         st = self._staging.get(n) if hasattr(self, "_staging") else None
         if st is None:
             if not hasattr(self, "_staging"):
                 self._staging = {}
+            tdata = {k: th.zeros((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device) for k, v in self.data.transition_data.items()}
+            for k, words in self._packed.items():      # the staging minibatch holds the BYTES the learner's C ABI takes
+                tdata[k] = th.zeros((n,) + tuple(words.shape[1:]) + (self._packed_width[k],), dtype=th.uint8, device=self.device)
             batch = EpisodeBatch(self.scheme, self.groups, n, self.max_seq_length, device=self.device,
                                  data=SimpleNamespace(
-                                     transition_data={k: th.zeros((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device)
-                                                      for k, v in self.data.transition_data.items()},
+                                     transition_data=tdata,
                                      episode_data={k: th.zeros((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device)
                                                    for k, v in self.data.episode_data.items()}))
             ids_host = [(th.empty(n, dtype=th.int64).pin_memory(), th.cuda.Event()) for _ in range(8)]
             ids_dev = th.empty(n, dtype=th.int64, device=self.device)
-            fields = (_lib.GatherField * 32)()
+            fields = (_lib.GatherField * _lib.MAX_GATHER_FIELDS)()
             nf = 0
             for store_src, store_dst in ((self.data.transition_data, batch.data.transition_data),
                                          (self.data.episode_data, batch.data.episode_data)):
@@ -210,13 +296,18 @@ class ReplayBuffer(EpisodeBatch):
                     dst = store_dst[k]
                     assert src.is_contiguous() and dst.is_contiguous()
                     eb = src[0].numel() * src.element_size()
-                    fields[nf] = _lib.GatherField(src.data_ptr(), dst.data_ptr(), eb, eb, eb)
+                    fields[nf] = _lib.GatherField(src.data_ptr(), dst.data_ptr(), eb, eb, eb, 0, 0)
                     nf += 1
+            for k, words in self._packed.items():
+                dst = batch.data.transition_data[k]
+                fields[nf] = _lib.GatherField(words.data_ptr(), dst.data_ptr(), words[0].numel() * 8, dst[0].numel(), dst[0].numel(),
+                                              self._packed_width[k], 0)
+                nf += 1
             st = self._staging[n] = {"batch": batch, "ids_host": ids_host, "ids_dev": ids_dev, "fields": fields, "nf": nf, "slot": 0}
         host, ev = st["ids_host"][st["slot"]]
         st["slot"] = (st["slot"] + 1) % len(st["ids_host"])
         ev.synchronize()                                   # (the async upload issued 8 samples ago has long completed)
-        host.copy_(th.from_numpy(np.ascontiguousarray(ep_ids, dtype=np.int64)))
+        host.copy_(th.from_numpy(ep_ids))
         st["ids_dev"].copy_(host, non_blocking=True)
         ev.record()
         _lib.check(_lib.lib().refil_replay_gather(st["fields"], C.c_int32(st["nf"]), _lib.ptr(st["ids_dev"]), C.c_int32(n),

@@ -1,21 +1,20 @@
-// Matrix-core (v_mfma_f32_16x16x4_f32) version of the masked entity attention core, forward + backward.
+// Matrix-core (v_mfma_f32_16x16x4_f32) masked entity attention core, forward + backward.
 // Same math as attention.hip (reference: src/modules/layers/attention.py:48-64); that VALU kernel stays
 // as the generic fallback for tile shapes not instantiated here.
 //
-// One WAVE owns one (row=(b,t), head); a workgroup = 4 waves = 4 heads of the same row, so the mask
-// bytes of the row are fetched once. Q/K/V (and dO) head slices are staged in wave-private LDS
-// (pitch hd+2 floats: the strided b32 fragment reads are conflict-free), everything else lives in
-// registers. Key trick: compute the TRANSPOSED logits  S^T[key,agent] = K Q^T.  In the MFMA D layout a
-// lane then holds 4 consecutive keys of ONE agent, so
+// One WAVE owns one job = (row (b,t), net, head) at a time; the 4 waves of a workgroup take the jobs of the same row.
+// Q / K / V (and dO) head slices live in wave-private LDS (pitch 16 NCT + 2 floats: the strided b32 fragment reads are
+// conflict-free) or go straight from global memory into the MFMA operand registers (forward: K, Q), everything else lives
+// in registers. Key trick: compute the TRANSPOSED logits  S^T[key,agent] = K Q^T.  In the MFMA D layout a lane then holds
+// 4 consecutive keys of ONE agent, so
 //   * the softmax over keys is lane-local + 2 shuffles (lanes ^16, ^32),
-//   * the normalised weights are already the B operand (k = key) of  O^T = V^T P^T  -- no LDS
-//     round trip, no transposition,
+//   * the normalised weights are already the B operand (k = key) of  O^T = V^T P^T  -- no LDS round trip, no transposition,
 //   * the result lane holds 4 consecutive channels of one agent -> 16-byte stores.
-// The MFMA k order is a free permutation as long as A and B agree; every product here maps
-// virtual k (step s, lane group q) to the index the D registers of the previous product hold.
-// Backward needs products contracted over agents as well (dV, dK), for which the logits are
-// recomputed in the other orientation S[agent,key] too -- MFMA work is free here, the kernel is
-// bound by its HBM traffic.
+// The MFMA k order is a free permutation as long as A and B agree; every product here maps virtual k (step s, lane group q)
+// to the index the D registers of the previous product hold. Backward needs products contracted over agents as well
+// (dV, dK): it computes the logits in the other orientation S[agent,key] and gets dS^T through a wave-private LDS transpose.
+// The launches are persistent and software-pipelined (below): what bounds them is the matrix-core issue of the ~200 small
+// MFMAs per job and the VALU softmax beside it (PMC: 0.34 / 0.21 MFMA-busy, 3.0 / 3.9 TB/s backward / forward at cfg-T).
 #include <stdlib.h>
 #include <string.h>
 
@@ -86,55 +85,6 @@ __device__ inline bool premask_m(int code, const MaskLds& s, int ne, int i, int 
         default: return (same && !s.gt[i * ne + j]) || in0;   // REFIL_MASK_RGTI
     }
 }
-
-// stage `rows` x hd floats (row-major, ld) into wave-private LDS rows of pitch pd; rows [rows, rows_pad) zeroed
-__device__ inline void stage(float* dst, const float* src, long row0, int rows, int rows_pad, int ld, int col0, int hd, int pd, int lane) {
-    const int c4n = hd >> 2;
-    for (int idx = lane; idx < rows_pad * c4n; idx += 64) {
-        const int r = idx / c4n, c4 = idx % c4n;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < rows) v = *reinterpret_cast<const float4*>(src + (row0 + r) * (long)ld + col0 + c4 * 4);
-        float2* d = reinterpret_cast<float2*>(dst + r * pd + c4 * 4);
-        d[0] = make_float2(v.x, v.y);
-        d[1] = make_float2(v.z, v.w);
-    }
-}
-
-// Two-phase staging with compile-time trip counts: ALL global loads of a head (Q, K, V [, dO]) are issued
-// back to back into registers and only then written to LDS -- the runtime-bound loop above costs one
-// dependent HBM round trip per iteration (10 per head at ne=32, hd=32).
-template <int ROWS_PAD, int C4MAX>
-struct Stage {
-    static constexpr int N = ROWS_PAD * C4MAX / 64;
-    float4 v[N];
-    // dead: bit r set -> row r is not fetched at all (its producer skipped it; it enters as zeros). The lanes of such rows
-    // issue no load: with row lists more than half of the K / V rows of a step are dead, i.e. more than half of the traffic
-    __device__ inline void load(const float* src, long row0, int rows, int ld, int col0, int hd, int lane, unsigned long long dead = 0ull) {
-        const int c4n = hd >> 2;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int idx = lane + 64 * i, r = idx / C4MAX, c4 = idx % C4MAX;
-            const bool ok = r < rows && c4 < c4n && !((dead >> r) & 1ull);
-            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) v[i] = *reinterpret_cast<const float4*>(src + (row0 + r) * (long)ld + col0 + c4 * 4);
-        }
-    }
-    // dead: bit r set -> row r was not computed by its producer (it cannot influence the result): it enters as zeros,
-    // whatever the buffer holds (applied here, not at the load: the loads are issued before the words are known)
-    __device__ inline void store(float* dst, int hd, int pd, int lane, unsigned long long dead = 0ull) const {
-        const int c4n = hd >> 2;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int idx = lane + 64 * i, r = idx / C4MAX, c4 = idx % C4MAX;
-            if (c4 < c4n) {
-                const bool z = (dead >> r) & 1ull;
-                float2* d = reinterpret_cast<float2*>(dst + r * pd + c4 * 4);
-                d[0] = z ? make_float2(0.f, 0.f) : make_float2(v[i].x, v[i].y);
-                d[1] = z ? make_float2(0.f, 0.f) : make_float2(v[i].z, v[i].w);
-            }
-        }
-    }
-};
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -318,288 +268,13 @@ __global__ __launch_bounds__(256) void attn_mask_words_kernel(AttnM p, int na_pa
     if (tid == 0) { p.rbits_out[3 * (long)r] = rm.kdw; p.rbits_out[3 * (long)r + 1] = rm.qdw; p.rbits_out[3 * (long)r + 2] = rm.emtw; }
 }
 
-// NJT/NAT/NCT: 16-tiles along keys / agents / head channels
-// HDX: the head dimension is exactly 16 NCT (compile-time: the fragment loops unroll and their LDS reads are batched)
-template <int NJT, int NAT, int NCT, bool HDX>
-__global__ __launch_bounds__(256) void attn_fwd_mfma(AttnM p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, q = lane >> 4;
-    const int r = blockIdx.x;
-    if (row_skipped(p, r)) return;
-    const int hd = HDX ? 16 * NCT : p.hd;
-    const int pd = hd + 2;
-    const int njobs = p.nnets * p.heads;                   // job = (net, head); a wave takes jobs wave, wave + 4, ...
-    Stage<NAT * 16, 4 * NCT> sq;
-    Stage<NJT * 16, 4 * NCT> sk, sv;
-    // HDX: the K and Q operands of S^T = K Q^T never touch LDS. In the v_mfma_f32_16x16x4_f32 operand layouts lane
-    // (l15, q) supplies row l15 of its tile at reduction index k = q of every step; the k order is a free permutation,
-    // so lane group q takes the CONTIGUOUS channels 4 NCT q .. 4 NCT (q+1) - 1 of "its" K row (key 16 jt + l15) and of
-    // "its" Q row (agent 16 at + l15): NCT 16-byte global loads per tile, already in operand layout.
-    float4 kf[HDX ? NJT : 1][NCT], qf[HDX ? NAT : 1][NCT];
-    // precomputed mask words: the row's dead-row words are three scalar loads away, so the operand fetch can leave out the
-    // K / V / Q rows nobody computed (more than half of a step's entity rows with row lists) instead of loading and zeroing
-    // them. (In-kernel mask phase: the words are not known yet, everything is fetched.)
-    unsigned long long fk = 0ull, fq = 0ull;
-    if (p.mwords) { fk = p.rbits[3 * (long)r]; fq = p.rbits[3 * (long)r + 1]; }
-    auto fetch = [&](int job) {
-        const AttnNet& n = p.net[job / p.heads];
-        const int head = job % p.heads;
-        if (HDX) {
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) {
-                const int key = 16 * jt + l15;
-                const bool ok = key < p.ne && !((fk >> key) & 1ull);
-                const float* src = n.K + ((long)r * p.ne + key) * p.ldkv + head * hd + 4 * NCT * q;
-#pragma unroll
-                for (int u = 0; u < NCT; ++u) {
-                    kf[HDX ? jt : 0][u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (ok) kf[HDX ? jt : 0][u] = *reinterpret_cast<const float4*>(src + 4 * u);
-                }
-            }
-#pragma unroll
-            for (int at = 0; at < NAT; ++at) {
-                const int ag = 16 * at + l15;
-                const bool ok = ag < p.na && !((fq >> ag) & 1ull);
-                const float* src = n.Q + ((long)r * p.na + ag) * p.ldq + head * hd + 4 * NCT * q;
-#pragma unroll
-                for (int u = 0; u < NCT; ++u) {
-                    qf[HDX ? at : 0][u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (ok) qf[HDX ? at : 0][u] = *reinterpret_cast<const float4*>(src + 4 * u);
-                }
-            }
-        } else {
-            sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * hd, hd, lane, fq);
-            sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane, fk);
-        }
-        sv.load(n.V, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane, fk);
-    };
-    if (wave < njobs) fetch(wave);                         // the first job's operands are in flight during the mask phase
-    const RowMasks rm = p.mwords ? mask_words_of(p, NAT * 16, r) : mask_phase(p, smem, NAT * 16, r, tid);
-    const unsigned long long* mw = rm.mw;
-    if (p.nact && tid == 0) p.nact[r] = (float)__popcll(~rm.emtw & ((p.na >= 64) ? ~0ull : ((1ull << p.na) - 1ull)));
-    float* Qs = smem + wave * p.wave_floats;
-    float* Ks = Qs + NAT * 16 * pd;
-    float* Vs = Ks + NJT * 16 * pd;
-    const float inv_scale = 1.0f / sqrtf((float)hd);
-    for (int job = wave; job < njobs; job += 4) {
-        const AttnNet& n = p.net[job / p.heads];
-        const int head = job % p.heads;
-        f32x4 stt[HDX ? NAT : 1][NJT];                     // HDX: all S^T tiles of the job, straight from the operand registers
-        if (HDX) {
-            sv.store(Vs, hd, pd, lane, rm.kdw);
-#pragma unroll
-            for (int at = 0; at < NAT; ++at) {
-                const int ag = 16 * at + l15;
-                const bool qz = ag >= p.na || ((rm.qdw >> ag) & 1ull);           // padded / skipped query row: zeros
-#pragma unroll
-                for (int jt = 0; jt < NJT; ++jt) {
-                    const int key = 16 * jt + l15;
-                    const bool kz = key >= p.ne || ((rm.kdw >> key) & 1ull);     // padded / skipped key row: zeros
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int u = 0; u < NCT; ++u) {
-                        const float4 kv = kf[HDX ? jt : 0][u], qv = qf[HDX ? at : 0][u];
-                        acc = MFMA16(kz ? 0.f : kv.x, qz ? 0.f : qv.x, acc);
-                        acc = MFMA16(kz ? 0.f : kv.y, qz ? 0.f : qv.y, acc);
-                        acc = MFMA16(kz ? 0.f : kv.z, qz ? 0.f : qv.z, acc);
-                        acc = MFMA16(kz ? 0.f : kv.w, qz ? 0.f : qv.w, acc);
-                    }
-                    stt[HDX ? at : 0][jt] = acc;
-                }
-            }
-        } else {
-            sq.store(Qs, hd, pd, lane, rm.qdw); sk.store(Ks, hd, pd, lane, rm.kdw); sv.store(Vs, hd, pd, lane, rm.kdw);
-        }
-        if (job + 4 < njobs) fetch(job + 4);               // in flight while this job is computed (operand registers / LDS are free)
-        f32x4 osum[NCT];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) osum[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int at = 0; at < NAT; ++at) {
-            const int agent = 16 * at + l15;
-            f32x4 st0[NJT];
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) st0[jt] = HDX ? stt[HDX ? at : 0][jt] : dot_tile(Ks, 16 * jt, Qs, 16 * at, hd, pd, l15, q);
-            for (int v = 0; v < n.nvar; ++v) {
-                f32x4 pt[NJT];
-#pragma unroll
-                for (int jt = 0; jt < NJT; ++jt)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) pt[jt][reg] = st0[jt][reg] * inv_scale;   // attention.py:54
-                softmax_T<NJT>(pt, mw[v * NAT * 16 + agent], q);
-                float* O = n.O + v * p.sO;
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    // O^T[c][agent] = sum_key V[key][c] P^T[key][agent]; virtual k (jt,reg | q) <-> key 16jt+4q+reg
-                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int jt = 0; jt < NJT; ++jt)
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg)
-                            o = MFMA16(Vs[(16 * jt + 4 * q + reg) * pd + 16 * ct + l15], pt[jt][reg], o);
-                    const int c = 16 * ct + 4 * q;
-                    if (n.sum_agents) {          // padded / inactive agents have P = 0, hence o = 0: plain sum over the 16 lanes
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) osum[ct][e] += group16_sum(o[e]);
-                    } else if (agent < p.na && c < hd) {
-                        if (p.zero_dead && ((rm.emtw >> agent) & 1ull)) o = f32x4{0.f, 0.f, 0.f, 0.f};
-                        *reinterpret_cast<float4*>(O + ((long)r * p.na + agent) * p.ldo + head * hd + c) = make_float4(o[0], o[1], o[2], o[3]);
-                    }
-                }
-            }
-        }
-        if (n.sum_agents && l15 == 0) {
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const int c = 16 * ct + 4 * q;
-                if (c < hd)
-                    *reinterpret_cast<float4*>(n.O + (long)r * p.ldo + head * hd + c) = make_float4(osum[ct][0], osum[ct][1], osum[ct][2], osum[ct][3]);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();                   // (the next job's operands overwrite the wave's LDS tiles)
-    }
-}
-
-template <int NJT, int NAT, int NCT, bool HDX>
-__global__ __launch_bounds__(256, 2) void attn_bwd_mfma(AttnM p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, q = lane >> 4;
-    const int r = blockIdx.x;
-    if (row_skipped(p, r)) return;
-    const int hd = HDX ? 16 * NCT : p.hd;
-    const int pd = hd + 2;
-    const RowMasks rm = p.mwords ? mask_words_of(p, NAT * 16, r) : mask_phase(p, smem, NAT * 16, r, tid);
-    const unsigned long long* mw = rm.mw;
-    float* Qs = smem + wave * p.wave_floats;
-    float* Ks = Qs + NAT * 16 * pd;
-    float* Vs = Ks + NJT * 16 * pd;
-    float* Ds = Vs + NJT * 16 * pd;          // dO of one (variant, agent tile): 16 rows
-    constexpr int TP = NJT * 16 + 4;         // pitch of the dS transposition tile (16 agents x keys)
-    float* Ts = Qs + p.wave_floats - 16 * TP;
-    const float inv_scale = 1.0f / sqrtf((float)hd);
-    const int njobs = p.nnets * p.heads;                   // job = (net, head); a wave takes jobs wave, wave + 4, ...
-    for (int job = wave; job < njobs; job += 4) {
-        const AttnNet& n = p.net[job / p.heads];
-        const int head = job % p.heads;
-        {
-            Stage<NAT * 16, 4 * NCT> sq;
-            Stage<NJT * 16, 4 * NCT> sk, sv;
-            sq.load(n.Q, (long)r * p.na, p.na, p.ldq, head * hd, hd, lane, rm.qdw);       // (dead rows are not fetched)
-            sk.load(n.K, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane, rm.kdw);
-            sv.load(n.V, (long)r * p.ne, p.ne, p.ldkv, head * hd, hd, lane, rm.kdw);
-            sq.store(Qs, hd, pd, lane, rm.qdw); sk.store(Ks, hd, pd, lane, rm.kdw); sv.store(Vs, hd, pd, lane, rm.kdw);
-        }
-        f32x4 dKt[NCT][NJT], dVt[NCT][NJT];     // [c 16ct+4q+reg][key 16jt+l15]
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) {
-                dKt[ct][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dVt[ct][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll 1
-        for (int at = 0; at < NAT; ++at) {
-            const int agentT = 16 * at + l15;        // agent of this lane in the transposed orientation (dQ^T columns)
-            const int agentN0 = 16 * at + 4 * q;     // first agent of this lane in the normal orientation
-            // dO of variant v+1 is fetched into registers while variant v is being processed: one exposed HBM
-            // round trip per agent tile instead of one per variant (LDS operations of a wave execute in order,
-            // so overwriting Ds at the top of the next iteration is safe)
-            const int na_t = min(16, p.na - 16 * at);
-            Stage<16, 4 * NCT> sd;
-            // (bcast_do: one dO row per (b,t), shared by its agents -- leading dimension 0 re-reads the same row)
-            const float* dO0 = n.bcast_do ? n.dO + (long)r * p.ldo : n.dO;
-            const long drow0 = n.bcast_do ? 0 : (long)r * p.na + 16 * at;
-            const int dld = n.bcast_do ? 0 : p.ldo;
-            const unsigned long long ddead = n.bcast_do ? 0ull : (rm.qdw >> (16 * at));
-            sd.load(dO0, drow0, na_t, dld, head * hd, hd, lane, ddead);
-            f32x4 sn0[NJT];
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) sn0[jt] = dot_tile(Qs, 16 * at, Ks, 16 * jt, hd, pd, l15, q);   // S[agent][key]
-            f32x4 dQt[NCT];                           // [c][agent 16at+l15]
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) dQt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int v = 0; v < n.nvar; ++v) {
-                sd.store(Ds, hd, pd, lane, ddead);
-                if (v + 1 < n.nvar) sd.load(dO0 + (v + 1) * p.sO, drow0, na_t, dld, head * hd, hd, lane, ddead);
-                f32x4 pn[NJT];
-#pragma unroll
-                for (int jt = 0; jt < NJT; ++jt)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) pn[jt][reg] = sn0[jt][reg] * inv_scale;
-                const unsigned long long* mv = mw + v * NAT * 16;
-                const unsigned long long wn[4] = {mv[agentN0], mv[agentN0 + 1], mv[agentN0 + 2], mv[agentN0 + 3]};
-                softmax_N<NJT>(pn, wn, l15);
-                // dP[agent][key] = dO V^T ; dS = P (dP - sum_key P dP) / scale
-                f32x4 dsn[NJT];
-                float rdN[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int jt = 0; jt < NJT; ++jt) {
-                    dsn[jt] = dot_tile(Ds, 0, Vs, 16 * jt, hd, pd, l15, q);
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) rdN[reg] += pn[jt][reg] * dsn[jt][reg];
-                }
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) rdN[reg] = group16_sum(rdN[reg]);
-#pragma unroll
-                for (int jt = 0; jt < NJT; ++jt)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        dsn[jt][reg] = pn[jt][reg] * (dsn[jt][reg] - rdN[reg]) * inv_scale;
-                        Ts[(4 * q + reg) * TP + 16 * jt + l15] = dsn[jt][reg];
-                    }
-                // the transposed copy dS^T[key 16jt+4q+reg][agent l15] (B operand of the contraction over keys)
-                // comes back through wave-private LDS (same-wave LDS operations execute in order)
-                __builtin_amdgcn_wave_barrier();
-                f32x4 dst[NJT];
-#pragma unroll
-                for (int jt = 0; jt < NJT; ++jt) dst[jt] = *reinterpret_cast<const f32x4*>(Ts + l15 * TP + 16 * jt + 4 * q);
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-#pragma unroll
-                    for (int jt = 0; jt < NJT; ++jt)
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) {
-                            // contraction over agents: virtual k (reg | q) <-> agent 16at+4q+reg (rows of Ds / Qs)
-                            dVt[ct][jt] = MFMA16(Ds[(4 * q + reg) * pd + 16 * ct + l15], pn[jt][reg], dVt[ct][jt]);
-                            dKt[ct][jt] = MFMA16(Qs[(16 * at + 4 * q + reg) * pd + 16 * ct + l15], dsn[jt][reg], dKt[ct][jt]);
-                            // contraction over keys: virtual k (jt,reg | q) <-> key 16jt+4q+reg
-                            dQt[ct] = MFMA16(Ks[(16 * jt + 4 * q + reg) * pd + 16 * ct + l15], dst[jt][reg], dQt[ct]);
-                        }
-                }
-            }
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const int c = 16 * ct + 4 * q;
-                if (agentT < p.na && c < hd && !((rm.qdw >> agentT) & 1ull))       // (rows of skipped agents: nobody reads them)
-                    *reinterpret_cast<float4*>(n.dQ + ((long)r * p.na + agentT) * p.ldq + head * hd + c) =
-                        make_float4(dQt[ct][0], dQt[ct][1], dQt[ct][2], dQt[ct][3]);
-            }
-        }
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) {
-                const int key = 16 * jt + l15, c = 16 * ct + 4 * q;
-                if (key < p.ne && c < hd && !((rm.kdw >> key) & 1ull)) {               // (dead K / V rows: their gradients are exact zeros nobody reads)
-                    const long off = ((long)r * p.ne + key) * p.ldkv + head * hd + c;
-                    *reinterpret_cast<float4*>(n.dK + off) = make_float4(dKt[ct][jt][0], dKt[ct][jt][1], dKt[ct][jt][2], dKt[ct][jt][3]);
-                    *reinterpret_cast<float4*>(n.dV + off) = make_float4(dVt[ct][jt][0], dVt[ct][jt][1], dVt[ct][jt][2], dVt[ct][jt][3]);
-                }
-            }
-        __builtin_amdgcn_wave_barrier();                   // (the next job's operands overwrite the wave's LDS tiles)
-    }
-}
-
 // ================================================================================================
-// Second generation: PERSISTENT workgroups with a software-pipelined operand fetch (attn_fwd_pipe / attn_bwd_pipe).
+// PERSISTENT workgroups with a software-pipelined operand fetch (attn_fwd_pipe / attn_bwd_pipe).
 //
-// What bounded the kernels above was neither HBM bandwidth (0.24-0.33 of the roof by the PMC counters) nor the matrix
-// cores (0.30): every wave walked load -> wait -> LDS -> compute -> store once per job, its operand fetch was a chain
-// of dependent round trips (net pointers looked up with per-lane loads, one conditional load per operand tile, each
-// behind its own s_waitcnt), and a workgroup lived for ONE row. Here
+// The first generation of these kernels (one workgroup per row, rounds 1-2) ran at 0.24-0.33 of the HBM roof and 0.30 of the
+// matrix cores: every wave walked load -> wait -> LDS -> compute -> store once per job, its operand fetch was a chain of
+// dependent round trips (net pointers looked up with per-lane loads, one conditional load per operand tile, each behind its
+// own s_waitcnt), and a workgroup lived for ONE row. Here
 //   * a launch is (CUs x resident workgroups) workgroups; each walks the LIVE rows (b,t <= t_last[b]) it owns -- the
 //     live-row ordinals are mapped to rows through a prefix sum of the episodes' live steps built in LDS once per
 //     workgroup -- and each of its 4 waves walks its own stream of (row, net, head) jobs;
@@ -1254,23 +929,6 @@ int pool_launch(const refil_attn_desc& d, int mode, bool bwd, hipStream_t st) {
 }
 
 
-template <int NJT, int NAT, int NCT, bool HDX>
-static int launch_pair_x(const AttnM& k, bool bwd, size_t smem, hipStream_t st) {
-    if (bwd) {
-        if (smem > 64 * 1024) REFIL_HIP(hipFuncSetAttribute((const void*)attn_bwd_mfma<NJT, NAT, NCT, HDX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((attn_bwd_mfma<NJT, NAT, NCT, HDX>), dim3(k.R), dim3(256), smem, st, k);
-    } else {
-        if (smem > 64 * 1024) REFIL_HIP(hipFuncSetAttribute((const void*)attn_fwd_mfma<NJT, NAT, NCT, HDX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((attn_fwd_mfma<NJT, NAT, NCT, HDX>), dim3(k.R), dim3(256), smem, st, k);
-    }
-    REFIL_LAUNCH_CHECK();
-    return 0;
-}
-template <int NJT, int NAT, int NCT>
-static int launch_pair(const AttnM& k, bool bwd, size_t smem, hipStream_t st) {
-    return k.hd == 16 * NCT ? launch_pair_x<NJT, NAT, NCT, true>(k, bwd, smem, st) : launch_pair_x<NJT, NAT, NCT, false>(k, bwd, smem, st);
-}
-
 static int device_cus() {
     static const int n = [] {
         int dev = 0, v = 0;
@@ -1313,11 +971,8 @@ static int launch_pipe(const AttnM& k, bool bwd, hipStream_t st) {
     return k.mwords ? launch_pipe_x<NJT, NAT, NCT, true>(k, bwd, st) : launch_pipe_x<NJT, NAT, NCT, false>(k, bwd, st);
 }
 
-static bool attn_v1() { static const bool v = [] { const char* e = getenv("REFIL_ATTN_V1"); return e && e[0] == '1'; }(); return v; }
-
 bool attn_mfma_supported(int ne, int na, int hd) {
     const int j = tiles16(ne), a = tiles16(na), c = tiles16(hd);
-    if (attn_v1()) return (j == 1 && a == 1 && c <= 2) || (j == 2 && a == 1 && c <= 2) || (a == 2 && c == 2 && j >= 2 && j <= 4);
     return hd % 4 == 0 && na <= ne && ((j <= 2 && a == 1 && c <= 2) || (j >= 2 && j <= 4 && a <= 2 && c == 2));
 }
 
@@ -1394,19 +1049,6 @@ int attn_mfma_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts
     }
     if (!attn_mfma_supported(d.ne, d.na, d.hd)) return -1;
     ProfScope prof(bwd ? "attn_bwd_mfma" : "attn_fwd_mfma", flops, bytes, st);
-    if (attn_v1()) {
-        const int pd = d.hd + 2;
-        // +16 floats of slack: fragment reads of a partial channel tile (hd < 16*nct) run past the last row
-        k.wave_floats = ((nat * 16 + 2 * njt * 16 + (bwd ? 16 : 0)) * pd + 16 + 3) & ~3;
-        if (bwd) k.wave_floats += 16 * (njt * 16 + 4);     // dS transposition tile at the end of the wave region
-        k.mask_floats = (int)(mask_region_bytes(d.ne, d.na) / 4);
-        const size_t smem = (size_t)4 * k.wave_floats * 4 + (size_t)k.mask_floats * 4 + (size_t)3 * nat * 16 * 8;
-        if (smem > 160 * 1024) return -1;
-#define CASE(J, A, C) if (njt == J && nat == A && nct == C) return launch_pair<J, A, C>(k, bwd, smem, st)
-        CASE(1, 1, 1); CASE(1, 1, 2); CASE(2, 1, 1); CASE(2, 1, 2); CASE(2, 2, 2); CASE(3, 2, 2); CASE(4, 2, 2);
-#undef CASE
-        return -1;
-    }
 #define CASE(J, A, C) if (njt == J && nat == A && nct == C) return launch_pipe<J, A, C>(k, bwd, st)
     CASE(1, 1, 1); CASE(1, 1, 2); CASE(2, 1, 1); CASE(2, 1, 2); CASE(2, 2, 2); CASE(3, 1, 2); CASE(3, 2, 2); CASE(4, 1, 2); CASE(4, 2, 2);
 #undef CASE

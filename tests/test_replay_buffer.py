@@ -83,6 +83,7 @@ def test_device_gather_equals_fancy_indexing():
         ids = np.random.choice(12, 6, replace=False)
         ref = buf[ids]                                        # the reference's path
         th.cuda.synchronize()
+        assert "obs_mask" in buf._packed and "obs_mask" not in buf.data.transition_data        # stored as words, served as bytes
         assert set(got.data.transition_data) == set(ref.data.transition_data)
         for k, v in ref.data.transition_data.items():
             assert th.equal(got.data.transition_data[k], v), k
@@ -97,7 +98,40 @@ def test_device_gather_equals_fancy_indexing():
 def test_gather_rejects_bad_arguments():
     import ctypes as C
     from refil_amd import _lib
-    f = (_lib.GatherField * 1)(_lib.GatherField(0, 0, 16, 16, 16))
+    f = (_lib.GatherField * 1)(_lib.GatherField(0, 0, 16, 16, 16, 0, 0))
     ids = th.zeros(2, dtype=th.int64, device="cuda")
     assert _lib.lib().refil_replay_gather(f, 1, _lib.ptr(ids), 2, 4, None) != 0
     assert b"field 0" in _lib.lib().refil_last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ne", [8, 33, 64])
+def test_bit_packed_mask_storage_equals_byte_storage(ne):
+    """obs_mask kept as one int64 word per row in the device buffer against the byte storage
+    (pack_masks=False): insertion with ring wrap-around, buffer["obs_mask"], fancy indexing and the gather launch's expansion
+    into the staging minibatch are bit-identical; the packed buffer holds 8 bytes per mask row instead of ne."""
+    scheme, groups, pre = _scheme(ne=ne, na=4, ed=7, A=5)
+    bufs = [ReplayBuffer(scheme, groups, 10, 6, preprocess=pre, device="cuda", pack_masks=pm) for pm in (True, False)]
+    for tag, n in ((10, 7), (50, 6)):                       # the second insertion wraps
+        eps = _episodes(n, 6, tag, device="cuda", ne=ne, na=4, ed=7, A=5)
+        for b in bufs:
+            b.insert_episode_batch(eps)
+    packed, plain = bufs
+    assert "obs_mask" in packed._packed and packed._packed["obs_mask"].shape == (10, 6, ne) and packed._packed["obs_mask"].dtype == th.int64
+    assert not plain._packed and plain["obs_mask"].shape == (10, 6, ne, ne)
+    assert th.equal(packed["obs_mask"], plain["obs_mask"])
+    ids = [7, 0, 3]
+    assert th.equal(packed[ids]["obs_mask"], plain[ids]["obs_mask"])
+    for seed in (1, 2):
+        np.random.seed(seed)
+        a = packed.sample(5)
+        np.random.seed(seed)
+        b = plain.sample(5)
+        th.cuda.synchronize()
+        assert a["obs_mask"].dtype == th.uint8 and a["obs_mask"].shape == (5, 6, ne, ne)
+        for k in b.data.transition_data:
+            assert th.equal(a[k], b[k]), k
+    s1 = packed.sample(5, copy=True)
+    keep = s1["entities"].clone()
+    packed.sample(5)                                          # overwrites the staging minibatch, not the copy
+    assert th.equal(s1["entities"], keep)
