@@ -78,6 +78,8 @@ struct ListArgs {
     uint8_t* ever;                         // [B*na] scratch: agent active at some live step
     int* list_t;                           // [NA+256]
     struct Rep { int* list; int src, copies, trash; } rep[4];   // lengths -> counts[4 + k]; list = NULL: unused
+    unsigned long long* sync;              // [B][8] scratch of the one-launch version: per-episode list lengths as {tag, value} granules
+    unsigned tag;                          // set by lists_launch
 };
 int lists_launch(const ListArgs& a, hipStream_t st);
 

@@ -125,6 +125,7 @@ struct Work {
     int *t_last, *list_ea, *list_eh, *list_a, *counts, *lcnt, *loff;
     int *list_t, *list_t3, *list_h, *list_ht;      // agent-row lists of the layers behind the attention cores (kernels.h: ListArgs)
     uint8_t *kdead_a, *kdead_h, *ever;
+    unsigned long long* lsync;     // [B][8] exchange area of the one-launch list kernel
     // mask words of the step, built once for all attention launches (attention_mfma.hip: attn_mask_words_kernel)
     unsigned long long *mw_a, *rb_a, *mw_h, *rb_h;
 };
@@ -227,6 +228,7 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     w.list_t = a.take<int>(s.NA + 256); w.list_t3 = a.take<int>((long)s.G * s.NA + 256);
     w.list_h = a.take<int>((long)s.nv0 * s.NA + 256); w.list_ht = a.take<int>(s.NA + 256);
     w.kdead_a = a.take<uint8_t>(s.NE); w.kdead_h = a.take<uint8_t>(s.NE); w.ever = a.take<uint8_t>((long)d.B * d.na);
+    w.lsync = a.take<unsigned long long>(256 * 8 + (long)d.B * 8);
     {
         const long na_pad = (d.na + 15) / 16 * 16;
         w.mw_a = a.take<unsigned long long>(s.R * 3 * na_pad); w.rb_a = a.take<unsigned long long>(s.R * 3);
@@ -1043,6 +1045,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         la.rep[1] = ListArgs::Rep{w.list_h, 0, s.nv0, (int)(s.NV * s.NA)};
         la.rep[2] = ListArgs::Rep{w.list_ht, 0, 1, (int)(s.nets * s.NA)};
         la.hint_out = row_hints_dev();
+        la.sync = w.lsync;
         RUN(lists_launch(la, c.st));
         RUN(stream_after(sd, ps, c.st));                   // (the chains fork from c.st: they start with the inputs assembled)
     }

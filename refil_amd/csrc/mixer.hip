@@ -284,9 +284,192 @@ __global__ __launch_bounds__(256) void lists_fill_kernel(ListArgs a) {          
     }
 }
 
-int lists_launch(const ListArgs& a, hipStream_t st) {
+// ------------------------------------------------------------------------------------------------
+// The same four phases in ONE launch (the row lists open every step: four dependent launches are ~35-45 us of nearly idle
+// GPU). Workgroup b = episode b (16 waves): t_last / ever, the flags and per-row counts of its T1 rows (kept in LDS as
+// ballots), an exclusive scan over its rows, then ONE grid-wide exchange: every workgroup publishes its five totals as
+// {tag, value} granules (relaxed agent-scope 8-byte stores; the tag changes every launch, nothing is reset) and reads all
+// B x 5 of them (agent-scope loads: L2, never a stale L1 line) -- the sum over the earlier episodes is its base offset, the
+// sum over all of them the list length the shifted copies need -- and fills its rows' list entries. All B workgroups must be
+// resident for the exchange: used for B <= 256 outside stream capture, the four-launch version otherwise.
+// ------------------------------------------------------------------------------------------------
+constexpr int LF_WAVES = 8;
+// grid = B x nsub: workgroup (b, sb) takes rows t in [sb * chunk, (sb + 1) * chunk) of episode b
+__global__ __launch_bounds__(64 * LF_WAVES) void lists_fused_kernel(ListArgs a, int nsub, int chunk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lf_smem[];
+    __shared__ int any_s[64];
+    __shared__ int tl_s;
+    __shared__ int tot_s[4];
+    __shared__ int base_s[5], grand_s[5];
+    const int T1 = a.T1, b = blockIdx.x / nsub, sb = blockIdx.x - b * nsub;
+    const int ta = sb * chunk, tb = min(T1, ta + chunk), nr = max(tb - ta, 0);        // this workgroup's rows [ta, tb)
+    unsigned long long* bal = lf_smem;                        // [4][chunk] ballots of the rows: agent-net keys, hypernet keys, active agents, tail agents
+    int* cnt = reinterpret_cast<int*>(bal + 4 * chunk);       // [4][chunk]
+    int* off = cnt + 4 * chunk;                               // [4][chunk] exclusive scans inside the workgroup's rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long R = (long)a.B * T1;
+    // ---- phase 1: the episode (lists_episode_kernel; every workgroup of the episode computes it, workgroup sb = 0 stores it)
+    if (threadIdx.x < 64) any_s[threadIdx.x] = 0;
+    if (wave == 0) {
+        const int T = T1 - 1;
+        int last = -1;
+        if (!a.learner) last = T1 - 1;
+        else {
+            for (int t = lane; t < T; t += 64) {
+                float m = (float)a.b.filled[b * a.b.fl_sB + t * a.b.fl_sT];
+                if (t > 0) m *= 1.0f - (float)a.b.terminated[b * a.b.tm_sB + (t - 1) * a.b.tm_sT];     // q_learner.py:71-72
+                if (m != 0.f) last = t + 1;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o, 64));
+        }
+        if (lane == 0) { tl_s = last; if (sb == 0) a.t_last[b] = last; }
+        if (sb == 0 && lane < a.ne) a.em0[(long)b * a.ne + lane] = a.b.entity_mask[b * a.b.em_sB + lane];
+    }
+    __syncthreads();
+    const int tl = tl_s;
+    {
+        const int n = (tl + 1) * a.na;
+        for (int idx = threadIdx.x; idx < n; idx += 64 * LF_WAVES)
+            if (a.b.entity_mask[b * a.b.em_sB + (idx / a.na) * a.b.em_sT + idx % a.na] == 0) any_s[idx % a.na] = 1;      // (benign race: every writer stores 1)
+    }
+    __syncthreads();
+    if (sb == 0 && threadIdx.x < a.na) a.ever[(long)b * a.na + threadIdx.x] = any_s[threadIdx.x] ? 1 : 0;
+    // ---- phase 2: flags of the rows (lists_flags_kernel), one wave per row
+    for (int k = wave; k < nr; k += LF_WAVES) {
+        const int t = ta + k;
+        const long r = (long)b * T1 + t;
+        const bool row_live = t <= tl;
+        bool ka = false, kh = false, la = false;
+        uint8_t emt = 1;
+        if (lane < a.ne) {
+            emt = a.b.entity_mask[b * a.b.em_sB + t * a.b.em_sT + lane];
+            a.emc[r * a.ne + lane] = emt;
+            if (lane < a.na) { a.amask[r * a.na + lane] = emt; a.actf[r * a.na + lane] = emt ? 0.f : 1.f; }
+        }
+        if (lane < a.ne && row_live) {
+            const uint8_t em0 = a.b.entity_mask[b * a.b.em_sB + lane];
+            la = lane < a.na && emt == 0;
+            kh = !(emt && em0) || la;
+            const uint8_t* om = a.use_gt_obs ? a.b.gt_mask + b * a.b.gt_sB + t * a.b.gt_sT : a.b.obs_mask + b * a.b.om_sB + t * a.b.om_sT;
+            bool seen = false;
+            for (int i = 0; i < a.na; ++i) seen |= om[i * a.ne + lane] == 0;
+            ka = seen || la;
+        }
+        if (lane < a.ne) { a.kdead_a[r * a.ne + lane] = ka ? 0 : 1; a.kdead_h[r * a.ne + lane] = kh ? 0 : 1; }
+        const bool lt = row_live && lane < a.na && any_s[lane < a.na ? lane : 0];
+        const unsigned long long ba = __ballot(ka), bh = __ballot(kh), bl = __ballot(la), bt = __ballot(lt);
+        if (lane == 0) {
+            bal[k] = ba; bal[chunk + k] = bh; bal[2 * chunk + k] = bl; bal[3 * chunk + k] = bt;
+            cnt[k] = __popcll(ba); cnt[chunk + k] = __popcll(bh); cnt[2 * chunk + k] = __popcll(bl); cnt[3 * chunk + k] = __popcll(bt);
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: exclusive scan of the four count arrays over the workgroup's rows (wave l: list l)
+    if (wave < 4) {
+        const int per = (nr + 63) / 64, k0 = min(lane * per, nr), k1 = min(nr, k0 + per);
+        int s = 0;
+        for (int k = k0; k < k1; ++k) s += cnt[wave * chunk + k];
+        int inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        int run = inc - s;
+        for (int k = k0; k < k1; ++k) { off[wave * chunk + k] = run; run += cnt[wave * chunk + k]; }
+        if (lane == 63) tot_s[wave] = inc;
+    }
+    __syncthreads();
+    // ---- phase 4: grid-wide exchange of the five per-workgroup totals
+    const unsigned long long tag = (unsigned long long)a.tag << 32;
+    const int me = blockIdx.x, nblk = gridDim.x;
+    if (threadIdx.x < 5) {
+        const int live = max(0, min(tl + 1, tb) - ta);                  // live rows among [ta, tb)
+        const unsigned v = threadIdx.x < 4 ? (unsigned)tot_s[threadIdx.x] : (unsigned)live;
+        __hip_atomic_store(a.sync + (long)me * 8 + threadIdx.x, tag | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (wave < 5) {
+        int base = 0, grand = 0;
+        for (int bb = lane; bb < nblk; bb += 64) {
+            unsigned long long g;
+            do {
+                g = __hip_atomic_load(a.sync + (long)bb * 8 + wave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((g >> 32) != a.tag) __builtin_amdgcn_s_sleep(2);
+            } while ((g >> 32) != a.tag);
+            const int v = (int)(unsigned)g;
+            grand += v;
+            if (bb < me) base += v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { base += __shfl_xor(base, o, 64); grand += __shfl_xor(grand, o, 64); }
+        if (lane == 0) { base_s[wave] = base; grand_s[wave] = grand; }
+    }
+    __syncthreads();
+    // ---- phase 5: the rows' list entries (lists_fill_kernel)
+    const long NA = R * a.na;
+    for (int k = wave; k < nr; k += LF_WAVES) {
+        const long r = (long)b * T1 + ta + k;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const unsigned long long ba = bal[k], bh = bal[chunk + k], bl = bal[2 * chunk + k], bt = bal[3 * chunk + k];
+        if ((ba >> lane) & 1ull) a.list_ea[base_s[0] + off[k] + __popcll(ba & below)] = (int)(r * a.ne + lane);
+        if ((bh >> lane) & 1ull) a.list_eh[base_s[1] + off[chunk + k] + __popcll(bh & below)] = (int)(r * a.ne + lane);
+        if ((bl >> lane) & 1ull) {
+            const int pos = base_s[2] + off[2 * chunk + k] + __popcll(bl & below), total = grand_s[2];
+            a.list_a[pos] = (int)(r * a.na + lane);
+            for (int q = 0; q < 4; ++q)                           // shifted copies (ListArgs::rep with src 0)
+                if (a.rep[q].list && a.rep[q].src == 0)
+                    for (int c = 0; c < a.rep[q].copies; ++c) a.rep[q].list[c * total + pos] = (int)(r * a.na + lane + c * NA);
+        }
+        if ((bt >> lane) & 1ull) {
+            const int pos = base_s[3] + off[3 * chunk + k] + __popcll(bt & below), total = grand_s[3];
+            a.list_t[pos] = (int)(r * a.na + lane);
+            for (int q = 0; q < 4; ++q)
+                if (a.rep[q].list && a.rep[q].src == 1)
+                    for (int c = 0; c < a.rep[q].copies; ++c) a.rep[q].list[c * total + pos] = (int)(r * a.na + lane + c * NA);
+        }
+    }
+    // ---- phase 6 (workgroup 0): lengths, padding, hints (lists_scan_kernel's tail); 128 threads per list
+    if (me == 0) {
+        const int tid = threadIdx.x & 127, l = threadIdx.x >> 7;
+        const int total = grand_s[l];
+        if (tid == 0) a.counts[l < 3 ? l : 7] = total;
+        int* list = l == 0 ? a.list_ea : (l == 1 ? a.list_eh : (l == 2 ? a.list_a : a.list_t));
+        const int trash = l >= 2 ? (int)(R * a.na) : (int)(R * a.ne);
+        const int padded = ((total + 63) & ~63) + 128;
+        for (int i = tid; i < 192; i += 128) if (total + i < padded) list[total + i] = trash;
+        if (threadIdx.x == 0) a.counts[3] = grand_s[4];
+        if (l == 2 || l == 3) {
+            for (int q = 0; q < 4; ++q) {
+                const ListArgs::Rep rp = a.rep[q];
+                if (!rp.list || rp.src != (l == 3 ? 1 : 0)) continue;
+                const int tot = total * rp.copies, pad = ((tot + 63) & ~63) + 128;
+                if (tid == 0) a.counts[4 + q] = tot;
+                for (int i = tid; i < 192; i += 128) if (tot + i < pad) rp.list[tot + i] = rp.trash;
+            }
+        }
+        __syncthreads();
+        if (a.hint_out && threadIdx.x < 8) a.hint_out[threadIdx.x] = a.counts[threadIdx.x];
+    }
+}
+
+int lists_launch(const ListArgs& a0, hipStream_t st) {
+    ListArgs a = a0;
     const long R = (long)a.B * a.T1;
     ProfScope prof("lists_kernels", 0.0, 0.0, st);
+    static const bool fused_env = [] { const char* e = getenv("REFIL_LISTS_FUSED"); return !(e && e[0] == '0'); }();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    // sub-blocks per episode: as many workgroups as stay resident with room to spare (<= 256), at least ~8 rows each
+    int nsub = 256 / (a.B > 0 ? a.B : 1);
+    nsub = nsub < 1 ? 1 : (nsub > (a.T1 + 7) / 8 ? (a.T1 + 7) / 8 : nsub);
+    const int chunk = (a.T1 + nsub - 1) / nsub;
+    nsub = (a.T1 + chunk - 1) / chunk;
+    const size_t smem = (size_t)chunk * (4 * 8 + 8 * 4);
+    if (fused_env && a.sync && a.B <= 256 && a.ne <= 64 && smem <= 60 * 1024 && cap == hipStreamCaptureStatusNone) {
+        static unsigned epoch = 0;
+        a.tag = (++epoch & 0x7fffffffu) | 0x80000000u;        // never 0, never the tag of the previous launches on this arena
+        hipLaunchKernelGGL(lists_fused_kernel, dim3(a.B * nsub), dim3(64 * LF_WAVES), smem, st, a, nsub, chunk);
+        REFIL_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(lists_episode_kernel, dim3(a.B), dim3(256), 0, st, a);
     hipLaunchKernelGGL(lists_flags_kernel, dim3((int)cdivl(R, 4)), dim3(256), 0, st, a);
     hipLaunchKernelGGL(lists_scan_kernel, dim3(1), dim3(1024), 0, st, a);
