@@ -1025,10 +1025,13 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     }
     if (!c.lists) RUN(run_prep(c, 1, 3));
     else {
-        // Row lists: four small dependent launches (their kernels also write the contiguous mask copies). The input
-        // assembly does not depend on them: it runs beside them on an idle stream (all rows: cheaper than waiting for the lists).
-        const hipStream_t ps = overlap ? sd->g[0] : c.st;
-        RUN(stream_after(sd, c.st, ps));
+        // Row lists (one launch; its kernel also writes the contiguous mask copies). The input assembly does not depend on
+        // them (all rows: cheaper than waiting for the lists).
+        // (A/B on one box: the input assembly on the caller's stream, in front of the list kernel, beats the side stream by
+        // 0.3 % at cfg-T and 1.6 % at cfg2 -- a cross-stream join at the head of the step costs more than the ~30 us of overlap)
+        static const bool prep_side = [] { const char* e = getenv("REFIL_PREP_SIDE"); return e && e[0] == '1'; }();
+        const hipStream_t ps = (overlap && prep_side) ? sd->g[0] : c.st;
+        if (ps != c.st) RUN(stream_after(sd, c.st, ps));
         {
             Ctx cp = c;
             cp.st = ps; cp.lists = false;
@@ -1047,7 +1050,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         la.hint_out = row_hints_dev();
         la.sync = w.lsync;
         RUN(lists_launch(la, c.st));
-        RUN(stream_after(sd, ps, c.st));                   // (the chains fork from c.st: they start with the inputs assembled)
+        if (ps != c.st) RUN(stream_after(sd, ps, c.st));   // (the chains fork from c.st: they start with the inputs assembled)
     }
     if (c.mwords) {
         // mask words of every row, once per step: agent nets (observability variants) and hypernets (entity variants);
