@@ -304,62 +304,101 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N == 8 ? 4 
 // sum the split partials (plain store or +=). 16 waves per workgroup: lane = output element (coalesced),
 // wave w adds splits w, w+16, ... (independent loads in flight), then a 16-way LDS reduction.
 constexpr int RED_WAVES = 16;
-__global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_kernel(GemmK p) {
-    __shared__ float red[RED_WAVES][64];
+template <class P>
+__device__ inline void reduce_chunk(const P& p, long chunk, float (*red)[64]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long MN = (long)p.M * p.N;
     const long total = (long)p.batch * MN;
     const long nchunk = cdivl(total, 64);
     const bool with_cs = p.flags & REFIL_GEMM_COLSUM_A;
     const long tot2 = with_cs ? (long)p.batch * p.M : 0;
-    const long nchunk2 = cdivl(tot2, 64);
-    for (long chunk = blockIdx.x; chunk < nchunk + nchunk2; chunk += gridDim.x) {
-        const bool cs = chunk >= nchunk;
-        const long idx = (cs ? chunk - nchunk : chunk) * 64 + lane;
-        const long lim = cs ? tot2 : total;
-        float s = 0.f;
-        int b = 0, m = 0, n = 0;
-        if (idx < lim) {
-            const float* src;
-            long sstride;
-            if (!cs) {
-                b = idx / MN;
-                const long rem = idx - (long)b * MN;
-                m = rem / p.N; n = rem % p.N;
-                src = p.partial + (long)b * p.splits * MN + rem;
-                sstride = MN;
-            } else {
-                b = idx / p.M; m = idx % p.M;
-                src = p.partial + (long)p.batch * p.splits * MN + (long)b * p.splits * p.M + m;
-                sstride = p.M;
-            }
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int sp = w;
-            for (; sp + 3 * RED_WAVES < p.splits; sp += 4 * RED_WAVES) {
-                s0 += src[(long)sp * sstride];
-                s1 += src[(long)(sp + RED_WAVES) * sstride];
-                s2 += src[(long)(sp + 2 * RED_WAVES) * sstride];
-                s3 += src[(long)(sp + 3 * RED_WAVES) * sstride];
-            }
-            for (; sp < p.splits; sp += RED_WAVES) s0 += src[(long)sp * sstride];
-            s = (s0 + s1) + (s2 + s3);
+    const bool cs = chunk >= nchunk;
+    const long idx = (cs ? chunk - nchunk : chunk) * 64 + lane;
+    const long lim = cs ? tot2 : total;
+    float s = 0.f;
+    int b = 0, m = 0, n = 0;
+    if (idx < lim) {
+        const float* src;
+        long sstride;
+        if (!cs) {
+            b = idx / MN;
+            const long rem = idx - (long)b * MN;
+            m = rem / p.N; n = rem % p.N;
+            src = p.partial + (long)b * p.splits * MN + rem;
+            sstride = MN;
+        } else {
+            b = idx / p.M; m = idx % p.M;
+            src = p.partial + (long)p.batch * p.splits * MN + (long)b * p.splits * p.M + m;
+            sstride = p.M;
         }
-        red[w][lane] = s;
-        __syncthreads();
-        if (w == 0 && idx < lim) {
-            float t = 0.f;
-#pragma unroll
-            for (int k = 0; k < RED_WAVES; ++k) t += red[k][lane];
-            if (!cs) {
-                float* dst = p.C + b * p.sC + p.cmap(m) * (long)p.ldc + n;
-                if (p.flags & REFIL_GEMM_ACCUM) t += *dst;
-                *dst = t;
-            } else {
-                p.colsum[b * p.sColsum + m] = t;
-            }
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int sp = w;
+        for (; sp + 3 * RED_WAVES < p.splits; sp += 4 * RED_WAVES) {
+            s0 += src[(long)sp * sstride];
+            s1 += src[(long)(sp + RED_WAVES) * sstride];
+            s2 += src[(long)(sp + 2 * RED_WAVES) * sstride];
+            s3 += src[(long)(sp + 3 * RED_WAVES) * sstride];
         }
-        __syncthreads();
+        for (; sp < p.splits; sp += RED_WAVES) s0 += src[(long)sp * sstride];
+        s = (s0 + s1) + (s2 + s3);
     }
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && idx < lim) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < RED_WAVES; ++k) t += red[k][lane];
+        if (!cs) {
+            float* dst = p.C + b * p.sC + p.cmap(m) * (long)p.ldc + n;
+            if (p.flags & REFIL_GEMM_ACCUM) t += *dst;
+            *dst = t;
+        } else {
+            p.colsum[b * p.sColsum + m] = t;
+        }
+    }
+    __syncthreads();
+}
+template <class P>
+__host__ __device__ inline long reduce_chunks(const P& p) {
+    return cdivl((long)p.batch * p.M * p.N, 64) + ((p.flags & REFIL_GEMM_COLSUM_A) ? cdivl((long)p.batch * p.M, 64) : 0);
+}
+__global__ __launch_bounds__(64 * RED_WAVES) void reduce_partials_kernel(GemmK p) {
+    __shared__ float red[RED_WAVES][64];
+    const long n = reduce_chunks(p);
+    for (long chunk = blockIdx.x; chunk < n; chunk += gridDim.x) reduce_chunk(p, chunk, red);
+}
+// The reductions of many split launches in one launch (the step's weight gradients: nothing but the optimiser reads them,
+// so their reductions wait for the end of the step instead of sitting between the GEMMs on the weight-gradient streams).
+// Same summation order per output element as reduce_partials_kernel: the results are bit-identical.
+struct ReduceMulti { ReduceK r[RED_MULTI]; int first[RED_MULTI + 1]; int n; };
+__global__ __launch_bounds__(64 * RED_WAVES) void reduce_multi_kernel(ReduceMulti m) {
+    __shared__ float red[RED_WAVES][64];
+    const int total = m.first[m.n];
+    int i = 0;
+    for (int chunk = blockIdx.x; chunk < total; chunk += gridDim.x) {
+        while (chunk >= m.first[i + 1]) ++i;            // (workgroup-uniform: scalar loads from the kernel arguments)
+        reduce_chunk(m.r[i], (long)(chunk - m.first[i]), red);
+    }
+}
+int reduce_multi_launch(const ReduceK* r, int n, hipStream_t st) {
+    for (int at = 0; at < n; at += RED_MULTI) {
+        ReduceMulti m = {};
+        m.n = min(RED_MULTI, n - at);
+        long chunks = 0, bytes = 0;
+        for (int i = 0; i < m.n; ++i) {
+            m.r[i] = r[at + i];
+            m.first[i] = (int)chunks;
+            chunks += reduce_chunks(m.r[i]);
+            bytes += 4L * m.r[i].batch * m.r[i].M * m.r[i].N * (m.r[i].splits + 1);
+        }
+        REFIL_CHECK(chunks < (1L << 31), "refil: reduce_multi: too many output elements");
+        m.first[m.n] = (int)chunks;
+        if (!chunks) continue;
+        ProfScope prof("reduce_multi_kernel", 0.0, (double)bytes, st);
+        hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)min(chunks, 4096L)), dim3(64 * RED_WAVES), 0, st, m);
+        REFIL_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 static const char* gemm_name(int wm, int tm, int tn, bool ao, bool bo) {
@@ -425,7 +464,8 @@ static bool dw_stream_on() {
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
+int gemm_launch(const refil_gemm_desc& d, hipStream_t st, ReduceK* defer) {
+    if (defer) defer->splits = 0;
     static const bool log_shapes = [] { const char* e = getenv("REFIL_GEMM_LOG"); return e && e[0] == '1'; }();
     if (log_shapes)   // debugging aid: one line per launch, in launch order (pair with a rocprofv3 kernel trace)
         fprintf(stderr, "refil_gemm M=%d N=%d K=%d batch=%d splits=%d flags=0x%x\n", d.M, d.N, d.K, d.batch, d.splits, d.flags);
@@ -494,7 +534,9 @@ int gemm_launch(const refil_gemm_desc& d, hipStream_t st) {
     else rc = launch_cfg<4, 1, 1, 1>(k, st);
     if (rc) return rc;
     REFIL_LAUNCH_CHECK();
-    if (d.splits > 1) {
+    if (d.splits > 1 && defer) {
+        *defer = ReduceK{k.partial, k.C, k.colsum, k.sC, k.sColsum, k.cmap, k.ldc, k.M, k.N, k.batch, k.splits, k.flags};
+    } else if (d.splits > 1) {
         const long total = (long)d.batch * d.M * d.N;
         const int blocks = (int)min((long)2048, cdivl(total, 64) + cdivl((long)d.batch * d.M, 64));
         ProfScope prof("reduce_partials_kernel", 0.0, 4.0 * total * (d.splits + 1), st);

@@ -15,7 +15,18 @@ __host__ __device__ inline bool mask_uses_groups(int c) {   // same(i,j): group 
 }
 __host__ __device__ inline bool mask_uses_inactive0(int c) { return mask_uses_groups(c) || c == REFIL_MASK_GTW || c == REFIL_MASK_GTI; }
 
-int gemm_launch(const refil_gemm_desc& d, hipStream_t st);
+// A split GEMM's pending reduction (sum of its partials into C / colsum): what reduce_partials needs and nothing else.
+struct ReduceK {
+    const float* partial; float* C; float* colsum;
+    long sC, sColsum;
+    RowMap cmap;
+    int ldc, M, N, batch, splits, flags;
+};
+constexpr int RED_MULTI = 28;        // reductions one reduce_multi launch takes
+// defer != nullptr: a split launch writes its partials only and describes the reduction in *defer (splits == 0 there when the
+// launch needed none); the caller runs it later with reduce_multi_launch -- many reductions, one launch
+int gemm_launch(const refil_gemm_desc& d, hipStream_t st, ReduceK* defer = nullptr);
+int reduce_multi_launch(const ReduceK* r, int n, hipStream_t st);
 // weight-resident kernel for short-reduction forward projections (gemm_wres.hip); gemm_launch dispatches to it
 bool gemm_wres_eligible(const refil_gemm_desc& d);
 // streaming weight-gradient kernel (gemm_dw.hip): writes the split partials, gemm_launch runs the reduction

@@ -96,6 +96,7 @@ struct Arena {
 };
 
 constexpr long PARTIAL_FLOATS = 40L << 20;   // split-K scratch (160 MiB)
+constexpr long DPOOL_FLOATS = 128L << 20;    // partials of the step's deferred reductions (512 MiB; a launch that does not fit reduces at once)
 
 struct AgentBufs {     // one entity-attention recurrent agent evaluation (G mask variants)
     float *x1, *kv, *q, *ao, *x2, *x3, *gi, *hsx, *sr, *sz, *sn, *sg, *qv;
@@ -121,6 +122,7 @@ struct Work {
     float* partial;
     float* partial2;   // split-K scratch of the side (agent-chain) stream
     float* partial3; float* partial4;   // split-K scratch of the chains' own streams (their last weight gradients)
+    float* dpool;      // partials of the weight gradients whose reductions wait for the end of the step (DeferredReduce)
     // row lists (kernels.h: ListArgs): rows that cannot influence the step are skipped
     int *t_last, *list_ea, *list_eh, *list_a, *counts, *lcnt, *loff;
     int *list_t, *list_t3, *list_h, *list_ht;      // agent-row lists of the layers behind the attention cores (kernels.h: ListArgs)
@@ -222,6 +224,7 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     w.partial2 = a.take<float>(PARTIAL_FLOATS);
     w.partial3 = a.take<float>(PARTIAL_FLOATS);
     w.partial4 = a.take<float>(PARTIAL_FLOATS);
+    w.dpool = a.take<float>(DPOOL_FLOATS);
     w.t_last = a.take<int>(d.B);
     w.list_ea = a.take<int>(s.NE + 256); w.list_eh = a.take<int>(s.NE + 256); w.list_a = a.take<int>(s.NA + 256);
     w.counts = a.take<int>(8); w.lcnt = a.take<int>(4 * s.R); w.loff = a.take<int>(4 * (s.R + 1));
@@ -380,6 +383,17 @@ static bool overlap_enabled() {
     return !(e && e[0] == '1');
 }
 
+// Parameter gradients are read by nobody before the optimiser, so the reductions of their split launches are collected here
+// and run as ONE launch after the step's last join (reduce_multi_launch) instead of one small launch behind every weight
+// gradient: each deferred launch keeps its partials in its own slice of Work::dpool until then. Same arithmetic, same order.
+struct DeferredReduce {
+    ReduceK r[64];
+    hipStream_t on[64];        // the stream each launch ran on
+    int n = 0;
+    int mode = 2;              // 1: one launch after the step's last join; 2: one launch per stream, at the end of that stream
+    float* pool = nullptr; long cap = 0, used = 0;
+    const float* lo = nullptr; const float* hi = nullptr;      // the gradient buffer: only launches writing into it are deferred
+};
 struct Ctx {
     refil_dims d; Sizes s; refil_batch b; refil_param_layout L; Work w; hipStream_t st;
     // FlexQMixer's hyper_w_final / hyper_b_1 / V are consumed only through their MEAN over the agents
@@ -403,18 +417,35 @@ struct Ctx {
     // parameter gradients are enqueued behind the in_trans gradient instead of in front of it
     int tail_dw; float* tpartial;
     hipStream_t mwst;  // stream the step's mask words are built on (the chain waits for it right before its first attention launch)
+    DeferredReduce* defer;
 };
+
+static int gemm_launch_dw(const Ctx& c, refil_gemm_desc& g, hipStream_t st) {
+    DeferredReduce* df = c.defer;
+    if (df && g.splits > 1 && df->n < 64 && !(g.flags & REFIL_GEMM_ACCUM) && g.C >= df->lo && g.C < df->hi &&
+        (!g.colsum || (g.colsum >= df->lo && g.colsum < df->hi))) {
+        const long need = ((long)g.batch * g.splits * ((long)g.M * g.N + g.M) + 63) & ~63L;
+        if (df->used + need <= df->cap) {
+            g.partial = df->pool + df->used;
+            ReduceK r;
+            if (int e = gemm_launch(g, st, &r)) return e;
+            if (r.splits > 1) { df->on[df->n] = st; df->r[df->n++] = r; df->used += need; }
+            return 0;
+        }
+    }
+    return gemm_launch(g, st);
+}
 
 // weight gradients (+ their reductions) leave the chain: forked behind everything enqueued on the chain so far
 static int launch_dw(const Ctx& c, refil_gemm_desc g) {
     g.partial = c.gpartial;
     if (int e = stream_after(c.sd, c.st, c.gst)) return e;
-    return gemm_launch(g, c.gst);
+    return gemm_launch_dw(c, g, c.gst);
 }
 static int launch_dw_tail(const Ctx& c, refil_gemm_desc g, int bit) {
     if (!(c.tail_dw & bit)) return launch_dw(c, g);
     g.partial = c.tpartial;
-    return gemm_launch(g, c.st);
+    return gemm_launch_dw(c, g, c.st);
 }
 
 // List lengths of an earlier step, copied back asynchronously into pinned host memory (one slot per device): a HINT
@@ -891,7 +922,7 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
     REFIL_CHECK(dims && batch && ws, "refil: null dims/batch/workspace");
     if (int e = check_dims(*dims)) return e;
     c.d = *dims; c.s = sizes_of(*dims); c.b = *batch; c.st = (hipStream_t)stream;
-    c.gst = c.st; c.gpartial = nullptr; c.sd = nullptr; c.mwst = c.st; c.tail_dw = 0; c.tpartial = nullptr;
+    c.gst = c.st; c.gpartial = nullptr; c.sd = nullptr; c.mwst = c.st; c.tail_dw = 0; c.tpartial = nullptr; c.defer = nullptr;
     param_layout(c.d, c.L);
     const char* pe = getenv("REFIL_PRESUM");          // read per call: tests compare both paths in one process
     const bool presum_on = !(pe && pe[0] == '0');
@@ -993,6 +1024,13 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     const long BT = (long)d.B * T;
     float* stats = grads + L.total;
     REFIL_HIP(hipMemsetAsync(grads, 0, (L.total + REFIL_NSTAT) * sizeof(float), c.st));
+    // (with a gradient hook the mixer's gradients must be complete when it fires: no deferral then)
+    const char* defer_e = getenv("REFIL_DEFER_REDUCE");       // (read per call: tests compare the modes in one process)
+    const int defer_env = defer_e ? atoi(defer_e) : 2;
+    DeferredReduce deferred;
+    deferred.pool = c.w.dpool; deferred.cap = DPOOL_FLOATS; deferred.lo = grads; deferred.hi = grads + L.total;
+    deferred.mode = defer_env;
+    if (defer_env && !g_mixer_hook) c.defer = &deferred;
 
     // ---------------- forward ----------------
     // Streams (REFIL_NO_OVERLAP=1 / refil_set_overlap(0) serialise everything on the caller's stream):
@@ -1021,7 +1059,13 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         // (the target agent on a third stream was measured slower: three GEMM trains thrash each other more than the lone
         // recurrence at the end of the forward costs)
         static const bool mwside = [] { const char* e = getenv("REFIL_MW_SIDE"); return !(e && e[0] == '0'); }();
-        if (mwside) { ca.mwst = sd->g[0]; ch.mwst = sd->g[1]; }
+        // (under stream capture the mask words stay on the chains' own streams: on ROCm 7.2 hipStreamEndCapture crashes when the
+        // weight-gradient streams also carried them -- tools/probes/graph_capture.py with REFIL_HIPGRAPH_MW=1 reproduces it, the
+        // stand-alone fork / join / re-fork patterns of tools/probes/capture_refork.hip do not)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(c.st, &cap);
+        static const bool mw_cap = [] { const char* e = getenv("REFIL_HIPGRAPH_MW"); return e && e[0] == '1'; }();
+        if (mwside && (cap == hipStreamCaptureStatusNone || mw_cap)) { ca.mwst = sd->g[0]; ch.mwst = sd->g[1]; }
     }
     if (!c.lists) RUN(run_prep(c, 1, 3));
     else {
@@ -1367,11 +1411,27 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         if (ag_compose_pending) RUN(compose_backward_launch(ag_compose, ca.gst));
         RUN(launch_dw_tail(ca, with_rows(linear_dw(w.dx1a, dd, w.xe, s.Ep, grads + L.ag_fc1_w, s.E, grads + L.ag_fc1_b, s.NE, dd, s.E, ca.w.partial, 1), ca, rows_ea(ca)), 2));
     }
+    if (deferred.n && deferred.mode == 2) {
+        // every stream reduces what it produced, behind its last launch (the other streams' tails run beside it)
+        bool done[64] = {};
+        for (int i = 0; i < deferred.n; ++i) {
+            if (done[i]) continue;
+            ReduceK mine[64];
+            int m = 0;
+            for (int j = i; j < deferred.n; ++j)
+                if (deferred.on[j] == deferred.on[i]) { mine[m++] = deferred.r[j]; done[j] = true; }
+            RUN(reduce_multi_launch(mine, m, deferred.on[i]));
+        }
+        deferred.n = 0;
+    }
     if (overlap) {                                                                 // join: hypernet chain, both weight-gradient streams
         REFIL_HIP(hipEventRecord(sd->ev[3], sd->s));
         REFIL_HIP(hipStreamWaitEvent(c.st, sd->ev[3], 0));
         for (int i = 0; i < 2; ++i) RUN(stream_after(sd, sd->g[i], c.st));
     }
+    if (deferred.n) RUN(reduce_multi_launch(deferred.r, deferred.n, c.st));
+    static const bool defer_log = [] { const char* e = getenv("REFIL_GEMM_LOG"); return e && e[0] == '1'; }();
+    if (defer_log) fprintf(stderr, "refil: %d deferred reductions, %.1f of %.1f MiB of partials\n", deferred.n, deferred.used / 262144.0, DPOOL_FLOATS / 262144.0);
     return 0;
 }
 

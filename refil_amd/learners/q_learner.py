@@ -206,16 +206,14 @@ class QLearner:
                                   a.weight_decay, a.grad_norm_clip)
 
     def _graphed_step(self, dims, fields, bits):
-        """REFIL_HIPGRAPH=1: the ~95 launches of a step (four streams, fork / join by events, no allocation, no host
+        """REFIL_HIPGRAPH=1 (opt-in): the ~80 launches of a step (four streams, fork / join by events, no allocation, no host
         sync) are captured into a hipGraph the second time a (shapes, buffer addresses) combination is seen and replayed
-        afterwards -- one launch per step. Single process: forward + backward + optimiser in one graph; data parallel:
+        afterwards -- one launch per step. Measured on ROCm 7.2 / MI355X (tools/probes/graph_capture.py, cfg2): the replay
+        is bit-identical to the eager schedule but SLOWER (0.99 ms against 0.84 ms per step; the graph launch itself costs
+        0.44 ms of host time), so it stays off by default. Single process: forward + backward + optimiser in one graph; data parallel:
         forward + backward only (the all-reduce and the optimiser stay eager). The batch tensors must keep their
         addresses (ReplayBuffer's device staging batch does); the kernels' grid sizes are frozen at the row counts of the
         captured step, which is safe (they loop over the device-side counts) but tuned for that batch."""
-        if os.environ.get("REFIL_GRADSTREAM") != "0":
-            # measured on ROCm 7.2: ending the capture of the four-stream schedule (weight-gradient streams that also carry
-            # the forward's mask-word kernels) crashes inside hipStreamEndCapture; the two-stream schedule captures fine
-            raise RuntimeError("REFIL_HIPGRAPH=1 needs REFIL_GRADSTREAM=0 (two-stream schedule) on this ROCm release")
         # the graph holds raw addresses: the batch fields, the partition bits, the flat parameter / gradient buffers AND the
         # engine's workspace arena (grow-only: a larger request re-allocates it, and a graph captured against the old arena
         # would replay into freed memory). The arena is sized for this step BEFORE the key is taken.

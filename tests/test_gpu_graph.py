@@ -48,7 +48,7 @@ def _run(env):
 
 def test_graph_replay_equals_eager_steps():
     import numpy as np
-    base = {"REFIL_GRADSTREAM": "0"}
+    base = {}                                   # the default four-stream schedule
     p0, s0, st0, n0 = _run(base)
     p1, s1, st1, n1 = _run(dict(base, REFIL_HIPGRAPH="1"))
     assert n0 == 0 and n1 == 1

@@ -586,3 +586,20 @@ def test_fused_join_equals_separate_launches(mode, monkeypatch):
     gmax = max(v.abs().max().item() for v in ref["grads"].values())
     for k in ref["grads"]:
         assert (got["grads"][k] - ref["grads"][k]).abs().max().item() <= 2e-6 * gmax, k
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_deferred_split_reductions_are_bit_identical(mode, monkeypatch):
+    """REFIL_DEFER_REDUCE: the split reductions of the parameter gradients run as one launch per stream at the end of that
+    stream (2, the default) or as one launch after the step's last join (1) instead of one launch behind every weight
+    gradient (0). The partials and the summation order per output element are the same: every gradient bit-identical."""
+    cfg, batch, bits, agent, mixer, tagent, tmixer = _oracle_case(8, 20, 32, seed=78, imagine=True, d=128, h=128)
+    monkeypatch.setenv("REFIL_DEFER_REDUCE", "0")
+    ref = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, profile=True)
+    monkeypatch.setenv("REFIL_DEFER_REDUCE", mode)
+    got = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, profile=True)
+    assert "reduce_multi_kernel" in got["kernels"] and "reduce_multi_kernel" not in ref["kernels"]
+    assert got["kernels"].get("reduce_partials_kernel", 0) < ref["kernels"]["reduce_partials_kernel"]
+    for k in ref["grads"]:
+        assert torch.equal(got["grads"][k], ref["grads"][k]), k
+
