@@ -25,6 +25,7 @@
 // every place where a load is awaited while a store is in flight degenerates to vmcnt(0) -- see the loop tail.
 #include <string.h>
 
+#include "bufops.h"
 #include "common.h"
 #include "kernels.h"
 #include "profile.h"
@@ -65,8 +66,12 @@ constexpr int vmcnt_only(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >
 // step are skipped without a host round trip). A wave fetches the 32 indices of a tile with ONE load per lane, two
 // tiles ahead of their use, and the epilogue gets its row indices from the neighbouring lanes (ds_bpermute), so the
 // list adds no dependent load to the pipeline.
+// bytes of LDS of an instantiation: the W slice + the waves' epilogue slabs
+constexpr size_t wres_smem(int tn, int nc, int npass) { return ((size_t)32 * tn * (8 * nc * npass + 4) + (size_t)WR_WAVES * 32 * WR_SLAB_P) * sizeof(float); }
+
+// (a second workgroup per CU -- and with it the 256-register cap -- only where two W slices fit the CU's 160 KB of LDS)
 template <int TN, int NC, int NPASS, bool BT, int EPI, bool ACC, bool RMASK, bool B2, bool IDX = false>
-__global__ __launch_bounds__(64 * WR_WAVES, 2) void gemm_wres_kernel(WresK p) {
+__global__ __launch_bounds__(64 * WR_WAVES, (wres_smem(TN, NC, NPASS) <= 80 * 1024 ? 2 : 1)) void gemm_wres_kernel(WresK p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lane31 = lane & 31, hf = lane >> 5;
@@ -151,8 +156,17 @@ __global__ __launch_bounds__(64 * WR_WAVES, 2) void gemm_wres_kernel(WresK p) {
     const float* csrc = A + p.amap(IDX ? currow : min(tile, last) * 32 + lane31) * (long)p.lda + 4 * hf;
 #pragma unroll
     for (int c = 0; c < NC; ++c) a[c] = *reinterpret_cast<const float4*>(csrc + min(8 * c, kmax));
+    // vmcnt counts loads and stores together, in order, and at the loop head the compiler takes the SMALLER count of the two
+    // incoming paths: with no stores behind the prologue's loads the wait for chunk 0 would be vmcnt(NC - 1), which on the
+    // back edge (NC refills, then the tile's 4 TN stores) drains everything -- including the refill issued last, a full HBM
+    // latency ago at most. As many dropped stores (zero-sized buffer, distinct offsets so that they are not merged) as a tile
+    // issues make both paths look the same, and every wait in the loop counts exactly.
+    {
+        const rsrc_t none = mk_rsrc(p.C, 0);
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(a[c].x), "+v"(a[c].y), "+v"(a[c].z), "+v"(a[c].w));   // (see the loop tail)
+        for (int i = 0; i < 4 * TN; ++i) buf_st4(none, BUF_OOB - 16 * i, z);
+    }
 
     while (tile < ntiles) {
         const int next = tile + stride;
@@ -199,6 +213,7 @@ __global__ __launch_bounds__(64 * WR_WAVES, 2) void gemm_wres_kernel(WresK p) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) bq[(ct + 1) & 1][j] = *reinterpret_cast<const float4*>(wb + 32 * j * KP + 8 * (ct + 1));
                 }
+                __builtin_amdgcn_sched_barrier(0);      // (left alone the scheduler sinks these reads to the end of the chunk)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const float4 b = bq[ct & 1][j];
@@ -212,16 +227,23 @@ __global__ __launch_bounds__(64 * WR_WAVES, 2) void gemm_wres_kernel(WresK p) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (ps_ + 1 < NPASS) a[c] = *reinterpret_cast<const float4*>(csrc + min(8 * (ct + NC), kmax));
                 else a[c] = *reinterpret_cast<const float4*>(nsrc + min(8 * c, kmax));
-                if (NPASS == 2 && ps_ == 0 && c == NC / 2)
-                    // the previous tile's stores were issued >= NC/2 chunks (~8k cycles) ago: retire them from the
-                    // compiler's bookkeeping so that the waits on the second-half chunks count loads only
-                    __builtin_amdgcn_s_waitcnt(vmcnt_only(NC / 2 + 1));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         // epilogue: one 32 x 32 tile at a time through the wave-private slab (same-wave LDS ops execute in order);
         // the transposed rows stay in registers (they replace the accumulators) until all of them are ready
         float4 outv[TN][4];
+        // The epilogue operands stay opaque until here: left alone the compiler evaluates relu'(aux) right behind the loads at
+        // the top of the tile (32 comparisons into scalar masks, to free the registers) and waits for them there with
+        // vmcnt(0) -- a full memory latency per tile with only the first few MFMAs issued.
+#pragma unroll
+        for (int j = 0; j < (EPI == 1 ? TN : 0); ++j)
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) asm volatile("" : "+v"(ax[j][ps].x), "+v"(ax[j][ps].y), "+v"(ax[j][ps].z), "+v"(ax[j][ps].w));
+#pragma unroll
+        for (int j = 0; j < (ACC ? TN : 0); ++j)
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) asm volatile("" : "+v"(cx[j][ps].x), "+v"(cx[j][ps].y), "+v"(cx[j][ps].z), "+v"(cx[j][ps].w));
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -249,10 +271,7 @@ __global__ __launch_bounds__(64 * WR_WAVES, 2) void gemm_wres_kernel(WresK p) {
             }
             __builtin_amdgcn_wave_barrier();
         }
-        // Collect the prefetched rows HERE (they had the whole transposition phase to arrive), and only then issue
-        // the stores -- they drain during the next tile's MFMAs and nothing waits on them.
-#pragma unroll
-        for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(a[c].x), "+v"(a[c].y), "+v"(a[c].z), "+v"(a[c].w));
+        // the stores drain during the next tile's MFMAs; nothing waits on them (the next tile's waits count past them)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -288,7 +307,7 @@ bool gemm_wres_eligible(const refil_gemm_desc& d) {
 
 template <int TN, int NC, int NPASS, bool BT, int EPI, bool ACC, bool RMASK, bool B2 = false, bool IDX = false>
 static int wres_launch_i(const WresK& k, dim3 grid, hipStream_t st) {
-    constexpr size_t smem = ((size_t)32 * TN * (8 * NC * NPASS + 4) + (size_t)WR_WAVES * 32 * WR_SLAB_P) * sizeof(float);
+    constexpr size_t smem = wres_smem(TN, NC, NPASS);
     static_assert(smem <= 160 * 1024, "W slice + slabs must fit the 160 KB LDS of a CU");
     static bool raised = false;                        // raise the dynamic-LDS cap of this instantiation once
     if (smem > 64 * 1024 && !raised) {

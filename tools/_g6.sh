@@ -1,0 +1,7 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+timeout 1200 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "gemm or linear or wres" 2>&1 | grep -E "passed|failed|error" | tail -3
+timeout 1500 python -m pytest tests/test_gpu_learner.py -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3
+for c in cfgT cfg2 cfg3 cfg5; do echo "== $c"; BENCH_ARGS="--config $c --no-traffic" bash tools/sweep.sh 3 REFIL_LIB_PATH=$PWD/tools/_libs/base.so REFIL_LIB_PATH=$PWD/refil_amd/librefil_hip.so; done
+python bench.py --no-cpu-baseline --no-traffic > gpurun_out/g6_new.json 2>/dev/null
+REFIL_LIB_PATH=$PWD/tools/_libs/base.so python bench.py --no-cpu-baseline --no-traffic > gpurun_out/g6_base.json 2>/dev/null
