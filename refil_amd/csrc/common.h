@@ -63,6 +63,9 @@ inline RowMap make_rowmap(int grp, int gstride, int off) {
 }
 inline bool rowmap_exact(int grp, long rows) { return !grp || ((long)grp <= (1L << 20) && rows * (long)grp < (1L << 40)); }
 
+// s_waitcnt immediate that waits for vmcnt <= n only (gfx9 encoding: vmcnt = [15:14][3:0], expcnt [6:4], lgkmcnt [11:8])
+constexpr int vmcnt_only(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }
+
 // Workgroup barrier that orders LDS traffic only. __syncthreads() is a workgroup-scope release/acquire FENCE around the
 // barrier: on gfx9 the compiler implements it with s_waitcnt vmcnt(0), i.e. every global load AND store in flight is
 // drained at every barrier -- in a recurrence step loop that puts the write-acknowledge latency of the step's own stores

@@ -140,6 +140,11 @@ __global__ __launch_bounds__(256, 1) void gemm_dw4_kernel(Dw4K p) {
 #pragma unroll
             for (int s = 0; s < D; ++s) ri[(s + D - 1) % D] = p.ridx[pf + 2 * s];    // entries of steps D-1 .. 2D-2
         }
+        // The prologue's loads are COMPLETE before the ring starts: the compiler orders them freely (the slot consumed first
+        // was fetched last), and at the loop head it takes the more conservative of the two incoming paths for every register --
+        // with anything of the prologue still in flight that is vmcnt(0) at the head of EVERY period, i.e. the ring runs empty
+        // once per D steps. With nothing pending on the entry path the waits inside the loop count the ring's loads exactly.
+        __builtin_amdgcn_s_waitcnt(vmcnt_only(0));
         for (int it = 0; it < nfull; ++it) {
 #pragma unroll
             for (int s = 0; s < D; ++s) {
@@ -157,8 +162,11 @@ __global__ __launch_bounds__(256, 1) void gemm_dw4_kernel(Dw4K p) {
                 __builtin_amdgcn_sched_group_barrier(0x008, (NM + 1) / 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, (TI == 3 ? 3 : 1) + (TJ == 3 ? 3 : 1) + (IDX ? 1 : 0), 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, NM / 2, 0);
+                // column sums of dy (the bias gradient). As plain C++ adds the scheduler gathers the adds of ALL D slots at the head
+                // of the ring period -- where every slot but one is still in flight, i.e. s_waitcnt vmcnt(0) once per period and
+                // the prefetch ring runs empty. A volatile asm stays between the loads of its own step.
 #pragma unroll
-                for (int i = 0; i < TI; ++i) csum[i] += ra[s].v[i];
+                for (int i = 0; i < TI; ++i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(csum[i]) : "v"(ra[s].v[i]));
             }
         }
     }

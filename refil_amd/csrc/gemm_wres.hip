@@ -55,9 +55,6 @@ __device__ inline float4 keep_if(bool in, float4 v) {
     return v;
 }
 
-// s_waitcnt immediate that waits for vmcnt <= n only (gfx9 encoding: vmcnt = [15:14][3:0], expcnt [6:4], lgkmcnt [11:8])
-constexpr int vmcnt_only(int n) { return (n & 15) | (7 << 4) | (15 << 8) | ((n >> 4) << 14); }
-
 // TN: 32-column tiles per workgroup. NC x NPASS: 8-wide k chunks of the reduction (K <= 8 NC NPASS, zero padded);
 // NPASS = 2 walks a row in two halves through the same NC register chunks. BT: W is [reduction][out] in memory
 // (backward product) and is transposed while staging. EPI 0: + bias, ReLU, row mask; EPI 1: * relu'(aux) (+ C if ACC).

@@ -17,6 +17,7 @@
 //    ring of registers.
 #include <stdlib.h>
 
+#include "bufops.h"
 #include "common.h"
 #include "profile.h"
 #include "../../include/refil_hip.h"
@@ -46,6 +47,24 @@ __device__ inline float ldg32(const float* base, unsigned byte_off) {
 }
 __device__ inline void stg32(float* base, unsigned byte_off, float v) {
     *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+// Stores of the 4-row step loops: buffer instructions, predicated by the OFFSET (lanes that own no row get an offset past
+// num_records: the store is dropped by the range check) instead of a branch. A branch around a step's stores gives the step
+// two paths with different numbers of vector-memory operations; the compiler then sizes every s_waitcnt of the input ring
+// for the path WITHOUT stores, and on the path with stores that count also drains the stores of the step before -- their
+// write latency lands on every step of the recurrence.
+constexpr unsigned GRU_BUF_ALL = 0xffff0000u, GRU_BUF_DROP = 0xffff0000u;    // (tensors < 4.0e9 bytes: checked by the launchers; DROP + small immediate offsets do not wrap)
+__device__ inline rsrc_t gru_rsrc(const void* base, bool live) {
+    // (the descriptor is chosen per workgroup -- GruK2 -- so the compiler cannot see that the base is wave-uniform, and a
+    // divergent resource turns every store into a waterfall loop)
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    void* ub = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    const int n = __builtin_amdgcn_readfirstlane(live ? (int)GRU_BUF_ALL : 0);
+    return __builtin_amdgcn_make_buffer_rsrc(ub, 0, n, 0x00020000);
+}
+__device__ inline void stb32(rsrc_t rs, unsigned byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (int)byte_off, 0, 0);
 }
 
 // ================================================================================================
@@ -129,9 +148,14 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
     hbuf[0][ks * HP + c] = hold;
     // byte offsets at step 0 (rows past the end / never-active rows alias row 0: loaded, never stored)
     const unsigned go = (unsigned)((gi_base * (3 * GH) + c) * sizeof(float));
-    unsigned so = (unsigned)((gi_base * GH + c) * sizeof(float));
-    unsigned ho = (unsigned)(((hs_base + p.na) * GH + c) * sizeof(float));
     const unsigned gi_step = (unsigned)(p.na * 3 * GH * sizeof(float)), row_step = (unsigned)(p.na * GH * sizeof(float));
+    // store offsets: lanes without a row keep the dropped offset for the whole loop (their step is 0)
+    unsigned so = valid ? (unsigned)((gi_base * GH + c) * sizeof(float)) : GRU_BUF_DROP;
+    unsigned ho = valid ? (unsigned)(((hs_base + p.na) * GH + c) * sizeof(float)) : GRU_BUF_DROP;
+    const unsigned st_step = valid ? row_step : 0u;
+    const rsrc_t rs_h = gru_rsrc(p.hsx, true);
+    const rsrc_t rs_r = gru_rsrc(p.save_r, save), rs_z = gru_rsrc(p.save_z, save), rs_n = gru_rsrc(p.save_n, save),
+                 rs_g = gru_rsrc(p.save_ghn, save), rs_none = gru_rsrc(p.hsx, false);
     // The per-step inputs are fetched PD steps ahead into a ring of registers (the loop is unrolled by PD: static ring
     // indices, no moves of in-flight registers). gfx9 retires loads and stores through ONE in-order counter: awaiting the
     // load of step t + PD also awaits every store issued before it, so the distance is what gives the step's own stores
@@ -143,17 +167,28 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
     for (int u = 0; u < PD; ++u) {
 #pragma unroll
         for (int g = 0; g < 3; ++g) gq[u][g] = ldg32(p.gi, go + (unsigned)min(u, tlast) * gi_step + g * GH * (unsigned)sizeof(float));
-        __builtin_amdgcn_sched_barrier(0);     // (issue order = ring order: slot u has the later slots' loads behind it on the way into the loop too)
+        // as many (dropped) stores as a step issues behind its loads: the way into the loop then looks like the back edge, and the
+        // compiler -- which sizes a wait for the more conservative of the paths into the loop head -- counts a full ring on both
+#pragma unroll
+        for (int k = 0; k < (SAVE ? 5 : 1); ++k) stb32(rs_none, 64u * (u * 5 + k), 0.f);    // (apart: adjacent ones would be merged into one wide store)
+        __builtin_amdgcn_sched_barrier(0);     // (issue order = ring order: slot u has the later slots' operations behind it on the way into the loop too)
     }
-    __syncthreads();
+    lds_barrier();
 
+    // The trip count is rounded up to whole ring periods: a step past the end issues the SAME vector-memory operations (its
+    // loads re-read the last step, its stores carry the dropped offset) and skips the arithmetic behind a uniform branch that
+    // contains none -- one back edge, no exit from the middle of the unrolled body, every path with the same operation count:
+    // the s_waitcnt in front of a slot's use then counts exactly the PD steps of loads and stores issued behind it.
     for (int t0 = 0; t0 < tend; t0 += PD) {
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
             const int t = t0 + u;
-            if (t >= tend) return;                         // (uniform; `return`, not `break`: a path from here back to the loop head would make the compiler wait for the youngest loads there)
-            const float* hb = hbuf[t & 1];
-            float* hn = hbuf[(t + 1) & 1];
+            // (uniform. Opaque to the compiler: the first copy of the unrolled body is always live, and with that knowledge its
+            // arithmetic is contracted into different fused multiply-adds than the other copies' -- a step's result must not
+            // depend on its position in the ring: tests/test_gpu_ops.py::test_gru_time_bounds compares bit for bit)
+            int t_op = t;
+            asm volatile("" : "+s"(t_op));
+            const bool live = t_op < tend;
             float gcur[3];
 #pragma unroll
             for (int g = 0; g < 3; ++g) { asm volatile("" : "+v"(gq[u][g])); gcur[g] = gq[u][g]; }
@@ -163,39 +198,43 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
                 for (int g = 0; g < 3; ++g) gq[u][g] = ldg32(p.gi, o + g * GH * (unsigned)sizeof(float));
             }
             __builtin_amdgcn_sched_barrier(0);             // the loads are ISSUED here
-            float a[KS];                                   // A operand: row j of the h tile over this lane's k slice
+            float rg = 0.f, zg = 0.f, gh = 0.f, ng = 0.f;
+            if (live) {
+                const float* hb = hbuf[t & 1];
+                float* hn = hbuf[(t + 1) & 1];
+                float a[KS];                               // A operand: row j of the h tile over this lane's k slice
 #pragma unroll
-            for (int s4 = 0; s4 < KS / 4; ++s4) {
-                const float4 v = *reinterpret_cast<const float4*>(hb + j * HP + KS * ks + 4 * s4);
-                a[4 * s4] = v.x; a[4 * s4 + 1] = v.y; a[4 * s4 + 2] = v.z; a[4 * s4 + 3] = v.w;
+                for (int s4 = 0; s4 < KS / 4; ++s4) {
+                    const float4 v = *reinterpret_cast<const float4*>(hb + j * HP + KS * ks + 4 * s4);
+                    a[4 * s4] = v.x; a[4 * s4 + 1] = v.y; a[4 * s4 + 2] = v.z; a[4 * s4 + 3] = v.w;
+                }
+                f32x4 acc[3][2];                           // two accumulators per gate: dependent chains half as long
+#pragma unroll
+                for (int g = 0; g < 3; ++g) { acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = acc[g][0]; }
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) acc[g][s & 1] = MFMA4(a[s], bw[g][s], acc[g][s & 1]);
+                float pre[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    f32x4 v = acc[g][0] + acc[g][1];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = quad4_sum(v[i]);
+                    pre[g] = pick4(v, ks);                 // (row ks, column c): the element this lane owns
+                }
+                rg = fast_sigmoid(gcur[0] + pre[0] + bhr);
+                zg = fast_sigmoid(gcur[1] + pre[1] + bhz);
+                gh = pre[2] + bhn;
+                ng = fast_tanh(gcur[2] + rg * gh);
+                hold = (1.0f - zg) * ng + zg * hold;
+                hn[ks * HP + c] = hold;
             }
-            f32x4 acc[3][2];                               // two accumulators per gate: dependent chains half as long
-#pragma unroll
-            for (int g = 0; g < 3; ++g) { acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = acc[g][0]; }
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int g = 0; g < 3; ++g) acc[g][s & 1] = MFMA4(a[s], bw[g][s], acc[g][s & 1]);
-            float pre[3];
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                f32x4 v = acc[g][0] + acc[g][1];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = quad4_sum(v[i]);
-                pre[g] = pick4(v, ks);                     // (row ks, column c): the element this lane owns
-            }
-            const float rg = fast_sigmoid(gcur[0] + pre[0] + bhr);
-            const float zg = fast_sigmoid(gcur[1] + pre[1] + bhz);
-            const float gh = pre[2] + bhn;
-            const float ng = fast_tanh(gcur[2] + rg * gh);
-            hold = (1.0f - zg) * ng + zg * hold;
-            hn[ks * HP + c] = hold;
-            if (valid) {
-                stg32(p.hsx, ho, hold);
-                if (save) { stg32(p.save_r, so, rg); stg32(p.save_z, so, zg); stg32(p.save_n, so, ng); stg32(p.save_ghn, so, gh); }
-            }
-            ho += row_step; so += row_step;
-            lds_barrier();                                 // (not __syncthreads(): its fence would drain the step's stores -- common.h)
+            const unsigned hod = live ? ho : GRU_BUF_DROP, sod = live ? so : GRU_BUF_DROP;
+            stb32(rs_h, hod, hold);
+            if (SAVE) { stb32(rs_r, sod, rg); stb32(rs_z, sod, zg); stb32(rs_n, sod, ng); stb32(rs_g, sod, gh); }   // (no save buffers: zero-sized resources)
+            ho += st_step; so += st_step;
+            if (live) lds_barrier();                       // (not __syncthreads(): its fence would drain the step's stores -- common.h)
         }
     }
 }
@@ -253,54 +292,66 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd4_kernel(GruK p) {
     constexpr int PD = REFIL_GRU_PD;
     float ring[PD][6];
     float carry = 0.f;
+    const rsrc_t rs_gi = gru_rsrc(p.dgi, true), rs_gh = gru_rsrc(p.dgh, true), rs_none = gru_rsrc(p.dgi, false);
 #pragma unroll
-    for (int u = 0; u < PD; ++u) { fetch(ring[u], max(tend - 1 - u, 0)); __builtin_amdgcn_sched_barrier(0); }     // (issue order = ring order)
+    for (int u = 0; u < PD; ++u) {                         // (issue order = ring order; dropped stores: see the forward kernel)
+        fetch(ring[u], max(tend - 1 - u, 0));
+#pragma unroll
+        for (int k = 0; k < 6; ++k) stb32(rs_none, 64u * (u * 6 + k), 0.f);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     int it = 0;
+    // (whole ring periods, dead steps past t = 0 with the same vector-memory operations: see the forward kernel)
     for (int tb = tend - 1; tb >= 0; tb -= PD) {
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
             const int t = tb - u;
-            if (t < 0) return;                             // (uniform; see the forward kernel)
-            float* gw = gbuf[it & 1];
-            ++it;
+            int t_op = t;                                  // (uniform; opaque: see the forward kernel)
+            asm volatile("" : "+s"(t_op));
+            const bool live = t_op >= 0;
             float cur[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) { asm volatile("" : "+v"(ring[u][k])); cur[k] = ring[u][k]; }
             fetch(ring[u], max(t - PD, 0));                // (unconditional: a branch here costs register copies and waits)
             __builtin_amdgcn_sched_barrier(0);             // the loads are ISSUED here, ahead of the step's arithmetic
-            const float dh = carry + cur[0];
-            const float rg = cur[1], zg = cur[2], ng = cur[3], ghn = cur[4], hp = cur[5];
-            const float dn = dh * (1.0f - zg);
-            const float dz = dh * (hp - ng);
-            const float dhz = dh * zg;
-            const float dn_pre = dn * (1.0f - ng * ng);
-            const float dr = dn_pre * ghn;
-            const float dghn = dn_pre * rg;
-            const float dr_pre = dr * rg * (1.0f - rg);
-            const float dz_pre = dz * zg * (1.0f - zg);
-            float* row = gw + ks * GP;
-            row[c] = dr_pre; row[GH + c] = dz_pre; row[2 * GH + c] = dghn;
-            lds_barrier();                                 // (not __syncthreads(): its fence would drain the step's loads and stores)
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+            float dr_pre = 0.f, dz_pre = 0.f, dn_pre = 0.f, dghn = 0.f;
+            if (live) {
+                float* gw = gbuf[it & 1];
+                ++it;
+                const float dh = carry + cur[0];
+                const float rg = cur[1], zg = cur[2], ng = cur[3], ghn = cur[4], hp = cur[5];
+                const float dn = dh * (1.0f - zg);
+                const float dz = dh * (hp - ng);
+                const float dhz = dh * zg;
+                dn_pre = dn * (1.0f - ng * ng);
+                const float dr = dn_pre * ghn;
+                dghn = dn_pre * rg;
+                dr_pre = dr * rg * (1.0f - rg);
+                dz_pre = dz * zg * (1.0f - zg);
+                float* row = gw + ks * GP;
+                row[c] = dr_pre; row[GH + c] = dz_pre; row[2 * GH + c] = dghn;
+                lds_barrier();                             // (not __syncthreads(): its fence would drain the step's loads and stores)
+                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
 #pragma unroll
-            for (int s = 0; s < KS; s += 12) {
-                const float4 v0 = *reinterpret_cast<const float4*>(gw + j * GP + KS * ks + s);
-                const float4 v1 = *reinterpret_cast<const float4*>(gw + j * GP + KS * ks + s + 4);
-                const float4 v2 = *reinterpret_cast<const float4*>(gw + j * GP + KS * ks + s + 8);
-                a0 = MFMA4(v0.x, bw[s], a0); a1 = MFMA4(v0.y, bw[s + 1], a1); a2 = MFMA4(v0.z, bw[s + 2], a2);
-                a0 = MFMA4(v0.w, bw[s + 3], a0); a1 = MFMA4(v1.x, bw[s + 4], a1); a2 = MFMA4(v1.y, bw[s + 5], a2);
-                a0 = MFMA4(v1.z, bw[s + 6], a0); a1 = MFMA4(v1.w, bw[s + 7], a1); a2 = MFMA4(v2.x, bw[s + 8], a2);
-                a0 = MFMA4(v2.y, bw[s + 9], a0); a1 = MFMA4(v2.z, bw[s + 10], a1); a2 = MFMA4(v2.w, bw[s + 11], a2);
+                for (int s = 0; s < KS; s += 12) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(gw + j * GP + KS * ks + s);
+                    const float4 v1 = *reinterpret_cast<const float4*>(gw + j * GP + KS * ks + s + 4);
+                    const float4 v2 = *reinterpret_cast<const float4*>(gw + j * GP + KS * ks + s + 8);
+                    a0 = MFMA4(v0.x, bw[s], a0); a1 = MFMA4(v0.y, bw[s + 1], a1); a2 = MFMA4(v0.z, bw[s + 2], a2);
+                    a0 = MFMA4(v0.w, bw[s + 3], a0); a1 = MFMA4(v1.x, bw[s + 4], a1); a2 = MFMA4(v1.y, bw[s + 5], a2);
+                    a0 = MFMA4(v1.z, bw[s + 6], a0); a1 = MFMA4(v1.w, bw[s + 7], a1); a2 = MFMA4(v2.x, bw[s + 8], a2);
+                    a0 = MFMA4(v2.y, bw[s + 9], a0); a1 = MFMA4(v2.z, bw[s + 10], a1); a2 = MFMA4(v2.w, bw[s + 11], a2);
+                }
+                f32x4 v = a0 + a1 + a2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = quad4_sum(v[i]);
+                carry = dhz + pick4(v, ks);
             }
-            f32x4 v = a0 + a1 + a2;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = quad4_sum(v[i]);
-            carry = dhz + pick4(v, ks);
-            if (valid) {
+            {
                 constexpr unsigned G1 = GH * sizeof(float);
-                const unsigned o = so + 3u * (unsigned)t * row_step;
-                stg32(p.dgi, o, dr_pre); stg32(p.dgi, o + G1, dz_pre); stg32(p.dgi, o + 2 * G1, dn_pre);
-                stg32(p.dgh, o, dr_pre); stg32(p.dgh, o + G1, dz_pre); stg32(p.dgh, o + 2 * G1, dghn);
+                const unsigned o = (valid && live) ? so + 3u * (unsigned)t * row_step : GRU_BUF_DROP;
+                stb32(rs_gi, o, dr_pre); stb32(rs_gi, o + G1, dz_pre); stb32(rs_gi, o + 2 * G1, dn_pre);
+                stb32(rs_gh, o, dr_pre); stb32(rs_gh, o + G1, dz_pre); stb32(rs_gh, o + 2 * G1, dghn);
             }
         }
     }
