@@ -159,6 +159,9 @@ def build(dims, imagine, B, T, seed, device, shard=None, dense=False, fresh=0):
             eb.update({kk: v for kk, v in dk.items() if kk != "filled"}, mark_filled=False)
             eb.data.transition_data["filled"].copy_(dk["filled"])
             buffer.insert_episode_batch(eb)
+    if device.type == "cuda":
+        batch.ready_event = torch.cuda.Event()             # the batch is complete here: lets train() run its prologue early
+        batch.ready_event.record()
     return args, batch, learner, data, buffer
 
 

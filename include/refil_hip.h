@@ -116,6 +116,13 @@ typedef struct refil_batch {
      * Needs a shape the MFMA attention kernels take and attention (not pooling) hypernets. */
     const uint64_t* mask_words;
     const uint64_t* mask_row_bits;
+    /* refil_learner_forward_backward only, optional: a hipEvent_t recorded behind the last write of the per-step fields above
+     * (entities ... gt_mask; group_bits / mask_words are NOT covered: they follow `stream`). The step's input assembly and row
+     * lists depend on those fields alone; with the event they are enqueued on one of the library's side streams into one of two
+     * alternating workspace slots, so that they run beside the END of the previous step on `stream` instead of in front of this
+     * one. The caller must not rewrite the fields before the work enqueued on `stream` by this call has completed.
+     * NULL: everything is ordered behind `stream` (what the reference's train() does implicitly). Results are identical. */
+    void* ready_event;
 } refil_batch;
 
 /* Scalars produced by a step, as a device array of REFIL_NSTAT floats (sums over this rank's shard,

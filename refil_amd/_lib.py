@@ -51,6 +51,7 @@ class Batch(C.Structure):
         ("gt_mask", C.c_void_p), ("gt_sB", C.c_int64), ("gt_sT", C.c_int64),
         ("group_bits", C.c_void_p),
         ("mask_words", C.c_void_p), ("mask_row_bits", C.c_void_p),
+        ("ready_event", C.c_void_p),
     ]
 
 
@@ -253,6 +254,7 @@ def make_batch(fields: dict, group_bits=None, device=None, mask_words=None, mask
     Converted tensors are kept alive on the returned struct until it is dropped."""
     import torch
     b = Batch()
+    b._converted = False        # a field was converted HERE, on the current stream: no earlier event covers it
     keep = []
     names = {"entities": "ent", "obs_mask": "om", "entity_mask": "em", "actions": "ac", "avail_actions": "av",
              "reward": "rw", "terminated": "tm", "filled": "fl", "gt_mask": "gt"}
@@ -276,6 +278,7 @@ def make_batch(fields: dict, group_bits=None, device=None, mask_words=None, mask
             else:
                 raise TypeError(f"batch field {name}: dtype {t.dtype} cannot stand in for {want[name]}")
             keep.append(t)
+            b._converted = True
         inner = t[0, 0]
         if not inner.is_contiguous():
             raise ValueError(f"batch field {name}: inner dims must be contiguous")

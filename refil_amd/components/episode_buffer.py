@@ -20,6 +20,9 @@ class EpisodeBatch:
         self.max_seq_length = max_seq_length
         self.preprocess = {} if preprocess is None else preprocess
         self.device = device
+        # optional th.cuda.Event recorded behind the last write of the fields by whoever assembled the batch ahead of time: lets
+        # QLearner.train start the step's input-only kernels before the previous step has finished (q_learner.py: early prologue)
+        self.ready_event = None
         if data is not None:
             self.data = data
             return
@@ -312,6 +315,8 @@ class ReplayBuffer(EpisodeBatch):
         ev.record()
         _lib.check(_lib.lib().refil_replay_gather(st["fields"], C.c_int32(st["nf"]), _lib.ptr(st["ids_dev"]), C.c_int32(n),
                                                   C.c_int64(self.buffer_size), _lib.current_stream_ptr()), "refil_replay_gather")
+        # (no ready_event: the gather is ordered behind the previous step on this stream, an event recorded here would complete
+        # when that step does -- nothing to start early, and the early prologue's cross-stream join would only cost)
         return st["batch"]
 
     def __repr__(self):

@@ -130,7 +130,23 @@ struct Work {
     unsigned long long* lsync;     // [B][8] exchange area of the one-launch list kernel
     // mask words of the step, built once for all attention launches (attention_mfma.hip: attn_mask_words_kernel)
     unsigned long long *mw_a, *rb_a, *mw_h, *rb_h;
+    // Second copy of everything the step's input-only prologue writes (input assembly, row lists, mask words): a step whose
+    // batch fields are ready early (refil_batch.ready_event) builds them beside the end of the previous step, which still reads its own.
+    struct Early {
+        float* xe; uint8_t *emc, *amask, *em0; float* actf;
+        int *t_last, *list_ea, *list_eh, *list_a, *counts, *lcnt, *loff, *list_t, *list_t3, *list_h, *list_ht;
+        uint8_t *kdead_a, *kdead_h, *ever;
+        unsigned long long *lsync, *mw_a, *rb_a, *mw_h, *rb_h;
+    } alt;
 };
+static void use_alt_slot(Work& w) {
+    const Work::Early& e = w.alt;
+    w.xe = e.xe; w.emc = e.emc; w.amask = e.amask; w.em0 = e.em0; w.actf = e.actf;
+    w.t_last = e.t_last; w.list_ea = e.list_ea; w.list_eh = e.list_eh; w.list_a = e.list_a; w.counts = e.counts; w.lcnt = e.lcnt;
+    w.loff = e.loff; w.list_t = e.list_t; w.list_t3 = e.list_t3; w.list_h = e.list_h; w.list_ht = e.list_ht;
+    w.kdead_a = e.kdead_a; w.kdead_h = e.kdead_h; w.ever = e.ever;
+    w.lsync = e.lsync; w.mw_a = e.mw_a; w.rb_a = e.rb_a; w.mw_h = e.mw_h; w.rb_h = e.rb_h;
+}
 
 struct Sizes {
     long R, NE, NA; int G, nv0, NV, E, Ep, nets;
@@ -236,6 +252,19 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
         const long na_pad = (d.na + 15) / 16 * 16;
         w.mw_a = a.take<unsigned long long>(s.R * 3 * na_pad); w.rb_a = a.take<unsigned long long>(s.R * 3);
         w.mw_h = a.take<unsigned long long>(s.R * 3 * na_pad); w.rb_h = a.take<unsigned long long>(s.R * 3);
+        Work::Early& e = w.alt;
+        e.mw_a = a.take<unsigned long long>(s.R * 3 * na_pad); e.rb_a = a.take<unsigned long long>(s.R * 3);
+        e.mw_h = a.take<unsigned long long>(s.R * 3 * na_pad); e.rb_h = a.take<unsigned long long>(s.R * 3);
+        e.t_last = a.take<int>(d.B);
+        e.xe = a.take<float>(s.NEa * s.Ep);
+        e.emc = a.take<uint8_t>(s.NE); e.amask = a.take<uint8_t>(s.NA); e.em0 = a.take<uint8_t>((long)d.B * d.ne);
+        e.actf = a.take<float>(s.NA);
+        e.list_ea = a.take<int>(s.NE + 256); e.list_eh = a.take<int>(s.NE + 256); e.list_a = a.take<int>(s.NA + 256);
+        e.counts = a.take<int>(8); e.lcnt = a.take<int>(4 * s.R); e.loff = a.take<int>(4 * (s.R + 1));
+        e.list_t = a.take<int>(s.NA + 256); e.list_t3 = a.take<int>((long)s.G * s.NA + 256);
+        e.list_h = a.take<int>((long)s.nv0 * s.NA + 256); e.list_ht = a.take<int>(s.NA + 256);
+        e.kdead_a = a.take<uint8_t>(s.NE); e.kdead_h = a.take<uint8_t>(s.NE); e.ever = a.take<uint8_t>((long)d.B * d.na);
+        e.lsync = a.take<unsigned long long>(256 * 8 + (long)d.B * 8);
     }
 }
 
@@ -418,6 +447,9 @@ struct Ctx {
     int tail_dw; float* tpartial;
     hipStream_t mwst;  // stream the step's mask words are built on (the chain waits for it right before its first attention launch)
     DeferredReduce* defer;
+    // this workspace's previous call was a learner step of the same shape (the carve did not move) / the prologue slot of this
+    // call (alternates on an unchanged layout) / the events behind the last readers of the two slots
+    bool same_layout; int slot; hipEvent_t* slot_free; hipEvent_t pre_done;
 };
 
 static int gemm_launch_dw(const Ctx& c, refil_gemm_desc& g, hipStream_t st) {
@@ -923,6 +955,7 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
     if (int e = check_dims(*dims)) return e;
     c.d = *dims; c.s = sizes_of(*dims); c.b = *batch; c.st = (hipStream_t)stream;
     c.gst = c.st; c.gpartial = nullptr; c.sd = nullptr; c.mwst = c.st; c.tail_dw = 0; c.tpartial = nullptr; c.defer = nullptr;
+    c.same_layout = false; c.slot = 0; c.slot_free = nullptr; c.pre_done = nullptr;
     param_layout(c.d, c.L);
     const char* pe = getenv("REFIL_PRESUM");          // read per call: tests compare both paths in one process
     const bool presum_on = !(pe && pe[0] == '0');
@@ -956,20 +989,34 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
     // (all ones). When the layout on this workspace changes (another T1 / B, another entry point) float regions of the new
     // carve may overlay them: clear those regions of the previous carve first (a few MB, stream-ordered, only on a change).
     {
-        struct Prev { refil_dims d; int mode; };
+        struct Prev { refil_dims d; int mode; int slot; hipEvent_t slot_free[2]; hipEvent_t pre_done; };
         static std::unordered_map<void*, Prev> prev;
         auto it = prev.find(ws);
-        if (it != prev.end() && it->second.mode == CARVE_LEARNER && (mode != CARVE_LEARNER || memcmp(&it->second.d, dims, sizeof(refil_dims)) != 0)) {
+        const bool had = it != prev.end();
+        const bool same = had && it->second.mode == CARVE_LEARNER && mode == CARVE_LEARNER && memcmp(&it->second.d, dims, sizeof(refil_dims)) == 0;
+        if (had && it->second.mode == CARVE_LEARNER && !same) {
             Arena ao{(char*)ws, ws_bytes, 0, false};
             Work wo;
             carve(ao, it->second.d, wo, CARVE_LEARNER);
             const Sizes so = sizes_of(it->second.d);
             if (!ao.overflow) {
+                // (t_last of the second prologue slot sits right behind its mask words: one range covers both)
                 REFIL_HIP(hipMemsetAsync(wo.t_last, 0, (size_t)it->second.d.B * sizeof(int), c.st));
-                REFIL_HIP(hipMemsetAsync(wo.mw_a, 0, (size_t)(reinterpret_cast<char*>(wo.rb_h + so.R * 3) - reinterpret_cast<char*>(wo.mw_a)), c.st));
+                REFIL_HIP(hipMemsetAsync(wo.mw_a, 0, (size_t)(reinterpret_cast<char*>(wo.alt.t_last + it->second.d.B) - reinterpret_cast<char*>(wo.mw_a)), c.st));
             }
         }
-        prev[ws] = Prev{*dims, (int)mode};
+        if (!had) {
+            Prev p0;
+            memset(&p0, 0, sizeof(p0));
+            for (auto& e : p0.slot_free) REFIL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            REFIL_HIP(hipEventCreateWithFlags(&p0.pre_done, hipEventDisableTiming));
+            it = prev.emplace(ws, p0).first;
+        }
+        Prev& pr = it->second;
+        pr.d = *dims; pr.mode = (int)mode;
+        pr.slot = same ? pr.slot ^ 1 : 0;
+        c.same_layout = same; c.slot = pr.slot; c.slot_free = pr.slot_free; c.pre_done = pr.pre_done;
+        if (mode == CARVE_LEARNER && c.slot) use_alt_slot(c.w);
     }
     return 0;
 }
@@ -1067,6 +1114,28 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         static const bool mw_cap = [] { const char* e = getenv("REFIL_HIPGRAPH_MW"); return e && e[0] == '1'; }();
         if (mwside && (cap == hipStreamCaptureStatusNone || mw_cap)) { ca.mwst = sd->g[0]; ch.mwst = sd->g[1]; }
     }
+    // Early prologue (refil_batch.ready_event): the input assembly and the row lists depend on the batch fields alone. With the
+    // caller's "fields are ready" event they are enqueued on the hypernet chain's stream, i.e. behind the previous step's
+    // hypernet backward -- which ends before the agent chain's tail does -- and write the prologue slot the previous step does
+    // not read; the slot's last reader (the step before the previous one) is awaited through its event. The caller's stream
+    // joins in front of the first projection. Only on an unchanged layout (a moved carve, or another entry point in between,
+    // may overlay anything) and outside stream capture. (The list kernel takes its four-launch form there: the one-launch form
+    // spins on a grid-wide exchange, and beside a saturated GPU its workgroups do not become resident together.)
+    bool early = false;
+    {
+        static const bool early_env = [] { const char* e = getenv("REFIL_EARLY"); return !(e && e[0] == '0'); }();
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(c.st, &cap);
+        early = early_env && overlap && c.lists && batch->ready_event && c.same_layout && cap == hipStreamCaptureStatusNone;
+    }
+    hipStream_t P = c.st;                                  // stream of the prologue
+    if (early) {
+        // REFIL_EARLY_ON: 1 (default) = the hypernet chain's stream, 2 / 3 = a weight-gradient stream
+        static const int on = [] { const char* e = getenv("REFIL_EARLY_ON"); return e ? atoi(e) : 1; }();
+        P = on == 2 ? sd->g[1] : (on == 3 ? sd->g[0] : sd->s);
+        REFIL_HIP(hipStreamWaitEvent(P, (hipEvent_t)batch->ready_event, 0));
+        REFIL_HIP(hipStreamWaitEvent(P, c.slot_free[c.slot], 0));
+    }
     if (!c.lists) RUN(run_prep(c, 1, 3));
     else {
         // Row lists (one launch; its kernel also writes the contiguous mask copies). The input assembly does not depend on
@@ -1074,8 +1143,8 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         // (A/B on one box: the input assembly on the caller's stream, in front of the list kernel, beats the side stream by
         // 0.3 % at cfg-T and 1.6 % at cfg2 -- a cross-stream join at the head of the step costs more than the ~30 us of overlap)
         static const bool prep_side = [] { const char* e = getenv("REFIL_PREP_SIDE"); return e && e[0] == '1'; }();
-        const hipStream_t ps = (overlap && prep_side) ? sd->g[0] : c.st;
-        if (ps != c.st) RUN(stream_after(sd, c.st, ps));
+        const hipStream_t ps = (overlap && prep_side && !early) ? sd->g[0] : P;
+        if (ps != P) RUN(stream_after(sd, c.st, ps));
         {
             Ctx cp = c;
             cp.st = ps; cp.lists = false;
@@ -1092,9 +1161,13 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         la.rep[1] = ListArgs::Rep{w.list_h, 0, s.nv0, (int)(s.NV * s.NA)};
         la.rep[2] = ListArgs::Rep{w.list_ht, 0, 1, (int)(s.nets * s.NA)};
         la.hint_out = row_hints_dev();
-        la.sync = w.lsync;
-        RUN(lists_launch(la, c.st));
-        if (ps != c.st) RUN(stream_after(sd, ps, c.st));   // (the chains fork from c.st: they start with the inputs assembled)
+        la.sync = early ? nullptr : w.lsync;
+        RUN(lists_launch(la, P));
+        if (ps != P) RUN(stream_after(sd, ps, c.st));      // (the chains fork from c.st: they start with the inputs assembled)
+    }
+    if (early) {                                           // join: the caller's stream continues behind the prologue
+        REFIL_HIP(hipEventRecord(c.pre_done, P));
+        REFIL_HIP(hipStreamWaitEvent(c.st, c.pre_done, 0));
     }
     if (c.mwords) {
         // mask words of every row, once per step: agent nets (observability variants) and hypernets (entity variants);
@@ -1430,6 +1503,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         for (int i = 0; i < 2; ++i) RUN(stream_after(sd, sd->g[i], c.st));
     }
     if (deferred.n) RUN(reduce_multi_launch(deferred.r, deferred.n, c.st));
+    REFIL_HIP(hipEventRecord(c.slot_free[c.slot], c.st));      // this step's prologue slot has no reader left behind this point
     static const bool defer_log = [] { const char* e = getenv("REFIL_GEMM_LOG"); return e && e[0] == '1'; }();
     if (defer_log) fprintf(stderr, "refil: %d deferred reductions, %.1f of %.1f MiB of partials\n", deferred.n, deferred.used / 262144.0, DPOOL_FLOATS / 262144.0);
     return 0;

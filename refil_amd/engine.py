@@ -67,13 +67,17 @@ class LearnerEngine:
     # -- q_learner.py:66-176 -------------------------------------------------------------------
     def forward_backward(self, dims: Dims, fields: Dict[str, torch.Tensor], group_bits: Optional[torch.Tensor],
                          params_live: torch.Tensor, params_target: torch.Tensor, grads: torch.Tensor,
-                         debug: bool = False):
-        """grads: flat fp32 [layout.total + REFIL_NSTAT]. Returns dict of debug tensors if debug."""
+                         debug: bool = False, ready_event: Optional[torch.cuda.Event] = None):
+        """grads: flat fp32 [layout.total + REFIL_NSTAT]. Returns dict of debug tensors if debug.
+        ready_event: recorded behind the last write of the batch fields (refil_batch.ready_event): the step's input
+        assembly and row lists then run on a side stream, beside the end of the previous step on the current stream."""
         nbytes = lib().refil_learner_workspace_bytes(C.byref(dims))
         if nbytes == 0:
             raise RuntimeError("refil_learner_workspace_bytes: " + lib().refil_last_error().decode())
         wp, wsz = self.ws.ptr_size(nbytes)
         b = _lib.make_batch(fields, group_bits)
+        if ready_event is not None and not b._converted:
+            b.ready_event = ready_event.cuda_event
         dbg = None
         out = {}
         if debug:

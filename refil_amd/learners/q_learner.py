@@ -158,6 +158,13 @@ class QLearner:
             bits = group_bits.to(dev).to(th.uint8).contiguous() if group_bits is not None else \
                 self._draw_partition(B, args.n_entities, dev, bernoulli=dims.gt_factors != 1)
         self._last_dims = dims
+        # Early prologue: a batch that carries `ready_event` (ReplayBuffer.sample / whoever assembled it records it behind the
+        # last write of its fields) lets the step's input assembly and row lists run on a side stream beside the END of the
+        # previous step (refil_batch.ready_event, include/refil_hip.h). Same results; REFIL_EARLY=0 switches it off.
+        ready = getattr(batch, "ready_event", None)
+        if ready is not None and (os.environ.get("REFIL_EARLY") == "0" or os.environ.get("REFIL_HIPGRAPH") == "1" or
+                                  any(fields[k].data_ptr() != batch[k].data_ptr() for k in fields)):      # (a field was copied just now)
+            ready = None
         # data parallel over episodes: all-reduce(SUM) of [grads | stat sums]; the global sum(mask) normaliser is
         # applied afterwards by the optimiser kernel (q_learner.py:165). One collective after the step, or
         # (REFIL_DP_BUCKETS=1) the mixer bucket underneath the agent's BPTT + the agent bucket after the step.
@@ -165,13 +172,13 @@ class QLearner:
             if self._buckets is None:
                 self._buckets = dp.BucketedAllReduce(self.grads, self._na)
             with self._buckets:
-                self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads)
+                self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready)
             self._buckets.finish()
             self._optimiser_step()
         elif os.environ.get("REFIL_HIPGRAPH") == "1" and group_bits is None:
             self._graphed_step(dims, fields, bits)
         else:
-            self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads)
+            self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready)
             dp.allreduce_sum_(self.grads)
             self._optimiser_step()
         self._step_count += 1

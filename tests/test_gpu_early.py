@@ -1,0 +1,48 @@
+"""Early prologue (refil_batch.ready_event, QLearner.train with batch.ready_event): the input assembly and row lists of
+step k+1 run on a side stream beside the end of step k, in alternating workspace slots. Two identically seeded
+learners take the same steps on two alternating batches, one with the events and one without: bit-identical parameters."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg4"])
+def test_early_prologue_is_bit_identical(cfg, monkeypatch):
+    import bench
+    from refil_amd import _lib
+    monkeypatch.delenv("REFIL_EARLY", raising=False)
+    W = dict(bench.CONFIGS[cfg])
+    dims = bench.workload_dims(W)
+    dev = torch.device("cuda", 0)
+    B = 8
+    _, b1, la, _, _ = bench.build(dims, W["imagine"], B, W["T"], seed=100, device=dev)
+    _, b2, lb, _, _ = bench.build(dims, W["imagine"], B, W["T"], seed=200, device=dev)
+    assert b1.ready_event is not None and b2.ready_event is not None
+    la._check_flat(); lb._check_flat()
+    assert torch.equal(la.flat_live, lb.flat_live)
+
+    class Plain:                                   # the same batch without the event: the prologue stays on the caller's stream
+        def __init__(self, b):
+            self._b = b
+            self.ready_event = None
+
+        def __getattr__(self, k):
+            return getattr(self._b, k)
+
+        def __getitem__(self, k):
+            return self._b[k]
+
+    _lib.profile_enable(True)
+    for i in range(9):
+        b = (b1, b2, b2)[i % 3]                    # (b2 twice in a row: the slot alternates even when the batch does not)
+        la.train(b, t_env=0, episode_num=i)
+        lb.train(Plain(b), t_env=0, episode_num=i)
+        torch.cuda.synchronize()
+        assert torch.equal(la.flat_live, lb.flat_live), f"step {i}: max |d| = {(la.flat_live - lb.flat_live).abs().max().item():.3e}"
+    _lib.profile_enable(False)
+    _lib.profile_collect()
