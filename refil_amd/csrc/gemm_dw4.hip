@@ -283,8 +283,10 @@ bool gemm_dw4_eligible(const refil_gemm_desc& d) {
     // Measured on MI355X (cfg-T shapes): the big wave tiles win when the output is large enough to give every CU a
     // workgroup with a long row range (the four hypernets' in_trans / fc1 gradients: 181 -> 119, 70 -> 52, 96 -> 70 us);
     // small outputs (agent nets, GRU, thin tails) are faster on the 2 x 2-tile streaming kernel / the LDS-tiled one.
-    static const long min_out = [] { const char* e = getenv("REFIL_DW4_MIN_OUT"); return e ? atol(e) : 30000L; }();
-    if ((long)d.batch * d.M * d.N < min_out) return false;
+    // (re-swept after the ring fix, tools/sweep.sh: with fewer than ~64 k reduction rows -- cfg2, the per-net launches -- the thin
+    // outputs are faster here as well: cfg2 0.767 -> 0.749 ms; with more rows everything from 10 k outputs on: cfg-T 1.750 -> 1.745)
+    static const long min_out = [] { const char* e = getenv("REFIL_DW4_MIN_OUT"); return e ? atol(e) : -1L; }();
+    if ((long)d.batch * d.M * d.N < (min_out >= 0 ? min_out : (d.K >= 65536 ? 10000L : 2000L))) return false;
     int ti, tj, wmt;
     dw4_shape(d.M, d.N, ti, tj, wmt);
     // the operand vectors (ti resp. tj consecutive floats; 3 floats need 4-byte alignment only) must be naturally aligned
