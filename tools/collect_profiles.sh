@@ -45,4 +45,11 @@ python bench.py --serial --no-cpu-baseline --no-traffic > $OUT/${TAG}_bench_cfgT
 bash tools/pmc_mfma.sh $TAG > $OUT/${TAG}_pmc_mfma.log 2>&1
 # one step WITHOUT a tracer: HIP events around every launch (library profiler), stream + start + duration per launch
 python tools/probes/timeline.py --out $OUT/${TAG}_timeline_untraced.txt > /dev/null 2>&1; rm -f $OUT/${TAG}_timeline_untraced.txt.raw
+python tools/probes/timeline.py --config cfg2 --out $OUT/${TAG}_timeline_untraced_cfg2.txt > /dev/null 2>&1; rm -f $OUT/${TAG}_timeline_untraced_cfg2.txt.raw
+# the strong-scaling regime (small shards), the acting path, hipGraph replay against the eager schedule, the projection GEMM alone
+for b in 4 8 16; do python bench.py --batch $b --no-cpu-baseline --no-profile --no-traffic 2>/dev/null | cut -c1-330; done > $OUT/${TAG}_small_batches.txt
+(python tools/acting_latency.py; python tools/acting_latency.py --envs 1) > $OUT/${TAG}_acting.txt 2>&1
+python tools/probes/graph_capture.py 30 cfg2 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_hipgraph_cfg2.txt
+python tools/probes/wres_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_wres_bench.txt
+REFIL_EARLY=0 python bench.py --no-cpu-baseline --no-profile --no-traffic 2>/dev/null | cut -c1-330 > $OUT/${TAG}_bench_cfgT_no_early_prologue.txt
 ls -la $OUT | grep ${TAG}_
