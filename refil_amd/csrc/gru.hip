@@ -112,9 +112,10 @@ __device__ inline float quad4_sum(float v) { v += dpp_rot<0x124>(v); v += dpp_ro
 __device__ inline float pick4(const f32x4& v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3])); }
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
 
-template <bool SAVE, int GH>
+// VALU: the recurrent product on the vector ALUs (packed FMAs) instead of the matrix cores -- see gru_valu_enabled()
+template <bool SAVE, int GH, bool VALU = false>
 __global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
-    constexpr int HP = GH + 4, KS = GH / 4;                // KS: reduction indices per k slice
+    constexpr int HP = GH + 4, KS = VALU ? GH : GH / 4;    // KS: reduction indices per lane (MFMA: per k slice)
     __shared__ __attribute__((aligned(16))) float hbuf[2][GR4 * HP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 3, ks = (lane >> 2) & 3, cg = lane >> 4;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
     for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int s4 = 0; s4 < KS / 4; ++s4) {
-            const float4 v = *reinterpret_cast<const float4*>(p.w_hh + (long)(g * GH + c) * GH + KS * ks + 4 * s4);
+            const float4 v = *reinterpret_cast<const float4*>(p.w_hh + (long)(g * GH + c) * GH + (VALU ? 0 : KS * ks) + 4 * s4);
             bw[g][4 * s4] = v.x; bw[g][4 * s4 + 1] = v.y; bw[g][4 * s4 + 2] = v.z; bw[g][4 * s4 + 3] = v.w;
         }
     const float bhr = p.b_hh[c], bhz = p.b_hh[GH + c], bhn = p.b_hh[2 * GH + c];
@@ -202,6 +203,27 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
             if (live) {
                 const float* hb = hbuf[t & 1];
                 float* hn = hbuf[(t + 1) & 1];
+                float pre[3];
+                if (VALU) {
+                    // the lane's own element over the whole reduction: row ks of h (an LDS broadcast per 16 bytes) against its
+                    // column of W_hh in registers, packed FMAs, two accumulator pairs per gate
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    f32x2 acc[3][2];
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) { acc[g][0] = f32x2{0.f, 0.f}; acc[g][1] = acc[g][0]; }
+#pragma unroll
+                    for (int s4 = 0; s4 < GH / 4; ++s4) {
+                        const float4 v = *reinterpret_cast<const float4*>(hb + ks * HP + 4 * s4);
+                        const f32x2 h0 = {v.x, v.y}, h1 = {v.z, v.w};
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            acc[g][0] = __builtin_elementwise_fma(h0, f32x2{bw[g][4 * s4], bw[g][4 * s4 + 1]}, acc[g][0]);
+                            acc[g][1] = __builtin_elementwise_fma(h1, f32x2{bw[g][4 * s4 + 2], bw[g][4 * s4 + 3]}, acc[g][1]);
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) { const f32x2 t2 = acc[g][0] + acc[g][1]; pre[g] = t2[0] + t2[1]; }
+                } else {
                 float a[KS];                               // A operand: row j of the h tile over this lane's k slice
 #pragma unroll
                 for (int s4 = 0; s4 < KS / 4; ++s4) {
@@ -215,13 +237,13 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
                 for (int s = 0; s < KS; ++s)
 #pragma unroll
                     for (int g = 0; g < 3; ++g) acc[g][s & 1] = MFMA4(a[s], bw[g][s], acc[g][s & 1]);
-                float pre[3];
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
                     f32x4 v = acc[g][0] + acc[g][1];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = quad4_sum(v[i]);
                     pre[g] = pick4(v, ks);                 // (row ks, column c): the element this lane owns
+                }
                 }
                 rg = fast_sigmoid(gcur[0] + pre[0] + bhr);
                 zg = fast_sigmoid(gcur[1] + pre[1] + bhz);
@@ -244,9 +266,9 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
 //   dn_pre = dn (1-n^2);  dr = dn_pre ghn;  dgh_n = dn_pre r
 //   dr_pre = dr r (1-r);  dz_pre = dz z (1-z)
 //   dgi[t] = (dr_pre, dz_pre, dn_pre);  dgh[t] = (dr_pre, dz_pre, dgh_n);  carry' += dgh[t] W_hh
-template <int GH>
+template <int GH, bool VALU = false>
 __global__ __launch_bounds__(4 * GH) void gru_bwd4_kernel(GruK p) {
-    constexpr int GP = 3 * GH + 4, KS = 3 * GH / 4, NW = GH / 16;
+    constexpr int GP = 3 * GH + 4, KS = VALU ? 3 * GH : 3 * GH / 4, NW = GH / 16;
     __shared__ __attribute__((aligned(16))) float gbuf[2][GR4 * GP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 3, ks = (lane >> 2) & 3, cg = lane >> 4;
@@ -258,7 +280,7 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd4_kernel(GruK p) {
     // carry[row][c] += sum_k dgh[row][k] W_hh[k][c]: bw[s] = W_hh[KS ks + s][c]
     float bw[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) bw[s] = p.w_hh[(long)(KS * ks + s) * GH + c];
+    for (int s = 0; s < KS; ++s) bw[s] = p.w_hh[(long)((VALU ? 0 : KS * ks) + s) * GH + c];
 
     const int rr = r0 + ks;
     bool valid = rr < p.NR;
@@ -331,6 +353,23 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd4_kernel(GruK p) {
                 float* row = gw + ks * GP;
                 row[c] = dr_pre; row[GH + c] = dz_pre; row[2 * GH + c] = dghn;
                 lds_barrier();                             // (not __syncthreads(): its fence would drain the step's loads and stores)
+                if (VALU) {
+                    // the lane's own carry element over all 3 GH gate gradients of its row (LDS broadcasts) against its column of
+                    // W_hh in registers: packed FMAs on the vector ALUs, no matrix-core instruction (gru_valu_enabled())
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    f32x2 b0 = {0.f, 0.f}, b1 = b0, b2 = b0, b3 = b0;
+#pragma unroll
+                    for (int s = 0; s < KS; s += 8) {
+                        const float4 v0 = *reinterpret_cast<const float4*>(gw + ks * GP + s);
+                        const float4 v1 = *reinterpret_cast<const float4*>(gw + ks * GP + s + 4);
+                        b0 = __builtin_elementwise_fma(f32x2{v0.x, v0.y}, f32x2{bw[s], bw[s + 1]}, b0);
+                        b1 = __builtin_elementwise_fma(f32x2{v0.z, v0.w}, f32x2{bw[s + 2], bw[s + 3]}, b1);
+                        b2 = __builtin_elementwise_fma(f32x2{v1.x, v1.y}, f32x2{bw[s + 4], bw[s + 5]}, b2);
+                        b3 = __builtin_elementwise_fma(f32x2{v1.z, v1.w}, f32x2{bw[s + 6], bw[s + 7]}, b3);
+                    }
+                    const f32x2 t2 = (b0 + b1) + (b2 + b3);
+                    carry = dhz + (t2[0] + t2[1]);
+                } else {
                 f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
 #pragma unroll
                 for (int s = 0; s < KS; s += 12) {
@@ -346,6 +385,7 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd4_kernel(GruK p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = quad4_sum(v[i]);
                 carry = dhz + pick4(v, ks);
+                }
             }
             {
                 constexpr unsigned G1 = GH * sizeof(float);
@@ -635,6 +675,17 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd16_kernel(GruK p) {
     }
 }
 
+// REFIL_GRU_VALU (opt-in, read per call): bit 0 = backward, bit 1 = forward recurrence of the 4-row kernels with the recurrent
+// product on the vector ALUs (packed FMAs, the lane's own element over the whole reduction: no matrix-core instruction, no
+// k-slice reduction; rnn_hidden_dim 64). Measured at cfg-T: the same time alone (85 / 102 us against 89 / 100), 20 % / 11 %
+// FASTER in situ (171 / 174 us against 213 / 196: the 8-cycle 4x4x1 MFMAs queue behind the other chain's 64-cycle ones) -- and
+// the step 0.9-1.5 % SLOWER (cfg2: +2.7 %): what the recurrences no longer wait for, the other chain's kernels now do.
+static int gru_valu_bits() {
+    const char* e = getenv("REFIL_GRU_VALU");
+    return e ? atoi(e) : 0;
+}
+static bool gru_valu_enabled() { return gru_valu_bits() & 1; }
+static bool gru_valu_fwd_enabled() { return gru_valu_bits() & 2; }
 // rows per workgroup: 4-row tiles while there are fewer than three per CU (REFIL_GRU_ROWS=4 / 16 forces one). Measured: cfg3's
 // backward (768 tiles on 256 CUs) 38 us faster on 16-row tiles, its forward (1024) 45 us; cfg5 (768 / 576) 20 us faster on 4-row tiles
 static int gru_rows_per_wg(long rows) {
@@ -683,6 +734,10 @@ int gru_forward_launch2(const refil_gru_desc& d, const refil_gru_desc* second, h
                                                   else hipLaunchKernelGGL((gru_fwd16_kernel<false, HH>), grid, dim3(4 * HH), 0, st, k); } \
                         else { if (save) hipLaunchKernelGGL((gru_fwd4_kernel<true, HH>), grid, dim3(4 * HH), 0, st, k); \
                                else hipLaunchKernelGGL((gru_fwd4_kernel<false, HH>), grid, dim3(4 * HH), 0, st, k); } } while (0)
+    if (GH == 64 && rows_wg != GROWS && gru_valu_fwd_enabled()) {
+        if (save) hipLaunchKernelGGL((gru_fwd4_kernel<true, 64, true>), grid, dim3(256), 0, st, k);
+        else hipLaunchKernelGGL((gru_fwd4_kernel<false, 64, true>), grid, dim3(256), 0, st, k);
+    } else
     if (GH == 32) GRU_FWD(32); else if (GH == 64) GRU_FWD(64); else GRU_FWD(128);
 #undef GRU_FWD
     REFIL_LAUNCH_CHECK();
@@ -706,6 +761,7 @@ int gru_backward_launch(const refil_gru_desc& d, hipStream_t st) {
         else hipLaunchKernelGGL(gru_bwd16_kernel<128>, dim3(cdiv(d.NR, GROWS)), dim3(512), 0, st, k);
     } else {
         if (GH == 32) hipLaunchKernelGGL(gru_bwd4_kernel<32>, dim3(cdiv(d.NR, GR4)), dim3(128), 0, st, k);
+        else if (GH == 64 && gru_valu_enabled()) hipLaunchKernelGGL((gru_bwd4_kernel<64, true>), dim3(cdiv(d.NR, GR4)), dim3(256), 0, st, k);
         else if (GH == 64) hipLaunchKernelGGL(gru_bwd4_kernel<64>, dim3(cdiv(d.NR, GR4)), dim3(256), 0, st, k);
         else hipLaunchKernelGGL(gru_bwd4_kernel<128>, dim3(cdiv(d.NR, GR4)), dim3(512), 0, st, k);
     }

@@ -324,11 +324,14 @@ def test_pool_forward_backward(mode, B, T1, ne, na, w, codes):
 # ------------------------------------------------------------------------------------------------
 # persistent GRU
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("GB,T1,na,H", [(6, 9, 16, 64), (5, 4, 3, 64), (2, 1, 8, 64), (3, 21, 5, 64),
-                                        (5, 6, 7, 32), (2, 1, 8, 32), (4, 7, 6, 128), (3, 5, 16, 128)])
-def test_gru_forward_backward(GB, T1, na, H):
+@pytest.mark.parametrize("GB,T1,na,H,valu", [(6, 9, 16, 64, 0), (5, 4, 3, 64, 0), (2, 1, 8, 64, 0), (3, 21, 5, 64, 0),
+                                             (5, 6, 7, 32, 0), (2, 1, 8, 32, 0), (4, 7, 6, 128, 0), (3, 5, 16, 128, 0),
+                                             (6, 9, 16, 64, 3), (3, 21, 5, 64, 3)])
+def test_gru_forward_backward(GB, T1, na, H, valu, monkeypatch):
+    """valu = 3: the opt-in vector-ALU form of the recurrent products (REFIL_GRU_VALU, gru.hip), same reference."""
     import hip_ops
     from oracle.refil_oracle import gru_cell
+    monkeypatch.setenv("REFIL_GRU_VALU", str(valu))
     torch.manual_seed(GB * 7 + T1)
     NR = GB * na
     w_ih = (torch.randn(3 * H, H) / 8).requires_grad_(True)
