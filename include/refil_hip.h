@@ -121,7 +121,9 @@ typedef struct refil_batch {
      * lists depend on those fields alone; with the event they are enqueued on one of the library's side streams into one of two
      * alternating workspace slots, so that they run beside the END of the previous step on `stream` instead of in front of this
      * one. The caller must not rewrite the fields before the work enqueued on `stream` by this call has completed.
-     * NULL: everything is ordered behind `stream` (what the reference's train() does implicitly). Results are identical. */
+     * NULL: everything is ordered behind `stream` (what the reference's train() does implicitly). Results are identical.
+     * Leave it NULL on the first call after the workspace was (re)allocated or zeroed on `stream`: the early work is not
+     * ordered behind that zero fill. */
     void* ready_event;
 } refil_batch;
 
@@ -424,6 +426,12 @@ int refil_profile_collect(refil_profile_entry* out, int max_entries);
  * 1 = on (default), 0 = serialise everything on the caller's stream (profiling one kernel at a time),
  * -1 = follow the environment variable REFIL_NO_OVERLAP. */
 int refil_set_overlap(int on);
+
+/* The calling thread's internal hypernet-chain stream on the current device (hipStream_t, created lazily; valid until
+ * refil_release_streams). For producers of learner batches: work enqueued there runs behind the previous step's hypernet
+ * backward and in front of the next step's early prologue (refil_batch.ready_event) -- ReplayBuffer.sample() puts its
+ * gather launch there (episode_buffer.py:233-240 has no counterpart: the reference samples synchronously). */
+int refil_side_stream(void** stream_out);
 
 /* Destroys the calling thread's internal side streams / events (all devices). They are re-created lazily by
  * the next refil_learner_forward_backward; call before tearing the HIP context down. */

@@ -4,6 +4,8 @@ of episodes with uniform sampling. Kept device-resident so that a sampled, time-
 handed to the HIP learner without copies (the C ABI takes batch/time strides)."""
 from types import SimpleNamespace
 
+import os
+
 import numpy as np
 import torch as th
 
@@ -23,6 +25,7 @@ class EpisodeBatch:
         # optional th.cuda.Event recorded behind the last write of the fields by whoever assembled the batch ahead of time: lets
         # QLearner.train start the step's input-only kernels before the previous step has finished (q_learner.py: early prologue)
         self.ready_event = None
+        self.consumed_event = None       # recorded by QLearner.train behind its last read of the batch (ReplayBuffer's staging reuse)
         if data is not None:
             self.data = data
             return
@@ -241,6 +244,10 @@ class ReplayBuffer(EpisodeBatch):
         self.buffer_index += n
         self.episodes_in_buffer = max(self.episodes_in_buffer, self.buffer_index)
         self.buffer_index %= self.buffer_size
+        if th.device(self.device).type == "cuda":              # (the early gather of sample() waits for the last insert)
+            if getattr(self, "_write_event", None) is None:
+                self._write_event = th.cuda.Event()
+            self._write_event.record()
 
     def can_sample(self, batch_size):
         return self.episodes_in_buffer >= batch_size
@@ -277,47 +284,90 @@ class ReplayBuffer(EpisodeBatch):
         nfields = len(self.data.transition_data) + len(self.data.episode_data) + len(self._packed)
         if nfields > _lib.MAX_GATHER_FIELDS:            # (more scheme keys than one gather launch takes: the reference's path)
             return self[ep_ids]
+        early = os.environ.get("REFIL_EARLY") != "0" and os.environ.get("REFIL_HIPGRAPH") != "1"
         st = self._staging.get(n) if hasattr(self, "_staging") else None
         if st is None:
             if not hasattr(self, "_staging"):
                 self._staging = {}
-            tdata = {k: th.zeros((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device) for k, v in self.data.transition_data.items()}
-            for k, words in self._packed.items():      # the staging minibatch holds the BYTES the learner's C ABI takes
-                tdata[k] = th.zeros((n,) + tuple(words.shape[1:]) + (self._packed_width[k],), dtype=th.uint8, device=self.device)
-            batch = EpisodeBatch(self.scheme, self.groups, n, self.max_seq_length, device=self.device,
-                                 data=SimpleNamespace(
-                                     transition_data=tdata,
-                                     episode_data={k: th.zeros((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device)
-                                                   for k, v in self.data.episode_data.items()}))
-            ids_host = [(th.empty(n, dtype=th.int64).pin_memory(), th.cuda.Event()) for _ in range(8)]
-            ids_dev = th.empty(n, dtype=th.int64, device=self.device)
-            fields = (_lib.GatherField * _lib.MAX_GATHER_FIELDS)()
-            nf = 0
-            for store_src, store_dst in ((self.data.transition_data, batch.data.transition_data),
-                                         (self.data.episode_data, batch.data.episode_data)):
-                for k, src in store_src.items():
-                    dst = store_dst[k]
-                    assert src.is_contiguous() and dst.is_contiguous()
-                    eb = src[0].numel() * src.element_size()
-                    fields[nf] = _lib.GatherField(src.data_ptr(), dst.data_ptr(), eb, eb, eb, 0, 0)
+            slots = []
+            for _ in range(2):                             # two staging minibatches: the previous sample may still be training
+                tdata = {k: th.zeros((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device) for k, v in self.data.transition_data.items()}
+                for k, words in self._packed.items():      # the staging minibatch holds the BYTES the learner's C ABI takes
+                    tdata[k] = th.zeros((n,) + tuple(words.shape[1:]) + (self._packed_width[k],), dtype=th.uint8, device=self.device)
+                batch = EpisodeBatch(self.scheme, self.groups, n, self.max_seq_length, device=self.device,
+                                     data=SimpleNamespace(
+                                         transition_data=tdata,
+                                         episode_data={k: th.zeros((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device)
+                                                       for k, v in self.data.episode_data.items()}))
+                fields = (_lib.GatherField * _lib.MAX_GATHER_FIELDS)()
+                nf = 0
+                for store_src, store_dst in ((self.data.transition_data, batch.data.transition_data),
+                                             (self.data.episode_data, batch.data.episode_data)):
+                    for k, src in store_src.items():
+                        dst = store_dst[k]
+                        assert src.is_contiguous() and dst.is_contiguous()
+                        eb = src[0].numel() * src.element_size()
+                        fields[nf] = _lib.GatherField(src.data_ptr(), dst.data_ptr(), eb, eb, eb, 0, 0)
+                        nf += 1
+                for k, words in self._packed.items():
+                    dst = batch.data.transition_data[k]
+                    fields[nf] = _lib.GatherField(words.data_ptr(), dst.data_ptr(), words[0].numel() * 8, dst[0].numel(), dst[0].numel(),
+                                                  self._packed_width[k], 0)
                     nf += 1
-            for k, words in self._packed.items():
-                dst = batch.data.transition_data[k]
-                fields[nf] = _lib.GatherField(words.data_ptr(), dst.data_ptr(), words[0].numel() * 8, dst[0].numel(), dst[0].numel(),
-                                              self._packed_width[k], 0)
-                nf += 1
-            st = self._staging[n] = {"batch": batch, "ids_host": ids_host, "ids_dev": ids_dev, "fields": fields, "nf": nf, "slot": 0}
+                slots.append({"batch": batch, "fields": fields, "nf": nf, "ids_dev": th.empty(n, dtype=th.int64, device=self.device),
+                              "handed_out": False})
+            ids_host = [(th.empty(n, dtype=th.int64).pin_memory(), th.cuda.Event()) for _ in range(8)]
+            st = self._staging[n] = {"slots": slots, "ids_host": ids_host, "slot": 0, "which": 0}
         host, ev = st["ids_host"][st["slot"]]
         st["slot"] = (st["slot"] + 1) % len(st["ids_host"])
         ev.synchronize()                                   # (the async upload issued 8 samples ago has long completed)
         host.copy_(th.from_numpy(ep_ids))
-        st["ids_dev"].copy_(host, non_blocking=True)
-        ev.record()
-        _lib.check(_lib.lib().refil_replay_gather(st["fields"], C.c_int32(st["nf"]), _lib.ptr(st["ids_dev"]), C.c_int32(n),
-                                                  C.c_int64(self.buffer_size), _lib.current_stream_ptr()), "refil_replay_gather")
-        # (no ready_event: the gather is ordered behind the previous step on this stream, an event recorded here would complete
-        # when that step does -- nothing to start early, and the early prologue's cross-stream join would only cost)
-        return st["batch"]
+        if not early:
+            # in order on the caller's stream, always into the same staging minibatch (fixed addresses: REFIL_HIPGRAPH)
+            sl = st["slots"][0]
+            sl["ids_dev"].copy_(host, non_blocking=True)
+            ev.record()
+            _lib.check(_lib.lib().refil_replay_gather(sl["fields"], C.c_int32(sl["nf"]), _lib.ptr(sl["ids_dev"]), C.c_int32(n),
+                                                      C.c_int64(self.buffer_size), _lib.current_stream_ptr()), "refil_replay_gather")
+            sl["batch"].ready_event = None
+            return sl["batch"]
+        # Early: the gather runs on the library's hypernet-chain stream (refil_side_stream: behind the previous train step's
+        # hypernet backward, in front of the next step's early prologue -- NOT behind the whole previous step, and not on a fifth
+        # stream), alternating between the two staging minibatches. It waits for the buffer's last insert and for the last reader
+        # of the staging minibatch it overwrites (QLearner.train records batch.consumed_event; a consumer that does not is
+        # covered by an event on the caller's stream at this point). The caller's stream waits for the gather, so whatever else
+        # reads the batch there is ordered as before; train()'s early prologue waits for batch.ready_event only.
+        st["which"] ^= 1
+        sl = st["slots"][st["which"]]
+        batch = sl["batch"]
+        sp = C.c_void_p()
+        _lib.check(_lib.lib().refil_side_stream(C.byref(sp)), "refil_side_stream")
+        if st.get("side_ptr") != sp.value:                 # (the library re-creates its streams after refil_release_streams)
+            st["side_ptr"], st["side"] = sp.value, th.cuda.ExternalStream(sp.value, device=self.device)
+        side = st["side"]
+        cur = th.cuda.current_stream(self.device)
+        wev = getattr(self, "_write_event", None)
+        if wev is not None:
+            side.wait_event(wev)
+        # the last reader of this staging minibatch -- or, for a consumer that records nothing and on first use (the zero fill
+        # of a new staging tensor is enqueued on the caller's stream), everything enqueued on the caller's stream so far
+        cev = batch.consumed_event if sl["handed_out"] else None
+        if cev is None:
+            cev = sl.setdefault("cur_ev", th.cuda.Event())
+            cev.record(cur)
+        side.wait_event(cev)
+        with th.cuda.stream(side):
+            sl["ids_dev"].copy_(host, non_blocking=True)
+            ev.record()
+            _lib.check(_lib.lib().refil_replay_gather(sl["fields"], C.c_int32(sl["nf"]), _lib.ptr(sl["ids_dev"]), C.c_int32(n),
+                                                      C.c_int64(self.buffer_size), C.c_void_p(sp.value)), "refil_replay_gather")
+            if batch.ready_event is None:
+                batch.ready_event = th.cuda.Event()
+            batch.ready_event.record()
+        cur.wait_event(batch.ready_event)
+        batch.consumed_event = None
+        sl["handed_out"] = True
+        return batch
 
     def __repr__(self):
         return (f"ReplayBuffer. {self.episodes_in_buffer}/{self.buffer_size} episodes. "

@@ -1539,6 +1539,18 @@ extern "C" int refil_learner_row_counts(const refil_dims* dims, void* workspace,
     return 0;
 }
 
+// The calling thread's hypernet-chain stream on the current device (created lazily): the stream the early prologue of a
+// learner step runs on. A producer of batches (ReplayBuffer.sample) enqueues its gather THERE -- behind the previous step's
+// hypernet backward, in front of the next step's prologue -- instead of on a stream of its own (a fifth busy stream shares a
+// hardware queue with one of the step's four and slowed the step by 7-13 %).
+extern "C" int refil_side_stream(void** out) {
+    REFIL_CHECK(out, "refil_side_stream: null out");
+    SideStream* sd = nullptr;
+    if (int e = side_stream(sd)) return e;
+    *out = (void*)sd->s;
+    return 0;
+}
+
 // Destroys this thread's side streams and events (all devices). Safe to call at any time: they are re-created lazily.
 extern "C" int refil_release_streams(void) {
     int cur = 0;

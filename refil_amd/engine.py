@@ -42,10 +42,12 @@ class Workspace:
     def __init__(self, device):
         self.device = device
         self.buf: Optional[torch.Tensor] = None
+        self.fresh = False      # the zero fill of a new arena is enqueued on the current stream: the first call on it stays in order
 
     def get(self, nbytes: int) -> torch.Tensor:
         if self.buf is None or self.buf.numel() < nbytes:
             self.buf = None
+            self.fresh = True
             # zeroed once: rows the step skips (padded entities, steps after an episode's end) are never written, and
             # whatever they hold is multiplied by exact zeros downstream -- it has to be finite
             self.buf = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
@@ -76,8 +78,11 @@ class LearnerEngine:
             raise RuntimeError("refil_learner_workspace_bytes: " + lib().refil_last_error().decode())
         wp, wsz = self.ws.ptr_size(nbytes)
         b = _lib.make_batch(fields, group_bits)
-        if ready_event is not None and not b._converted:
+        # (not on a new arena: its zero fill sits on the current stream, the early prologue would write the arena on another one --
+        # and the allocator may hand a new arena the address of an old one the library remembers the layout of)
+        if ready_event is not None and not b._converted and not self.ws.fresh:
             b.ready_event = ready_event.cuda_event
+        self.ws.fresh = False
         dbg = None
         out = {}
         if debug:

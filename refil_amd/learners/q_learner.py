@@ -181,6 +181,12 @@ class QLearner:
             self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready)
             dp.allreduce_sum_(self.grads)
             self._optimiser_step()
+        if ready is not None:                          # (a producer that reuses the batch's memory waits for this: ReplayBuffer.sample)
+            ce = batch.__dict__.get("_consumed_ev")
+            if ce is None:
+                ce = batch.__dict__["_consumed_ev"] = th.cuda.Event()
+            ce.record()
+            batch.consumed_event = ce
         self._step_count += 1
 
         if (episode_num - self.last_target_update_episode) / args.target_update_interval >= 1.0:

@@ -46,3 +46,34 @@ def test_early_prologue_is_bit_identical(cfg, monkeypatch):
         assert torch.equal(la.flat_live, lb.flat_live), f"step {i}: max |d| = {(la.flat_live - lb.flat_live).abs().max().item():.3e}"
     _lib.profile_enable(False)
     _lib.profile_collect()
+
+
+def test_sampled_batches_early_gather_is_bit_identical(monkeypatch):
+    """ReplayBuffer.sample() with the early path: the gather runs on the library's hypernet-chain stream into two alternating
+    staging minibatches, train() starts its prologue from the batch's ready event. A second learner / buffer pair takes the same
+    samples with REFIL_EARLY=0 (gather and prologue in order on the caller's stream, one staging minibatch): bit-identical
+    parameters after every step. (The pairs alternate step by step so that both see the same row-count hints.)"""
+    import numpy as np
+
+    import bench
+    W = dict(bench.CONFIGS["cfg2"])
+    dims = bench.workload_dims(W)
+    dev = torch.device("cuda", 0)
+    B = 8
+    monkeypatch.delenv("REFIL_EARLY", raising=False)
+    _, _, la, _, bufa = bench.build(dims, W["imagine"], B, W["T"], seed=300, device=dev, fresh=4)
+    _, _, lb, _, bufb = bench.build(dims, W["imagine"], B, W["T"], seed=300, device=dev, fresh=4)
+    la._check_flat(); lb._check_flat()
+    for i in range(8):
+        monkeypatch.delenv("REFIL_EARLY", raising=False)
+        np.random.seed(100 + i)
+        b = bufa.sample(B)
+        assert b.ready_event is not None
+        la.train(b, t_env=0, episode_num=i)
+        monkeypatch.setenv("REFIL_EARLY", "0")
+        np.random.seed(100 + i)
+        b = bufb.sample(B)
+        assert b.ready_event is None
+        lb.train(b, t_env=0, episode_num=i)
+        torch.cuda.synchronize()
+        assert torch.equal(la.flat_live, lb.flat_live), f"step {i}: max |d| = {(la.flat_live - lb.flat_live).abs().max().item():.3e}"
