@@ -253,9 +253,10 @@ class ReplayBuffer(EpisodeBatch):
         return self.episodes_in_buffer >= batch_size
 
     def sample(self, batch_size, copy=False):
-        """Uniform sample without replacement (episode_buffer.py:233-240). On a device buffer the result is the buffer's
-        STAGING minibatch for this batch size -- fixed addresses, overwritten by the next sample(batch_size); pass copy=True
-        to get an independent batch (the reference always returns a fresh copy) when two samples must be alive at once."""
+        """Uniform sample without replacement (episode_buffer.py:233-240). On a device buffer the result is one of the buffer's
+        two STAGING minibatches for this batch size -- fixed addresses, alternating, overwritten by the sample(batch_size) after
+        the next one (with REFIL_EARLY=0 / REFIL_HIPGRAPH=1: a single one, overwritten by the next call); pass copy=True to get
+        an independent batch (the reference always returns a fresh copy) when more samples must be alive at once."""
         assert self.can_sample(batch_size)
         if self.episodes_in_buffer == batch_size:
             return self[:batch_size]
