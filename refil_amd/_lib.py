@@ -215,6 +215,9 @@ def ptr(t):
 
 def current_stream_ptr():
     import torch
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)      # (10x cheaper than building a Stream object, four times per step)
+    if raw is not None:
+        return C.c_void_p(raw(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

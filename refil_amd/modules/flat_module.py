@@ -29,7 +29,7 @@ class FlatParamModule(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = None if k in ("_engine", "_flat", "_named_cache") else copy.deepcopy(v, memo)
+            new.__dict__[k] = None if k in ("_engine", "_flat", "_named_cache", "_flat_pairs") else copy.deepcopy(v, memo)
         return new
 
     def _named(self):
@@ -44,10 +44,16 @@ class FlatParamModule(nn.Module):
         flat = getattr(self, "_flat", None)
         if flat is None:
             return False
-        named = self._named()
-        for name, off, shape in self._fields():
-            p = named[name]
-            if p.device != flat.device or not p.is_contiguous() or p.data_ptr() != flat.data_ptr() + 4 * off:
+        # (per training step: the (Parameter, offset) pairs are walked once per module instance -- the layout is a function of the
+        # constructor arguments, the Parameter objects are stable, only their .data can be moved by the user)
+        pairs = self.__dict__.get("_flat_pairs")
+        if pairs is None:
+            named = self._named()
+            pairs = [(named[name], 4 * off) for name, off, shape in self._fields()]
+            object.__setattr__(self, "_flat_pairs", pairs)
+        base, dev = flat.data_ptr(), flat.device
+        for p, boff in pairs:
+            if p.data_ptr() != base + boff or p.device != dev or not p.is_contiguous():
                 return False
         return True
 
