@@ -719,7 +719,22 @@ enum { HY_PRE = 1, HY_ATTN = 2, HY_POST = 4, HY_ALL = 7 };
 static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int nv0, int phases = HY_ALL, const HyperBufs* second = nullptr) {
     const refil_dims& d = c.d; const Sizes& s = c.s; const refil_param_layout& L = c.L;
     const int h = d.hyp, M = d.M, nets = s.nets;
+    // The composed tail maps depend on the parameters alone: built in front of the projections they are off the dependent
+    // launches between the attention core and the join of the chains (A/B on one box: cfg-T 1.752 -> 1.742 ms; at 16 entities,
+    // where the step is launch-bound rather than saturated, 0.754 -> 0.758: there they stay behind the attention core).
+    // REFIL_COMPOSE_EARLY=0/1 forces it
+    static const int compose_env = [] { const char* e = getenv("REFIL_COMPOSE_EARLY"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const bool compose_early = compose_env >= 0 ? compose_env == 1 : d.ne > 16;
+    auto compose = [&]() -> int {
+        ComposeArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.W2 = P + L.mix_fc2_w; ca.sW2 = L.mix_fc2_w_stride; ca.b2 = P + L.mix_fc2_b; ca.sb2 = L.mix_fc2_b_stride;
+        ca.Wo = P + L.mix_out_w; ca.sWo = L.mix_out_w_stride; ca.bo = P + L.mix_out_b; ca.sbo = L.mix_out_b_stride;
+        ca.Wc = b.wc; ca.bc = b.bc; ca.nets = nets; ca.M = M; ca.h = h;
+        return compose_forward_launch(ca, c.st);
+    };
     if (phases & HY_PRE) {
+    if (c.presum && compose_early) RUN(compose());
     RUN(gemm_launch(with_rows(linear(c.w.xe, s.Ep, P + L.mix_fc1_w, s.E, P + L.mix_fc1_b, b.x1, nets * h, s.NE, nets * h, s.E, REFIL_GEMM_RELU), c, rows_eh(c)), c.st));
     if (d.pooling) {
         refil_gemm_desc g = linear(b.x1, nets * h, P + L.mix_in_w, h, P + L.mix_in_w + (long)h * h, b.kv, 2 * h, s.NE, h, h, 0);
@@ -775,12 +790,7 @@ static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int n
     if (c.presum) {
         // out_trans o fc2 is one linear map per hypernet: x3 = mask(a W_c^T + b_c), W_c = W_2 W_o (kernels.h: ComposeArgs).
         // x2 is never formed. hyper_w_1 (matrix mode) per agent row; the other nets on the agent-summed rows.
-        ComposeArgs ca;
-        memset(&ca, 0, sizeof(ca));
-        ca.W2 = P + L.mix_fc2_w; ca.sW2 = L.mix_fc2_w_stride; ca.b2 = P + L.mix_fc2_b; ca.sb2 = L.mix_fc2_b_stride;
-        ca.Wo = P + L.mix_out_w; ca.sWo = L.mix_out_w_stride; ca.bo = P + L.mix_out_b; ca.sbo = L.mix_out_b_stride;
-        ca.Wc = b.wc; ca.bc = b.bc; ca.nets = nets; ca.M = M; ca.h = h;
-        RUN(compose_forward_launch(ca, c.st));
+        if (!compose_early) RUN(compose());
         refil_gemm_desc g = linear(b.ao, h, b.wc, h, b.bc, b.x3, M, (long)nv0 * s.NA, M, h, 0);
         g.rowmask = c.w.amask; g.rowmask_mod = (int)s.NA;
         RUN(gemm_launch(with_rows(g, c, rows_h(c, nv0)), c.st));
