@@ -1000,7 +1000,7 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
     // carve may overlay them: clear those regions of the previous carve first (a few MB, stream-ordered, only on a change).
     {
         struct Prev { refil_dims d; int mode; int slot; hipEvent_t slot_free[2]; hipEvent_t pre_done; };
-        static std::unordered_map<void*, Prev> prev;
+        static thread_local std::unordered_map<void*, Prev> prev;        // (per thread, like the side streams the events order)
         auto it = prev.find(ws);
         const bool had = it != prev.end();
         const bool same = had && it->second.mode == CARVE_LEARNER && mode == CARVE_LEARNER && memcmp(&it->second.d, dims, sizeof(refil_dims)) == 0;
