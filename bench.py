@@ -35,6 +35,11 @@ import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4 = the step's four streams). A process group on RCCL
+# creates streams of its own: with four queues they share with the step's streams and EVERY step is 17 % (cfg-T) to 40 %
+# (cfg2) slower, with or without a collective in it (tools/probes/dp_overhead.py, one-rank group on one GPU); with eight the
+# step is unchanged and the all-reduce costs ~10 us. Single-process runs are unaffected (A/B +-0.2 %). Read at HIP initialisation.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch
 import torch.distributed as dist

@@ -32,8 +32,10 @@ _oneshot = {}        # (data_ptr, numel) -> OneShotAllReduce
 def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     """In-place SUM over ranks of the flat [grads | stats] buffer (no-op for a single process).
     REFIL_ALLREDUCE=oneshot: the library's one-hop peer-memory all-reduce instead of the backend's collective."""
-    if world() > 1:
-        if os.environ.get("REFIL_ALLREDUCE") == "oneshot" and flat.is_cuda:
+    if world() > 1 or (os.environ.get("REFIL_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized()):
+        # (REFIL_DP_FORCE=1: the collective also in a one-rank group -- tools/probes/dp_overhead.py measures what the backend's
+        # extra stream costs a rank's step on ONE GPU)
+        if os.environ.get("REFIL_ALLREDUCE") == "oneshot" and flat.is_cuda and world() > 1:
             key = (flat.data_ptr(), flat.numel())
             if key not in _oneshot:
                 _oneshot[key] = OneShotAllReduce(flat.numel(), flat.device)
