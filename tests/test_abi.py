@@ -102,3 +102,18 @@ def test_every_dims_limit_is_reported(L, bad, needle):
     assert L.refil_get_param_layout(C.byref(d), C.byref(out)) != 0
     assert needle in L.refil_last_error(), L.refil_last_error()
     assert L.refil_learner_workspace_bytes(C.byref(d)) == 0
+
+
+def test_import_sets_hardware_queue_default(monkeypatch):
+    """import refil_amd asks HIP for eight hardware queues unless the user chose otherwise: with HIP's four, the streams of an
+    RCCL process group share queues with the step's four (every step 17-40 % slower)."""
+    import importlib
+    import os
+
+    import refil_amd
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    importlib.reload(refil_amd)
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "8"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "5")
+    importlib.reload(refil_amd)
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "5"

@@ -77,3 +77,23 @@ def test_sampled_batches_early_gather_is_bit_identical(monkeypatch):
         lb.train(b, t_env=0, episode_num=i)
         torch.cuda.synchronize()
         assert torch.equal(la.flat_live, lb.flat_live), f"step {i}: max |d| = {(la.flat_live - lb.flat_live).abs().max().item():.3e}"
+
+
+def test_side_stream_is_stable_and_usable():
+    """refil_side_stream: the library's hypernet-chain stream -- the same handle on every call, usable as a torch stream."""
+    import ctypes as C
+
+    from refil_amd import _lib
+    a, b = C.c_void_p(), C.c_void_p()
+    _lib.check(_lib.lib().refil_side_stream(C.byref(a)), "refil_side_stream")
+    _lib.check(_lib.lib().refil_side_stream(C.byref(b)), "refil_side_stream")
+    assert a.value and a.value == b.value
+    s = torch.cuda.ExternalStream(a.value, device=torch.device("cuda", 0))
+    x = torch.zeros(1024, device="cuda")
+    ev = torch.cuda.Event()
+    ev.record()
+    s.wait_event(ev)
+    with torch.cuda.stream(s):
+        x += 1
+    s.synchronize()
+    assert float(x.sum()) == 1024.0
