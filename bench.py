@@ -519,7 +519,10 @@ def main():
                        "algorithmic_gflop_per_step_per_gpu": round(flops_step / 1e9, 2),
                        "batches": f"{a.fresh_batches} x B episodes in a device ReplayBuffer, a fresh sample(B) per step inside the timed region" if a.fresh_batches
                                   else "one resident minibatch (every step trains on the same episodes)",
-                       "padding": "none (--dense-data: every entity alive, full-length episodes)" if a.dense_data else "SC2-law padding / deaths / ragged episode ends"},
+                       "padding": "none (--dense-data: every entity alive, full-length episodes)" if a.dense_data else "SC2-law padding / deaths / ragged episode ends",
+                       "schedule_autotune": (lambda t: {"chosen": t or "built-in defaults", "measured_ms (knob, value, default, candidate)": getattr(learner, "_autotune_log", None),
+                                                        "note": "QLearner's first train() call on a shape measures launch-size knobs in situ (before the warm-up steps); REFIL_AUTOTUNE=0 disables"})(
+                           type(learner)._TUNED.get(bytes(learner._last_dims)))},
             "rows": {"lists_active": bool(rows["lists"]), "live_step_frac": round(rows["live_steps"] / max(rows["steps"], 1), 4),
                      "entity_rows_frac_agent_nets": round(rows["entity_rows_agent"] / max(nE, 1), 4),
                      "entity_rows_frac_hypernets": round(rows["entity_rows_hyper"] / max(nE, 1), 4),

@@ -427,6 +427,14 @@ int refil_profile_collect(refil_profile_entry* out, int max_entries);
  * -1 = follow the environment variable REFIL_NO_OVERLAP. */
 int refil_set_overlap(int on);
 
+/* Schedule knobs that do not change the arithmetic of a step but its launch sizes / launch order (the summation order of the
+ * split weight-gradient reductions follows the launch size: results agree to rounding): "dw4_target" / "dw_target" workgroups
+ * per 4x4-tile / streamed weight-gradient launch, "dw4_min_out" smallest output taken by the 4x4-tile kernel, "compose_early"
+ * 0 / 1. value -1 restores the built-in rule (or its environment switch). Process-wide. The best setting depends on the shape
+ * AND on what shares the GPU, so QLearner.train measures the candidates in situ on its first call per shape
+ * (refil_amd/learners/q_learner.py: _autotune). No counterpart in the reference. */
+int refil_set_tuning(const char* name, int64_t value);
+
 /* The calling thread's internal hypernet-chain stream on the current device (hipStream_t, created lazily; valid until
  * refil_release_streams). For producers of learner batches: work enqueued there runs behind the previous step's hypernet
  * backward and in front of the next step's early prologue (refil_batch.ready_event) -- ReplayBuffer.sample() puts its

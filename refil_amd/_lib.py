@@ -129,7 +129,7 @@ EXPORTS = [
     "refil_profile_enable", "refil_profile_collect", "refil_set_overlap", "refil_release_streams", "refil_replay_gather",
     "refil_learner_row_counts", "refil_attn_mask_words", "refil_set_mixer_grads_hook",
     "refil_oneshot_create", "refil_oneshot_connect", "refil_oneshot_allreduce", "refil_oneshot_status", "refil_oneshot_destroy",
-    "refil_allreduce_flat", "refil_pack_mask_bits", "refil_side_stream",
+    "refil_allreduce_flat", "refil_pack_mask_bits", "refil_side_stream", "refil_set_tuning",
 ]
 IPC_HANDLE_BYTES = 64
 
@@ -174,6 +174,7 @@ def lib():
     L.refil_gru_backward.argtypes = [C.POINTER(GruDesc), C.c_void_p]
     L.refil_set_overlap.argtypes = [C.c_int]
     L.refil_side_stream.argtypes = [C.POINTER(C.c_void_p)]
+    L.refil_set_tuning.argtypes = [C.c_char_p, C.c_int64]
     L.refil_set_mixer_grads_hook.argtypes = [GRADS_HOOK, C.c_void_p]
     L.refil_oneshot_create.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p)]
     L.refil_oneshot_connect.argtypes = [C.c_void_p, C.c_void_p]

@@ -27,6 +27,8 @@
 
 namespace refil {
 
+Tuning g_tuning;
+
 struct GemmK {
     const float* A; const float* B; float* C;
     const float* bias; const float* aux; const uint8_t* rowmask; float* colsum; float* partial;

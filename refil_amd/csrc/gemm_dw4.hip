@@ -286,7 +286,8 @@ bool gemm_dw4_eligible(const refil_gemm_desc& d) {
     // (re-swept after the ring fix, tools/sweep.sh: with fewer than ~64 k reduction rows -- cfg2, the per-net launches -- the thin
     // outputs are faster here as well: cfg2 0.767 -> 0.749 ms; with more rows everything from 10 k outputs on: cfg-T 1.750 -> 1.745)
     static const long min_out = [] { const char* e = getenv("REFIL_DW4_MIN_OUT"); return e ? atol(e) : -1L; }();
-    if ((long)d.batch * d.M * d.N < (min_out >= 0 ? min_out : (d.K >= 65536 ? 10000L : 2000L))) return false;
+    const long min_out_t = g_tuning.dw4_min_out >= 0 ? g_tuning.dw4_min_out : min_out;
+    if ((long)d.batch * d.M * d.N < (min_out_t >= 0 ? min_out_t : (d.K >= 65536 ? 10000L : 2000L))) return false;
     int ti, tj, wmt;
     dw4_shape(d.M, d.N, ti, tj, wmt);
     // the operand vectors (ti resp. tj consecutive floats; 3 floats need 4-byte alignment only) must be naturally aligned
@@ -313,7 +314,7 @@ int gemm_dw4_splits(int M, int N, int batch, long R) {
     const long tiles = (long)cdiv(M, 32 * ti * wmt) * cdiv(N, 32 * tj) * batch;
     // (swept with the step's four streams running, tools/sweep.sh: 128 workgroups beat one per CU by 1 % of the step, 64 lose 5 %)
     static const long target = [] { const char* e = getenv("REFIL_DW4_TARGET"); return e ? atol(e) : 128L; }();
-    long splits = max(2L, target / tiles);
+    long splits = max(2L, (g_tuning.dw4_target > 0 ? g_tuning.dw4_target : target) / tiles);
     splits = min(splits, max(2L, R / 512));          // >= 512 rows per workgroup: the LDS reduction + partial tile are amortised
     return (int)splits;
 }

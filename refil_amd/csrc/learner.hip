@@ -320,7 +320,7 @@ static refil_gemm_desc linear_dw(const float* dy, int lddy, const float* x, int 
     // (tools/sweep.sh): 512 beats 1024 and 256 -- these launches share the GPU with three other streams, and fewer splits
     // mean less partial traffic and a shorter reduction
     static const long target = [] { const char* e = getenv("REFIL_DW_TARGET"); return e ? atol(e) : 512L; }();
-    long splits = target / tiles;
+    long splits = (g_tuning.dw_target > 0 ? g_tuning.dw_target : target) / tiles;
     splits = min(splits, cdivl(R, N <= 64 ? 128 : 256));      // thin layers run narrow tiles: more, shorter splits
     splits = max(splits, 1L);
     while (splits > 1 && (long)batch * splits * ((long)N * K + N) > PARTIAL_FLOATS) --splits;
@@ -724,7 +724,7 @@ static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int n
     // where the step is launch-bound rather than saturated, 0.754 -> 0.758: there they stay behind the attention core).
     // REFIL_COMPOSE_EARLY=0/1 forces it
     static const int compose_env = [] { const char* e = getenv("REFIL_COMPOSE_EARLY"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-    const bool compose_early = compose_env >= 0 ? compose_env == 1 : d.ne > 16;
+    const bool compose_early = g_tuning.compose_early >= 0 ? g_tuning.compose_early == 1 : (compose_env >= 0 ? compose_env == 1 : d.ne > 16);
     auto compose = [&]() -> int {
         ComposeArgs ca;
         memset(&ca, 0, sizeof(ca));
@@ -1047,6 +1047,15 @@ using namespace refil;
 extern "C" const char* refil_last_error(void) { return g_err; }
 extern "C" int refil_set_mixer_grads_hook(refil_grads_hook hook, void* user) {
     g_mixer_hook = hook; g_mixer_hook_user = user;
+    return 0;
+}
+extern "C" int refil_set_tuning(const char* name, int64_t value) {
+    REFIL_CHECK(name, "refil_set_tuning: null name");
+    if (!strcmp(name, "dw4_target")) g_tuning.dw4_target = value;
+    else if (!strcmp(name, "dw4_min_out")) g_tuning.dw4_min_out = value;
+    else if (!strcmp(name, "dw_target")) g_tuning.dw_target = value;
+    else if (!strcmp(name, "compose_early")) g_tuning.compose_early = value;
+    else { set_error("refil_set_tuning: unknown knob '%s'", name); return 1; }
     return 0;
 }
 extern "C" int refil_set_overlap(int on) { g_overlap = on < 0 ? -1 : (on != 0); return 0; }

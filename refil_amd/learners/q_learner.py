@@ -124,6 +124,70 @@ class QLearner:
         ev.record()
         return self._bits_dev
 
+    # ------------------------------------------------------------------------------------------
+    # First-call autotuner. A few launch-size / launch-order knobs of the step (include/refil_hip.h: refil_set_tuning) have no
+    # best value that a rule predicts: the step runs four streams deep, a kernel's time alone says little about the step's
+    # (DESIGN.md lessons 10, 22), and the optimum moves with the shape (cfg-T: 96 workgroups per 4x4-tile weight-gradient launch
+    # -1.4 %, cfg4: +1.7 %). So the first train() call on a shape MEASURES the candidates in situ -- forward_backward on the
+    # caller's own batch, parameters untouched, no RNG consumed -- greedily, one knob at a time, interleaved A/B/A/B, and keeps a
+    # candidate only if it wins by more than the run-to-run spread. Process-wide per shape (replicas of a process agree);
+    # ~0.2 s once. The knobs move the summation order of the split weight-gradient reductions with them: results agree to
+    # rounding, not bit for bit, between settings. REFIL_AUTOTUNE=0 switches it off.
+    _TUNED = {}          # bytes(dims) -> {knob: value}
+    _APPLIED = [None]
+    _KNOBS = (("dw4_target", (96,)), ("dw4_min_out", (2000,)), ("compose_early", (0, 1)))
+
+    @staticmethod
+    def _apply_tuning(setting):
+        if QLearner._APPLIED[0] == setting:
+            return
+        for k, _ in QLearner._KNOBS:
+            _lib.check(_lib.lib().refil_set_tuning(k.encode(), int(setting.get(k, -1))), "refil_set_tuning")
+        QLearner._APPLIED[0] = dict(setting)
+
+    def _tune(self, dims, fields, bits, ready):
+        key = bytes(dims)
+        got = QLearner._TUNED.get(key)
+        if got is None:
+            rows = dims.B * dims.T1 * dims.ne
+            off = (os.environ.get("REFIL_AUTOTUNE") == "0" or os.environ.get("REFIL_HIPGRAPH") == "1" or rows < 20000 or
+                   os.environ.get("REFIL_DP_BUCKETS") == "1" or os.environ.get("REFIL_DENSE") == "1")
+            got = QLearner._TUNED[key] = {} if off else self._autotune(dims, fields, bits, ready)
+        QLearner._apply_tuning(got)
+
+    def _autotune(self, dims, fields, bits, ready):
+        e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+
+        def timed(setting, n=6):
+            QLearner._apply_tuning(setting)
+            for _ in range(3):
+                self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready)
+            e0.record()
+            for _ in range(n):
+                self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready)
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / n
+
+        best = {}
+        timed(best)                                        # (first touch: workspace, lazy initialisation)
+        log = []
+        for knob, values in QLearner._KNOBS:
+            for v in values:
+                cand = dict(best, **{knob: v})
+                ta = tb = 0.0
+                for _ in range(2):                         # interleaved: drift hits both alike
+                    ta += timed(best)
+                    tb += timed(cand)
+                log.append((knob, v, round(ta / 2, 4), round(tb / 2, 4)))
+                if tb < 0.993 * ta:
+                    best = cand
+        self._autotune_log = log
+        if os.environ.get("REFIL_AUTOTUNE_LOG") == "1":
+            print(f"refil autotune B={dims.B} T1={dims.T1} ne={dims.ne}: {best or 'defaults'}  (knob, value, ms default, ms candidate): {log}",
+                  flush=True)
+        return best
+
     def _fields(self, batch):
         names = ["entities", "obs_mask", "entity_mask", "actions", "avail_actions", "reward", "terminated", "filled"]
         if getattr(self.args, "gt_mask_avail", False):
@@ -165,6 +229,7 @@ class QLearner:
         if ready is not None and (os.environ.get("REFIL_EARLY") == "0" or os.environ.get("REFIL_HIPGRAPH") == "1" or
                                   any(fields[k].data_ptr() != batch[k].data_ptr() for k in fields)):      # (a field was copied just now)
             ready = None
+        self._tune(dims, fields, bits, ready)
         # data parallel over episodes: all-reduce(SUM) of [grads | stat sums]; the global sum(mask) normaliser is
         # applied afterwards by the optimiser kernel (q_learner.py:165). One collective after the step, or
         # (REFIL_DP_BUCKETS=1) the mixer bucket underneath the agent's BPTT + the agent bucket after the step.

@@ -97,3 +97,41 @@ def test_side_stream_is_stable_and_usable():
         x += 1
     s.synchronize()
     assert float(x.sum()) == 1024.0
+
+
+def test_first_call_autotune(monkeypatch):
+    """QLearner's first-call autotuner: measures the launch-size knobs in situ on a shape large enough for the row lists, keeps
+    what wins, touches neither the parameters nor the RNG; the step's results agree with the untuned schedule to rounding
+    (the knobs move the summation order of the split weight-gradient reductions)."""
+    import bench
+    from refil_amd.learners.q_learner import QLearner
+    W = dict(bench.CONFIGS["cfg2"])
+    dims = bench.workload_dims(W)
+    dev = torch.device("cuda", 0)
+    saved = dict(QLearner._TUNED)
+    try:
+        QLearner._TUNED.clear()
+        monkeypatch.delenv("REFIL_AUTOTUNE", raising=False)
+        _, batch, la, _, _ = bench.build(dims, W["imagine"], W["B"], W["T"], seed=100, device=dev)
+        la._check_flat()
+        p0 = la.flat_live.clone()
+        st = la.generator.get_state().clone()
+        la._last_dims = None
+        la.train(batch, t_env=0, episode_num=0)
+        assert len(QLearner._TUNED) == 1 and len(la._autotune_log) == 4          # measured: one entry per candidate
+        monkeypatch.setenv("REFIL_AUTOTUNE", "0")
+        QLearner._TUNED.clear()
+        _, _, lb, _, _ = bench.build(dims, W["imagine"], W["B"], W["T"], seed=100, device=dev)
+        lb._check_flat()
+        assert torch.equal(p0, lb.flat_live)
+        lb.generator.set_state(st)
+        lb.train(batch, t_env=0, episode_num=0)
+        torch.cuda.synchronize()
+        assert not hasattr(lb, "_autotune_log") and QLearner._TUNED == {bytes(lb._last_dims): {}}
+        ga, gb = la.grads[:la._n], lb.grads[:lb._n]
+        assert (ga - gb).abs().max().item() <= 2e-6 * gb.abs().max().item()
+        assert torch.equal(la.generator.get_state(), lb.generator.get_state())      # the tuner drew nothing
+    finally:
+        QLearner._TUNED.clear()
+        QLearner._TUNED.update(saved)
+        QLearner._apply_tuning({})
