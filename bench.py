@@ -225,7 +225,7 @@ def cpu_baseline(dims, imagine, data_full, target_seconds=20.0):
                       f"d={dims['d']}), fp32 torch CPU, {threads} threads (fastest of {cands})", "ms_per_step": round(best * 1e3, 1)}
 
 
-def collect_traffic(argv_cfg, timeout_s=240):
+def collect_traffic(argv_cfg, timeout_s=240, tuning=None):
     """HBM bytes per launch and per step from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, kernel-trace +
     pmc only) of a short serialised run of THIS bench configuration, folded exactly like tools/pmc_summarize.py:
     bytes = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes; the factor 2 is gfx950's FETCH_SIZE under-report for wide coalesced reads,
@@ -239,7 +239,9 @@ def collect_traffic(argv_cfg, timeout_s=240):
     import pmc_summarize as ps
     steps_prof = 5
     tmp = tempfile.mkdtemp(prefix="refil_pmc_")
-    env = dict(os.environ, TMPDIR=tmp)
+    # (the profiled runs take the schedule the timed region ran with -- given, not measured again: the autotuner's launches would
+    # be counted into the five profiled steps)
+    env = dict(os.environ, TMPDIR=tmp, REFIL_AUTOTUNE=",".join(f"{k}={v}" for k, v in (tuning or {}).items()) or "0")
     dirs = {}
     try:
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -426,7 +428,7 @@ def main():
             hbm_step, traffic_src = tj.get("hbm_bytes_per_step_all_kernels"), "--traffic-json"
         elif not a.no_traffic and world == 1 and rank == 0:
             cfg_argv = ["--config", a.config] + (["--batch", str(a.batch)] if a.batch else []) + (["--dense-data"] if a.dense_data else [])
-            tr = collect_traffic(cfg_argv)
+            tr = collect_traffic(cfg_argv, tuning=type(learner)._TUNED.get(bytes(learner._last_dims)))
             if tr:
                 traffic, hbm_step, traffic_src = tr["per_launch"].get(dom["name"]), tr["hbm_bytes_per_step"], "rocprofv3 PMC passes run by bench.py"
         # what the launches of one step execute: the GEMM scopes report the listed rows (device counts); the attention scopes

@@ -135,7 +135,7 @@ class QLearner:
     # rounding, not bit for bit, between settings. REFIL_AUTOTUNE=0 switches it off.
     _TUNED = {}          # bytes(dims) -> {knob: value}
     _APPLIED = [None]
-    _KNOBS = (("dw4_target", (96,)), ("dw4_min_out", (2000,)), ("compose_early", (0, 1)))
+    _KNOBS = (("dw4_target", (96,)), ("dw4_min_out", (2000,)), ("dw_target", (384,)), ("compose_early", (0, 1)))
 
     @staticmethod
     def _apply_tuning(setting):
@@ -150,10 +150,44 @@ class QLearner:
         got = QLearner._TUNED.get(key)
         if got is None:
             rows = dims.B * dims.T1 * dims.ne
-            off = (os.environ.get("REFIL_AUTOTUNE") == "0" or os.environ.get("REFIL_HIPGRAPH") == "1" or rows < 20000 or
+            env = os.environ.get("REFIL_AUTOTUNE", "")
+            off = (env == "0" or os.environ.get("REFIL_HIPGRAPH") == "1" or rows < 20000 or
                    os.environ.get("REFIL_DP_BUCKETS") == "1" or os.environ.get("REFIL_DENSE") == "1")
-            got = QLearner._TUNED[key] = {} if off else self._autotune(dims, fields, bits, ready)
+            cache = os.environ.get("REFIL_AUTOTUNE_CACHE")
+            if off:
+                got = {}
+            elif "=" in env:                                # REFIL_AUTOTUNE="dw4_target=96,dw4_min_out=2000": given, not measured
+                got = {k: int(v) for k, v in (kv.split("=") for kv in env.split(",") if kv)}
+            else:
+                got = self._cache_get(cache, key)           # REFIL_AUTOTUNE_CACHE=<file>: measured once, reused by later processes
+                if got is None:
+                    got = self._autotune(dims, fields, bits, ready)
+                    self._cache_put(cache, key, got)
+            QLearner._TUNED[key] = got
         QLearner._apply_tuning(got)
+
+    @staticmethod
+    def _cache_get(path, key):
+        if not path or not os.path.exists(path):
+            return None
+        import json
+        try:
+            return json.load(open(path)).get(key.hex())
+        except (OSError, ValueError):
+            return None
+
+    @staticmethod
+    def _cache_put(path, key, setting):
+        if not path:
+            return
+        import json
+        try:
+            d = json.load(open(path)) if os.path.exists(path) else {}
+        except (OSError, ValueError):
+            d = {}
+        d[key.hex()] = setting
+        with open(path, "w") as f:
+            json.dump(d, f)
 
     def _autotune(self, dims, fields, bits, ready):
         e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)

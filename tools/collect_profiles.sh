@@ -11,6 +11,12 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
+# the schedule knobs QLearner autotunes on its first call are measured ONCE per config here (plain runs, no tracer) and reused by
+# every profiled run below: a tracer changes what overlaps, and the tuner's own launches would be counted into the profiled steps
+export REFIL_AUTOTUNE_CACHE=$OUT/${TAG}_autotune_cache.json
+rm -f $REFIL_AUTOTUNE_CACHE
+for c in cfgT cfg2 cfg3 cfg4 cfg5; do python $ROOT/bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-traffic > /dev/null 2>&1; done
+for b in 4 8 16; do python $ROOT/bench.py --batch $b --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-traffic > /dev/null 2>&1; done
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o p -- \
     python $ROOT/bench.py --no-cpu-baseline --no-traffic > $OUT/${TAG}_bench_n1_under_rocprofv3.json 2> $OUT/${TAG}_stats.log
