@@ -131,18 +131,32 @@ class QLearner:
     # -1.4 %, cfg4: +1.7 %). So the first train() call on a shape MEASURES the candidates in situ -- forward_backward on the
     # caller's own batch, parameters untouched, no RNG consumed -- greedily, one knob at a time, interleaved A/B/A/B, and keeps a
     # candidate only if it wins by more than the run-to-run spread. Process-wide per shape (replicas of a process agree);
-    # ~0.2 s once. The knobs move the summation order of the split weight-gradient reductions with them: results agree to
+    # ~1 s once. The knobs move the summation order of the split weight-gradient reductions with them: results agree to
     # rounding, not bit for bit, between settings. REFIL_AUTOTUNE=0 switches it off.
     _TUNED = {}          # bytes(dims) -> {knob: value}
     _APPLIED = [None]
-    _KNOBS = (("dw4_target", (96,)), ("dw4_min_out", (2000,)), ("dw_target", (384,)), ("compose_early", (0, 1)))
+    # ("env:NAME": a switch the library reads per call from the environment; left alone when the user has set it)
+    _KNOBS = (("dw4_target", (96,)), ("dw4_min_out", (2000,)), ("dw_target", (384,)), ("compose_early", (0, 1)),
+              ("env:REFIL_JOIN_FUSED", (2, 3)))
+    _USER_ENV = {}
 
     @staticmethod
     def _apply_tuning(setting):
         if QLearner._APPLIED[0] == setting:
             return
         for k, _ in QLearner._KNOBS:
-            _lib.check(_lib.lib().refil_set_tuning(k.encode(), int(setting.get(k, -1))), "refil_set_tuning")
+            if k.startswith("env:"):
+                name = k[4:]
+                if name not in QLearner._USER_ENV:
+                    QLearner._USER_ENV[name] = os.environ.get(name)          # what the user had (None: unset)
+                if QLearner._USER_ENV[name] is not None:
+                    continue
+                if k in setting:
+                    os.environ[name] = str(setting[k])
+                else:
+                    os.environ.pop(name, None)
+            else:
+                _lib.check(_lib.lib().refil_set_tuning(k.encode(), int(setting.get(k, -1))), "refil_set_tuning")
         QLearner._APPLIED[0] = dict(setting)
 
     def _tune(self, dims, fields, bits, ready):
@@ -192,7 +206,7 @@ class QLearner:
     def _autotune(self, dims, fields, bits, ready):
         e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
 
-        def timed(setting, n=6):
+        def timed(setting, n=10):
             QLearner._apply_tuning(setting)
             for _ in range(3):
                 self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready)
@@ -207,14 +221,16 @@ class QLearner:
         timed(best)                                        # (first touch: workspace, lazy initialisation)
         log = []
         for knob, values in QLearner._KNOBS:
+            if knob.startswith("env:") and QLearner._USER_ENV.get(knob[4:], os.environ.get(knob[4:])) is not None:
+                continue
             for v in values:
                 cand = dict(best, **{knob: v})
                 ta = tb = 0.0
-                for _ in range(2):                         # interleaved: drift hits both alike
+                for _ in range(3):                         # interleaved: drift hits both alike
                     ta += timed(best)
                     tb += timed(cand)
-                log.append((knob, v, round(ta / 2, 4), round(tb / 2, 4)))
-                if tb < 0.993 * ta:
+                log.append((knob, v, round(ta / 3, 4), round(tb / 3, 4)))
+                if tb < 0.994 * ta:
                     best = cand
         self._autotune_log = log
         if os.environ.get("REFIL_AUTOTUNE_LOG") == "1":
