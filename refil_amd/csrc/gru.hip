@@ -19,6 +19,7 @@
 
 #include "bufops.h"
 #include "common.h"
+#include "kernels.h"
 #include "profile.h"
 #include "../../include/refil_hip.h"
 
@@ -113,7 +114,7 @@ __device__ inline float pick4(const f32x4& v, int k) { return k == 0 ? v[0] : (k
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
 
 // VALU: the recurrent product on the vector ALUs (packed FMAs) instead of the matrix cores -- see gru_valu_enabled()
-template <bool SAVE, int GH, bool VALU = false>
+template <bool SAVE, int GH, bool VALU = false, int PD_ = REFIL_GRU_PD>
 __global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
     constexpr int HP = GH + 4, KS = VALU ? GH : GH / 4;    // KS: reduction indices per lane (MFMA: per k slice)
     __shared__ __attribute__((aligned(16))) float hbuf[2][GR4 * HP];
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
     // indices, no moves of in-flight registers). gfx9 retires loads and stores through ONE in-order counter: awaiting the
     // load of step t + PD also awaits every store issued before it, so the distance is what gives the step's own stores
     // (and the HBM latency under load, > 1 us) PD steps to complete instead of one.
-    constexpr int PD = REFIL_GRU_PD;
+    constexpr int PD = PD_;
     float gq[PD][3];
     const int tlast = max(tend - 1, 0);
 #pragma unroll
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
 //   dn_pre = dn (1-n^2);  dr = dn_pre ghn;  dgh_n = dn_pre r
 //   dr_pre = dr r (1-r);  dz_pre = dz z (1-z)
 //   dgi[t] = (dr_pre, dz_pre, dn_pre);  dgh[t] = (dr_pre, dz_pre, dgh_n);  carry' += dgh[t] W_hh
-template <int GH, bool VALU = false>
+template <int GH, bool VALU = false, int PD_ = REFIL_GRU_PD>
 __global__ __launch_bounds__(4 * GH) void gru_bwd4_kernel(GruK p) {
     constexpr int GP = 3 * GH + 4, KS = VALU ? 3 * GH : 3 * GH / 4, NW = GH / 16;
     __shared__ __attribute__((aligned(16))) float gbuf[2][GR4 * GP];
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd4_kernel(GruK p) {
     }
     if (tend <= 0) return;
     // inputs fetched PD steps ahead into a ring of register sets (loop unrolled by PD: static indices; see the forward kernel)
-    constexpr int PD = REFIL_GRU_PD;
+    constexpr int PD = PD_;
     float ring[PD][6];
     float carry = 0.f;
     const rsrc_t rs_gi = gru_rsrc(p.dgi, true), rs_gh = gru_rsrc(p.dgh, true), rs_none = gru_rsrc(p.dgi, false);
@@ -732,8 +733,14 @@ int gru_forward_launch2(const refil_gru_desc& d, const refil_gru_desc* second, h
                    4.0 * rows_t * GH * (save ? 8.0 : 4.0), st);
 #define GRU_FWD(HH) do { if (rows_wg == GROWS) { if (save) hipLaunchKernelGGL((gru_fwd16_kernel<true, HH>), grid, dim3(4 * HH), 0, st, k); \
                                                   else hipLaunchKernelGGL((gru_fwd16_kernel<false, HH>), grid, dim3(4 * HH), 0, st, k); } \
+                        else if (pd2) { if (save) hipLaunchKernelGGL((gru_fwd4_kernel<true, HH, false, 2>), grid, dim3(4 * HH), 0, st, k); \
+                                        else hipLaunchKernelGGL((gru_fwd4_kernel<false, HH, false, 2>), grid, dim3(4 * HH), 0, st, k); } \
                         else { if (save) hipLaunchKernelGGL((gru_fwd4_kernel<true, HH>), grid, dim3(4 * HH), 0, st, k); \
                                else hipLaunchKernelGGL((gru_fwd4_kernel<false, HH>), grid, dim3(4 * HH), 0, st, k); } } while (0)
+    // prefetch distance of the step inputs: 4 steps (REFIL_GRU_PD) or 2 ("gru_pd", refil_set_tuning / REFIL_GRU_PD_RT: fewer
+    // registers in flight; cfg-T -1.1 %, cfg2 +0.6 % -- one of the knobs QLearner's first call measures per shape)
+    static const int pd_env = [] { const char* e = getenv("REFIL_GRU_PD_RT"); return e ? atoi(e) : -1; }();
+    const bool pd2 = (g_tuning.gru_pd > 0 ? g_tuning.gru_pd : pd_env) == 2;
     if (GH == 64 && rows_wg != GROWS && gru_valu_fwd_enabled()) {
         if (save) hipLaunchKernelGGL((gru_fwd4_kernel<true, 64, true>), grid, dim3(256), 0, st, k);
         else hipLaunchKernelGGL((gru_fwd4_kernel<false, 64, true>), grid, dim3(256), 0, st, k);
@@ -760,6 +767,13 @@ int gru_backward_launch(const refil_gru_desc& d, hipStream_t st) {
         else if (GH == 64) hipLaunchKernelGGL(gru_bwd16_kernel<64>, dim3(cdiv(d.NR, GROWS)), dim3(256), 0, st, k);
         else hipLaunchKernelGGL(gru_bwd16_kernel<128>, dim3(cdiv(d.NR, GROWS)), dim3(512), 0, st, k);
     } else {
+        static const int pd_env = [] { const char* e = getenv("REFIL_GRU_PD_RT"); return e ? atoi(e) : -1; }();
+        const bool pd2 = (g_tuning.gru_pd > 0 ? g_tuning.gru_pd : pd_env) == 2;
+        if (pd2 && !(GH == 64 && gru_valu_enabled())) {
+            if (GH == 32) hipLaunchKernelGGL((gru_bwd4_kernel<32, false, 2>), dim3(cdiv(d.NR, GR4)), dim3(128), 0, st, k);
+            else if (GH == 64) hipLaunchKernelGGL((gru_bwd4_kernel<64, false, 2>), dim3(cdiv(d.NR, GR4)), dim3(256), 0, st, k);
+            else hipLaunchKernelGGL((gru_bwd4_kernel<128, false, 2>), dim3(cdiv(d.NR, GR4)), dim3(512), 0, st, k);
+        } else
         if (GH == 32) hipLaunchKernelGGL(gru_bwd4_kernel<32>, dim3(cdiv(d.NR, GR4)), dim3(128), 0, st, k);
         else if (GH == 64 && gru_valu_enabled()) hipLaunchKernelGGL((gru_bwd4_kernel<64, true>), dim3(cdiv(d.NR, GR4)), dim3(256), 0, st, k);
         else if (GH == 64) hipLaunchKernelGGL(gru_bwd4_kernel<64>, dim3(cdiv(d.NR, GR4)), dim3(256), 0, st, k);

@@ -136,8 +136,7 @@ class QLearner:
     _TUNED = {}          # bytes(dims) -> {knob: value}
     _APPLIED = [None]
     # ("env:NAME": a switch the library reads per call from the environment; left alone when the user has set it)
-    _KNOBS = (("dw4_target", (96,)), ("dw4_min_out", (2000,)), ("dw_target", (384,)), ("compose_early", (0, 1)),
-              ("env:REFIL_JOIN_FUSED", (2, 3)))
+    _KNOBS = (("dw4_target", (96,)), ("gru_pd", (2,)), ("dw4_min_out", (2000,)), ("dw_target", (384,)), ("compose_early", (0, 1)))
     _USER_ENV = {}
 
     @staticmethod
@@ -219,6 +218,7 @@ class QLearner:
 
         best = {}
         timed(best)                                        # (first touch: workspace, lazy initialisation)
+        n_steps = max(10, min(40, int(25.0 / max(timed(best), 1e-3))))      # >= 25 ms per measurement: short steps need more of them
         log = []
         for knob, values in QLearner._KNOBS:
             if knob.startswith("env:") and QLearner._USER_ENV.get(knob[4:], os.environ.get(knob[4:])) is not None:
@@ -227,10 +227,10 @@ class QLearner:
                 cand = dict(best, **{knob: v})
                 ta = tb = 0.0
                 for _ in range(3):                         # interleaved: drift hits both alike
-                    ta += timed(best)
-                    tb += timed(cand)
+                    ta += timed(best, n_steps)
+                    tb += timed(cand, n_steps)
                 log.append((knob, v, round(ta / 3, 4), round(tb / 3, 4)))
-                if tb < 0.994 * ta:
+                if tb < 0.993 * ta:
                     best = cand
         self._autotune_log = log
         if os.environ.get("REFIL_AUTOTUNE_LOG") == "1":

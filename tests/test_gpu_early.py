@@ -118,7 +118,7 @@ def test_first_call_autotune(monkeypatch):
         st = la.generator.get_state().clone()
         la._last_dims = None
         la.train(batch, t_env=0, episode_num=0)
-        assert len(QLearner._TUNED) == 1 and len(la._autotune_log) == 7          # measured: one entry per candidate
+        assert len(QLearner._TUNED) == 1 and len(la._autotune_log) == 6          # measured: one entry per candidate
         monkeypatch.setenv("REFIL_AUTOTUNE", "0")
         QLearner._TUNED.clear()
         _, _, lb, _, _ = bench.build(dims, W["imagine"], W["B"], W["T"], seed=100, device=dev)
