@@ -144,9 +144,12 @@ def build(dims, imagine, B, T, seed, device, shard=None, dense=False, fresh=0):
         "terminated": {"vshape": (1,), "dtype": torch.uint8},
     }
     groups = {"agents": dims["na"], "entities": dims["ne"]}
-    batch = EpisodeBatch(scheme, groups, B, T + 1, preprocess={"actions": ("actions_onehot", [OneHot(dims["A"])])}, device=device)
-    batch.update({k: v for k, v in data.items() if k != "filled"}, mark_filled=False)
-    batch.data.transition_data["filled"].copy_(data["filled"])
+    def episode_batch(dk):
+        eb = EpisodeBatch(scheme, groups, B, T + 1, preprocess={"actions": ("actions_onehot", [OneHot(dims["A"])])}, device=device)
+        eb.update({kk: v for kk, v in dk.items() if kk != "filled"}, mark_filled=False)
+        eb.data.transition_data["filled"].copy_(dk["filled"])
+        return eb
+    batch = episode_batch(data)
     torch.manual_seed(0)                                   # identical replicas on every rank
     mac = mac_REGISTRY[args.mac](batch.scheme, groups, args)
     learner = le_REGISTRY[args.learner](mac, batch.scheme, _Logger(), args)
@@ -160,13 +163,11 @@ def build(dims, imagine, B, T, seed, device, shard=None, dense=False, fresh=0):
             dk = data if k == 0 else make_batch_fast(B, T, dims["ne"], seed=seed + 1000 * k)
             if dense and k:
                 dk = densify(dk)
-            eb = EpisodeBatch(scheme, groups, B, T + 1, preprocess={"actions": ("actions_onehot", [OneHot(dims["A"])])}, device=device)
-            eb.update({kk: v for kk, v in dk.items() if kk != "filled"}, mark_filled=False)
-            eb.data.transition_data["filled"].copy_(dk["filled"])
-            buffer.insert_episode_batch(eb)
+            buffer.insert_episode_batch(episode_batch(dk))
     if device.type == "cuda":
         batch.ready_event = torch.cuda.Event()             # the batch is complete here: lets train() run its prologue early
         batch.ready_event.record()
+    learner._bench_episode_batch = episode_batch           # (bench.py's second, densified timed region builds its batch with it)
     return args, batch, learner, data, buffer
 
 
@@ -248,7 +249,7 @@ def collect_traffic(argv_cfg, timeout_s=240, tuning=None):
             d = os.path.join(tmp, c)
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-profile", "--serial",
-                   "--no-traffic"] + argv_cfg
+                   "--no-traffic", "--no-dense-region"] + argv_cfg
             r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
             if r.returncode != 0:
                 return None
@@ -295,9 +296,14 @@ def main():
     ap.add_argument("--fresh-batches", type=int, default=0, help="K > 0: a device replay buffer of K*B episodes is filled once and every step "
                     "trains on a FRESH ReplayBuffer.sample(B) drawn INSIDE the timed region (the gather launch and stale row-count hints "
                     "are part of the step); default: one resident batch")
+    ap.add_argument("--no-dense-region", action="store_true", help="skip the second short timed region on the densified batch (`dense_data` object)")
     ap.add_argument("--dense-data", action="store_true", help="synthetic data without padding: every entity alive, full-length episodes "
                     "(nothing for the row lists to skip: the dense-equivalent FLOPs are the executed FLOPs)")
     a = ap.parse_args()
+    # The library's default schedule is deterministic (no measuring). The bench opts into the first-call autotuner
+    # (refil_amd/tuning.py): it may only pick knob values of tuning.PARITY_TESTED -- every one of them is compared with the torch /
+    # oracle references by tests/ -- and the line reports what it chose (config.schedule_autotune). REFIL_AUTOTUNE=0 times the defaults.
+    os.environ.setdefault("REFIL_AUTOTUNE", "1")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -368,6 +374,66 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
+    from refil_amd import dp, tuning
+    tuned = tuning.check(learner.tuning_chosen(), "bench.py: the timed schedule")       # refuses a knob value without parity coverage
+    # transitions that carry loss weight (sum of the TD mask, q_learner.py:68-72 -- all-reduced under data parallelism): the
+    # headline counts B*T slots per step like BASELINE.json's metric, this is the rate of the slots that are not padding
+    mask_sum = float(learner.grads[learner._n + _lib.STAT_MASK_SUM].item())
+    rank_ms = [elapsed / a.steps * 1e3]
+    comm = None
+    if world > 1:
+        tl = [None] * world
+        dist.all_gather_object(tl, rank_ms[0])
+        rank_ms = tl
+        # the step's collective alone, on the stream the step issues it on (10 back-to-back all-reduces of the [grads | stats] buffer)
+        ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        gb = learner.grads.clone()
+        dp.allreduce_sum_(gb)
+        barrier()
+        ce0.record()
+        for _ in range(10):
+            dp.allreduce_sum_(gb)
+        ce1.record()
+        ce1.synchronize()
+        try:
+            ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+        comm = {"bytes": gb.numel() * 4, "allreduce_us_per_step": round(ce0.elapsed_time(ce1) * 100.0, 1), "backend": backend,
+                "nccl_version": ver, "algorithm": os.environ.get("REFIL_ALLREDUCE", "backend all_reduce(SUM), one collective per step"),
+                "buckets": os.environ.get("REFIL_DP_BUCKETS") == "1"}
+    # a second, short timed region on the DENSIFIED batch (no padding, full-length episodes: nothing for the row lists to skip),
+    # so that the headline cannot be read as a dense rate
+    dense = None
+    if not a.dense_data and not a.no_dense_region and buffer is None:
+        db = learner._bench_episode_batch(densify(data))        # (`data` is this rank's shard)
+        db.ready_event = torch.cuda.Event()
+        db.ready_event.record()
+        nd = max(5, min(a.steps, 10))
+        for i in range(3):
+            learner.train(db, t_env=0, episode_num=0)
+        barrier()
+        td0 = time.perf_counter()
+        for i in range(nd):
+            learner.train(db, t_env=0, episode_num=0)
+        barrier()
+        td = time.perf_counter() - td0
+        if world > 1:
+            t = torch.tensor([td], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            td = t.item()
+        dense = {"value": round(global_B * T * nd / td, 1), "ms_per_step": round(td / nd * 1e3, 3), "steps": nd}
+        if not a.no_profile:
+            _lib.profile_enable(True)
+            for i in range(3):
+                learner.train(db, t_env=0, episode_num=0)
+            dfl = sum(e["flops"] for e in _lib.profile_collect()) / 3
+            _lib.profile_enable(False)
+            dense["executed_gflop_per_step"] = round(dfl / 1e9, 2)
+            dense["step_frac_executed"] = round(dfl / (td / nd) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+        for i in range(3):                                  # (back on the bench batch: row-count hints, early-prologue slots)
+            step(a.warmup + a.steps)
+        barrier()
     profiled = not a.no_profile       # every rank runs the extra passes (train() all-reduces); rank 0 reports
     ents, nprof = [], max(3, min(a.steps, 10))
     if profiled:
@@ -428,7 +494,7 @@ def main():
             hbm_step, traffic_src = tj.get("hbm_bytes_per_step_all_kernels"), "--traffic-json"
         elif not a.no_traffic and world == 1 and rank == 0:
             cfg_argv = ["--config", a.config] + (["--batch", str(a.batch)] if a.batch else []) + (["--dense-data"] if a.dense_data else [])
-            tr = collect_traffic(cfg_argv, tuning=type(learner)._TUNED.get(bytes(learner._last_dims)))
+            tr = collect_traffic(cfg_argv, tuning=tuned)
             if tr:
                 traffic, hbm_step, traffic_src = tr["per_launch"].get(dom["name"]), tr["hbm_bytes_per_step"], "rocprofv3 PMC passes run by bench.py"
         # what the launches of one step execute: the GEMM scopes report the listed rows (device counts); the attention scopes
@@ -512,6 +578,9 @@ def main():
             "unit": "transitions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 3), "median_ms_per_step": round(statistics.median(per_step), 3),
             "host_enqueue_ms_per_step": round(host_enqueue / a.steps * 1e3, 3), "higher_is_better": True, "scaling": a.scaling,
+            "filled_transitions_per_s": round(mask_sum * a.steps / elapsed, 1),
+            "dense_data": dense, "comm": comm,
+            "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.config}: synthetic replay (B={B}/GPU, T={T}, n_entities={dims['ne']}, n_agents={dims['na']}, "
                                    f"d={dims['d']}, hypernet={dims['h']}), {'refil' if W['imagine'] else 'qmix_atten'} learner "
@@ -522,9 +591,11 @@ def main():
                        "batches": f"{a.fresh_batches} x B episodes in a device ReplayBuffer, a fresh sample(B) per step inside the timed region" if a.fresh_batches
                                   else "one resident minibatch (every step trains on the same episodes)",
                        "padding": "none (--dense-data: every entity alive, full-length episodes)" if a.dense_data else "SC2-law padding / deaths / ragged episode ends",
-                       "schedule_autotune": (lambda t: {"chosen": t or "built-in defaults", "measured_ms (knob, value, default, candidate)": getattr(learner, "_autotune_log", None),
-                                                        "note": "QLearner's first train() call on a shape measures launch-size knobs in situ (before the warm-up steps); REFIL_AUTOTUNE=0 disables"})(
-                           type(learner)._TUNED.get(bytes(learner._last_dims)))},
+                       "schedule_autotune": {"chosen": tuned or "built-in defaults", "parity_tested_values": {k: list(v) for k, v in tuning.PARITY_TESTED.items()},
+                                             "measured_ms (knob, value, default, candidate)": getattr(learner, "_autotune_log", None),
+                                             "note": "bench.py sets REFIL_AUTOTUNE=1: QLearner's first train() call on a shape bucket measures launch-size knobs in situ "
+                                                     "(before the warm-up steps), restricted to values with parity coverage (refil_amd/tuning.py; a setting outside "
+                                                     "it is refused); the library default is the deterministic built-in schedule"}},
             "rows": {"lists_active": bool(rows["lists"]), "live_step_frac": round(rows["live_steps"] / max(rows["steps"], 1), 4),
                      "entity_rows_frac_agent_nets": round(rows["entity_rows_agent"] / max(nE, 1), 4),
                      "entity_rows_frac_hypernets": round(rows["entity_rows_hyper"] / max(nE, 1), 4),

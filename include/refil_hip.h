@@ -42,7 +42,7 @@ typedef struct refil_dims {
     int32_t A;            /* n_actions                                                             */
     int32_t d;            /* attn_embed_dim (agent)                                                */
     int32_t heads;        /* attn_n_heads                                                          */
-    int32_t H;            /* rnn_hidden_dim (must be 64)                                           */
+    int32_t H;            /* rnn_hidden_dim (32, 64 or 128)                                        */
     int32_t hyp;          /* hypernet_embed                                                        */
     int32_t M;            /* mixing_embed_dim (<= 64)                                              */
     int32_t entity_last_action;      /* append one-hot previous action to agent entities          */

@@ -126,8 +126,15 @@ class EpisodeBatch:
         sl = self._parse_slices(item)
         new = SimpleNamespace(transition_data={k: v[sl] for k, v in self.data.transition_data.items()},
                               episode_data={k: v[sl[0]] for k, v in self.data.episode_data.items()})
-        return EpisodeBatch(self.scheme, self.groups, self._count(sl[0], self.batch_size),
-                            self._count(sl[1], self.max_seq_length), data=new, device=self.device)
+        out = EpisodeBatch(self.scheme, self.groups, self._count(sl[0], self.batch_size),
+                           self._count(sl[1], self.max_seq_length), data=new, device=self.device)
+        # a basic slice (e.g. the reference's batch[:, :max_t_filled()] trim, run.py:269-270) is a VIEW of this batch's memory: it
+        # is ready when this batch is, and whoever consumes it has consumed (part of) this batch -- QLearner.train records
+        # consumed_event on the whole chain of parents, so ReplayBuffer.sample's staging reuse stays ordered behind the reader
+        if all(isinstance(i, slice) for i in sl):
+            out.ready_event = self.ready_event
+            out._parent = self
+        return out
 
     @staticmethod
     def _count(idx, size):
@@ -199,19 +206,39 @@ class ReplayBuffer(EpisodeBatch):
         sh = th.arange(w, device=words.device, dtype=th.int64)
         return ((words[..., None] >> sh) & 1).to(th.uint8)
 
+    def to(self, device):
+        super().to(device)
+        for k in self._packed:
+            self._packed[k] = self._packed[k].to(device)
+
     def update(self, data, bs=slice(None), ts=slice(None), mark_filled=True):
         packed = {k: v for k, v in data.items() if k in self._packed}
         if packed:
             sl = self._parse_slices((bs, ts))
             for k, v in packed.items():
                 dest = self._packed[k][sl]
-                self._packed[k][sl] = self._pack(k, v if isinstance(v, th.Tensor) else th.as_tensor(v)).view_as(dest)
+                v = v if isinstance(v, th.Tensor) else th.as_tensor(v)
+                self._check_safe_view(v, th.empty(tuple(dest.shape) + (self._packed_width[k],), device="meta"))
+                self._packed[k][sl] = self._pack(k, v).view_as(dest)
+            if mark_filled:                                 # (packed keys are transition data: same rule as EpisodeBatch.update)
+                self.data.transition_data["filled"][sl] = 1
+                mark_filled = False
             data = {k: v for k, v in data.items() if k not in self._packed}
-            if not data:
-                return
-        super().update(data, bs, ts, mark_filled)
+        if data:
+            super().update(data, bs, ts, mark_filled)
+        self._record_write()
+
+    def _record_write(self):
+        """Every write path of the buffer ends here: sample()'s early gather runs on the library's side stream and waits for
+        this event, so a write through the public update() on the caller's stream is ordered before the gather that follows."""
+        if th.device(self.device).type == "cuda":
+            if getattr(self, "_write_event", None) is None:
+                self._write_event = th.cuda.Event()
+            self._write_event.record()
 
     def __getitem__(self, item):
+        if th.device(self.device).type == "cuda":
+            self._views_handed_out = True                  # (sample()'s early gather then also waits for the caller's stream)
         if not self._packed:
             return super().__getitem__(item)
         if isinstance(item, str):
@@ -243,11 +270,7 @@ class ReplayBuffer(EpisodeBatch):
         self.update(ep_batch.data.episode_data, where)
         self.buffer_index += n
         self.episodes_in_buffer = max(self.episodes_in_buffer, self.buffer_index)
-        self.buffer_index %= self.buffer_size
-        if th.device(self.device).type == "cuda":              # (the early gather of sample() waits for the last insert)
-            if getattr(self, "_write_event", None) is None:
-                self._write_event = th.cuda.Event()
-            self._write_event.record()
+        self.buffer_index %= self.buffer_size               # (update() recorded the write event the early gather of sample() waits for)
 
     def can_sample(self, batch_size):
         return self.episodes_in_buffer >= batch_size
@@ -350,6 +373,12 @@ class ReplayBuffer(EpisodeBatch):
         wev = getattr(self, "_write_event", None)
         if wev is not None:
             side.wait_event(wev)
+        if getattr(self, "_views_handed_out", False):
+            # buffer[...] handed out a tensor that aliases buffer storage: a write through it bypasses update() and its event,
+            # so the gather is also ordered behind everything enqueued on the caller's stream so far
+            aev = st.setdefault("alias_ev", th.cuda.Event())
+            aev.record(cur)
+            side.wait_event(aev)
         # the last reader of this staging minibatch -- or, for a consumer that records nothing and on first use (the zero fill
         # of a new staging tensor is enqueued on the caller's stream), everything enqueued on the caller's stream so far
         cev = batch.consumed_event if sl["handed_out"] else None

@@ -17,7 +17,8 @@
 //
 // Validation status: exercised by two processes sharing ONE GPU (tests/test_gpu_dp.py: IPC handles, flag protocol,
 // double buffering, equality with torch.distributed.all_reduce). No multi-GPU box was available: cross-device
-// visibility of the staged data relies on the kernel-end release of the copy and on cache-bypassing peer loads.
+// visibility of the staged data rests on fine-grained (system-coherent) staging memory (hipExtMallocWithFlags), the
+// system-scope release / acquire pair on the flag and cache-bypassing peer loads -- and on the start-up equality check.
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
@@ -36,6 +37,7 @@ struct OneShot {
     unsigned* peer_flag[16];
     unsigned epoch;
     bool connected;
+    bool finegrained;              // staging + flag live in fine-grained (system-coherent) device memory
     unsigned* status_host;         // pinned, device-mapped word: the reduce kernel sets it when a peer did not arrive
     unsigned* status_dev;          // its device address
     unsigned long long timeout_ticks;   // 100 MHz wall-clock ticks a rank waits for its peers
@@ -108,11 +110,24 @@ extern "C" int refil_oneshot_create(int32_t world, int32_t rank, int64_t n_float
     memset(o, 0, sizeof(*o));
     o->world = world; o->rank = rank; o->n = n_floats;
     const size_t bytes = (((size_t)n_floats * sizeof(float)) + 255) & ~(size_t)255;
+    // Staging buffers and the flag word are read by PEER devices while this device keeps running: fine-grained (system-coherent)
+    // device memory, so that a peer's loads are not served from a stale copy in this device's L2 and the staged data is visible
+    // at the release store of the flag, not only at the end of the kernel. (Plain hipMalloc memory is coarse-grained: coherent
+    // across devices at kernel boundaries only.) REFIL_ONESHOT_COARSE=1 goes back to hipMalloc; the start-up equality check of
+    // dp.OneShotAllReduce guards either choice.
+    static const bool coarse = [] { const char* e = getenv("REFIL_ONESHOT_COARSE"); return e && e[0] == '1'; }();
+    auto alloc = [&](void** p, size_t n) -> hipError_t {
+        if (!coarse) {
+            if (hipExtMallocWithFlags(p, n, hipDeviceMallocFinegrained) == hipSuccess) { o->finegrained = true; return hipSuccess; }
+            (void)hipGetLastError();
+        }
+        return hipMalloc(p, n);
+    };
     for (int k = 0; k < 2; ++k) {
-        REFIL_HIP(hipMalloc((void**)&o->in[k], bytes));
+        REFIL_HIP(alloc((void**)&o->in[k], bytes));
         REFIL_HIP(hipMemset(o->in[k], 0, bytes));
     }
-    REFIL_HIP(hipMalloc((void**)&o->flag, 256));
+    REFIL_HIP(alloc((void**)&o->flag, 256));
     REFIL_HIP(hipMemset(o->flag, 0, 256));
     REFIL_HIP(hipHostMalloc((void**)&o->status_host, 64, hipHostMallocMapped));
     *o->status_host = 0;

@@ -95,6 +95,7 @@ struct ListArgs {
     struct Rep { int* list; int src, copies, trash; } rep[4];   // lengths -> counts[4 + k]; list = NULL: unused
     unsigned long long* sync;              // [B][8] scratch of the one-launch version: per-episode list lengths as {tag, value} granules
     unsigned tag;                          // set by lists_launch
+    int* err_out; const int* err_host;     // optional: device / host view of a sticky pinned error word (one-launch form: grid exchange timed out)
 };
 int lists_launch(const ListArgs& a, hipStream_t st);
 

@@ -17,7 +17,8 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
-#include <unordered_map>
+#include <map>
+#include <utility>
 
 #include "kernels.h"
 
@@ -500,8 +501,9 @@ static int* row_hints() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) { (void)hipGetLastError(); return nullptr; }
     if (!g_hint[dev]) {
         void* p = nullptr;
-        if (hipHostMalloc(&p, 8 * sizeof(int), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        memset(p, 0, 8 * sizeof(int));
+        // [0..7] row-count hints, [8] sticky error word of the one-launch row-list kernel (mixer.hip: lists_fused_kernel)
+        if (hipHostMalloc(&p, 16 * sizeof(int), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        memset(p, 0, 16 * sizeof(int));
         g_hint[dev] = static_cast<int*>(p);
     }
     return g_hint[dev];
@@ -960,6 +962,14 @@ static int copy_out(float* dst, const float* src, long n, hipStream_t st) {
     return 0;
 }
 
+// What the library remembers about a workspace arena between calls: the layout of its last carve (NaN-pattern regions are cleared
+// when it changes), the early-prologue slot and the events behind the slots' last readers. Keyed by (device, arena address) -- the
+// events belong to the device that was current when they were created -- per thread like the side streams whose work they order;
+// refil_release_streams destroys the events and forgets the arenas.
+struct Prev { refil_dims d; int mode; int slot; hipEvent_t slot_free[2]; hipEvent_t pre_done; };
+typedef std::pair<int, void*> PrevKey;
+static thread_local std::map<PrevKey, Prev> g_prev;
+
 static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, void* ws, size_t ws_bytes, CarveMode mode, void* stream) {
     REFIL_CHECK(dims && batch && ws, "refil: null dims/batch/workspace");
     if (int e = check_dims(*dims)) return e;
@@ -999,9 +1009,11 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
     // (all ones). When the layout on this workspace changes (another T1 / B, another entry point) float regions of the new
     // carve may overlay them: clear those regions of the previous carve first (a few MB, stream-ordered, only on a change).
     {
-        struct Prev { refil_dims d; int mode; int slot; hipEvent_t slot_free[2]; hipEvent_t pre_done; };
-        static thread_local std::unordered_map<void*, Prev> prev;        // (per thread, like the side streams the events order)
-        auto it = prev.find(ws);
+        int dev_now = 0;
+        REFIL_HIP(hipGetDevice(&dev_now));
+        auto& prev = g_prev;
+        const PrevKey pkey{dev_now, ws};
+        auto it = prev.find(pkey);
         const bool had = it != prev.end();
         const bool same = had && it->second.mode == CARVE_LEARNER && mode == CARVE_LEARNER && memcmp(&it->second.d, dims, sizeof(refil_dims)) == 0;
         if (had && it->second.mode == CARVE_LEARNER && !same) {
@@ -1020,7 +1032,7 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
             memset(&p0, 0, sizeof(p0));
             for (auto& e : p0.slot_free) REFIL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             REFIL_HIP(hipEventCreateWithFlags(&p0.pre_done, hipEventDisableTiming));
-            it = prev.emplace(ws, p0).first;
+            it = prev.emplace(pkey, p0).first;
         }
         Prev& pr = it->second;
         pr.d = *dims; pr.mode = (int)mode;
@@ -1181,6 +1193,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         la.rep[1] = ListArgs::Rep{w.list_h, 0, s.nv0, (int)(s.NV * s.NA)};
         la.rep[2] = ListArgs::Rep{w.list_ht, 0, 1, (int)(s.nets * s.NA)};
         la.hint_out = row_hints_dev();
+        if (la.hint_out) { la.err_out = la.hint_out + 8; la.err_host = row_hints() + 8; }
         la.sync = early ? nullptr : w.lsync;
         RUN(lists_launch(la, P));
         if (ps != P) RUN(stream_after(sd, ps, c.st));      // (the chains fork from c.st: they start with the inputs assembled)
@@ -1523,7 +1536,12 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         for (int i = 0; i < 2; ++i) RUN(stream_after(sd, sd->g[i], c.st));
     }
     if (deferred.n) RUN(reduce_multi_launch(deferred.r, deferred.n, c.st));
-    REFIL_HIP(hipEventRecord(c.slot_free[c.slot], c.st));      // this step's prologue slot has no reader left behind this point
+    {   // this step's prologue slot has no reader left behind this point (not under capture: a captured record would be a graph
+        // node, and the eager step that later waits on the event would wait on nothing)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(c.st, &cap);
+        if (cap == hipStreamCaptureStatusNone) REFIL_HIP(hipEventRecord(c.slot_free[c.slot], c.st));
+    }
     static const bool defer_log = [] { const char* e = getenv("REFIL_GEMM_LOG"); return e && e[0] == '1'; }();
     if (defer_log) fprintf(stderr, "refil: %d deferred reductions, %.1f of %.1f MiB of partials\n", deferred.n, deferred.used / 262144.0, DPOOL_FLOATS / 262144.0);
     return 0;
@@ -1575,6 +1593,12 @@ extern "C" int refil_side_stream(void** out) {
 extern "C" int refil_release_streams(void) {
     int cur = 0;
     if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    for (auto& kv : g_prev) {                               // per-arena events (created on kv.first.first)
+        if (hipSetDevice(kv.first.first) != hipSuccess) { (void)hipGetLastError(); continue; }
+        for (auto& e : kv.second.slot_free) if (e) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); }
+        if (kv.second.pre_done) { (void)hipEventSynchronize(kv.second.pre_done); (void)hipEventDestroy(kv.second.pre_done); }
+    }
+    g_prev.clear();
     for (int dev = 0; dev < MAX_DEVICES; ++dev) {
         SideStream& sd = g_side[dev];
         if (!sd.ok) continue;

@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256) void lists_fill_kernel(ListArgs a) {          
 // resident for the exchange: used for B <= 256 outside stream capture, the four-launch version otherwise.
 // ------------------------------------------------------------------------------------------------
 constexpr int LF_WAVES = 8;
+constexpr unsigned long long LF_TIMEOUT_TICKS = 200000000ull;       // 2 s of wall_clock64() (100 MHz on gfx9)
 // grid = B x nsub: workgroup (b, sb) takes rows t in [sb * chunk, (sb + 1) * chunk) of episode b
 __global__ __launch_bounds__(64 * LF_WAVES) void lists_fused_kernel(ListArgs a, int nsub, int chunk) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lf_smem[];
@@ -389,12 +390,21 @@ __global__ __launch_bounds__(64 * LF_WAVES) void lists_fused_kernel(ListArgs a, 
     if (wave < 5) {
         int base = 0, grand = 0;
         for (int bb = lane; bb < nblk; bb += 64) {
+            // bounded: a workgroup that never becomes resident (a CU-masked / partitioned device the host-side occupancy gate did
+            // not know about) must not hang the GPU. After LF_TIMEOUT_TICKS of the 100 MHz wall clock the waiter gives up, counts the
+            // missing total as 0 (positions stay in range: they only shrink) and raises the sticky error word -- the host refuses the
+            // NEXT call on this device with a message naming REFIL_LISTS_FUSED=0 (lists_launch)
             unsigned long long g;
+            const unsigned long long t_start = wall_clock64();
+            bool ok = true;
             do {
                 g = __hip_atomic_load(a.sync + (long)bb * 8 + wave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((g >> 32) != a.tag) __builtin_amdgcn_s_sleep(2);
-            } while ((g >> 32) != a.tag);
-            const int v = (int)(unsigned)g;
+                if ((g >> 32) == a.tag) break;
+                __builtin_amdgcn_s_sleep(2);
+                ok = wall_clock64() - t_start < LF_TIMEOUT_TICKS;
+            } while (ok);
+            if (!ok && a.err_out) { __hip_atomic_store(a.err_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+            const int v = ok ? (int)(unsigned)g : 0;
             grand += v;
             if (bb < me) base += v;
         }
@@ -463,7 +473,34 @@ int lists_launch(const ListArgs& a0, hipStream_t st) {
     const int chunk = (a.T1 + nsub - 1) / nsub;
     nsub = (a.T1 + chunk - 1) / chunk;
     const size_t smem = (size_t)chunk * (4 * 8 + 8 * 4);
-    if (fused_env && a.sync && a.B <= 256 && a.ne <= 64 && smem <= 60 * 1024 && cap == hipStreamCaptureStatusNone) {
+    // The one-launch form spins on a grid-wide exchange in a NORMAL launch: every workgroup of the grid has to be resident at the
+    // same time. That is checked, per device, against what the runtime says fits (occupancy x compute units) -- a partitioned
+    // part (CPX: ~32 CUs) or a smaller gfx9 device takes the four-launch form --, refused outright under a CU mask the runtime's
+    // count does not reflect (HSA_CU_MASK / ROC_GLOBAL_CU_MASK), and the spin itself is bounded (err_out, above).
+    static const bool cu_masked = getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK");
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); dev = -1; }
+    static int resident_60k[16] = {}, resident_8k[16] = {};          // co-resident workgroups of this kernel: 60 KB / 8 KB of dynamic LDS
+    long resident = 0;
+    if (dev >= 0 && !cu_masked && fused_env && a.sync) {
+        int& slot = smem <= 8 * 1024 ? resident_8k[dev] : resident_60k[dev];
+        if (!slot) {
+            int per_cu = 0, cus = 0;
+            const size_t probe = smem <= 8 * 1024 ? 8 * 1024 : 60 * 1024;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lists_fused_kernel, 64 * LF_WAVES, probe) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+            slot = per_cu > 0 && cus > 0 ? per_cu * cus : -1;
+        }
+        resident = slot;
+    }
+    if (a.err_host && *reinterpret_cast<const volatile int*>(a.err_host)) {
+        set_error("refil: the one-launch row-list kernel timed out waiting for its grid (the device could not hold all %d workgroups "
+                  "at once: partitioned / CU-masked GPU?). The row lists of that step were incomplete; set REFIL_LISTS_FUSED=0", a.B * nsub);
+        return 3;
+    }
+    // (other streams' workgroups occupy CUs too, but they drain: the exchange only needs this grid to FIT)
+    if (fused_env && a.sync && a.B <= 256 && a.ne <= 64 && smem <= 60 * 1024 && cap == hipStreamCaptureStatusNone &&
+        (long)a.B * nsub <= resident) {
         static unsigned epoch = 0;
         a.tag = (++epoch & 0x7fffffffu) | 0x80000000u;        // never 0, never the tag of the previous launches on this arena
         hipLaunchKernelGGL(lists_fused_kernel, dim3(a.B * nsub), dim3(64 * LF_WAVES), smem, st, a, nsub, chunk);

@@ -8,7 +8,7 @@ import copy
 import os
 
 import torch as th
-from .. import _lib, dp
+from .. import _lib, dp, tuning
 from ..engine import LearnerEngine, dims_from_args
 from ..modules.mixers.flex_qmix import FlexQMixer, LinearFlexQMixer
 from ..modules.mixers.vdn import VDNMixer
@@ -125,82 +125,53 @@ class QLearner:
         return self._bits_dev
 
     # ------------------------------------------------------------------------------------------
-    # First-call autotuner. A few launch-size / launch-order knobs of the step (include/refil_hip.h: refil_set_tuning) have no
-    # best value that a rule predicts: the step runs four streams deep, a kernel's time alone says little about the step's
-    # (DESIGN.md lessons 10, 22), and the optimum moves with the shape (cfg-T: 96 workgroups per 4x4-tile weight-gradient launch
-    # -1.4 %, cfg4: +1.7 %). So the first train() call on a shape MEASURES the candidates in situ -- forward_backward on the
+    # First-call autotuner (opt-in: REFIL_AUTOTUNE=1; refil_amd/tuning.py holds the policy and the parity-tested value sets).
+    # A few launch-size / launch-order knobs of the step (include/refil_hip.h: refil_set_tuning) have no best value that a rule
+    # predicts: the step runs four streams deep, a kernel's time alone says little about the step's (DESIGN.md lessons 10, 22),
+    # and the optimum moves with the shape (cfg-T: 96 workgroups per 4x4-tile weight-gradient launch -1.4 %, cfg4: +1.7 %). With
+    # REFIL_AUTOTUNE=1 the first train() call on a shape BUCKET measures the candidates in situ -- forward_backward on the
     # caller's own batch, parameters untouched, no RNG consumed -- greedily, one knob at a time, interleaved A/B/A/B, and keeps a
-    # candidate only if it wins by more than the run-to-run spread. Process-wide per shape (replicas of a process agree);
-    # ~1 s once. The knobs move the summation order of the split weight-gradient reductions with them: results agree to
-    # rounding, not bit for bit, between settings. REFIL_AUTOTUNE=0 switches it off.
-    _TUNED = {}          # bytes(dims) -> {knob: value}
+    # candidate only if it wins by more than the run-to-run spread. ~1 s once per bucket, at most tuning.MAX_TUNES buckets per
+    # process. The knobs move the summation order of the split weight-gradient reductions with them: results agree to
+    # rounding, not bit for bit, between settings -- which is why the DEFAULT is the deterministic built-in schedule.
+    _TUNED = {}          # tuning.bucket_key(dims) -> {knob: value}
     _APPLIED = [None]
-    # ("env:NAME": a switch the library reads per call from the environment; left alone when the user has set it)
-    _KNOBS = (("dw4_target", (96,)), ("gru_pd", (2,)), ("dw4_min_out", (2000,)), ("dw_target", (384,)), ("compose_early", (0, 1)))
-    _USER_ENV = {}
+    _MEASURED = [0]      # buckets measured by this process
 
     @staticmethod
     def _apply_tuning(setting):
         if QLearner._APPLIED[0] == setting:
             return
-        for k, _ in QLearner._KNOBS:
-            if k.startswith("env:"):
-                name = k[4:]
-                if name not in QLearner._USER_ENV:
-                    QLearner._USER_ENV[name] = os.environ.get(name)          # what the user had (None: unset)
-                if QLearner._USER_ENV[name] is not None:
-                    continue
-                if k in setting:
-                    os.environ[name] = str(setting[k])
-                else:
-                    os.environ.pop(name, None)
-            else:
-                _lib.check(_lib.lib().refil_set_tuning(k.encode(), int(setting.get(k, -1))), "refil_set_tuning")
+        for k in tuning.PARITY_TESTED:
+            _lib.check(_lib.lib().refil_set_tuning(k.encode(), int(setting.get(k, -1))), "refil_set_tuning")
         QLearner._APPLIED[0] = dict(setting)
 
+    def tuning_chosen(self):
+        """The setting the last train() call ran with ({} = built-in defaults)."""
+        return dict(QLearner._APPLIED[0] or {})
+
     def _tune(self, dims, fields, bits, ready):
-        key = bytes(dims)
+        key = tuning.bucket_key(dims)
         got = QLearner._TUNED.get(key)
         if got is None:
+            mode = tuning.mode()
             rows = dims.B * dims.T1 * dims.ne
-            env = os.environ.get("REFIL_AUTOTUNE", "")
-            off = (env == "0" or os.environ.get("REFIL_HIPGRAPH") == "1" or rows < 20000 or
-                   os.environ.get("REFIL_DP_BUCKETS") == "1" or os.environ.get("REFIL_DENSE") == "1")
-            cache = os.environ.get("REFIL_AUTOTUNE_CACHE")
-            if off:
+            if isinstance(mode, dict):                      # REFIL_AUTOTUNE="dw4_target=96,...": given, not measured
+                got = mode
+            elif (mode == "off" or rows < tuning.MIN_ROWS or os.environ.get("REFIL_HIPGRAPH") == "1" or
+                  os.environ.get("REFIL_DP_BUCKETS") == "1" or os.environ.get("REFIL_DENSE") == "1"):
                 got = {}
-            elif "=" in env:                                # REFIL_AUTOTUNE="dw4_target=96,dw4_min_out=2000": given, not measured
-                got = {k: int(v) for k, v in (kv.split("=") for kv in env.split(",") if kv)}
             else:
-                got = self._cache_get(cache, key)           # REFIL_AUTOTUNE_CACHE=<file>: measured once, reused by later processes
+                got = tuning.cache_get(key)                 # REFIL_AUTOTUNE_CACHE=<file>: measured once, reused by later processes
                 if got is None:
-                    got = self._autotune(dims, fields, bits, ready)
-                    self._cache_put(cache, key, got)
+                    if QLearner._MEASURED[0] >= tuning.MAX_TUNES:
+                        got = {}
+                    else:
+                        QLearner._MEASURED[0] += 1
+                        got = self._autotune(dims, fields, bits, ready)
+                        tuning.cache_put(key, got)
             QLearner._TUNED[key] = got
         QLearner._apply_tuning(got)
-
-    @staticmethod
-    def _cache_get(path, key):
-        if not path or not os.path.exists(path):
-            return None
-        import json
-        try:
-            return json.load(open(path)).get(key.hex())
-        except (OSError, ValueError):
-            return None
-
-    @staticmethod
-    def _cache_put(path, key, setting):
-        if not path:
-            return
-        import json
-        try:
-            d = json.load(open(path)) if os.path.exists(path) else {}
-        except (OSError, ValueError):
-            d = {}
-        d[key.hex()] = setting
-        with open(path, "w") as f:
-            json.dump(d, f)
 
     def _autotune(self, dims, fields, bits, ready):
         e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
@@ -220,11 +191,9 @@ class QLearner:
         timed(best)                                        # (first touch: workspace, lazy initialisation)
         n_steps = max(10, min(40, int(25.0 / max(timed(best), 1e-3))))      # >= 25 ms per measurement: short steps need more of them
         log = []
-        for knob, values in QLearner._KNOBS:
-            if knob.startswith("env:") and QLearner._USER_ENV.get(knob[4:], os.environ.get(knob[4:])) is not None:
-                continue
+        for knob, values in tuning.CANDIDATES:
             for v in values:
-                cand = dict(best, **{knob: v})
+                cand = tuning.check(dict(best, **{knob: v}), "autotune candidate")
                 ta = tb = 0.0
                 for _ in range(3):                         # interleaved: drift hits both alike
                     ta += timed(best, n_steps)
@@ -301,7 +270,10 @@ class QLearner:
             if ce is None:
                 ce = batch.__dict__["_consumed_ev"] = th.cuda.Event()
             ce.record()
-            batch.consumed_event = ce
+            b = batch
+            while b is not None:                       # (a time-trimmed view consumes its parents' memory: EpisodeBatch.__getitem__)
+                b.consumed_event = ce
+                b = getattr(b, "_parent", None)
         self._step_count += 1
 
         if (episode_num - self.last_target_update_episode) / args.target_update_interval >= 1.0:

@@ -98,3 +98,15 @@ def rel_err(a, b):
     a = torch.as_tensor(a, dtype=torch.float64)
     b = torch.as_tensor(b, dtype=torch.float64)
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def assert_allclose(a, b, rtol, atol_frac, what=""):
+    """Elementwise |a - b| <= atol + rtol |b| with atol = atol_frac * max|b| (rel_err above is max-abs over max-abs: one
+    large element can hide many small wrong ones; here every element is held to its own scale, the absolute floor only
+    covers cancellation around zero)."""
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    atol = atol_frac * b.abs().max().clamp_min(1e-30)
+    viol = (a - b).abs() - (atol + rtol * b.abs())
+    n_bad = int((viol > 0).sum().item())
+    assert n_bad == 0, f"{what}: {n_bad} of {viol.numel()} elements outside atol {atol.item():.2e} + rtol {rtol:.0e} (worst excess {viol.max().item():.2e})"

@@ -100,18 +100,23 @@ def test_side_stream_is_stable_and_usable():
 
 
 def test_first_call_autotune(monkeypatch):
-    """QLearner's first-call autotuner: measures the launch-size knobs in situ on a shape large enough for the row lists, keeps
-    what wins, touches neither the parameters nor the RNG; the step's results agree with the untuned schedule to rounding
-    (the knobs move the summation order of the split weight-gradient reductions)."""
+    """QLearner's first-call autotuner (opt-in, REFIL_AUTOTUNE=1): measures the launch-size knobs in situ on a shape large enough
+    for the row lists, keeps what wins -- only values of tuning.PARITY_TESTED --, touches neither the parameters nor the RNG; the
+    step's results agree with the untuned schedule to rounding (the knobs move the summation order of the split weight-gradient
+    reductions). The key ignores B and T1 (a run loop that trims to max_t_filled() tunes once per row bucket, not per length);
+    without the switch nothing is measured and the schedule is the deterministic built-in one."""
     import bench
+    from refil_amd import tuning
     from refil_amd.learners.q_learner import QLearner
     W = dict(bench.CONFIGS["cfg2"])
     dims = bench.workload_dims(W)
     dev = torch.device("cuda", 0)
-    saved = dict(QLearner._TUNED)
+    saved, measured = dict(QLearner._TUNED), QLearner._MEASURED[0]
     try:
         QLearner._TUNED.clear()
-        monkeypatch.delenv("REFIL_AUTOTUNE", raising=False)
+        QLearner._MEASURED[0] = 0
+        monkeypatch.setenv("REFIL_AUTOTUNE", "1")
+        monkeypatch.delenv("REFIL_AUTOTUNE_CACHE", raising=False)
         _, batch, la, _, _ = bench.build(dims, W["imagine"], W["B"], W["T"], seed=100, device=dev)
         la._check_flat()
         p0 = la.flat_live.clone()
@@ -119,7 +124,15 @@ def test_first_call_autotune(monkeypatch):
         la._last_dims = None
         la.train(batch, t_env=0, episode_num=0)
         assert len(QLearner._TUNED) == 1 and len(la._autotune_log) == 6          # measured: one entry per candidate
-        monkeypatch.setenv("REFIL_AUTOTUNE", "0")
+        assert QLearner._MEASURED[0] == 1
+        tuning.check(la.tuning_chosen())
+        # a shorter view of the same batch (the reference's max_t_filled() trim) lands in the same bucket or the next one down:
+        # no second measurement for a batch one step shorter
+        key_full = tuning.bucket_key(la._last_dims)
+        from refil_amd.engine import clone_dims
+        assert tuning.bucket_key(clone_dims(la._last_dims, T1=la._last_dims.T1 - 1)) == key_full
+        assert tuning.bucket_key(clone_dims(la._last_dims, T1=la._last_dims.T1 // 4)) != key_full
+        monkeypatch.delenv("REFIL_AUTOTUNE")               # the default: no measuring, built-in schedule
         QLearner._TUNED.clear()
         _, _, lb, _, _ = bench.build(dims, W["imagine"], W["B"], W["T"], seed=100, device=dev)
         lb._check_flat()
@@ -127,11 +140,18 @@ def test_first_call_autotune(monkeypatch):
         lb.generator.set_state(st)
         lb.train(batch, t_env=0, episode_num=0)
         torch.cuda.synchronize()
-        assert not hasattr(lb, "_autotune_log") and QLearner._TUNED == {bytes(lb._last_dims): {}}
+        assert not hasattr(lb, "_autotune_log") and QLearner._TUNED == {tuning.bucket_key(lb._last_dims): {}}
+        assert lb.tuning_chosen() == {}
         ga, gb = la.grads[:la._n], lb.grads[:lb._n]
         assert (ga - gb).abs().max().item() <= 2e-6 * gb.abs().max().item()
         assert torch.equal(la.generator.get_state(), lb.generator.get_state())      # the tuner drew nothing
+        # a given setting outside the parity-tested set is refused
+        monkeypatch.setenv("REFIL_AUTOTUNE", "dw4_target=77")
+        QLearner._TUNED.clear()
+        with pytest.raises(ValueError):
+            lb.train(batch, t_env=0, episode_num=0)
     finally:
         QLearner._TUNED.clear()
         QLearner._TUNED.update(saved)
+        QLearner._MEASURED[0] = measured
         QLearner._apply_tuning({})

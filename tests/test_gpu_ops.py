@@ -324,14 +324,38 @@ def test_pool_forward_backward(mode, B, T1, ne, na, w, codes):
 # ------------------------------------------------------------------------------------------------
 # persistent GRU
 # ------------------------------------------------------------------------------------------------
+@pytest.fixture
+def set_tuning():
+    """refil_set_tuning for the duration of a test (every knob back to its built-in default afterwards)"""
+    from refil_amd import _lib, tuning
+    touched = []
+
+    def apply(**kw):
+        for k, v in kw.items():
+            assert v == -1 or v in tuning.PARITY_TESTED[k], (k, v)
+            _lib.check(_lib.lib().refil_set_tuning(k.encode(), int(v)), "refil_set_tuning")
+            touched.append(k)
+    yield apply
+    for k in touched:
+        _lib.check(_lib.lib().refil_set_tuning(k.encode(), -1), "refil_set_tuning")
+
+
+# pd: the recurrences' prefetch distance ("gru_pd": 2 selects OTHER template instantiations of the 4-row kernels -- a different
+# register ring and vmcnt schedule -- and is what the autotuned bench line runs at cfg-T; -1 = the built-in default, 4)
+@pytest.mark.parametrize("pd", [-1, 2, 4])
 @pytest.mark.parametrize("GB,T1,na,H,valu", [(6, 9, 16, 64, 0), (5, 4, 3, 64, 0), (2, 1, 8, 64, 0), (3, 21, 5, 64, 0),
                                              (5, 6, 7, 32, 0), (2, 1, 8, 32, 0), (4, 7, 6, 128, 0), (3, 5, 16, 128, 0),
+                                             (3, 23, 9, 32, 0), (2, 30, 16, 128, 0),
                                              (6, 9, 16, 64, 3), (3, 21, 5, 64, 3)])
-def test_gru_forward_backward(GB, T1, na, H, valu, monkeypatch):
-    """valu = 3: the opt-in vector-ALU form of the recurrent products (REFIL_GRU_VALU, gru.hip), same reference."""
+def test_gru_forward_backward(GB, T1, na, H, valu, pd, monkeypatch, set_tuning):
+    """valu = 3: the opt-in vector-ALU form of the recurrent products (REFIL_GRU_VALU, gru.hip), same reference.
+    Reference: torch autograd through the oracle's GRUCell restatement (entity_rnn_agent.py:49-55)."""
     import hip_ops
     from oracle.refil_oracle import gru_cell
+    if valu and pd != -1:
+        pytest.skip("the vector-ALU form has one prefetch distance")
     monkeypatch.setenv("REFIL_GRU_VALU", str(valu))
+    set_tuning(gru_pd=pd)
     torch.manual_seed(GB * 7 + T1)
     NR = GB * na
     w_ih = (torch.randn(3 * H, H) / 8).requires_grad_(True)
@@ -525,13 +549,17 @@ def test_attention_row_skipping():
         assert (O1[b, tl + 1:] == 5.0).all() and (dK1[b, tl + 1:] == 5.0).all() and (dQ1[b, tl + 1:] == 5.0).all()
 
 
-def test_gru_time_bounds():
-    """t_last: the recurrence of an episode stops after its last contributing step; BPTT starts there and zero-fills."""
+@pytest.mark.parametrize("pd", [-1, 2])
+@pytest.mark.parametrize("T1,t_last,H", [(7, (6, 3, 0), 64), (19, (18, 9, 2), 64), (13, (5, 12, 0), 32), (11, (10, 1, 6), 128)])
+def test_gru_time_bounds(T1, t_last, H, pd, set_tuning):
+    """t_last: the recurrence of an episode stops after its last contributing step; BPTT starts there and zero-fills.
+    Both prefetch distances, all three hidden sizes, episodes ending at every position of the unrolled ring."""
     import hip_ops
     torch.manual_seed(11)
-    G, B, T1, na, H = 2, 3, 7, 16, 64
+    set_tuning(gru_pd=pd)
+    G, B, na = 2, 3, 16
     GB, NR = G * B, G * B * na
-    t_last = torch.tensor([6, 3, 0], dtype=torch.int32)
+    t_last = torch.tensor(t_last, dtype=torch.int32)
     gi = torch.randn(GB * T1 * na, 3 * H, device=DEV)
     whh, bhh = torch.randn(3 * H, H, device=DEV) / 8, torch.randn(3 * H, device=DEV) / 8
     h0 = torch.randn(GB, na, H, device=DEV) / 2
@@ -547,7 +575,7 @@ def test_gru_time_bounds():
             hip_ops.gru_skip(d, t_last.to(DEV), B)
         hip_ops.gru_forward(d)
         dgi = torch.full((GB * T1 * na, 3 * H), 9.0, device=DEV); dgh = torch.full((GB * T1 * na, 3 * H), 9.0, device=DEV)
-        d = hip_ops.gru_desc(gi, hsx, whh, bhh, NR, T1, na, saves=saves, dhs=dhs, dgi=dgi, dgh=dgh)
+        d = hip_ops.gru_desc(gi, hsx, whh, bhh, NR, T1, na, H=H, saves=saves, dhs=dhs, dgi=dgi, dgh=dgh)
         if skip:
             hip_ops.gru_skip(d, t_last.to(DEV), B)
         hip_ops.gru_backward(d)

@@ -281,7 +281,7 @@ def test_qlearner_without_mixer(tmp_path):
 def test_long_trajectory_tracks_oracle():
     """40 consecutive train() calls on one batch (RMSprop state carried, hard target syncs every 7 episodes, a fresh
     partition every call): the HIP learner stays on the oracle's trajectory -- errors of single steps must not
-    accumulate into a different optimisation path (tools/soak_test.py runs the long unattended version)."""
+    accumulate into a different optimisation path (tools/soak.py runs the long unattended version)."""
     g, args, batch, mac, learner, logger = _build("refil_abs_masked", target_update_interval=7)
     cfg, z = g["cfg"], g["z"]
     agent = {k[len("agent0."):]: th.from_numpy(z[k]).clone() for k in z.files if k.startswith("agent0.")}

@@ -137,3 +137,56 @@ def test_bit_packed_mask_storage_equals_byte_storage(ne):
     keep = s1["entities"].clone()
     packed.sample(5)                                          # overwrites the staging minibatch, not the copy
     assert th.equal(s1["entities"], keep)
+
+
+def test_slices_are_views_that_share_events():
+    """batch[:, :max_t] (the reference's max_t_filled() trim, run.py:269-270) is a view of the batch's memory: it carries the
+    parent's ready_event and hands a consumer's consumed_event up the chain (EpisodeBatch.__getitem__)."""
+    b = _episodes(4, 6, 1)
+    b.ready_event = object()
+    v = b[:, :3]
+    assert v.ready_event is b.ready_event and v._parent is b and v.max_seq_length == 3
+    assert v["entities"].data_ptr() == b["entities"].data_ptr()
+    w = v[1:3]
+    assert w._parent is v and w.batch_size == 2
+    f = b[[0, 2]]                                            # fancy indexing copies: no parent, no event
+    assert getattr(f, "_parent", None) is None and f.ready_event is None
+
+
+@pytest.mark.gpu
+def test_update_on_packed_keys_marks_filled_and_orders_the_gather():
+    """ReplayBuffer.update is a legal write path (reference: episode_buffer.py:77-105): with ONLY bit-packed keys in `data` it
+    still marks `filled`, checks the shape, and records the write event the early gather of sample() waits for."""
+    scheme, groups, pre = _scheme(ne=8, na=4, ed=7, A=5)
+    buf = ReplayBuffer(scheme, groups, 6, 5, preprocess=pre, device="cuda")
+    om = (th.rand(2, 5, 8, 8) < 0.5).to(th.uint8)
+    assert getattr(buf, "_write_event", None) is None
+    buf.update({"obs_mask": om}, bs=slice(1, 3), ts=slice(0, 5))
+    assert buf._write_event is not None
+    assert th.equal(buf["obs_mask"][1:3].cpu(), om)
+    assert (buf["filled"][1:3] == 1).all() and (buf["filled"][0] == 0).all() and (buf["filled"][3:] == 0).all()
+    with pytest.raises(ValueError):
+        buf.update({"obs_mask": om[:, :, :4]}, bs=slice(1, 3), ts=slice(0, 5))
+    buf.update({"obs_mask": om}, bs=slice(3, 5), ts=slice(0, 5), mark_filled=False)
+    assert (buf["filled"][3:5] == 0).all()
+    buf.to("cuda")                                           # (moves the packed words as well)
+    assert buf._packed["obs_mask"].is_cuda
+
+
+@pytest.mark.gpu
+def test_direct_update_is_ordered_before_the_early_gather():
+    """A write through the public update() on the caller's stream, then sample(): the gather on the library's side stream must see
+    it (it waits for the buffer's write event). Repeated with a slow kernel in front of the write to open the race window."""
+    scheme, groups, pre = _scheme(ne=8, na=4, ed=7, A=5)
+    buf = ReplayBuffer(scheme, groups, 8, 9, preprocess=pre, device="cuda")
+    buf.insert_episode_batch(_episodes(8, 9, 10, device="cuda", ne=8, na=4, ed=7, A=5))
+    big = th.randn(4096, 4096, device="cuda")
+    for it in range(6):
+        np.random.seed(it)
+        for _ in range(3):
+            big = big @ big * 1e-3                          # keeps the caller's stream busy in front of the write
+        new = th.full((8, 9, 1), 1000.0 + it, device="cuda")
+        buf.update({"reward": new}, mark_filled=False)
+        s = buf.sample(5)
+        th.cuda.synchronize()
+        assert (s["reward"] == 1000.0 + it).all(), it
