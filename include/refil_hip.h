@@ -125,6 +125,15 @@ typedef struct refil_batch {
      * Leave it NULL on the first call after the workspace was (re)allocated or zeroed on `stream`: the early work is not
      * ordered behind that zero fill. */
     void* ready_event;
+    /* refil_learner_forward_backward only, optional: a counter the caller changes whenever params_target has been (or is being,
+     * on `stream`) rewritten since its previous call with this workspace (q_learner.py:203-207 `_update_targets`, checkpoint
+     * loads); 0 = unknown. The target networks' forward depends on the batch fields and on params_target alone: on a call whose
+     * ready_event is set AND whose target_version (non-zero) and params_target pointer equal the previous call's, it is
+     * enqueued right behind the early prologue, on the library's hypernet-chain stream -- beside the END of the previous step --
+     * instead of inside this step's forward. Same kernels, same data: results are bit-identical. The
+     * caller must keep params_target unchanged until the work enqueued on `stream` by this call has completed, or change
+     * target_version at the next call. */
+    uint64_t target_version;
 } refil_batch;
 
 /* Scalars produced by a step, as a device array of REFIL_NSTAT floats (sums over this rank's shard,
@@ -434,6 +443,11 @@ int refil_set_overlap(int on);
  * AND on what shares the GPU, so QLearner.train measures the candidates in situ on its first call per shape
  * (refil_amd/learners/q_learner.py: _autotune). No counterpart in the reference. */
 int refil_set_tuning(const char* name, int64_t value);
+
+/* Schedule counters of the calling thread since the library was loaded (diagnostics: which learner steps took the early paths of
+ * refil_batch.ready_event / target_version). name: "learner_steps", "early_prologue_steps", "early_target_hypernet_steps",
+ * "early_target_agent_steps". Returns -1 for an unknown name. No reference counterpart (q_learner.py runs everything in order). */
+int64_t refil_get_stat(const char* name);
 
 /* The calling thread's internal hypernet-chain stream on the current device (hipStream_t, created lazily; valid until
  * refil_release_streams). For producers of learner batches: work enqueued there runs behind the previous step's hypernet

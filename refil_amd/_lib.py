@@ -52,6 +52,7 @@ class Batch(C.Structure):
         ("group_bits", C.c_void_p),
         ("mask_words", C.c_void_p), ("mask_row_bits", C.c_void_p),
         ("ready_event", C.c_void_p),
+        ("target_version", C.c_uint64),
     ]
 
 
@@ -129,7 +130,7 @@ EXPORTS = [
     "refil_profile_enable", "refil_profile_collect", "refil_set_overlap", "refil_release_streams", "refil_replay_gather",
     "refil_learner_row_counts", "refil_attn_mask_words", "refil_set_mixer_grads_hook",
     "refil_oneshot_create", "refil_oneshot_connect", "refil_oneshot_allreduce", "refil_oneshot_status", "refil_oneshot_destroy",
-    "refil_allreduce_flat", "refil_pack_mask_bits", "refil_side_stream", "refil_set_tuning",
+    "refil_allreduce_flat", "refil_pack_mask_bits", "refil_side_stream", "refil_set_tuning", "refil_get_stat",
 ]
 IPC_HANDLE_BYTES = 64
 
@@ -175,6 +176,8 @@ def lib():
     L.refil_set_overlap.argtypes = [C.c_int]
     L.refil_side_stream.argtypes = [C.POINTER(C.c_void_p)]
     L.refil_set_tuning.argtypes = [C.c_char_p, C.c_int64]
+    L.refil_get_stat.argtypes = [C.c_char_p]
+    L.refil_get_stat.restype = C.c_int64
     L.refil_set_mixer_grads_hook.argtypes = [GRADS_HOOK, C.c_void_p]
     L.refil_oneshot_create.argtypes = [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p)]
     L.refil_oneshot_connect.argtypes = [C.c_void_p, C.c_void_p]
@@ -188,6 +191,11 @@ def lib():
     L.refil_profile_collect.argtypes = [C.POINTER(ProfileEntry), C.c_int]
     _lib = L
     return L
+
+
+def get_stat(name: str) -> int:
+    """refil_get_stat: schedule counters of this thread (learner_steps, early_prologue_steps, early_target_*_steps)."""
+    return int(lib().refil_get_stat(name.encode()))
 
 
 def profile_enable(on: bool):

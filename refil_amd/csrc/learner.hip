@@ -131,22 +131,25 @@ struct Work {
     unsigned long long* lsync;     // [B][8] exchange area of the one-launch list kernel
     // mask words of the step, built once for all attention launches (attention_mfma.hip: attn_mask_words_kernel)
     unsigned long long *mw_a, *rb_a, *mw_h, *rb_h;
+    // variant-0 words alone (observability / entity mask: no partition bits needed) for the target nets' EARLY forward
+    unsigned long long *mw_at, *rb_at, *mw_ht, *rb_ht;
     // Second copy of everything the step's input-only prologue writes (input assembly, row lists, mask words): a step whose
     // batch fields are ready early (refil_batch.ready_event) builds them beside the end of the previous step, which still reads its own.
     struct Early {
-        float* xe; uint8_t *emc, *amask, *em0; float* actf;
+        float* xe; uint8_t *emc, *amask, *em0; float* actf; float* nact;
         int *t_last, *list_ea, *list_eh, *list_a, *counts, *lcnt, *loff, *list_t, *list_t3, *list_h, *list_ht;
         uint8_t *kdead_a, *kdead_h, *ever;
-        unsigned long long *lsync, *mw_a, *rb_a, *mw_h, *rb_h;
+        unsigned long long *lsync, *mw_a, *rb_a, *mw_h, *rb_h, *mw_at, *rb_at, *mw_ht, *rb_ht;
     } alt;
 };
 static void use_alt_slot(Work& w) {
     const Work::Early& e = w.alt;
-    w.xe = e.xe; w.emc = e.emc; w.amask = e.amask; w.em0 = e.em0; w.actf = e.actf;
+    w.xe = e.xe; w.emc = e.emc; w.amask = e.amask; w.em0 = e.em0; w.actf = e.actf; w.nact = e.nact;
     w.t_last = e.t_last; w.list_ea = e.list_ea; w.list_eh = e.list_eh; w.list_a = e.list_a; w.counts = e.counts; w.lcnt = e.lcnt;
     w.loff = e.loff; w.list_t = e.list_t; w.list_t3 = e.list_t3; w.list_h = e.list_h; w.list_ht = e.list_ht;
     w.kdead_a = e.kdead_a; w.kdead_h = e.kdead_h; w.ever = e.ever;
     w.lsync = e.lsync; w.mw_a = e.mw_a; w.rb_a = e.rb_a; w.mw_h = e.mw_h; w.rb_h = e.rb_h;
+    w.mw_at = e.mw_at; w.rb_at = e.rb_at; w.mw_ht = e.mw_ht; w.rb_ht = e.rb_ht;
 }
 
 struct Sizes {
@@ -253,13 +256,17 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
         const long na_pad = (d.na + 15) / 16 * 16;
         w.mw_a = a.take<unsigned long long>(s.R * 3 * na_pad); w.rb_a = a.take<unsigned long long>(s.R * 3);
         w.mw_h = a.take<unsigned long long>(s.R * 3 * na_pad); w.rb_h = a.take<unsigned long long>(s.R * 3);
+        w.mw_at = a.take<unsigned long long>(s.R * na_pad); w.rb_at = a.take<unsigned long long>(s.R * 3);
+        w.mw_ht = a.take<unsigned long long>(s.R * na_pad); w.rb_ht = a.take<unsigned long long>(s.R * 3);
         Work::Early& e = w.alt;
         e.mw_a = a.take<unsigned long long>(s.R * 3 * na_pad); e.rb_a = a.take<unsigned long long>(s.R * 3);
         e.mw_h = a.take<unsigned long long>(s.R * 3 * na_pad); e.rb_h = a.take<unsigned long long>(s.R * 3);
+        e.mw_at = a.take<unsigned long long>(s.R * na_pad); e.rb_at = a.take<unsigned long long>(s.R * 3);
+        e.mw_ht = a.take<unsigned long long>(s.R * na_pad); e.rb_ht = a.take<unsigned long long>(s.R * 3);
         e.t_last = a.take<int>(d.B);
         e.xe = a.take<float>(s.NEa * s.Ep);
         e.emc = a.take<uint8_t>(s.NE); e.amask = a.take<uint8_t>(s.NA); e.em0 = a.take<uint8_t>((long)d.B * d.ne);
-        e.actf = a.take<float>(s.NA);
+        e.actf = a.take<float>(s.NA); e.nact = a.take<float>(s.R);
         e.list_ea = a.take<int>(s.NE + 256); e.list_eh = a.take<int>(s.NE + 256); e.list_a = a.take<int>(s.NA + 256);
         e.counts = a.take<int>(8); e.lcnt = a.take<int>(4 * s.R); e.loff = a.take<int>(4 * (s.R + 1));
         e.list_t = a.take<int>(s.NA + 256); e.list_t3 = a.take<int>((long)s.G * s.NA + 256);
@@ -406,6 +413,8 @@ static int stream_after(SideStream* sd, hipStream_t from, hipStream_t to) {
 static thread_local refil_grads_hook g_mixer_hook = nullptr;
 static thread_local void* g_mixer_hook_user = nullptr;
 
+static thread_local int64_t g_stat_steps = 0, g_stat_early = 0, g_stat_et_h = 0, g_stat_et_a = 0;      // refil_get_stat
+
 static int g_overlap = -1;      // -1: follow the environment, 0/1: set by refil_set_overlap
 static bool overlap_enabled() {
     if (g_overlap >= 0) return g_overlap != 0;
@@ -451,6 +460,9 @@ struct Ctx {
     // this workspace's previous call was a learner step of the same shape (the carve did not move) / the prologue slot of this
     // call (alternates on an unchanged layout) / the events behind the last readers of the two slots
     bool same_layout; int slot; hipEvent_t* slot_free; hipEvent_t pre_done;
+    struct Prev* prev; // what the library remembers about this workspace (make_ctx)
+    int mw_nvar;       // variants per row in w.mw_a / w.mw_h (the step's G; 1 for the target nets' early variant-0 words)
+    bool target_same;  // params_target is what the previous call on this workspace saw (refil_batch.target_version)
 };
 
 static int gemm_launch_dw(const Ctx& c, refil_gemm_desc& g, hipStream_t st) {
@@ -527,7 +539,7 @@ static RowList rows_t(const Ctx& c, int G) { return G == 1 ? RowList{c.w.list_t,
 static RowList rows_h(const Ctx& c, int nv0) { return nv0 == c.s.nv0 ? RowList{c.w.list_h, c.w.counts + 5, 5} : RowList{c.w.list_ht, c.w.counts + 6, 6}; }
 static void attn_rows(const Ctx& c, refil_attn_desc& a, bool hyper) {
     if (c.lists) { a.t_last = c.w.t_last; a.kv_dead = hyper ? c.w.kdead_h : c.w.kdead_a; a.q_dead = c.w.amask; }
-    if (c.mwords) { a.mask_words = hyper ? c.w.mw_h : c.w.mw_a; a.row_bits = hyper ? c.w.rb_h : c.w.rb_a; a.mask_words_nvar = c.s.G; }
+    if (c.mwords) { a.mask_words = hyper ? c.w.mw_h : c.w.mw_a; a.row_bits = hyper ? c.w.rb_h : c.w.rb_a; a.mask_words_nvar = c.mw_nvar; }
 }
 
 static refil_rowmap agent_rows(const Ctx& c) { return refil_rowmap{c.d.na, c.d.ne, 0}; }
@@ -966,7 +978,7 @@ static int copy_out(float* dst, const float* src, long n, hipStream_t st) {
 // when it changes), the early-prologue slot and the events behind the slots' last readers. Keyed by (device, arena address) -- the
 // events belong to the device that was current when they were created -- per thread like the side streams whose work they order;
 // refil_release_streams destroys the events and forgets the arenas.
-struct Prev { refil_dims d; int mode; int slot; hipEvent_t slot_free[2]; hipEvent_t pre_done; };
+struct Prev { refil_dims d; int mode; int slot; hipEvent_t slot_free[2]; hipEvent_t pre_done; uint64_t target_version; const void* target_ptr; };
 typedef std::pair<int, void*> PrevKey;
 static thread_local std::map<PrevKey, Prev> g_prev;
 
@@ -975,7 +987,7 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
     if (int e = check_dims(*dims)) return e;
     c.d = *dims; c.s = sizes_of(*dims); c.b = *batch; c.st = (hipStream_t)stream;
     c.gst = c.st; c.gpartial = nullptr; c.sd = nullptr; c.mwst = c.st; c.tail_dw = 0; c.tpartial = nullptr; c.defer = nullptr;
-    c.same_layout = false; c.slot = 0; c.slot_free = nullptr; c.pre_done = nullptr;
+    c.same_layout = false; c.slot = 0; c.slot_free = nullptr; c.pre_done = nullptr; c.mw_nvar = c.s.G; c.target_same = false; c.prev = nullptr;
     param_layout(c.d, c.L);
     const char* pe = getenv("REFIL_PRESUM");          // read per call: tests compare both paths in one process
     const bool presum_on = !(pe && pe[0] == '0');
@@ -1037,7 +1049,7 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
         Prev& pr = it->second;
         pr.d = *dims; pr.mode = (int)mode;
         pr.slot = same ? pr.slot ^ 1 : 0;
-        c.same_layout = same; c.slot = pr.slot; c.slot_free = pr.slot_free; c.pre_done = pr.pre_done;
+        c.same_layout = same; c.slot = pr.slot; c.slot_free = pr.slot_free; c.pre_done = pr.pre_done; c.prev = &pr;
         if (mode == CARVE_LEARNER && c.slot) use_alt_slot(c.w);
     }
     return 0;
@@ -1071,6 +1083,14 @@ extern "C" int refil_set_tuning(const char* name, int64_t value) {
     else { set_error("refil_set_tuning: unknown knob '%s'", name); return 1; }
     return 0;
 }
+extern "C" int64_t refil_get_stat(const char* name) {
+    if (!name) return -1;
+    if (!strcmp(name, "learner_steps")) return g_stat_steps;
+    if (!strcmp(name, "early_prologue_steps")) return g_stat_early;
+    if (!strcmp(name, "early_target_hypernet_steps")) return g_stat_et_h;
+    if (!strcmp(name, "early_target_agent_steps")) return g_stat_et_a;
+    return -1;
+}
 extern "C" int refil_set_overlap(int on) { g_overlap = on < 0 ? -1 : (on != 0); return 0; }
 extern "C" int refil_version(void) { return 1; }
 
@@ -1102,6 +1122,11 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     const int T = d.T1 - 1, G = s.G, nv0 = s.nv0, H = d.H, h = d.hyp, M = d.M, dd = d.d;
     const long BT = (long)d.B * T;
     float* stats = grads + L.total;
+    if (c.prev) {       // refil_batch.target_version: were the target parameters rewritten since this workspace's previous call?
+        c.target_same = c.same_layout && batch->target_version != 0 && c.prev->target_version == batch->target_version &&
+                        c.prev->target_ptr == (const void*)params_target;
+        c.prev->target_version = batch->target_version; c.prev->target_ptr = params_target;
+    }
     REFIL_HIP(hipMemsetAsync(grads, 0, (L.total + REFIL_NSTAT) * sizeof(float), c.st));
     // (with a gradient hook the mixer's gradients must be complete when it fires: no deferral then)
     const char* defer_e = getenv("REFIL_DEFER_REDUCE");       // (read per call: tests compare the modes in one process)
@@ -1202,6 +1227,44 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         REFIL_HIP(hipEventRecord(c.pre_done, P));
         REFIL_HIP(hipStreamWaitEvent(c.st, c.pre_done, 0));
     }
+    // Early target forward. The target mixer's hypernets and the target agent depend on the batch fields and on params_target
+    // alone -- not on what the previous step's optimiser is still writing, not on this step's partition draw (they run under the
+    // plain observability / entity masks: variant-0 words, built here without the partition bits). With an early prologue and
+    // unchanged target parameters (refil_batch.target_version) their forward is enqueued right behind the prologue, on the same
+    // stream: it runs beside the under-filled END of the previous step (its last weight gradients, the reductions, the
+    // optimiser) instead of widening this step's forward -- 22 % of the step's dense FLOPs leave the two chains between the
+    // start of the step and their join. Same kernels on the same data: bit-identical to the in-order schedule
+    // (tests/test_gpu_early.py). The outputs (Work::ta / th) were last read at the previous step's join, which precedes that
+    // step's hypernet backward on this stream. REFIL_EARLY_TARGET: bit 0 hypernets, bit 1 agent (default 1; 0 = off). Measured
+    // (interleaved A/B on one box, tools/sweep.sh): hypernets early cfg-T 1.702 -> 1.675 ms, cfg2 0.757 -> 0.746; the agent early
+    // as well LOSES (cfg-T 1.797, cfg2 0.809, cfg4 1.481 -> 1.58): it gives up the two-net projection launches and the shared
+    // recurrence launch, and its nine launches sit in front of the live hypernets on the same stream.
+    const bool hypernets = !d.mixer_vdn && !d.mixer_none;
+    const char* et_e = getenv("REFIL_EARLY_TARGET");      // (read per call: tests/test_gpu_early.py runs both settings in one process)
+    const int et_env = et_e ? atoi(et_e) : 1;
+    const bool et_ok = early && c.target_same && c.mwords && !debug && P == sd->s;
+    const bool et_h = et_ok && (et_env & 1) && hypernets && !d.pooling && attn_mfma_supported(d.ne, d.na, d.hyp / d.heads);
+    const bool et_a = et_ok && (et_env & 2) && !d.agent_ff && c.compose_agent && !d.pooling && (G * d.B * d.na) % 16 == 0 &&
+                      attn_mfma_supported(d.ne, d.na, d.d / d.heads);
+    ++g_stat_steps; g_stat_early += early; g_stat_et_h += et_h; g_stat_et_a += et_a;
+    hipEvent_t et_done = nullptr;
+    if (et_h || et_a) {
+        Ctx ce = c;                                        // everything on the prologue's stream, in order
+        ce.st = P; ce.gst = P; ce.mwst = P; ce.sd = sd; ce.defer = nullptr; ce.mw_nvar = 1;
+        ce.w.mw_a = w.mw_at; ce.w.rb_a = w.rb_at; ce.w.mw_h = w.mw_ht; ce.w.rb_h = w.rb_ht;
+        for (int hyper = 0; hyper < 2; ++hyper) {
+            if (!(hyper ? et_h : et_a)) continue;
+            refil_attn_desc a = attn_base(c, hyper ? d.hyp : d.d);
+            a.t_last = w.t_last; a.kv_dead = hyper ? w.kdead_h : w.kdead_a; a.q_dead = w.amask;
+            a.nvar = 1; a.var[0] = hyper ? REFIL_MASK_ENTITY : REFIL_MASK_OBS;
+            RUN(attn_mask_words_launch(a, hyper ? w.mw_ht : w.mw_at, hyper ? w.rb_ht : w.rb_at, P));
+        }
+        if (et_h) RUN(hyper_forward(ce, params_target, w.th, 1));
+        if (et_a) RUN(agent_forward(ce, params_target, w.ta, 1, nullptr, AG_ALL));
+        et_done = sd->pool[sd->next_ev];
+        sd->next_ev = (sd->next_ev + 1) % 128;
+        REFIL_HIP(hipEventRecord(et_done, P));
+    }
     if (c.mwords) {
         // mask words of every row, once per step: agent nets (observability variants) and hypernets (entity variants);
         // they are needed by the first attention launches only, so they are built beside the first projections
@@ -1218,13 +1281,12 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         }
     }
     RUN(stream_after(sd, c.st, ch.st));                    // fork: inputs assembled
-    const bool hypernets = !d.mixer_vdn && !d.mixer_none;
     if (hypernets) {
         // A/B on one box: with imagined copies (live net 0 under three mask variants) the merged launch LOSES 1.1 % (cfg-T) to
         // 3.5 % (cfg2) -- the projections of both mixers in front of it no longer interleave with an attention launch of the
         // other chain; without them (qmix_atten: two symmetric light launches) it wins 2.5 % (cfg4). REFIL_HYPER_MERGE=0/1 forces it
         static const int hy_env = [] { const char* e = getenv("REFIL_HYPER_MERGE"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-        const bool hy_merge = hy_env >= 0 ? hy_env == 1 : nv0 == 1;
+        const bool hy_merge = !et_h && (hy_env >= 0 ? hy_env == 1 : nv0 == 1);
         if (hy_merge && 2 * s.nets <= 8 && !d.pooling && attn_mfma_supported(d.ne, d.na, d.hyp / d.heads)) {
             // live and target mixers' hypernets: projections of both, then ONE attention launch for all eight nets, then the tails
             RUN(hyper_forward(ch, params_live, w.lh, nv0, HY_PRE));
@@ -1237,7 +1299,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         // mixer's heavier attention launch (three mask variants) then runs beside the recurrence instead of the agents' GEMMs
         static const bool live_first = [] { const char* e = getenv("REFIL_HYPER_ORDER"); return e && e[0] == '0'; }();
         if (live_first) RUN(hyper_forward(ch, params_live, w.lh, nv0));
-        RUN(hyper_forward(ch, params_target, w.th, 1));                           // target mixer hypernets
+        if (!et_h) RUN(hyper_forward(ch, params_target, w.th, 1));                // target mixer hypernets (et_h: already enqueued)
         if (!live_first) RUN(hyper_forward(ch, params_live, w.lh, nv0));          // live mixer hypernets
         }
     }
@@ -1265,21 +1327,22 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     if (!d.agent_ff && (G * d.B * d.na) % 16 == 0) {
         // live (q_learner.py:86-89 / 107) and target (:111-113) agents on one stream: their recurrences share one launch
         static const bool dual_env = [] { const char* e = getenv("REFIL_AGENT_DUAL"); return !(e && e[0] == '0'); }();
-        const bool dual = dual_env && c.lists && c.compose_agent && !d.pooling && attn_mfma_supported(d.ne, d.na, d.d / d.heads) &&
+        const bool dual = !et_a && dual_env && c.lists && c.compose_agent && !d.pooling && attn_mfma_supported(d.ne, d.na, d.d / d.heads) &&
                           (params_target - params_live) % 4 == 0;
         if (dual) RUN(agent_entity_dual(ca, params_live, params_target, w.la, w.ta, G));
         RUN(agent_forward(ca, params_live, w.la, G, nullptr, AG_PRE | (dual ? AG_NO_ENTITY : 0)));
-        RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_PRE | (dual ? AG_NO_ENTITY : 0)));
+        if (!et_a) RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_PRE | (dual ? AG_NO_ENTITY : 0)));
         const refil_gru_desc gl = agent_gru_desc(ca, params_live, w.la, G, true), gt = agent_gru_desc(ca, params_target, w.ta, 1, true);
-        RUN(gru_forward_launch2(gl, &gt, ca.st));
+        RUN(gru_forward_launch2(gl, et_a ? nullptr : &gt, ca.st));
         if (!qhead_fused) {
             RUN(agent_forward(ca, params_live, w.la, G, nullptr, AG_POST));
-            RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_POST));
+            if (!et_a) RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_POST));
         }
     } else {
         RUN(agent_forward(ca, params_live, w.la, G, nullptr, qhead_fused ? (AG_PRE | AG_GRU) : AG_ALL));
         RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, qhead_fused ? (AG_PRE | AG_GRU) : AG_ALL));
     }
+    if (et_done) REFIL_HIP(hipStreamWaitEvent(c.st, et_done, 0));      // the early target forward's outputs (agent Q values; hypernets: ev[1] below)
     if (qhead_fused) {
         // the join of the two chains: Q head (fc3), inactive-agent fill, chosen-action gather and double-Q target selection
         // in ONE launch per (b,t) row straight from the hidden states (two thin GEMMs over all rows + a gather kernel before)

@@ -69,7 +69,7 @@ class LearnerEngine:
     # -- q_learner.py:66-176 -------------------------------------------------------------------
     def forward_backward(self, dims: Dims, fields: Dict[str, torch.Tensor], group_bits: Optional[torch.Tensor],
                          params_live: torch.Tensor, params_target: torch.Tensor, grads: torch.Tensor,
-                         debug: bool = False, ready_event: Optional[torch.cuda.Event] = None):
+                         debug: bool = False, ready_event: Optional[torch.cuda.Event] = None, target_version: int = 0):
         """grads: flat fp32 [layout.total + REFIL_NSTAT]. Returns dict of debug tensors if debug.
         ready_event: recorded behind the last write of the batch fields (refil_batch.ready_event): the step's input
         assembly and row lists then run on a side stream, beside the end of the previous step on the current stream."""
@@ -82,6 +82,7 @@ class LearnerEngine:
         # and the allocator may hand a new arena the address of an old one the library remembers the layout of)
         if ready_event is not None and not b._converted and not self.ws.fresh:
             b.ready_event = ready_event.cuda_event
+        b.target_version = int(target_version) & 0xFFFFFFFFFFFFFFFF         # (refil_batch.target_version: early target forward)
         self.ws.fresh = False
         dbg = None
         out = {}

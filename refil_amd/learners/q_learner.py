@@ -44,6 +44,7 @@ class QLearner:
         self.target_mac = copy.deepcopy(mac)
         self.log_stats_t = -self.args.learner_log_interval - 1
         self._step_count = 0
+        self._target_epoch = 0
         self._engine = None
         self._flat_ready = False
         self.generator = None      # optional torch.Generator for the partition draw (defaults to the global CPU RNG)
@@ -179,10 +180,10 @@ class QLearner:
         def timed(setting, n=10):
             QLearner._apply_tuning(setting)
             for _ in range(3):
-                self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready)
+                self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready, target_version=self._tv())
             e0.record()
             for _ in range(n):
-                self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready)
+                self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready, target_version=self._tv())
             e1.record()
             e1.synchronize()
             return e0.elapsed_time(e1) / n
@@ -256,13 +257,13 @@ class QLearner:
             if self._buckets is None:
                 self._buckets = dp.BucketedAllReduce(self.grads, self._na)
             with self._buckets:
-                self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready)
+                self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready, target_version=self._tv())
             self._buckets.finish()
             self._optimiser_step()
         elif os.environ.get("REFIL_HIPGRAPH") == "1" and group_bits is None:
             self._graphed_step(dims, fields, bits)
         else:
-            self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready)
+            self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready, target_version=self._tv())
             dp.allreduce_sum_(self.grads)
             self._optimiser_step()
         if ready is not None:                          # (a producer that reuses the batch's memory waits for this: ReplayBuffer.sample)
@@ -299,6 +300,13 @@ class QLearner:
             self.logger.log_stat("q_taken_mean", st[_lib.STAT_QTOT_SUM] / (msum * args.n_agents), t_env)    # :194 quirk kept
             self.logger.log_stat("target_mean", st[_lib.STAT_TARGET_SUM] / (msum * args.n_agents), t_env)
             self.log_stats_t = t_env
+
+    def _tv(self):
+        """refil_batch.target_version: changes whenever the target parameters may have been rewritten -- the explicit counter of
+        _update_targets / load_models plus torch's in-place version counter of the flat buffer (load_state_dict and any other
+        write through the parameter views bumps it). Unchanged since the previous call = the library may run the target nets'
+        forward early, beside the end of the previous step."""
+        return ((self._target_epoch + 1) << 32) | (self.flat_target._version & 0xFFFFFFFF)
 
     def _optimiser_step(self):
         a = self.args
@@ -366,6 +374,7 @@ class QLearner:
     def _update_targets(self):
         self._check_flat()
         self.flat_target.copy_(self.flat_live)          # one flat D2D copy (q_learner.py:203-207)
+        self._target_epoch += 1
         self.logger.console_logger.info("Updated target network")
 
     def cuda(self):
@@ -421,6 +430,7 @@ class QLearner:
     def load_models(self, path, evaluate=False):
         self.mac.load_models(path)
         self.target_mac.load_models(path)       # like the reference: targets are not checkpointed (:224-225)
+        self._target_epoch += 1
         if not evaluate:
             if self.mixer is not None:                  # q_learner.py:226-227
                 self.mixer.load_state_dict(th.load("{}/mixer.th".format(path), map_location=lambda storage, loc: storage))

@@ -11,11 +11,13 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+@pytest.mark.parametrize("et", ["1", "3", "0"])           # REFIL_EARLY_TARGET: target hypernets early (default) / + target agent / off
 @pytest.mark.parametrize("cfg", ["cfg2", "cfg4"])
-def test_early_prologue_is_bit_identical(cfg, monkeypatch):
+def test_early_prologue_is_bit_identical(cfg, et, monkeypatch):
     import bench
     from refil_amd import _lib
     monkeypatch.delenv("REFIL_EARLY", raising=False)
+    monkeypatch.setenv("REFIL_EARLY_TARGET", et)
     W = dict(bench.CONFIGS[cfg])
     dims = bench.workload_dims(W)
     dev = torch.device("cuda", 0)
@@ -25,6 +27,8 @@ def test_early_prologue_is_bit_identical(cfg, monkeypatch):
     assert b1.ready_event is not None and b2.ready_event is not None
     la._check_flat(); lb._check_flat()
     assert torch.equal(la.flat_live, lb.flat_live)
+    la.args.target_update_interval = lb.args.target_update_interval = 4      # target syncs after steps 4 and 8
+    st0 = {k: _lib.get_stat(k) for k in ("learner_steps", "early_prologue_steps", "early_target_hypernet_steps", "early_target_agent_steps")}
 
     class Plain:                                   # the same batch without the event: the prologue stays on the caller's stream
         def __init__(self, b):
@@ -38,14 +42,22 @@ def test_early_prologue_is_bit_identical(cfg, monkeypatch):
             return self._b[k]
 
     _lib.profile_enable(True)
-    for i in range(9):
+    for i in range(12):
         b = (b1, b2, b2)[i % 3]                    # (b2 twice in a row: the slot alternates even when the batch does not)
         la.train(b, t_env=0, episode_num=i)
         lb.train(Plain(b), t_env=0, episode_num=i)
         torch.cuda.synchronize()
         assert torch.equal(la.flat_live, lb.flat_live), f"step {i}: max |d| = {(la.flat_live - lb.flat_live).abs().max().item():.3e}"
+        assert torch.equal(la.flat_target, lb.flat_target)
     _lib.profile_enable(False)
     _lib.profile_collect()
+    # the early paths were taken: 24 learner steps, 11 of la's with the early prologue (not its first: new workspace), and the
+    # target nets' early forward (refil_batch.target_version) on every one of those whose target parameters had not just been
+    # rewritten -- the two steps behind the target syncs stay in order
+    st = {k: _lib.get_stat(k) - v for k, v in st0.items()}
+    assert st["learner_steps"] == 24 and st["early_prologue_steps"] == 11, st
+    assert st["early_target_hypernet_steps"] == (9 if et != "0" else 0) and st["early_target_agent_steps"] == (9 if et == "3" else 0), st
+    assert float((la.flat_live - la.flat_target).abs().max()) > 0
 
 
 def test_sampled_batches_early_gather_is_bit_identical(monkeypatch):

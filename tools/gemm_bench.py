@@ -59,6 +59,18 @@ def dw(R, N, K, batch=1, splits=256):
 
 
 only = sys.argv[2] if len(sys.argv) > 2 else ""      # e.g. "kv": just the dominant shape (for PMC runs)
+if only == "dvfs":
+    # the same launch on random, small-magnitude and all-zero operands: the chip clocks to its power budget (MI355X_MICROARCH.md,
+    # "DVFS give-back"), so the operand DATA moves the rate of a matrix-bound kernel -- how far is the 2.4 GHz peak reachable?
+    M, N, K, batch = NE, 256, 128, 4
+    for name, fill in (("random N(0,1)", lambda t: t.normal_()), ("zeros", lambda t: t.zero_()), ("ones", lambda t: t.fill_(1.0)),
+                       ("random N(0,1) again", lambda t: t.normal_())):
+        x = torch.empty(M, K * batch, device=dev); fill(x)
+        W = torch.empty(batch, N, K, device=dev); fill(W)
+        y = torch.empty(batch, M, N, device=dev)
+        fn = lambda: hip_ops.gemm(x, W, y, M, N, K, K * batch, K, N, batch=batch, sA=K, sB=N * K, sC=M * N, sBias=N)
+        timeit(f"NT kv {name}", fn, 2.0 * M * N * K * batch)
+    sys.exit(0)
 if only == "dw":
     dw(NE, 256, 128, batch=4, splits=128)
     dw(3 * NA, 128, 128, splits=486)
