@@ -32,6 +32,15 @@
 
 namespace refil {
 
+#ifdef REFIL_WR_TIMING
+// debug build only (REFIL_EXTRA_FLAGS=-DREFIL_WR_TIMING; tools/probes/wres_timing.py): per-wave cycle sums (shader clock) of the
+// tile phases, read back through refil_debug_wres_timing
+__device__ unsigned long long g_wr_dbg[8192 * 4];
+#define WR_TICK(acc_) { const unsigned long long t1_ = __builtin_readcyclecounter(); acc_ += t1_ - t0_; t0_ = t1_; }
+#else
+#define WR_TICK(acc_)
+#endif
+
 struct WresK {
     const float* A; const float* W; float* C; const float* bias; const uint8_t* rowmask; const float* aux;
     int M, N, K, lda, ldw, ldc;
@@ -168,6 +177,9 @@ __global__ __launch_bounds__(64 * WR_WAVES, (wres_smem(TN, NC, NPASS) <= 80 * 10
         for (int i = 0; i < 4 * TN; ++i) buf_st4(none, BUF_OOB - 16 * i, z);
     }
 
+#ifdef REFIL_WR_TIMING
+    unsigned long long t_top = 0, t_mf = 0, t_ep = 0, n_t = 0, t0_ = __builtin_readcyclecounter();
+#endif
     while (tile < ntiles) {
         const int next = tile + stride;
         int nnrow = 0;
@@ -200,6 +212,7 @@ __global__ __launch_bounds__(64 * WR_WAVES, (wres_smem(TN, NC, NPASS) <= 80 * 10
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        WR_TICK(t_top)
         // W fragments are read one chunk ahead of the MFMAs that use them (LDS latency off the MFMA issue path)
         float4 bq[2][TN];
 #pragma unroll
@@ -238,6 +251,7 @@ __global__ __launch_bounds__(64 * WR_WAVES, (wres_smem(TN, NC, NPASS) <= 80 * 10
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        WR_TICK(t_mf)
         // epilogue: one 32 x 32 tile at a time through the wave-private slab (same-wave LDS ops execute in order);
         // the transposed rows stay in registers (they replace the accumulators) until all of them are ready
         float4 outv[TN][4];
@@ -288,7 +302,17 @@ __global__ __launch_bounds__(64 * WR_WAVES, (wres_smem(TN, NC, NPASS) <= 80 * 10
         tile = next;
         csrc = nsrc;
         if (IDX) { currow = nrow; nrow = nnrow; }
+        WR_TICK(t_ep)
+#ifdef REFIL_WR_TIMING
+        ++n_t;
+#endif
     }
+#ifdef REFIL_WR_TIMING
+    if (lane == 0) {
+        const int w = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * WR_WAVES + wave;
+        if (w < 8192) { g_wr_dbg[4 * w] = t_top; g_wr_dbg[4 * w + 1] = t_mf; g_wr_dbg[4 * w + 2] = t_ep; g_wr_dbg[4 * w + 3] = n_t; }
+    }
+#endif
 }
 
 static inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -443,3 +467,9 @@ int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st) {
 }
 
 }  // namespace refil
+
+#ifdef REFIL_WR_TIMING
+extern "C" int refil_debug_wres_timing(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(refil::g_wr_dbg), (size_t)n * 4 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif

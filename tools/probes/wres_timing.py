@@ -23,7 +23,7 @@ torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); fn(); e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3
-nw = 1024
+nw = 2048
 buf = (C.c_ulonglong * (4 * nw))()
 rc = _lib.lib().refil_debug_wres_timing(buf, nw)
 assert rc == 0
