@@ -117,7 +117,7 @@ def densify(data):
     return d
 
 
-def build(dims, imagine, B, T, seed, device, shard=None, dense=False, fresh=0):
+def build(dims, imagine, B, T, seed, device, shard=None, dense=False, fresh=0, host_buffer=False):
     """shard = (rank, world): strong scaling -- generate the GLOBAL batch of B episodes and keep this rank's slice.
     fresh = K > 0: additionally a device ReplayBuffer holding K*B episodes (K independently seeded batches)."""
     from refil_amd.components.episode_buffer import EpisodeBatch
@@ -158,7 +158,9 @@ def build(dims, imagine, B, T, seed, device, shard=None, dense=False, fresh=0):
     buffer = None
     if fresh > 0:
         from refil_amd.components.episode_buffer import ReplayBuffer
-        buffer = ReplayBuffer(scheme, groups, fresh * B, T + 1, preprocess={"actions": ("actions_onehot", [OneHot(dims["A"])])}, device=device)
+        # host_buffer: the reference's buffer_cpu_only layout -- pinned host storage, device minibatches gathered over PCIe
+        buffer = ReplayBuffer(scheme, groups, fresh * B, T + 1, preprocess={"actions": ("actions_onehot", [OneHot(dims["A"])])},
+                              device="cpu" if host_buffer else device, sample_device=device if host_buffer else None)
         for k in range(fresh):
             dk = data if k == 0 else make_batch_fast(B, T, dims["ne"], seed=seed + 1000 * k)
             if dense and k:
@@ -296,6 +298,8 @@ def main():
     ap.add_argument("--fresh-batches", type=int, default=0, help="K > 0: a device replay buffer of K*B episodes is filled once and every step "
                     "trains on a FRESH ReplayBuffer.sample(B) drawn INSIDE the timed region (the gather launch and stale row-count hints "
                     "are part of the step); default: one resident batch")
+    ap.add_argument("--host-buffer", action="store_true", help="with --fresh-batches K: the replay buffer lives in pinned HOST memory (the reference's "
+                    "buffer_cpu_only) and every step's sample(B) is gathered over PCIe by the GPU inside the timed region: the PCIe-inclusive rate")
     ap.add_argument("--no-dense-region", action="store_true", help="skip the second short timed region on the densified batch (`dense_data` object)")
     ap.add_argument("--dense-data", action="store_true", help="synthetic data without padding: every entity alive, full-length episodes "
                     "(nothing for the row lists to skip: the dense-equivalent FLOPs are the executed FLOPs)")
@@ -337,11 +341,11 @@ def main():
         assert a.global_batch % world == 0, "--global-batch must be a multiple of the number of GPUs"
         B = a.global_batch // world                        # per rank
         args, batch, learner, data, buffer = build(dims, W["imagine"], a.global_batch, T, seed=100, device=device, shard=(rank, world),
-                                                    dense=a.dense_data, fresh=a.fresh_batches)
+                                                    dense=a.dense_data, fresh=a.fresh_batches, host_buffer=a.host_buffer)
         global_B = a.global_batch
     else:
         B = W["B"]
-        args, batch, learner, data, buffer = build(dims, W["imagine"], B, T, seed=100 + rank, device=device, dense=a.dense_data, fresh=a.fresh_batches)
+        args, batch, learner, data, buffer = build(dims, W["imagine"], B, T, seed=100 + rank, device=device, dense=a.dense_data, fresh=a.fresh_batches, host_buffer=a.host_buffer)
         global_B = B * world
 
     if a.serial:
@@ -588,7 +592,7 @@ def main():
                        "global_batch": global_B, "seq_len": T, "parallelism": f"dp{world}",
                        "world_size": dist.get_world_size() if world > 1 else 1, "backend": backend,
                        "algorithmic_gflop_per_step_per_gpu": round(flops_step / 1e9, 2),
-                       "batches": f"{a.fresh_batches} x B episodes in a device ReplayBuffer, a fresh sample(B) per step inside the timed region" if a.fresh_batches
+                       "batches": f"{a.fresh_batches} x B episodes in a {'pinned-HOST (PCIe-inclusive: the gather reads host memory)' if a.host_buffer else 'device'} ReplayBuffer, a fresh sample(B) per step inside the timed region" if a.fresh_batches
                                   else "one resident minibatch (every step trains on the same episodes)",
                        "padding": "none (--dense-data: every entity alive, full-length episodes)" if a.dense_data else "SC2-law padding / deaths / ragged episode ends",
                        "schedule_autotune": {"chosen": tuned or "built-in defaults", "parity_tested_values": {k: list(v) for k, v in tuning.PARITY_TESTED.items()},

@@ -130,7 +130,9 @@ typedef struct refil_batch {
      * loads); 0 = unknown. The target networks' forward depends on the batch fields and on params_target alone: on a call whose
      * ready_event is set AND whose target_version (non-zero) and params_target pointer equal the previous call's, it is
      * enqueued right behind the early prologue, on the library's hypernet-chain stream -- beside the END of the previous step --
-     * instead of inside this step's forward. Same kernels, same data: results are bit-identical. The
+     * instead of inside this step's forward, and the composed out_trans o fc2 maps of the target nets
+     * (functions of params_target alone) are kept from the previous call instead of being rebuilt. Same kernels, same data:
+     * results are bit-identical. Pass 0 on the first call after the workspace was (re)allocated or zeroed. The
      * caller must keep params_target unchanged until the work enqueued on `stream` by this call has completed, or change
      * target_version at the next call. */
     uint64_t target_version;
@@ -403,7 +405,9 @@ typedef struct refil_gru_desc {
     float* save_r; float* save_z; float* save_n; float* save_ghn;
     /* backward */
     const float* dhs;        /* [(gb*T1+t)*na+i, H] external gradient on h_t (from fc3)           */
-    float* dgi; float* dgh;  /* [(gb*T1+t)*na+i, 3H] outputs                                      */
+    float* dgi;              /* [(gb*T1+t)*na+i, 3H] output: d(gi) = (dr, dz, dn) pre-activation gradients          */
+    float* dgh;              /* [(gb*T1+t)*na+i, H]  output: the n block of d(gh) ONLY -- d(gh) = (dgi_r, dgi_z, dgh): the
+                                r / z blocks equal dgi's (GRUCell adds gi and gh there) and are not stored twice          */
     int32_t NR, T1, na, H;
     /* optional: t_last[b] for b = gb % B -- the recurrence of episode b stops after step t_last[b] (forward: later
      * hsx / save slots are left untouched; backward: starts there and writes zeros to dgi / dgh of the later steps). */

@@ -168,16 +168,31 @@ class ReplayBuffer(EpisodeBatch):
     one int64 word per row (bit j = mask[.., i, j]), 8 bytes instead of ne: `insert_episode_batch`
     packs (refil_pack_mask_bits), `sample` expands the sampled episodes into the staging minibatch inside the one gather
     launch, and `buffer["obs_mask"]` / `buffer[ids]` expand on demand with torch ops (API compatibility, not a hot path).
-    pack_masks=False keeps the bytes."""
+    pack_masks=False keeps the bytes.
+
+    Host-resident buffers (`buffer_cpu_only: True`, src/run.py:199-200,272-273, default.yaml:17): with device="cpu" and
+    sample_device=<the learner's GPU> the storage lives in PINNED host memory and `sample()` hands out a DEVICE minibatch:
+    the same one-launch gather reads the sampled episodes straight out of host memory (the pinned pages are mapped into
+    the GPU's address space: a zero-copy read over PCIe, no host-side fancy indexing, no staging copy), on the library's side
+    stream, beside the previous train step -- the reference's `episode_sample.to(args.device)` (a synchronous fancy-index copy
+    on the host followed by a blocking H2D) has nothing left to do. Inserts are host writes: they wait for gathers in flight."""
 
     PACKABLE = ("obs_mask", "gt_mask")
 
-    def __init__(self, scheme, groups, buffer_size, max_seq_length, preprocess=None, device="cpu", pack_masks=None):
+    def __init__(self, scheme, groups, buffer_size, max_seq_length, preprocess=None, device="cpu", pack_masks=None, sample_device=None):
         super().__init__(scheme, groups, buffer_size, max_seq_length, preprocess=preprocess, device=device)
         self.buffer_size = buffer_size
         self.buffer_index = 0
         self.episodes_in_buffer = 0
         self._packed = {}            # key -> int64 [N, T1, rows] words; the byte tensor of the key is dropped
+        self.sample_device = None    # host-resident storage, device minibatches (see the class docstring)
+        self._write_count = 0
+        self._gather_done = None     # event behind the last zero-copy gather (host writes wait for it)
+        if sample_device is not None and th.device(device).type == "cpu" and th.device(sample_device).type == "cuda":
+            self.sample_device = th.device(sample_device)
+            for store in (self.data.transition_data, self.data.episode_data):
+                for k in store:
+                    store[k] = store[k].pin_memory()
         on_gpu = th.device(device).type == "cuda"
         if pack_masks is None:
             pack_masks = on_gpu
@@ -212,6 +227,9 @@ class ReplayBuffer(EpisodeBatch):
             self._packed[k] = self._packed[k].to(device)
 
     def update(self, data, bs=slice(None), ts=slice(None), mark_filled=True):
+        if self._gather_done is not None:                   # host-resident storage: a gather launch may still be reading it
+            self._gather_done.synchronize()
+        self._write_count = getattr(self, "_write_count", 0) + 1
         packed = {k: v for k, v in data.items() if k in self._packed}
         if packed:
             sl = self._parse_slices((bs, ts))
@@ -281,6 +299,13 @@ class ReplayBuffer(EpisodeBatch):
         the next one (with REFIL_EARLY=0 / REFIL_HIPGRAPH=1: a single one, overwritten by the next call); pass copy=True to get
         an independent batch (the reference always returns a fresh copy) when more samples must be alive at once."""
         assert self.can_sample(batch_size)
+        if self.sample_device is not None:
+            out = self._sample_host(batch_size)
+            if copy:
+                out = EpisodeBatch(out.scheme, out.groups, out.batch_size, out.max_seq_length, device=out.device,
+                                   data=SimpleNamespace(transition_data={k: v.clone() for k, v in out.data.transition_data.items()},
+                                                        episode_data={k: v.clone() for k, v in out.data.episode_data.items()}))
+            return out
         if self.episodes_in_buffer == batch_size:
             return self[:batch_size]
         ep_ids = np.random.choice(self.episodes_in_buffer, batch_size, replace=False)     # uniform, w/o replacement
@@ -307,21 +332,55 @@ class ReplayBuffer(EpisodeBatch):
             raise IndexError(f"episode ids must lie in [0, {self.buffer_size})")
         nfields = len(self.data.transition_data) + len(self.data.episode_data) + len(self._packed)
         if nfields > _lib.MAX_GATHER_FIELDS:            # (more scheme keys than one gather launch takes: the reference's path)
-            return self[ep_ids]
+            out = self[ep_ids]
+            if self.sample_device is not None:
+                out.to(self.sample_device)
+            return out
         early = os.environ.get("REFIL_EARLY") != "0" and os.environ.get("REFIL_HIPGRAPH") != "1"
+        return self._gather_on(ep_ids, n, early, self.device)
+
+    # -- host-resident storage, device minibatches (buffer_cpu_only) -------------------------------
+    def _draw(self, n):
+        """episode_buffer.py:233-240: the first n episodes when the buffer holds exactly n, else uniform without replacement"""
+        if self.episodes_in_buffer == n:
+            return np.arange(n)
+        return np.random.choice(self.episodes_in_buffer, n, replace=False)
+
+    def _sample_host(self, n):
+        """Host-resident storage: the one-launch gather reads the sampled episodes out of pinned host memory (zero-copy over PCIe)
+        into a device staging minibatch, on the library's side stream like a device buffer's early gather. Measured and NOT
+        adopted: a look-ahead gather of the NEXT call's sample on a stream of the buffer's own (exact: the generator was put back
+        after the look-ahead draw and the prefetch dropped when anything had changed) -- a fifth busy stream is a cliff on this
+        runtime (cfg-T 2.28 -> 3.15 ms per step, cfg2 0.93 -> 2.25; DESIGN.md lesson 23), and on one of the step's four streams
+        the gather sits in front of that stream's chain whichever one it is."""
+        import ctypes  # noqa: F401
+        dev = self.sample_device
+        ep_ids = np.ascontiguousarray(self._draw(n), dtype=np.int64)
+        early = os.environ.get("REFIL_EARLY") != "0" and os.environ.get("REFIL_HIPGRAPH") != "1"
+        with th.cuda.device(dev):
+            out = self._gather_on(ep_ids, n, early, dev)
+            if self._gather_done is None:
+                self._gather_done = th.cuda.Event()
+            side = self._staging[n].get("side")
+            self._gather_done.record(side if (early and side is not None) else th.cuda.current_stream(dev))
+        return out
+
+    def _gather_on(self, ep_ids, n, early, dev):
+        import ctypes as C
+        from .. import _lib
         st = self._staging.get(n) if hasattr(self, "_staging") else None
         if st is None:
             if not hasattr(self, "_staging"):
                 self._staging = {}
             slots = []
             for _ in range(2):                             # two staging minibatches: the previous sample may still be training
-                tdata = {k: th.zeros((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device) for k, v in self.data.transition_data.items()}
+                tdata = {k: th.zeros((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev) for k, v in self.data.transition_data.items()}
                 for k, words in self._packed.items():      # the staging minibatch holds the BYTES the learner's C ABI takes
-                    tdata[k] = th.zeros((n,) + tuple(words.shape[1:]) + (self._packed_width[k],), dtype=th.uint8, device=self.device)
-                batch = EpisodeBatch(self.scheme, self.groups, n, self.max_seq_length, device=self.device,
+                    tdata[k] = th.zeros((n,) + tuple(words.shape[1:]) + (self._packed_width[k],), dtype=th.uint8, device=dev)
+                batch = EpisodeBatch(self.scheme, self.groups, n, self.max_seq_length, device=dev,
                                      data=SimpleNamespace(
                                          transition_data=tdata,
-                                         episode_data={k: th.zeros((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device)
+                                         episode_data={k: th.zeros((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=dev)
                                                        for k, v in self.data.episode_data.items()}))
                 fields = (_lib.GatherField * _lib.MAX_GATHER_FIELDS)()
                 nf = 0
@@ -338,7 +397,7 @@ class ReplayBuffer(EpisodeBatch):
                     fields[nf] = _lib.GatherField(words.data_ptr(), dst.data_ptr(), words[0].numel() * 8, dst[0].numel(), dst[0].numel(),
                                                   self._packed_width[k], 0)
                     nf += 1
-                slots.append({"batch": batch, "fields": fields, "nf": nf, "ids_dev": th.empty(n, dtype=th.int64, device=self.device),
+                slots.append({"batch": batch, "fields": fields, "nf": nf, "ids_dev": th.empty(n, dtype=th.int64, device=dev),
                               "handed_out": False})
             ids_host = [(th.empty(n, dtype=th.int64).pin_memory(), th.cuda.Event()) for _ in range(8)]
             st = self._staging[n] = {"slots": slots, "ids_host": ids_host, "slot": 0, "which": 0}
@@ -367,9 +426,9 @@ class ReplayBuffer(EpisodeBatch):
         sp = C.c_void_p()
         _lib.check(_lib.lib().refil_side_stream(C.byref(sp)), "refil_side_stream")
         if st.get("side_ptr") != sp.value:                 # (the library re-creates its streams after refil_release_streams)
-            st["side_ptr"], st["side"] = sp.value, th.cuda.ExternalStream(sp.value, device=self.device)
+            st["side_ptr"], st["side"] = sp.value, th.cuda.ExternalStream(sp.value, device=dev)
         side = st["side"]
-        cur = th.cuda.current_stream(self.device)
+        cur = th.cuda.current_stream(dev)
         wev = getattr(self, "_write_event", None)
         if wev is not None:
             side.wait_event(wev)

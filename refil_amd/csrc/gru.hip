@@ -266,7 +266,8 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
 //   dh = carry + dhs[t];  dn = dh (1-z);  dz = dh (h_{t-1} - n);  carry' = dh z
 //   dn_pre = dn (1-n^2);  dr = dn_pre ghn;  dgh_n = dn_pre r
 //   dr_pre = dr r (1-r);  dz_pre = dz z (1-z)
-//   dgi[t] = (dr_pre, dz_pre, dn_pre);  dgh[t] = (dr_pre, dz_pre, dgh_n);  carry' += dgh[t] W_hh
+//   dgi[t] = (dr_pre, dz_pre, dn_pre);  d(gh)[t] = (dr_pre, dz_pre, dgh_n) -- only dgh_n is STORED (p.dgh: [rows, GH]; the r / z
+//   blocks are dgi's: 41 MB of the 122 MB the recurrence wrote per launch at cfg-T);  carry' += d(gh)[t] W_hh
 template <int GH, bool VALU = false, int PD_ = REFIL_GRU_PD>
 __global__ __launch_bounds__(4 * GH) void gru_bwd4_kernel(GruK p) {
     constexpr int GP = 3 * GH + 4, KS = VALU ? 3 * GH : 3 * GH / 4, NW = GH / 16;
@@ -304,9 +305,9 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd4_kernel(GruK p) {
             const int row = idx / (3 * GH / 4), c4 = idx % (3 * GH / 4);
             const int r2 = r0 + row;
             if (r2 < p.NR && (!p.ever || p.ever[((r2 / p.na) % p.B) * p.na + r2 % p.na])) {
-                const long o = (((long)(r2 / p.na) * p.T1 + t) * p.na + r2 % p.na) * (3 * GH) + 4 * c4;
-                *reinterpret_cast<float4*>(p.dgi + o) = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(p.dgh + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+                const long orow = ((long)(r2 / p.na) * p.T1 + t) * p.na + r2 % p.na;
+                *reinterpret_cast<float4*>(p.dgi + orow * (3 * GH) + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c4 < GH / 4) *reinterpret_cast<float4*>(p.dgh + orow * GH + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     }
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd4_kernel(GruK p) {
     for (int u = 0; u < PD; ++u) {                         // (issue order = ring order; dropped stores: see the forward kernel)
         fetch(ring[u], max(tend - 1 - u, 0));
 #pragma unroll
-        for (int k = 0; k < 6; ++k) stb32(rs_none, 64u * (u * 6 + k), 0.f);
+        for (int k = 0; k < 4; ++k) stb32(rs_none, 64u * (u * 4 + k), 0.f);
         __builtin_amdgcn_sched_barrier(0);
     }
     int it = 0;
@@ -391,8 +392,10 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd4_kernel(GruK p) {
             {
                 constexpr unsigned G1 = GH * sizeof(float);
                 const unsigned o = (valid && live) ? so + 3u * (unsigned)t * row_step : GRU_BUF_DROP;
+                // (the r / z blocks of d(gh) equal d(gi)'s: only the n block of d(gh) is stored, in its own [rows, GH] tensor)
+                const unsigned oh = (valid && live) ? go + (unsigned)t * row_step : GRU_BUF_DROP;
                 stb32(rs_gi, o, dr_pre); stb32(rs_gi, o + G1, dz_pre); stb32(rs_gi, o + 2 * G1, dn_pre);
-                stb32(rs_gh, o, dr_pre); stb32(rs_gh, o + G1, dz_pre); stb32(rs_gh, o + 2 * G1, dghn);
+                stb32(rs_gh, oh, dghn);
             }
         }
     }
@@ -536,7 +539,8 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd16_kernel(GruK2 p2) {
 //   dh = carry + dhs[t];  dn = dh (1-z);  dz = dh (h_{t-1} - n);  carry' = dh z
 //   dn_pre = dn (1-n^2);  dr = dn_pre ghn;  dgh_n = dn_pre r
 //   dr_pre = dr r (1-r);  dz_pre = dz z (1-z)
-//   dgi[t] = (dr_pre, dz_pre, dn_pre);  dgh[t] = (dr_pre, dz_pre, dgh_n);  carry' += dgh[t] W_hh
+//   dgi[t] = (dr_pre, dz_pre, dn_pre);  d(gh)[t] = (dr_pre, dz_pre, dgh_n) -- only dgh_n is STORED (p.dgh: [rows, GH]; the r / z
+//   blocks are dgi's: 41 MB of the 122 MB the recurrence wrote per launch at cfg-T);  carry' += d(gh)[t] W_hh
 template <int GH>
 __global__ __launch_bounds__(4 * GH) void gru_bwd16_kernel(GruK p) {
     constexpr int GP = 3 * GH + 4, KQ = 3 * GH / 4, NW = GH / 16;
@@ -595,9 +599,9 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd16_kernel(GruK p) {
             const int row = idx / (3 * GH / 4), c4 = idx % (3 * GH / 4);
             const int rr = r0 + row;
             if (rr < p.NR && (!p.ever || p.ever[((rr / p.na) % p.B) * p.na + rr % p.na])) {
-                const long o = (((long)(rr / p.na) * p.T1 + t) * p.na + rr % p.na) * (3 * GH) + 4 * c4;
-                *reinterpret_cast<float4*>(p.dgi + o) = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(p.dgh + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+                const long orow = ((long)(rr / p.na) * p.T1 + t) * p.na + rr % p.na;
+                *reinterpret_cast<float4*>(p.dgi + orow * (3 * GH) + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c4 < GH / 4) *reinterpret_cast<float4*>(p.dgh + orow * GH + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     }
@@ -666,7 +670,7 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd16_kernel(GruK p) {
                 constexpr unsigned G1 = GH * sizeof(float);
                 const unsigned o = so[reg] + 3u * (unsigned)t * row_step;
                 stg32(p.dgi, o, sv[reg][0]); stg32(p.dgi, o + G1, sv[reg][1]); stg32(p.dgi, o + 2 * G1, sv[reg][2]);
-                stg32(p.dgh, o, sv[reg][0]); stg32(p.dgh, o + G1, sv[reg][1]); stg32(p.dgh, o + 2 * G1, sv[reg][3]);
+                stg32(p.dgh, go[reg] + (unsigned)t * row_step, sv[reg][3]);      // n block of d(gh) only: [rows, GH]
             }
         }
     };
@@ -761,7 +765,7 @@ int gru_backward_launch(const refil_gru_desc& d, hipStream_t st) {
     REFIL_CHECK(d.NR > 0 && d.T1 > 0 && d.na > 0, "refil_gru_backward: bad sizes");
     REFIL_CHECK((!d.t_last && !d.ever) || d.B > 0, "refil_gru: t_last / ever need B");
     GruK k = gru_k(d);
-    ProfScope prof("gru_bwd_kernel", 2.0 * d.NR * d.T1 * GH * 3 * GH, 4.0 * d.NR * d.T1 * GH * 12.0, st);
+    ProfScope prof("gru_bwd_kernel", 2.0 * d.NR * d.T1 * GH * 3 * GH, 4.0 * d.NR * d.T1 * GH * 10.0, st);
     if (gru_rows_per_wg(d.NR) == GROWS) {
         if (GH == 32) hipLaunchKernelGGL(gru_bwd16_kernel<32>, dim3(cdiv(d.NR, GROWS)), dim3(128), 0, st, k);
         else if (GH == 64) hipLaunchKernelGGL(gru_bwd16_kernel<64>, dim3(cdiv(d.NR, GROWS)), dim3(256), 0, st, k);

@@ -82,7 +82,9 @@ class LearnerEngine:
         # and the allocator may hand a new arena the address of an old one the library remembers the layout of)
         if ready_event is not None and not b._converted and not self.ws.fresh:
             b.ready_event = ready_event.cuda_event
-        b.target_version = int(target_version) & 0xFFFFFFFFFFFFFFFF         # (refil_batch.target_version: early target forward)
+        # (refil_batch.target_version: early target forward, kept composed maps -- never on a new arena: it is zero-filled, and the
+        # allocator may have given it the address of an old one the library still remembers)
+        b.target_version = 0 if self.ws.fresh else int(target_version) & 0xFFFFFFFFFFFFFFFF
         self.ws.fresh = False
         dbg = None
         out = {}

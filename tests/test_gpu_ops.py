@@ -382,10 +382,11 @@ def test_gru_forward_backward(GB, T1, na, H, valu, pd, monkeypatch, set_tuning):
     hip_ops.gru_forward(d)
     _close(hsx[:, 1:], hs, what="gru hs")
     dgi = torch.full((GB * T1 * na, 3 * H), float("nan"), device=DEV)
-    dgh = torch.full((GB * T1 * na, 3 * H), float("nan"), device=DEV)
+    dgh = torch.full((GB * T1 * na, H), float("nan"), device=DEV)           # the n block of d(gh) only (refil_gru_desc.dgh)
     d = hip_ops.gru_desc(gi, hsx, whh, bhh, NR, T1, na, H=H, saves=saves, dhs=dhs.to(DEV), dgi=dgi, dgh=dgh)
     hip_ops.gru_backward(d)
-    dgi_c, dgh_c = dgi.cpu(), dgh.cpu()
+    dgi_c = dgi.cpu()
+    dgh_c = torch.cat([dgi_c[:, :2 * H], dgh.cpu()], dim=1)                  # d(gh) = (dgi_r, dgi_z, dgh_n)
     _close(dgi_c.sum(0), b_ih.grad, tol=1e-4, what="db_ih")
     _close(dgh_c.sum(0), b_hh.grad, tol=1e-4, what="db_hh")
     _close(dgi_c.t() @ x.detach().reshape(-1, H), w_ih.grad, tol=1e-4, what="dW_ih")
@@ -574,12 +575,12 @@ def test_gru_time_bounds(T1, t_last, H, pd, set_tuning):
         if skip:
             hip_ops.gru_skip(d, t_last.to(DEV), B)
         hip_ops.gru_forward(d)
-        dgi = torch.full((GB * T1 * na, 3 * H), 9.0, device=DEV); dgh = torch.full((GB * T1 * na, 3 * H), 9.0, device=DEV)
+        dgi = torch.full((GB * T1 * na, 3 * H), 9.0, device=DEV); dgh = torch.full((GB * T1 * na, H), 9.0, device=DEV)
         d = hip_ops.gru_desc(gi, hsx, whh, bhh, NR, T1, na, H=H, saves=saves, dhs=dhs, dgi=dgi, dgh=dgh)
         if skip:
             hip_ops.gru_skip(d, t_last.to(DEV), B)
         hip_ops.gru_backward(d)
-        res.append((hsx.cpu(), dgi.cpu().view(GB, T1, na, 3 * H), dgh.cpu().view(GB, T1, na, 3 * H)))
+        res.append((hsx.cpu(), dgi.cpu().view(GB, T1, na, 3 * H), dgh.cpu().view(GB, T1, na, H)))
     (h_full, gi_full, gh_full), (h_skip, gi_skip, gh_skip) = res
     for gb in range(GB):
         tl = int(t_last[gb % B])

@@ -190,3 +190,35 @@ def test_direct_update_is_ordered_before_the_early_gather():
         s = buf.sample(5)
         th.cuda.synchronize()
         assert (s["reward"] == 1000.0 + it).all(), it
+
+
+@pytest.mark.gpu
+def test_host_resident_buffer_hands_out_device_minibatches():
+    """buffer_cpu_only (run.py:199-200): storage in pinned host memory, sample() = the one-launch gather reading host memory
+    from the GPU. Same episodes, same bytes as the reference's host-side fancy indexing; inserts between samples (ring wrap) are
+    seen; the early path (side stream, alternating staging minibatches) and the in-order path agree."""
+    scheme, groups, pre = _scheme(ne=8, na=4, ed=7, A=5)
+    buf = ReplayBuffer(scheme, groups, 12, 9, preprocess=pre, device="cpu", sample_device="cuda")
+    assert buf.sample_device is not None and all(v.is_pinned() and not v.is_cuda for v in buf.data.transition_data.values())
+    buf.insert_episode_batch(_episodes(7, 9, 10, ne=8, na=4, ed=7, A=5))
+    full = buf.sample(7)                                      # batch == buffer: the first episodes in order, on the device
+    assert full["reward"].is_cuda and full["reward"][:, 0, 0].tolist() == [10.0 + i for i in range(7)]
+    buf.insert_episode_batch(_episodes(9, 9, 50, device="cuda", ne=8, na=4, ed=7, A=5))      # from a device runner; wraps
+    assert buf.episodes_in_buffer == 12 and buf.buffer_index == 4
+    for seed in (1, 2, 3, 4):
+        np.random.seed(seed)
+        got = buf.sample(6)
+        np.random.seed(seed)
+        ids = np.random.choice(12, 6, replace=False)
+        ref = buf[ids]                                        # host-side fancy indexing (the reference's path)
+        th.cuda.synchronize()
+        assert got.device == th.device("cuda") or str(got.device).startswith("cuda")
+        for k, v in ref.data.transition_data.items():
+            assert got[k].is_cuda and th.equal(got[k].cpu(), v), k
+        for k, v in ref.data.episode_data.items():
+            assert th.equal(got[k].cpu(), v), k
+        if seed == 2:                                         # a host write between two samples waits for the gather in flight
+            buf.update({"reward": th.full((12, 9, 1), 777.0)}, mark_filled=False)
+            np.random.seed(99)
+            assert (buf.sample(6)["reward"] == 777.0).all()
+

@@ -14,6 +14,8 @@ import bench  # noqa: E402
 cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 W = dict(bench.CONFIGS[cfg])
+if len(sys.argv) > 3:
+    W["B"] = int(sys.argv[3])            # episodes per step (the strong-scaling regime: B = 4 / 8)
 dims = bench.workload_dims(W)
 _, batch, learner, _, _ = bench.build(dims, W["imagine"], W["B"], W["T"], seed=100, device=torch.device("cuda:0"))
 for i in range(10):
