@@ -6,7 +6,7 @@
 #   3b. the same step without a tracer (HIP events of the library profiler)                 -> gpurun_out/<tag>_timeline_untraced.txt
 #   4. the bench line of every BASELINE.json config (cfgT with the CPU baseline and the PMC traffic of step 2)
 # Copy the summaries into profiles/ afterwards (tools/pmc_summarize.py folds step 2).
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -58,4 +58,10 @@ for b in 4 8 16; do python bench.py --batch $b --no-cpu-baseline --no-profile --
 python tools/probes/graph_capture.py 30 cfg2 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_hipgraph_cfg2.txt
 python tools/probes/wres_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_wres_bench.txt
 REFIL_EARLY=0 python bench.py --no-cpu-baseline --no-profile --no-traffic 2>/dev/null | cut -c1-330 > $OUT/${TAG}_bench_cfgT_no_early_prologue.txt
+REFIL_EARLY_TARGET=0 python bench.py --no-cpu-baseline --no-profile --no-traffic 2>/dev/null | cut -c1-330 > $OUT/${TAG}_bench_cfgT_no_early_target.txt
+# the replay buffer in pinned HOST memory (buffer_cpu_only): the PCIe-inclusive rate
+python bench.py --fresh-batches 8 --host-buffer --no-cpu-baseline --no-traffic > $OUT/${TAG}_bench_cfgT_host_buffer.json 2> /dev/null
+# what the fp32 matrix pipes sustain on real operand data (DVFS): bare MFMA streams, and the dominant projection on random / zero data
+hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_dvfs_probe.hip -o /tmp/mfma_dvfs_probe 2>/dev/null && /tmp/mfma_dvfs_probe > $OUT/${TAG}_mfma_dvfs_probe.txt 2>&1
+python tools/gemm_bench.py 50 dvfs 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_gemm_dvfs.txt
 ls -la $OUT | grep ${TAG}_
