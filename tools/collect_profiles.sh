@@ -19,12 +19,12 @@ for c in cfgT cfg2 cfg3 cfg4 cfg5; do python $ROOT/bench.py --config $c --steps 
 for b in 4 8 16; do python $ROOT/bench.py --batch $b --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-traffic > /dev/null 2>&1; done
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o p -- \
-    python $ROOT/bench.py --no-cpu-baseline --no-traffic > $OUT/${TAG}_bench_n1_under_rocprofv3.json 2> $OUT/${TAG}_stats.log
+    python $ROOT/bench.py --no-cpu-baseline --no-traffic --no-dense-region > $OUT/${TAG}_bench_n1_under_rocprofv3.json 2> $OUT/${TAG}_stats.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_serial -o p -- \
-    python $ROOT/bench.py --no-cpu-baseline --no-traffic --serial > $OUT/${TAG}_bench_n1_serial_under_rocprofv3.json 2> $OUT/${TAG}_stats_serial.log
+    python $ROOT/bench.py --no-cpu-baseline --no-traffic --no-dense-region --serial > $OUT/${TAG}_bench_n1_serial_under_rocprofv3.json 2> $OUT/${TAG}_stats_serial.log
 for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${TAG}_pmc_$c -o p -- \
-        python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-traffic --serial > $OUT/${TAG}_pmc_$c.log 2>&1
+        python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-traffic --no-dense-region --serial > $OUT/${TAG}_pmc_$c.log 2>&1
 done
 cd $ROOT
 python tools/trace_step.py $(find $OUT/${TAG}_stats_serial -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_timeline_serial.txt
@@ -42,7 +42,7 @@ for c in cfg2 cfg3 cfg4 cfg5; do
     python bench.py --config $c --no-traffic > $OUT/${TAG}_bench_$c.json 2> $OUT/${TAG}_bench_$c.err
     # per-config rocprofv3 summary with the chains serialised (each kernel alone on the GPU: the kernel's own duration)
     (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_$c -o p -- \
-        python $ROOT/bench.py --config $c --no-cpu-baseline --no-traffic --serial --steps 20 --warmup 5 > /dev/null 2>&1)
+        python $ROOT/bench.py --config $c --no-cpu-baseline --no-traffic --no-dense-region --serial --steps 20 --warmup 5 > /dev/null 2>&1)
     cp $(find $OUT/${TAG}_stats_$c -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${c}_kernel_stats_serial.csv
     rm -rf $OUT/${TAG}_stats_$c
 done

@@ -14,7 +14,7 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_BUSY_CU_CYCLES SQ_WAVE
   g=$(echo $grp | tr ' ' '_')
   (cd /tmp && rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/probe_$g -o p -- /tmp/mfma_probe > $OUT/probe_$g.log 2>&1)
   (cd /tmp && rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/bench_$g -o p -- \
-      python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --serial --no-traffic > $OUT/bench_$g.log 2>&1)
+      python $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --serial --no-traffic --no-dense-region > $OUT/bench_$g.log 2>&1)
 done
 python tools/pmc_mfma.py $OUT > $OUT/summary.txt 2>&1
 cp $OUT/mfma.json $ROOT/gpurun_out/${TAG}_pmc_mfma.json; cp $OUT/summary.txt $ROOT/gpurun_out/${TAG}_pmc_mfma_summary.txt 2>/dev/null
