@@ -538,6 +538,10 @@ def main():
         gemm_iso = iso.get(gemm["name"], gemm) if gemm else None
         roofline = {"kernel": dom["name"], "bound": "hbm" if hbm_bound else "mfma", "achieved": round(ach_iso, 2), "peak": peak,
                     "unit": unit, "frac": round(ach_iso / peak, 4), "traffic": traffic,
+                    "peak_note": "peak = 256 CU x 2.4 GHz x 256 FLOP/clk (MI355X_MICROARCH.md). On real operand data the part clocks to its power "
+                                 "budget: cycle counters inside this kernel give 97.5 % MFMA issue in its main loop, 80 % over the row tile, at an "
+                                 "effective 1.9 GHz (profiles/r04_wres_timing_slab_vs_pipe.txt); the same launch runs 113 TFLOP/s on zeros, 92-103 on "
+                                 "N(0,1) (profiles/r04_gemm_dvfs.txt); DESIGN.md lessons 25-27" if not hbm_bound else None,
                     "traffic_unit": f"HBM bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE, {traffic_src})",
                     "hbm_gb_per_step": None if hbm_step is None else round(hbm_step / 1e9, 3),
                     "hbm_gb_per_s_over_step": None if hbm_step is None else round(hbm_step / (ms_per_step * 1e-3) / 1e9, 1),

@@ -1,0 +1,44 @@
+"""Policy around the launch-size knobs (refil_amd/tuning.py): what a timed run may use is a closed, parity-tested set; the autotuner
+is opt-in; its key ignores the batch length and size (the reference's run loop trims every sampled batch to max_t_filled(),
+src/run.py:269-270: a key with T1 in it would re-tune per distinct episode length)."""
+import pytest
+
+from refil_amd import _lib, tuning
+
+
+def _dims(B, T1, ne=32):
+    return _lib.make_dims(B=B, T1=T1, ne=ne, na=ne // 2, ed=62, A=22, d=128, heads=4, H=64, hyp=128, M=32, entity_last_action=1,
+                          imagine=1, softmax_mixing_weights=1, double_q=1, gamma=0.99, lmbda=0.5)
+
+
+def test_bucket_key_ignores_batch_length_and_size_within_a_row_bucket():
+    k = tuning.bucket_key(_dims(32, 81))
+    assert k == tuning.bucket_key(_dims(32, 80)) == tuning.bucket_key(_dims(32, 70))      # the same power-of-two row bucket
+    assert k == tuning.bucket_key(_dims(16, 160))                                          # B and T1 are not in the key, their product is
+    assert k != tuning.bucket_key(_dims(32, 40)) and k != tuning.bucket_key(_dims(64, 81))
+    assert k != tuning.bucket_key(_dims(32, 81, ne=16))                                    # network / environment dims are
+    lengths = {tuning.bucket_key(_dims(32, t)) for t in range(2, 152)}                     # every length a 150-step env can produce
+    assert len(lengths) <= 8                                                               # = at most MAX_TUNES measurements
+
+
+def test_only_parity_tested_values_pass():
+    assert tuning.check({"dw4_target": 96, "gru_pd": 2, "dw4_min_out": 2000, "dw_target": 384, "compose_early": 1})
+    for bad in ({"dw4_target": 112}, {"gru_pd": 3}, {"nonsense": 1}, {"dw_target": 1024}):
+        with pytest.raises(ValueError):
+            tuning.check(bad)
+    assert tuning.parse_env("dw4_target=96,gru_pd=2") == {"dw4_target": 96, "gru_pd": 2}
+    with pytest.raises(ValueError):
+        tuning.parse_env("dw4_target=77")
+    for knob, values in tuning.CANDIDATES:                   # what the tuner tries is inside what the tests cover
+        assert all(v in tuning.PARITY_TESTED[knob] for v in values)
+
+
+def test_autotune_is_opt_in(monkeypatch):
+    monkeypatch.delenv("REFIL_AUTOTUNE", raising=False)
+    assert tuning.mode() == "off"
+    monkeypatch.setenv("REFIL_AUTOTUNE", "0")
+    assert tuning.mode() == "off"
+    monkeypatch.setenv("REFIL_AUTOTUNE", "1")
+    assert tuning.mode() == "measure"
+    monkeypatch.setenv("REFIL_AUTOTUNE", "gru_pd=2")
+    assert tuning.mode() == {"gru_pd": 2}
