@@ -168,3 +168,45 @@ def test_first_call_autotune(monkeypatch):
         QLearner._TUNED.update(saved)
         QLearner._MEASURED[0] = measured
         QLearner._apply_tuning({})
+
+
+@pytest.mark.parametrize("cfg,B", [("cfgT", 32), ("cfg2", 32), ("cfg4", 16)])
+def test_unsynchronised_steps_equal_in_order_steps(cfg, B, monkeypatch):
+    """The race check the early paths need: WITHOUT a host synchronisation between the steps the early prologue and the early target
+    forward of step k+1 really run beside the tail of step k (the other tests synchronise after every step, where nothing is left to
+    overlap with). 40 back-to-back steps on two alternating batches with target syncs every 7 steps, against the same steps in order
+    (no ready event): bit-identical parameters, optimiser state and target parameters."""
+    import bench
+    monkeypatch.delenv("REFIL_EARLY", raising=False)
+    monkeypatch.delenv("REFIL_EARLY_TARGET", raising=False)
+    W = dict(bench.CONFIGS[cfg])
+    dims = bench.workload_dims(W)
+    dev = torch.device("cuda", 0)
+    _, b1, la, _, _ = bench.build(dims, W["imagine"], B, W["T"], seed=100, device=dev)
+    _, b2, lb, _, _ = bench.build(dims, W["imagine"], B, W["T"], seed=200, device=dev)
+    la._check_flat(); lb._check_flat()
+    la.args.target_update_interval = lb.args.target_update_interval = 7
+
+    class Plain:
+        def __init__(self, b):
+            self._b = b
+            self.ready_event = None
+
+        def __getattr__(self, k):
+            return getattr(self._b, k)
+
+        def __getitem__(self, k):
+            return self._b[k]
+
+    from refil_amd import _lib
+    e0 = _lib.get_stat("early_target_hypernet_steps")
+    for rnd in range(2):
+        for i in range(20):
+            la.train((b1, b2)[i % 2], t_env=0, episode_num=20 * rnd + i)        # no synchronisation: 20 steps in flight
+        torch.cuda.synchronize()
+        for i in range(20):
+            lb.train(Plain((b1, b2)[i % 2]), t_env=0, episode_num=20 * rnd + i)
+        torch.cuda.synchronize()
+        assert torch.equal(la.flat_live, lb.flat_live), f"round {rnd}: max |d| = {(la.flat_live - lb.flat_live).abs().max().item():.3e}"
+        assert torch.equal(la.flat_target, lb.flat_target) and torch.equal(la.square_avg, lb.square_avg)
+    assert _lib.get_stat("early_target_hypernet_steps") - e0 >= 28
