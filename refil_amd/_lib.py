@@ -146,6 +146,10 @@ def lib():
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -m refil_amd.build` (hipcc, gfx950). "
             "refil_amd has no CPU/PyTorch fallback for the learner hot path.")
+    # PyTorch first: its wheel ships its own HIP runtime (torch/lib/libamdhip64.so). Loaded before it, this library would bind to the
+    # system's copy instead and the process would hold two runtimes -- ours then sees no device ("no ROCm-capable device is detected")
+    # although torch does. With torch's runtime already mapped the loader resolves ours to the same one.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.refil_last_error.restype = C.c_char_p
     L.refil_version.restype = C.c_int
