@@ -97,7 +97,9 @@ struct Arena {
 };
 
 constexpr long PARTIAL_FLOATS = 40L << 20;   // split-K scratch (160 MiB)
-constexpr long DPOOL_FLOATS = 128L << 20;    // partials of the step's deferred reductions (512 MiB; a launch that does not fit reduces at once)
+// partials of the step's deferred split reductions: sized from the parameter count (measured 53-64 x the parameter floats across the
+// BASELINE configs: 28-119 MiB; twice that + a floor; a launch that does not fit reduces at once, gemm_launch_dw)
+static long dpool_floats(const refil_dims& d) { refil_param_layout L; param_layout(d, L); return 128L * L.total + (4L << 20); }
 
 struct AgentBufs {     // one entity-attention recurrent agent evaluation (G mask variants)
     float *x1, *kv, *q, *ao, *x2, *x3, *gi, *hsx, *sr, *sz, *sn, *sg, *qv;
@@ -244,7 +246,7 @@ static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     w.partial2 = a.take<float>(PARTIAL_FLOATS);
     w.partial3 = a.take<float>(PARTIAL_FLOATS);
     w.partial4 = a.take<float>(PARTIAL_FLOATS);
-    w.dpool = a.take<float>(DPOOL_FLOATS);
+    w.dpool = a.take<float>(dpool_floats(d));
     w.t_last = a.take<int>(d.B);
     w.list_ea = a.take<int>(s.NE + 256); w.list_eh = a.take<int>(s.NE + 256); w.list_a = a.take<int>(s.NA + 256);
     w.counts = a.take<int>(8); w.lcnt = a.take<int>(4 * s.R); w.loff = a.take<int>(4 * (s.R + 1));
@@ -1143,7 +1145,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     const char* defer_e = getenv("REFIL_DEFER_REDUCE");       // (read per call: tests compare the modes in one process)
     const int defer_env = defer_e ? atoi(defer_e) : 2;
     DeferredReduce deferred;
-    deferred.pool = c.w.dpool; deferred.cap = DPOOL_FLOATS; deferred.lo = grads; deferred.hi = grads + L.total;
+    deferred.pool = c.w.dpool; deferred.cap = dpool_floats(c.d); deferred.lo = grads; deferred.hi = grads + L.total;
     deferred.mode = defer_env;
     if (defer_env && !g_mixer_hook) c.defer = &deferred;
 
@@ -1639,7 +1641,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         if (cap == hipStreamCaptureStatusNone) REFIL_HIP(hipEventRecord(c.slot_free[c.slot], c.st));
     }
     static const bool defer_log = [] { const char* e = getenv("REFIL_GEMM_LOG"); return e && e[0] == '1'; }();
-    if (defer_log) fprintf(stderr, "refil: %d deferred reductions, %.1f of %.1f MiB of partials\n", deferred.n, deferred.used / 262144.0, DPOOL_FLOATS / 262144.0);
+    if (defer_log) fprintf(stderr, "refil: %d deferred reductions, %.1f of %.1f MiB of partials\n", deferred.n, deferred.used / 262144.0, dpool_floats(c.d) / 262144.0);
     return 0;
 }
 
