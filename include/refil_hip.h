@@ -215,6 +215,17 @@ int refil_oneshot_destroy(void* ctx);
  * refil_clip_rmsprop_step. librccl.so is resolved at the first call (REFIL_RCCL_LIB overrides the name). */
 int refil_allreduce_flat(float* buf, int64_t n_floats, void* comm, void* stream);
 
+/* One whole training step in ONE call (QLearner.train, q_learner.py:66-178: forward, loss, backward, the data-parallel collective
+ * when `comm` is given, clip_grad_norm_ + RMSprop): refil_learner_forward_backward, refil_allreduce_flat (comm != NULL: the caller's
+ * ncclComm_t; NULL: single process) and refil_clip_rmsprop_step enqueued back to back on `stream` -- same kernels, same order, same
+ * results bit for bit as the three calls; one FFI crossing per step for a host whose per-call overhead matters (small shards).
+ * `hyper` = {lr, alpha, eps, weight_decay, grad_norm_clip} (RMSprop as the reference configures it, q_learner.py:37-38,177).
+ * `scratch`: >= 4096 bytes of device memory for the gradient-norm reduction. */
+typedef struct refil_opt_hyper { float lr, alpha, eps, weight_decay, grad_norm_clip; } refil_opt_hyper;
+int refil_learner_step(const refil_dims* dims, const refil_batch* batch, float* params_live, const float* params_target,
+                       float* grads, float* square_avg, const refil_opt_hyper* hyper, void* comm,
+                       void* workspace, size_t workspace_bytes, void* scratch, void* stream);
+
 /* Diagnostics (synchronises the stream): which rows the LAST refil_learner_forward_backward on this workspace / dims
  * actually processed. The step skips rows that cannot influence the loss -- entity rows no query can attend to, query rows
  * of inactive agents, steps after an episode's last loss-carrying step -- through device-side row lists (no host round

@@ -56,6 +56,10 @@ class Batch(C.Structure):
     ]
 
 
+class OptHyper(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("lr", "alpha", "eps", "weight_decay", "grad_norm_clip")]
+
+
 class DebugOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "q", "chosen_q", "target_max_q", "q_tot", "q_tot_imagine", "target_q_tot", "targets")]
@@ -123,7 +127,7 @@ class ProfileEntry(C.Structure):
 
 # every symbol include/refil_hip.h declares (tests/test_abi.py checks the library exports them all)
 EXPORTS = [
-    "refil_get_param_layout", "refil_learner_workspace_bytes", "refil_learner_forward_backward",
+    "refil_get_param_layout", "refil_learner_workspace_bytes", "refil_learner_forward_backward", "refil_learner_step",
     "refil_clip_rmsprop_step", "refil_agent_workspace_bytes", "refil_agent_forward",
     "refil_mixer_workspace_bytes", "refil_mixer_forward", "refil_gemm", "refil_attn_forward",
     "refil_attn_backward", "refil_pool_forward", "refil_pool_backward", "refil_gru_forward", "refil_gru_backward", "refil_last_error", "refil_version",
@@ -160,6 +164,9 @@ def lib():
     L.refil_learner_forward_backward.argtypes = [
         C.POINTER(Dims), C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
         C.POINTER(DebugOut), C.c_void_p]
+    L.refil_learner_step.argtypes = [
+        C.POINTER(Dims), C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(OptHyper), C.c_void_p,
+        C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.refil_clip_rmsprop_step.argtypes = [
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
         C.c_void_p, C.c_void_p, C.c_void_p]

@@ -1654,6 +1654,18 @@ extern "C" int refil_learner_forward_backward(const refil_dims* dims, const refi
     return rc;
 }
 
+extern "C" int refil_learner_step(const refil_dims* dims, const refil_batch* batch, float* params_live, const float* params_target,
+                                  float* grads, float* square_avg, const refil_opt_hyper* hyper, void* comm,
+                                  void* workspace, size_t workspace_bytes_, void* scratch, void* stream) {
+    REFIL_CHECK(dims && hyper && square_avg && scratch, "refil_learner_step: null argument");
+    if (int e = refil_learner_forward_backward(dims, batch, params_live, params_target, grads, workspace, workspace_bytes_, nullptr, stream)) return e;
+    refil_param_layout L;
+    param_layout(*dims, L);
+    if (comm) RUN(refil_allreduce_flat(grads, L.total + REFIL_NSTAT, comm, stream));
+    return refil_clip_rmsprop_step(params_live, grads, square_avg, L.total, hyper->lr, hyper->alpha, hyper->eps, hyper->weight_decay,
+                                   hyper->grad_norm_clip, grads + L.total, scratch, stream);
+}
+
 // Diagnostics of the row lists of the LAST learner step run on `workspace` with these dims (synchronises `stream`):
 // out[0..5] = {row lists active (0/1), listed entity rows of the agent nets, of the hypernets, listed agent rows,
 //              live (b,t) rows, B * T1}. Benchmarks report the live-row fractions next to the dense FLOP count.

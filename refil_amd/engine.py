@@ -102,6 +102,23 @@ class LearnerEngine:
             C.byref(dbg) if dbg is not None else None, _lib.current_stream_ptr()), "refil_learner_forward_backward")
         return out
 
+    def step(self, dims: Dims, fields, group_bits, params_live, params_target, grads, square_avg, lr, alpha, eps, weight_decay, clip,
+             ready_event=None, target_version: int = 0):
+        """refil_learner_step: forward + backward + clip + RMSprop in ONE C call (single process: no collective in between)."""
+        nbytes = lib().refil_learner_workspace_bytes(C.byref(dims))
+        if nbytes == 0:
+            raise RuntimeError("refil_learner_workspace_bytes: " + lib().refil_last_error().decode())
+        wp, wsz = self.ws.ptr_size(nbytes)
+        b = _lib.make_batch(fields, group_bits)
+        if ready_event is not None and not b._converted and not self.ws.fresh:
+            b.ready_event = ready_event.cuda_event
+        b.target_version = 0 if self.ws.fresh else int(target_version) & 0xFFFFFFFFFFFFFFFF
+        self.ws.fresh = False
+        hy = _lib.OptHyper(lr, alpha, eps, weight_decay, clip)
+        check(lib().refil_learner_step(C.byref(dims), C.byref(b), _lib.ptr(params_live), _lib.ptr(params_target), _lib.ptr(grads),
+                                       _lib.ptr(square_avg), C.byref(hy), None, wp, wsz, _lib.ptr(self.scratch), _lib.current_stream_ptr()),
+              "refil_learner_step")
+
     def row_counts(self, dims: Dims):
         """Row-list diagnostics of the last forward_backward with these dims (host sync; benchmarks / tests only)."""
         nbytes = lib().refil_learner_workspace_bytes(C.byref(dims))

@@ -262,6 +262,10 @@ class QLearner:
             self._optimiser_step()
         elif os.environ.get("REFIL_HIPGRAPH") == "1" and group_bits is None:
             self._graphed_step(dims, fields, bits)
+        elif dp.world() == 1 and os.environ.get("REFIL_DP_FORCE") != "1":
+            a = self.args                              # one C call for the whole step (refil_learner_step)
+            self._engine.step(dims, fields, bits, self.flat_live, self.flat_target, self.grads, self.square_avg, a.lr, a.optim_alpha,
+                              a.optim_eps, a.weight_decay, a.grad_norm_clip, ready_event=ready, target_version=self._tv())
         else:
             self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready, target_version=self._tv())
             dp.allreduce_sum_(self.grads)
