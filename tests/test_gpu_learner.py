@@ -643,3 +643,41 @@ def test_deferred_split_reductions_are_bit_identical(mode, monkeypatch):
     for k in ref["grads"]:
         assert torch.equal(got["grads"][k], ref["grads"][k]), k
 
+
+
+def _fuzz_cases(n, seed=2024):
+    """seeded random (shape, algorithm) combinations inside the library's stated limits"""
+    import random
+    rnd = random.Random(seed)
+    out = []
+    for i in range(n):
+        ne = rnd.choice([2, 3, 5, 8, 11, 16, 17, 24, 31, 32, 33, 40, 48, 63, 64])
+        na = rnd.randint(1, max(1, min(ne - 1, 32))) if ne > 1 else 1
+        heads = rnd.choice([1, 2, 4])
+        hd = rnd.choice([4, 8, 16, 32])
+        kw = dict(B=rnd.randint(1, 5), T=rnd.randint(1, 12), ne=ne, na=na, A=rnd.randint(7, 20), d=heads * hd, h=heads * rnd.choice([4, 8, 16, 32]),
+                  heads=heads, H=rnd.choice([32, 64, 128]), M=rnd.choice([1, 7, 16, 32, 33, 64]), imagine=rnd.random() < 0.7,
+                  softmax=rnd.random() < 0.7, tanh=rnd.random() < 0.3, double_q=rnd.random() < 0.8, lmbda=rnd.choice([0.0, 0.3, 0.5, 1.0]),
+                  seed=1000 + i)
+        out.append(kw)
+    return out
+
+
+@pytest.mark.parametrize("kw", _fuzz_cases(int(__import__("os").environ.get("REFIL_FUZZ_N", "24")), int(__import__("os").environ.get("REFIL_FUZZ_SEED", "2024"))), ids=lambda kw: f"ne{kw['ne']}na{kw['na']}A{kw['A']}d{kw['d']}h{kw['h']}x{kw['heads']}H{kw['H']}M{kw['M']}B{kw['B']}T{kw['T']}{'i' if kw['imagine'] else 'q'}")
+def test_random_shapes_match_oracle(kw):
+    """Shape fuzz: odd entity / agent / action counts, head widths 4..32, 1 / 2 / 4 heads, every rnn_hidden_dim, mixing widths 1..64,
+    refil and qmix_atten, softmax / abs mixing weights, elu / tanh, single-step episodes -- whichever kernel route the dispatcher
+    takes for the shape (MFMA or vector-ALU attention, tiled or weight-resident GEMMs), against the oracle with the per-tensor bar."""
+    from refil_amd.synthetic import make_batch_fast
+    cfg = orc.Cfg(n_agents=kw["na"], n_entities=kw["ne"], n_actions=kw["A"], entity_shape=kw["ne"] + (kw["A"] - 2) + 10,
+                  attn_embed_dim=kw["d"], attn_n_heads=kw["heads"], hypernet_embed=kw["h"], rnn_hidden_dim=kw["H"], mixing_embed_dim=kw["M"],
+                  imagine=kw["imagine"], softmax_mixing_weights=kw["softmax"], mixer_non_lin="tanh" if kw["tanh"] else "elu",
+                  double_q=kw["double_q"], lmbda=kw["lmbda"])
+    batch = make_batch_fast(kw["B"], kw["T"], kw["ne"], seed=kw["seed"], na=kw["na"], A=kw["A"])
+    agent = orc.init_params(orc.agent_param_shapes(cfg), kw["seed"] + 1)
+    mixer = orc.init_params(orc.mixer_param_shapes(cfg), kw["seed"] + 2)
+    tagent = orc.init_params(orc.agent_param_shapes(cfg), kw["seed"] + 3)
+    tmixer = orc.init_params(orc.mixer_param_shapes(cfg), kw["seed"] + 4)
+    torch.manual_seed(kw["seed"])
+    bits = orc.draw_partition_bits(kw["B"], kw["ne"])
+    _assert_step_matches_oracle(cfg, batch, bits, agent, mixer, tagent, tmixer, kw["imagine"])
