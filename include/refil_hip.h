@@ -136,6 +136,11 @@ typedef struct refil_batch {
      * caller must keep params_target unchanged until the work enqueued on `stream` by this call has completed, or change
      * target_version at the next call. */
     uint64_t target_version;
+    /* refil_learner_forward_backward only, optional: the caller's time trim. The reference's run loop trains on
+     * batch[:, :max_t_filled()] (run.py:269-270); with t_limit = that length (2 <= t_limit <= T1) the FULL-length batch gives the
+     * same step -- transitions t >= t_limit - 1 carry no loss weight, their steps are never computed -- while dims.T1, and with it
+     * the workspace layout and the early paths above, stay the same from step to step. 0: every transition of the batch counts. */
+    int32_t t_limit;
 } refil_batch;
 
 /* Scalars produced by a step, as a device array of REFIL_NSTAT floats (sums over this rank's shard,

@@ -53,6 +53,7 @@ class Batch(C.Structure):
         ("mask_words", C.c_void_p), ("mask_row_bits", C.c_void_p),
         ("ready_event", C.c_void_p),
         ("target_version", C.c_uint64),
+        ("t_limit", C.c_int32),
     ]
 
 

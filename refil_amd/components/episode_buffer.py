@@ -134,6 +134,14 @@ class EpisodeBatch:
         if all(isinstance(i, slice) for i in sl):
             out.ready_event = self.ready_event
             out._parent = self
+            # batch[:, :batch.max_t_filled()] -- the reference's trim -- cuts off nothing but steps no episode has filled: the
+            # learner may train on the untrimmed parent instead (QLearner.train: same loss, and the batch shape stays the same from
+            # step to step). Recognised by VALUE: the stop of the time slice equals what max_t_filled() returned for this batch.
+            mtf = self.__dict__.get("_mtf")
+            bsl, tsl = sl
+            if (mtf is not None and bsl == slice(None) and tsl.start in (None, 0) and tsl.step in (None, 1) and tsl.stop is not None
+                    and int(tsl.stop) == mtf[0]):
+                out._untrimmed = self
         return out
 
     @staticmethod
@@ -154,7 +162,11 @@ class EpisodeBatch:
         return tuple(slice(it, it + 1) if isinstance(it, int) else it for it in items)
 
     def max_t_filled(self):
-        return th.sum(self.data.transition_data["filled"], 1).max(0)[0]
+        m = th.sum(self.data.transition_data["filled"], 1).max(0)[0]
+        # (remembered for __getitem__: recognising the reference's batch[:, :max_t_filled()] trim; the int() is the host
+        # synchronisation the caller's slice would perform anyway)
+        self.__dict__["_mtf"] = (int(m),)
+        return m
 
     def __repr__(self):
         return (f"EpisodeBatch. Batch Size:{self.batch_size} Max_seq_len:{self.max_seq_length} "

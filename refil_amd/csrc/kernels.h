@@ -186,6 +186,7 @@ struct TdArgs {
     const int* t_last;                // optional [B]: rows with t > t_last[b] hold stale values (they have mask == 0)
     const float* ingroup_rows;        // optional [B,T] -> stats[REFIL_STAT_INGROUP_SUM]
     int B, T, imagine; float gamma, lmbda;
+    int t_limit;                      // refil_batch.t_limit: transitions t >= t_limit - 1 carry no loss (0: none cut)
     int nq;                           // values per (b,t): 1 (mixed q_tot) or n_agents (args.mixer = None: per-agent TD, q_learner.py:131,161)
 };
 int td_loss_launch(const TdArgs& a, hipStream_t st);

@@ -1417,6 +1417,7 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     t.t_last = c.lists ? w.t_last : nullptr;
     t.ingroup_rows = ml.ingroup_rows;
     t.B = d.B; t.T = T; t.imagine = d.imagine; t.gamma = d.gamma; t.lmbda = d.lmbda;
+    t.t_limit = c.b.t_limit;
     // FlexQMixer: live mix, target mix, TD error and the live mix's backward in one launch (REFIL_MIX_FUSED=0: four launches)
     QHeadBwd qb;
     memset(&qb, 0, sizeof(qb));

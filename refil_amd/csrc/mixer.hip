@@ -139,7 +139,9 @@ __global__ __launch_bounds__(256) void lists_episode_kernel(ListArgs a) {       
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x;
     if (threadIdx.x < 64) any_s[threadIdx.x] = 0;
     if (wave == 0) {
-        const int T = a.T1 - 1;
+        // transitions t < T; a caller-side time trim (refil_batch.t_limit: only the first t_limit steps of the batch count) drops
+        // the transitions from t_limit - 1 on, exactly like the reference's batch[:, :t_limit] view does
+        const int T = (a.b.t_limit > 0 && a.b.t_limit < a.T1) ? a.b.t_limit - 1 : a.T1 - 1;
         int last = -1;
         if (!a.learner) last = a.T1 - 1;
         else {
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(64 * LF_WAVES) void lists_fused_kernel(ListArgs a, 
     // ---- phase 1: the episode (lists_episode_kernel; every workgroup of the episode computes it, workgroup sb = 0 stores it)
     if (threadIdx.x < 64) any_s[threadIdx.x] = 0;
     if (wave == 0) {
-        const int T = T1 - 1;
+        const int T = (a.b.t_limit > 0 && a.b.t_limit < T1) ? a.b.t_limit - 1 : T1 - 1;      // (refil_batch.t_limit, see lists_episode_kernel)
         int last = -1;
         if (!a.learner) last = T1 - 1;
         else {
@@ -1057,6 +1059,7 @@ __global__ __launch_bounds__(64 * MIXW) void mix_train_kernel(MixTrainArgs p) {
     // TD error of (b,tt) (q_learner.py:68-72,157-172)
     float mask = (float)d.filled[b * d.fl_sB + tt * d.fl_sT];
     if (tt > 0) mask *= 1.0f - (float)d.terminated[b * d.tm_sB + (tt - 1) * d.tm_sT];
+    if (d.t_limit > 0 && tt >= d.t_limit - 1) mask = 0.f;      // (refil_batch.t_limit: transitions the caller's time trim cuts off)
     const float term = (float)d.terminated[b * d.tm_sB + tt * d.tm_sT];
     const float target = d.reward[b * d.rw_sB + tt * d.rw_sT] + d.gamma * (1.0f - term) * tq;
     const float td = (qt - target) * mask;
@@ -1339,6 +1342,7 @@ __global__ __launch_bounds__(1024) void td_loss_kernel(TdArgs a) {
         const int b = bt / a.T, t = bt % a.T;
         float mask = (float)a.filled[b * a.fl_sB + t * a.fl_sT];
         if (t > 0) mask *= 1.0f - (float)a.terminated[b * a.tm_sB + (t - 1) * a.tm_sT];
+        if (a.t_limit > 0 && t >= a.t_limit - 1) mask = 0.f;
         const float term = (float)a.terminated[b * a.tm_sB + t * a.tm_sT];
         // steps after an episode's last contributing step are skipped by the nets (stale values): they have mask == 0
         // and enter every sum as exact zeros, like 0 * (finite value) does in the reference

@@ -69,7 +69,7 @@ class LearnerEngine:
     # -- q_learner.py:66-176 -------------------------------------------------------------------
     def forward_backward(self, dims: Dims, fields: Dict[str, torch.Tensor], group_bits: Optional[torch.Tensor],
                          params_live: torch.Tensor, params_target: torch.Tensor, grads: torch.Tensor,
-                         debug: bool = False, ready_event: Optional[torch.cuda.Event] = None, target_version: int = 0):
+                         debug: bool = False, ready_event: Optional[torch.cuda.Event] = None, target_version: int = 0, t_limit: int = 0):
         """grads: flat fp32 [layout.total + REFIL_NSTAT]. Returns dict of debug tensors if debug.
         ready_event: recorded behind the last write of the batch fields (refil_batch.ready_event): the step's input
         assembly and row lists then run on a side stream, beside the end of the previous step on the current stream."""
@@ -85,6 +85,7 @@ class LearnerEngine:
         # (refil_batch.target_version: early target forward, kept composed maps -- never on a new arena: it is zero-filled, and the
         # allocator may have given it the address of an old one the library still remembers)
         b.target_version = 0 if self.ws.fresh else int(target_version) & 0xFFFFFFFFFFFFFFFF
+        b.t_limit = int(t_limit)
         self.ws.fresh = False
         dbg = None
         out = {}
@@ -103,7 +104,7 @@ class LearnerEngine:
         return out
 
     def step(self, dims: Dims, fields, group_bits, params_live, params_target, grads, square_avg, lr, alpha, eps, weight_decay, clip,
-             ready_event=None, target_version: int = 0):
+             ready_event=None, target_version: int = 0, t_limit: int = 0):
         """refil_learner_step: forward + backward + clip + RMSprop in ONE C call (single process: no collective in between)."""
         nbytes = lib().refil_learner_workspace_bytes(C.byref(dims))
         if nbytes == 0:
@@ -113,6 +114,7 @@ class LearnerEngine:
         if ready_event is not None and not b._converted and not self.ws.fresh:
             b.ready_event = ready_event.cuda_event
         b.target_version = 0 if self.ws.fresh else int(target_version) & 0xFFFFFFFFFFFFFFFF
+        b.t_limit = int(t_limit)
         self.ws.fresh = False
         hy = _lib.OptHyper(lr, alpha, eps, weight_decay, clip)
         check(lib().refil_learner_step(C.byref(dims), C.byref(b), _lib.ptr(params_live), _lib.ptr(params_target), _lib.ptr(grads),

@@ -224,6 +224,16 @@ class QLearner:
     def train(self, batch, t_env: int, episode_num: int, group_bits=None):
         self._check_flat()
         args = self.args
+        # The reference's run loop trims every sampled batch to its longest episode (run.py:269-270). The library skips the steps no
+        # episode has filled by itself, so a batch[:, :max_t_filled()] view is trained through its untrimmed parent: same loss and
+        # gradients (the cut-off steps carry no loss weight and are never computed), and the batch shape -- hence the workspace
+        # layout, the early prologue / early target forward and the tuner's bucket -- stays the same from step to step.
+        # REFIL_UNTRIM=0: train on the view as given.
+        t_limit = 0
+        while (getattr(batch, "_untrimmed", None) is not None and os.environ.get("REFIL_UNTRIM") != "0" and
+               args.mixer != "lin_flex_qmix"):         # (lin_flex_qmix logs ingroup_prop as a mean over ALL (b,t) of the batch it was given)
+            t_limit = t_limit or batch.max_seq_length  # (refil_batch.t_limit: the transitions the view cut off stay cut off)
+            batch = batch._untrimmed
         B, T1 = batch.batch_size, batch.max_seq_length
         dims = dims_from_args(args, B, T1)
         tgt, trgt = bool(getattr(args, "train_gt_factors", False)), bool(getattr(args, "train_rand_gt_factors", False))
@@ -257,7 +267,7 @@ class QLearner:
             if self._buckets is None:
                 self._buckets = dp.BucketedAllReduce(self.grads, self._na)
             with self._buckets:
-                self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready, target_version=self._tv())
+                self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready, target_version=self._tv(), t_limit=t_limit)
             self._buckets.finish()
             self._optimiser_step()
         elif os.environ.get("REFIL_HIPGRAPH") == "1" and group_bits is None:
@@ -265,9 +275,9 @@ class QLearner:
         elif dp.world() == 1 and os.environ.get("REFIL_DP_FORCE") != "1":
             a = self.args                              # one C call for the whole step (refil_learner_step)
             self._engine.step(dims, fields, bits, self.flat_live, self.flat_target, self.grads, self.square_avg, a.lr, a.optim_alpha,
-                              a.optim_eps, a.weight_decay, a.grad_norm_clip, ready_event=ready, target_version=self._tv())
+                              a.optim_eps, a.weight_decay, a.grad_norm_clip, ready_event=ready, target_version=self._tv(), t_limit=t_limit)
         else:
-            self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready, target_version=self._tv())
+            self._engine.forward_backward(dims, fields, bits, self.flat_live, self.flat_target, self.grads, ready_event=ready, target_version=self._tv(), t_limit=t_limit)
             dp.allreduce_sum_(self.grads)
             self._optimiser_step()
         if ready is not None:                          # (a producer that reuses the batch's memory waits for this: ReplayBuffer.sample)

@@ -210,3 +210,50 @@ def test_unsynchronised_steps_equal_in_order_steps(cfg, B, monkeypatch):
         assert torch.equal(la.flat_live, lb.flat_live), f"round {rnd}: max |d| = {(la.flat_live - lb.flat_live).abs().max().item():.3e}"
         assert torch.equal(la.flat_target, lb.flat_target) and torch.equal(la.square_avg, lb.square_avg)
     assert _lib.get_stat("early_target_hypernet_steps") - e0 >= 28
+
+
+def test_max_t_filled_trim_trains_through_the_parent(monkeypatch):
+    """The reference's run loop hands train() batch[:, :batch.max_t_filled()] -- a different length almost every step. QLearner
+    trains through the untrimmed parent (the cut-off steps carry no loss weight and are skipped on the device anyway): the results
+    equal training on the view as given (REFIL_UNTRIM=0) up to the summation order of the split reductions, and the batch shape --
+    hence the early prologue and the early target forward -- survives from step to step."""
+    import bench
+    from refil_amd import _lib
+    W = dict(bench.CONFIGS["cfg2"])
+    dims = bench.workload_dims(W)
+    dev = torch.device("cuda", 0)
+    B = 8
+    learners, batches = [], []
+    for _ in range(2):
+        _, b1, l, _, _ = bench.build(dims, W["imagine"], B, W["T"], seed=100, device=dev)
+        _, b2, _, _, _ = bench.build(dims, W["imagine"], B, W["T"], seed=200, device=dev)
+        _, b3, _, _, _ = bench.build(dims, W["imagine"], B, W["T"], seed=300, device=dev)
+        for b, L in ((b1, 33), (b2, 57), (b3, 46)):              # longest episode of each batch; its last step is filled and NOT
+            b.data.transition_data["filled"][:, L:] = 0            # terminated, so the transition the trim cuts off (L-1 -> L)
+            b.data.transition_data["terminated"][:, L - 1:] = 0    # would carry loss weight in the parent without refil_batch.t_limit
+        l._check_flat()
+        learners.append(l); batches.append((b1, b2, b3))
+    la, lb = learners
+    assert torch.equal(la.flat_live, lb.flat_live)
+    e0, s0 = _lib.get_stat("early_prologue_steps"), _lib.get_stat("learner_steps")
+    for i in range(6):
+        monkeypatch.delenv("REFIL_UNTRIM", raising=False)
+        b = batches[0][i % 3]
+        v = b[:, :b.max_t_filled()]
+        assert v.max_seq_length in (33, 57, 46) and v._untrimmed is b
+        la.train(v, t_env=0, episode_num=i)
+        assert la._last_dims.T1 == W["T"] + 1                    # trained on the parent's length
+        monkeypatch.setenv("REFIL_UNTRIM", "0")
+        b = batches[1][i % 3]
+        lb.train(b[:, :b.max_t_filled()], t_env=0, episode_num=i)
+        assert lb._last_dims.T1 in (33, 57, 46)
+        torch.cuda.synchronize()
+        # same transitions, same loss, same gradients (up to the summation order of the split reductions: the grids differ)
+        ga, gb = la.grads[:la._n], lb.grads[:lb._n]
+        assert (ga - gb).abs().max().item() <= 2e-6 * gb.abs().max().item(), i
+        sa, sb = la.grads[la._n:].tolist(), lb.grads[lb._n:].tolist()
+        assert sa[_lib.STAT_MASK_SUM] == sb[_lib.STAT_MASK_SUM] and abs(sa[_lib.STAT_TD_SQ] - sb[_lib.STAT_TD_SQ]) <= 1e-5 * abs(sb[_lib.STAT_TD_SQ])
+        # (RMSprop's first steps are steep where |g| ~ eps: re-align the replicas so that every step is compared from one state)
+        lb.flat_live.copy_(la.flat_live); lb.square_avg.copy_(la.square_avg); lb.flat_target.copy_(la.flat_target)
+    # la kept its layout: every step after the first took the early prologue; lb's layout changed every step: none did
+    assert _lib.get_stat("learner_steps") - s0 == 12 and _lib.get_stat("early_prologue_steps") - e0 == 5

@@ -222,3 +222,16 @@ def test_host_resident_buffer_hands_out_device_minibatches():
             np.random.seed(99)
             assert (buf.sample(6)["reward"] == 777.0).all()
 
+
+
+def test_max_t_filled_trim_is_recognised():
+    """batch[:, :batch.max_t_filled()] (run.py:269-270) is marked as a trim that cuts off unfilled steps only; any other slice is not."""
+    b = _episodes(4, 9, 1)
+    b.data.transition_data["filled"][:, 6:] = 0
+    m = b.max_t_filled()
+    assert int(m) == 6
+    v = b[:, :m]
+    assert v._untrimmed is b and v.max_seq_length == 6
+    assert getattr(b[:, :5], "_untrimmed", None) is None          # a shorter cut drops filled steps
+    assert getattr(b[1:, :m], "_untrimmed", None) is None         # a batch slice is another batch
+    assert getattr(_episodes(4, 9, 2)[:, :6], "_untrimmed", None) is None     # max_t_filled() was never asked
