@@ -104,8 +104,9 @@ class LearnerEngine:
         return out
 
     def step(self, dims: Dims, fields, group_bits, params_live, params_target, grads, square_avg, lr, alpha, eps, weight_decay, clip,
-             ready_event=None, target_version: int = 0, t_limit: int = 0):
-        """refil_learner_step: forward + backward + clip + RMSprop in ONE C call (single process: no collective in between)."""
+             ready_event=None, target_version: int = 0, t_limit: int = 0, comm=None):
+        """refil_learner_step: forward + backward + clip + RMSprop in ONE C call. comm: an ncclComm_t (ctypes.c_void_p) for the
+        data-parallel all-reduce of [grads | stats] between backward and optimiser; None = single process."""
         nbytes = lib().refil_learner_workspace_bytes(C.byref(dims))
         if nbytes == 0:
             raise RuntimeError("refil_learner_workspace_bytes: " + lib().refil_last_error().decode())
@@ -118,7 +119,7 @@ class LearnerEngine:
         self.ws.fresh = False
         hy = _lib.OptHyper(lr, alpha, eps, weight_decay, clip)
         check(lib().refil_learner_step(C.byref(dims), C.byref(b), _lib.ptr(params_live), _lib.ptr(params_target), _lib.ptr(grads),
-                                       _lib.ptr(square_avg), C.byref(hy), None, wp, wsz, _lib.ptr(self.scratch), _lib.current_stream_ptr()),
+                                       _lib.ptr(square_avg), C.byref(hy), comm, wp, wsz, _lib.ptr(self.scratch), _lib.current_stream_ptr()),
               "refil_learner_step")
 
     def row_counts(self, dims: Dims):

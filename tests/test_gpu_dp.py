@@ -247,5 +247,30 @@ def test_allreduce_flat_on_a_caller_communicator():
     th.cuda.synchronize()
     assert th.equal(x, ref)
     assert L.refil_allreduce_flat(x.data_ptr(), x.numel(), None, _lib.current_stream_ptr()) != 0      # no communicator: an error, not a crash
+    # the whole step in one call with the collective inside (refil_learner_step with a communicator): on one rank the sum is the
+    # rank's own buffer, so the step must equal the single-process step bit for bit
+    from golden_util import load
+    from refil_amd import flat
+    from refil_amd.engine import LearnerEngine
+    from test_gpu_learner import _dims
+    g = load("refil_mid")
+    cfg, case = g["cfg"], g["case"]
+    dims = _dims(cfg, case["B"], case["T"] + 1)
+    n = flat.total(dims)
+    fields = {k: v.to("cuda") for k, v in g["batch"].items()}
+    res = []
+    for cm in (None, comm):
+        eng = LearnerEngine("cuda")
+        live = flat.pack(dims, g["agent"], g["mixer"], "cuda")
+        targ = flat.pack(dims, g["tagent"], g["tmixer"], "cuda")
+        sq = th.zeros(n, device="cuda")
+        grads = th.zeros(n + _lib.REFIL_NSTAT, device="cuda")
+        for _ in range(2):
+            eng.step(dims, fields, g["bits"].to("cuda"), live, targ, grads, sq, cfg.lr, cfg.optim_alpha, cfg.optim_eps, cfg.weight_decay,
+                     cfg.grad_norm_clip, comm=cm)
+        th.cuda.synchronize()
+        res.append((live.clone(), sq.clone(), grads.clone()))
+    for a, b in zip(*res):
+        assert th.equal(a, b)
     rccl.ncclCommDestroy.argtypes = [C.c_void_p]
     rccl.ncclCommDestroy(comm)
