@@ -681,3 +681,64 @@ def test_random_shapes_match_oracle(kw):
     torch.manual_seed(kw["seed"])
     bits = orc.draw_partition_bits(kw["B"], kw["ne"])
     _assert_step_matches_oracle(cfg, batch, bits, agent, mixer, tagent, tmixer, kw["imagine"])
+
+
+def _fuzz_list_cases(n, seed=4242):
+    """random shapes at production sizes (>= 2048 entity rows, >= 512 agent rows), half of them drawn INSIDE the row-list schedule's
+    conditions (learner.hip: make_ctx), half anywhere in the library's limits"""
+    import random
+    rnd = random.Random(seed)
+    out = []
+    t16 = lambda x: (x + 15) // 16
+    while len(out) < n:
+        inside = len(out) % 2 == 0
+        ne = rnd.choice([8, 12, 16, 20, 24, 32, 40, 48, 64] if inside else [5, 8, 11, 16, 17, 24, 31, 32, 33, 48, 63, 64])
+        na = rnd.choice([x for x in ((4, 6, 8, 12, 16, 24, 32) if inside else (1, 3, 4, 7, 8, 13, 16, 24, 32)) if x <= ne])
+        A = rnd.randint(7, 24)
+        heads = rnd.choice([1, 2, 4])
+        if inside:
+            d, h, H, M = rnd.choice([64, 128]), rnd.choice([64, 128]), 64, rnd.choice([32, 64])
+            if (ne + 2 * A + 8) % 4 or ne + 2 * A + 8 > 128 or d // heads > 32 or h // heads > 32:
+                continue
+        else:
+            d, h = heads * rnd.choice([4, 8, 12, 16, 24, 32]), heads * rnd.choice([4, 8, 12, 16, 24, 32])
+            H, M = rnd.choice([32, 64, 128]), rnd.choice([1, 5, 8, 16, 32, 40, 64])
+
+        def mfma_ok(hd):       # attention_mfma.hip: attn_mfma_supported
+            j, a, c = t16(ne), t16(na), t16(hd)
+            return hd % 4 == 0 and ((j <= 2 and a == 1 and c <= 2) or (2 <= j <= 4 and a <= 2 and c == 2))
+        E = ne + 2 * A + 8
+        lists = (E % 4 == 0 and E <= 128 and d % 64 == 0 and d <= 128 and h % 64 == 0 and h <= 128 and M % 32 == 0 and H == 64 and
+                 mfma_ok(d // heads) and mfma_ok(h // heads))
+        if inside and not lists:
+            continue
+        T = rnd.randint(6, 40)
+        B = max(2, -(-2048 // ((T + 1) * ne)), -(-512 // ((T + 1) * na))) + rnd.randint(0, 3)
+        if B * (T + 1) * ne > 60000:
+            continue
+        out.append(dict(B=B, T=T, ne=ne, na=na, A=A, d=d, h=h, heads=heads, H=H, imagine=rnd.random() < 0.75, M=M,
+                        lmbda=rnd.choice([0.3, 0.5]), seed=3000 + len(out), lists=lists))
+    return out
+
+
+@pytest.mark.parametrize("kw", _fuzz_list_cases(int(__import__("os").environ.get("REFIL_FUZZ_LIST_N", "12")), int(__import__("os").environ.get("REFIL_FUZZ_SEED", "4242"))),
+                         ids=lambda kw: f"ne{kw['ne']}na{kw['na']}A{kw['A']}d{kw['d']}h{kw['h']}x{kw['heads']}H{kw['H']}M{kw['M']}B{kw['B']}T{kw['T']}{'i' if kw['imagine'] else 'q'}{'L' if kw['lists'] else 'D'}")
+def test_random_row_list_shapes_match_oracle(kw):
+    """Shape fuzz at PRODUCTION sizes (>= 2048 entity rows): random entity / agent / action counts and layer widths around the
+    conditions of the row-list schedule (weight-resident / 4x4-tile GEMMs on row lists, persistent MFMA attention, 4-row recurrences,
+    agent-summed / composed tails) -- shapes inside them take it, shapes outside take the dense schedule, none is turned away."""
+    from refil_amd.synthetic import make_batch_fast
+    cfg = orc.Cfg(n_agents=kw["na"], n_entities=kw["ne"], n_actions=kw["A"], entity_shape=kw["ne"] + (kw["A"] - 2) + 10,
+                  attn_embed_dim=kw["d"], attn_n_heads=kw["heads"], hypernet_embed=kw["h"], mixing_embed_dim=kw["M"], imagine=kw["imagine"],
+                  rnn_hidden_dim=kw["H"], lmbda=kw["lmbda"])
+    batch = make_batch_fast(kw["B"], kw["T"], kw["ne"], seed=kw["seed"], na=kw["na"], A=kw["A"])
+    agent = orc.init_params(orc.agent_param_shapes(cfg), kw["seed"] + 1)
+    mixer = orc.init_params(orc.mixer_param_shapes(cfg), kw["seed"] + 2)
+    tagent = orc.init_params(orc.agent_param_shapes(cfg), kw["seed"] + 3)
+    tmixer = orc.init_params(orc.mixer_param_shapes(cfg), kw["seed"] + 4)
+    torch.manual_seed(kw["seed"])
+    bits = orc.draw_partition_bits(kw["B"], kw["ne"])
+    r = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, profile=True)
+    # the row-list schedule where every listed GEMM has whole tiles (learner.hip: make_ctx), the dense schedule elsewhere -- never an error
+    assert ("lists_kernels" in r["kernels"]) == kw["lists"], f"row lists: expected {kw['lists']} (kernels: {sorted(r['kernels'])})"
+    _assert_step_matches_oracle(cfg, batch, bits, agent, mixer, tagent, tmixer, kw["imagine"])
