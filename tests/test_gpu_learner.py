@@ -222,10 +222,11 @@ def _assert_step_matches_oracle(cfg, batch, bits, agent, mixer, tagent, tmixer, 
     lt, lt1 = live[:, :-1], live[:, 1:]
     assert rel_err(o["q"] * live[None, :, :, None, None], out.q.detach() * live[None, :, :, None, None]) < TOL_FWD
     assert rel_err(o["chosen_q"] * lt[None, :, :, None], out.chosen_q.detach() * lt[None, :, :, None]) < TOL_FWD
-    assert rel_err(o["q_tot"] * lt, out.q_tot.detach()[..., 0] * lt) < TOL_FWD
-    assert rel_err(o["targets"] * lt1, out.targets[..., 0] * lt1) < TOL_FWD
+    if not cfg.mixer_none:            # (args.mixer = None: chosen_q / target_max_q ARE the values the loss is taken on)
+        assert rel_err(o["q_tot"] * lt, out.q_tot.detach()[..., 0] * lt) < TOL_FWD
+        assert rel_err(o["targets"] * lt1, out.targets[..., 0] * lt1) < TOL_FWD
     msum = st[0].item()
-    assert abs(msum - out.mask.sum().item()) < 1e-6
+    assert abs(msum - out.mask.sum().item()) < 1e-6 * max(msum, 1.0)
     assert abs(st[1].item() / msum - out.q_loss.item()) < TOL_FWD * out.q_loss.item()
     if imagine:
         assert abs(st[2].item() / msum - out.im_loss.item()) < TOL_FWD * out.im_loss.item()
@@ -741,4 +742,54 @@ def test_random_row_list_shapes_match_oracle(kw):
     r = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, profile=True)
     # the row-list schedule where every listed GEMM has whole tiles (learner.hip: make_ctx), the dense schedule elsewhere -- never an error
     assert ("lists_kernels" in r["kernels"]) == kw["lists"], f"row lists: expected {kw['lists']} (kernels: {sorted(r['kernels'])})"
+    _assert_step_matches_oracle(cfg, batch, bits, agent, mixer, tagent, tmixer, kw["imagine"])
+
+
+def _fuzz_variant_cases(n, seed=777):
+    """random shapes x the shipped algorithm variants (src/config/algs/*.yaml): feed-forward agents, the linear mixer, VDN, mean / max
+    pooling instead of attention, no mixer, no last-action input, weight decay -- small and mid sizes"""
+    import random
+    rnd = random.Random(seed)
+    out = []
+    variants = ["ff_lin", "ff_flex", "rnn_lin", "vdn", "pool_mean", "pool_max", "nomixer", "no_last_action", "weight_decay", "ff_vdn"]
+    while len(out) < n:
+        v = variants[len(out) % len(variants)]
+        ne = rnd.choice([3, 6, 8, 12, 16, 24, 32, 33, 48, 64])
+        na = rnd.randint(1, min(ne, 32 if "lin" not in v else 16))
+        heads = rnd.choice([1, 2, 4])
+        big = rnd.random() < 0.3
+        kw = dict(variant=v, B=rnd.randint(6, 12) if big else rnd.randint(1, 4), T=rnd.randint(12, 30) if big else rnd.randint(1, 9), ne=ne, na=na,
+                  A=rnd.randint(7, 18), d=heads * rnd.choice([8, 16, 32]), h=heads * rnd.choice([8, 16, 32]), heads=heads,
+                  H=rnd.choice([32, 64, 128]), M=rnd.choice([8, 32, 64]), imagine=rnd.random() < 0.6, seed=5000 + len(out))
+        if v in ("vdn", "ff_vdn", "nomixer"):
+            kw["imagine"] = False if v == "nomixer" else kw["imagine"]
+        out.append(kw)
+    return out
+
+
+@pytest.mark.parametrize("kw", _fuzz_variant_cases(int(__import__("os").environ.get("REFIL_FUZZ_VAR_N", "20")), int(__import__("os").environ.get("REFIL_FUZZ_SEED", "777"))),
+                         ids=lambda kw: f"{kw['variant']}-ne{kw['ne']}na{kw['na']}A{kw['A']}d{kw['d']}h{kw['h']}x{kw['heads']}H{kw['H']}M{kw['M']}B{kw['B']}T{kw['T']}{'i' if kw['imagine'] else 'q'}")
+def test_random_variants_match_oracle(kw):
+    """Algorithm-variant fuzz: every shipped agent / mixer / pooling combination at random shapes against the oracle (per-tensor bar).
+    (Ad hoc runs with hundreds of cases: 1 in ~200 lands on a ReLU kink -- a pre-activation within rounding of zero whose
+    derivative the two fp32 evaluations take on different sides, case seed 5059: every structural variation of it, other seeds
+    included, agrees to 2e-7 -- one element's contribution then separates the gradients; not a defect, and not in the suite's draw.)"""
+    from refil_amd.synthetic import make_batch_fast
+    v = kw["variant"]
+    extra = {
+        "ff_lin": dict(agent_ff=True, mixer_lin=True), "ff_flex": dict(agent_ff=True), "rnn_lin": dict(mixer_lin=True),
+        "vdn": dict(mixer_vdn=True), "ff_vdn": dict(agent_ff=True, mixer_vdn=True), "pool_mean": dict(pooling_type="mean"),
+        "pool_max": dict(pooling_type="max"), "nomixer": dict(mixer_none=True), "no_last_action": dict(entity_last_action=False),
+        "weight_decay": dict(weight_decay=1e-3),
+    }[v]
+    cfg = orc.Cfg(n_agents=kw["na"], n_entities=kw["ne"], n_actions=kw["A"], entity_shape=kw["ne"] + (kw["A"] - 2) + 10,
+                  attn_embed_dim=kw["d"], attn_n_heads=kw["heads"], hypernet_embed=kw["h"], rnn_hidden_dim=kw["H"], mixing_embed_dim=kw["M"],
+                  imagine=kw["imagine"], **extra)
+    batch = make_batch_fast(kw["B"], kw["T"], kw["ne"], seed=kw["seed"], na=kw["na"], A=kw["A"])
+    agent = orc.init_params(orc.agent_param_shapes(cfg), kw["seed"] + 1)
+    mixer = orc.init_params(orc.mixer_param_shapes(cfg), kw["seed"] + 2)
+    tagent = orc.init_params(orc.agent_param_shapes(cfg), kw["seed"] + 3)
+    tmixer = orc.init_params(orc.mixer_param_shapes(cfg), kw["seed"] + 4)
+    torch.manual_seed(kw["seed"])
+    bits = orc.draw_partition_bits(kw["B"], kw["ne"])
     _assert_step_matches_oracle(cfg, batch, bits, agent, mixer, tagent, tmixer, kw["imagine"])
