@@ -793,3 +793,38 @@ def test_random_variants_match_oracle(kw):
     torch.manual_seed(kw["seed"])
     bits = orc.draw_partition_bits(kw["B"], kw["ne"])
     _assert_step_matches_oracle(cfg, batch, bits, agent, mixer, tagent, tmixer, kw["imagine"])
+
+
+@pytest.mark.parametrize("kw", _fuzz_cases(int(__import__("os").environ.get("REFIL_FUZZ_ACT_N", "12")), 909),
+                         ids=lambda kw: f"ne{kw['ne']}na{kw['na']}A{kw['A']}d{kw['d']}x{kw['heads']}H{kw['H']}B{kw['B']}T{kw['T']}")
+def test_random_shapes_acting_path_matches_oracle(kw):
+    """Acting-path fuzz (refil_agent_forward = BasicMAC.forward, basic_controller.py:28-67): the whole sequence in one call against
+    the oracle's agent, then step by step with the hidden state carried by the caller like a runner does (parallel_runner.py:121)
+    against the one-call result."""
+    from refil_amd import flat
+    from refil_amd.engine import LearnerEngine, clone_dims
+    from refil_amd.synthetic import make_batch_fast
+    cfg = orc.Cfg(n_agents=kw["na"], n_entities=kw["ne"], n_actions=kw["A"], entity_shape=kw["ne"] + (kw["A"] - 2) + 10,
+                  attn_embed_dim=kw["d"], attn_n_heads=kw["heads"], hypernet_embed=kw["h"], rnn_hidden_dim=kw["H"], mixing_embed_dim=kw["M"],
+                  imagine=False)
+    B, T1 = kw["B"], kw["T"] + 1
+    batch = make_batch_fast(B, kw["T"], kw["ne"], seed=kw["seed"], na=kw["na"], A=kw["A"])
+    agent = orc.init_params(orc.agent_param_shapes(cfg), kw["seed"] + 1)
+    mixer = orc.init_params(orc.mixer_param_shapes(cfg), kw["seed"] + 2)
+    xe = orc.build_entity_inputs(cfg, batch["entities"], batch["actions"])
+    q_ref, hs_ref, _ = orc.agent_forward(cfg, agent, xe, batch["obs_mask"], batch["entity_mask"])
+    dims = _dims(cfg, B, T1)
+    eng = LearnerEngine(DEV)
+    live = flat.pack(dims, agent, mixer, DEV)
+    fields = {k: v.to(DEV) for k, v in batch.items()}
+    q, h = eng.agent_forward(dims, fields, None, live, None, first_step_zero=True)
+    assert rel_err(q[0].cpu(), q_ref[0]) < TOL_FWD
+    assert rel_err(h[0].cpu(), hs_ref[0][:, -1]) < TOL_FWD
+    d1 = clone_dims(dims, T1=1)
+    hc = None
+    for t in range(T1):
+        ft = {k: v[:, t:t + 1] for k, v in fields.items()}
+        if t > 0:                      # the previous step's action feeds this step's input (entity_controller.py:17-24)
+            ft = dict(ft, actions=fields["actions"][:, t - 1:t])
+        qt, hc = eng.agent_forward(d1, ft, None, live, hc, first_step_zero=(t == 0))
+        assert rel_err(qt[0, :, 0].cpu(), q[0, :, t].cpu()) < 1e-5, t
