@@ -324,7 +324,10 @@ bool gemm_wres_eligible(const refil_gemm_desc& d) {
     if ((f & REFIL_GEMM_ACCUM) && !rb) return false;
     if (rb && (!bt || !d.aux || d.bias || d.rowmask || (f & REFIL_GEMM_RELU) || (d.N % 64))) return false;
     if (d.splits != 1 || d.K < 8 || (d.K % 4) != 0) return false;
-    if (d.K > (rb ? 256 : 128)) return false;
+    // reductions up to 128 (one pass over the row); up to 256 in two passes through the same register chunks: the dX launches through a
+    // ReLU, and the plain forward (no row mask / second bias: the fc1 layers of wide entity feature vectors -- 64 entities: E = 148)
+    if (d.K > 256) return false;
+    if (d.K > 128 && !rb && (bt || d.rowmask || d.bias2)) return false;
     if ((d.lda % 4) || (d.ldb % 4) || (d.sA % 4) || (d.sB % 4) || !al16(d.A) || !al16(d.B)) return false;
     if (d.M < (d.row_index ? 256 : 2048) || (d.N % 32) != 0) return false;  // tiny calls: tiled kernel
     if (d.row_index) {        // row list (padded to whole tiles by its producer)
@@ -369,8 +372,13 @@ static int wres_launch_fwd(const WresK& k, dim3 grid, hipStream_t st) {
     if (nc <= 4) FWD(4);
     if (nc <= 8) FWD(8);
     if (nc <= 11) FWD(11);      // K = 84: the fc1 layers at the SC2 shape law
-    FWD(16);
+    if (nc <= 16) FWD(16);
 #undef FWD
+    // 128 < K <= 256: two passes (plain epilogue only, gemm_wres_eligible)
+    if (nc <= 24) return k.ridx ? wres_launch_i<TN, 12, 2, false, 0, false, false, false, true>(k, grid, st)
+                                : wres_launch_i<TN, 12, 2, false, 0, false, false>(k, grid, st);
+    return k.ridx ? wres_launch_i<TN, 16, 2, false, 0, false, false, false, true>(k, grid, st)
+                  : wres_launch_i<TN, 16, 2, false, 0, false, false>(k, grid, st);
 }
 // backward products dx = dy W (+ row mask), reduction <= 128
 template <int TN>
@@ -443,7 +451,8 @@ int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st) {
     int ncp, npass = 1;
     if (rb) { if (nc8 <= 8) ncp = 8; else if (nc8 <= 16) ncp = 16; else if (nc8 <= 24) { ncp = 12; npass = 2; } else { ncp = 16; npass = 2; } }
     else if (bt) ncp = nc8 <= 4 ? 4 : (nc8 <= 8 ? 8 : 16);
-    else ncp = nc8 <= 4 ? 4 : (nc8 <= 8 ? 8 : (nc8 <= 11 ? 11 : 16));
+    else if (nc8 <= 16) ncp = nc8 <= 4 ? 4 : (nc8 <= 8 ? 8 : (nc8 <= 11 ? 11 : 16));
+    else { ncp = nc8 <= 24 ? 12 : 16; npass = 2; }
     static thread_local char names[64][64];
     static thread_local int n_names = 0;
     char nm[64];

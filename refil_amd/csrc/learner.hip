@@ -1005,11 +1005,11 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
         const refil_dims& d = *dims;
         const int E = in_dim(d);
         // every listed GEMM must take the weight-resident / streaming-dW kernels (gemm_wres_eligible): whole 32-column
-        // tiles, reductions <= 128 (<= 256 through the ReLU), 16-byte aligned rows, enough rows for a split reduction
+        // tiles, reductions <= 128 (<= 256 through the ReLU and for the fc1 layers), 16-byte aligned rows, enough rows for a split reduction
         // (widths: whole 64-column tiles -- the dX launches through a ReLU run 64-wide tiles only --, the hypernets' tail writes
         // mixing_embed_dim columns: whole 32-column tiles; rnn_hidden_dim 32 / 128 and everything else: the dense schedule. Found by
         // the shape fuzz of round 4: with `% 32` here, 85 of 100 random production-size shapes were turned away by refil_gemm)
-        const bool shapes = E % 4 == 0 && E <= 128 && d.d % 64 == 0 && d.d <= 128 && d.hyp % 64 == 0 && d.hyp <= 128 &&
+        const bool shapes = E % 4 == 0 && E <= 256 && d.d % 64 == 0 && d.d <= 128 && d.hyp % 64 == 0 && d.hyp <= 128 &&
                             d.M % 32 == 0 && d.H == 64 && c.s.NE >= 2048 && c.s.NA >= 512;
         c.lists = mode == CARVE_LEARNER && !(de && de[0] == '1') && shapes && c.presum && c.compose_agent;
         const char* me = getenv("REFIL_MASKWORDS");

@@ -246,6 +246,7 @@ PRODUCTION = {
     "cfg3": dict(B=64, T=80, ne=32, d=128, imagine=True),                 # configs[2], "roofline run"
     "cfg4_shape": dict(B=32, T=150, ne=16, d=128, imagine=False),         # configs[3]: qmix_atten on the 3-8sz shape
     "cfg5_ne48": dict(B=32, T=80, ne=48, d=128, imagine=True),            # configs[4] scaled to 48 entities
+    "ne64": dict(B=16, T=40, ne=64, d=128, imagine=True),                 # the largest entity count (one mask word): E = 148, two-pass fc1
     "cfgT_quarter_rnn32": dict(B=8, T=20, ne=32, d=128, imagine=True, H=32),    # rnn_hidden_dim is a free flag (default.yaml:47)
     "cfgT_quarter_rnn128": dict(B=8, T=20, ne=32, d=128, imagine=True, H=128),
     # configs[4] at the ACTUAL 3-8MMM shape: 16 entities, 8 agents, 22 actions (medivac heal targets), ed 46
@@ -699,7 +700,7 @@ def _fuzz_list_cases(n, seed=4242):
         heads = rnd.choice([1, 2, 4])
         if inside:
             d, h, H, M = rnd.choice([64, 128]), rnd.choice([64, 128]), 64, rnd.choice([32, 64])
-            if (ne + 2 * A + 8) % 4 or ne + 2 * A + 8 > 128 or d // heads > 32 or h // heads > 32:
+            if (ne + 2 * A + 8) % 4 or ne + 2 * A + 8 > 256 or d // heads > 32 or h // heads > 32:
                 continue
         else:
             d, h = heads * rnd.choice([4, 8, 12, 16, 24, 32]), heads * rnd.choice([4, 8, 12, 16, 24, 32])
@@ -709,7 +710,7 @@ def _fuzz_list_cases(n, seed=4242):
             j, a, c = t16(ne), t16(na), t16(hd)
             return hd % 4 == 0 and ((j <= 2 and a == 1 and c <= 2) or (2 <= j <= 4 and a <= 2 and c == 2))
         E = ne + 2 * A + 8
-        lists = (E % 4 == 0 and E <= 128 and d % 64 == 0 and d <= 128 and h % 64 == 0 and h <= 128 and M % 32 == 0 and H == 64 and
+        lists = (E % 4 == 0 and E <= 256 and d % 64 == 0 and d <= 128 and h % 64 == 0 and h <= 128 and M % 32 == 0 and H == 64 and
                  mfma_ok(d // heads) and mfma_ok(h // heads))
         if inside and not lists:
             continue

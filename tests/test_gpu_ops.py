@@ -135,6 +135,7 @@ def test_gemm_dw_stream_rowmaps(N, K, splits):
 
 # ---- weight-resident kernel (gemm_wres.hip): taken for M >= 2048, M % 32 == 0, N % 32 == 0, short reductions ----
 @pytest.mark.parametrize("M,N,K,batch", [(4096, 128, 128, 1), (2048 + 64, 256, 128, 2), (6400, 512, 84, 1), (4096, 192, 64, 1),
+                                         (4096, 128, 148, 1), (4096, 512, 200, 1), (2048, 64, 256, 2), (4096, 256, 132, 1),
                                          (2560, 64, 128, 1), (3200, 32, 128, 3), (2048, 128, 16, 1), (4096, 96, 40, 1)])
 def test_gemm_wres_forward(M, N, K, batch):
     import hip_ops
@@ -414,6 +415,7 @@ def _row_list(M, frac, seed, trash):
 
 
 @pytest.mark.parametrize("M,N,K,batch,frac", [(4096, 128, 84, 1, 0.45), (6400, 256, 128, 2, 0.6), (2048, 64, 52, 1, 0.3),
+                                              (4096, 128, 148, 1, 0.5), (4096, 512, 196, 1, 0.4),
                                               (4096, 512, 84, 1, 0.0), (4096, 128, 64, 1, 1.0)])
 def test_gemm_wres_forward_row_list(M, N, K, batch, frac):
     """x W^T over a device-side row list: listed rows are computed, every other row of C stays untouched."""
