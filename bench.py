@@ -51,7 +51,9 @@ CONFIGS = {
     "cfg2": dict(B=32, T=80, ne=16, d=64, h=64, imagine=True, what="BASELINE.json configs[1]"),
     "cfg3": dict(B=64, T=80, ne=32, d=128, h=128, imagine=True, what="BASELINE.json configs[2], roofline run"),
     "cfg4": dict(B=32, T=150, ne=16, d=128, h=128, imagine=False, what="BASELINE.json configs[3] shape: 3-8sz, qmix_atten (no imagination), T up to 150"),
-    "cfg5": dict(B=32, T=80, ne=48, d=128, h=128, imagine=True, what="BASELINE.json configs[4] scaled to 48 entities (MMM-shaped)"),
+    "cfg5": dict(B=32, T=80, ne=48, d=128, h=128, imagine=True, A=54,
+                 what="BASELINE.json configs[4] scaled to 48 entities, MMM action law (medivac heal targets: A = 6 + 24 + 24 = 54, entity width 110, "
+                      "E = 164: SURVEY.md section 8d 'scaled variant')"),
 }
 COMMON = dict(heads=4, H=64, M=32)
 
@@ -82,7 +84,8 @@ def workload_dims(W):
     from refil_amd.synthetic import sc2_shape_law
     W = dict(W, **COMMON)
     law = sc2_shape_law(W["ne"])
-    return dict(ne=W["ne"], na=law["n_agents"], A=law["n_actions"], ed=law["entity_shape"], d=W["d"], h=W["h"],
+    A = W.get("A", law["n_actions"])                       # (an action-count override: the entity width follows the feature layout)
+    return dict(ne=W["ne"], na=law["n_agents"], A=A, ed=W["ne"] + (A - 2) + 10, d=W["d"], h=W["h"],
                 heads=W["heads"], H=W["H"], M=W["M"])
 
 
@@ -126,7 +129,7 @@ def build(dims, imagine, B, T, seed, device, shard=None, dense=False, fresh=0, h
     from refil_amd.learners import REGISTRY as le_REGISTRY
     from refil_amd.synthetic import make_batch_fast
     args = make_args(dims, imagine)
-    data = make_batch_fast(B, T, dims["ne"], seed=seed)
+    data = make_batch_fast(B, T, dims["ne"], seed=seed, na=dims["na"], A=dims["A"])
     if dense:
         data = densify(data)
     if shard is not None:
@@ -162,7 +165,7 @@ def build(dims, imagine, B, T, seed, device, shard=None, dense=False, fresh=0, h
         buffer = ReplayBuffer(scheme, groups, fresh * B, T + 1, preprocess={"actions": ("actions_onehot", [OneHot(dims["A"])])},
                               device="cpu" if host_buffer else device, sample_device=device if host_buffer else None)
         for k in range(fresh):
-            dk = data if k == 0 else make_batch_fast(B, T, dims["ne"], seed=seed + 1000 * k)
+            dk = data if k == 0 else make_batch_fast(B, T, dims["ne"], seed=seed + 1000 * k, na=dims["na"], A=dims["A"])
             if dense and k:
                 dk = densify(dk)
             buffer.insert_episode_batch(episode_batch(dk))

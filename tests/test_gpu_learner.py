@@ -246,6 +246,7 @@ PRODUCTION = {
     "cfg3": dict(B=64, T=80, ne=32, d=128, imagine=True),                 # configs[2], "roofline run"
     "cfg4_shape": dict(B=32, T=150, ne=16, d=128, imagine=False),         # configs[3]: qmix_atten on the 3-8sz shape
     "cfg5_ne48": dict(B=32, T=80, ne=48, d=128, imagine=True),            # configs[4] scaled to 48 entities
+    "cfg5_ne48_mmm_law": dict(B=32, T=80, ne=48, d=128, imagine=True, A=54),     # SURVEY's scaled variant: A = 54, ed = 110, E = 164 (bench cfg5)
     "ne64": dict(B=16, T=40, ne=64, d=128, imagine=True),                 # the largest entity count (one mask word): E = 148, two-pass fc1
     "cfgT_quarter_rnn32": dict(B=8, T=20, ne=32, d=128, imagine=True, H=32),    # rnn_hidden_dim is a free flag (default.yaml:47)
     "cfgT_quarter_rnn128": dict(B=8, T=20, ne=32, d=128, imagine=True, H=128),
