@@ -235,3 +235,44 @@ def test_max_t_filled_trim_is_recognised():
     assert getattr(b[:, :5], "_untrimmed", None) is None          # a shorter cut drops filled steps
     assert getattr(b[1:, :m], "_untrimmed", None) is None         # a batch slice is another batch
     assert getattr(_episodes(4, 9, 2)[:, :6], "_untrimmed", None) is None     # max_t_filled() was never asked
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("REFIL_FUZZ_REPLAY_N", "10"))))
+def test_random_schemes_gather_equals_fancy_indexing(seed):
+    """Replay fuzz: random entity / agent counts (mask rows of 1..64 bits, packed and byte storage), feature widths that are not
+    multiples of 4 (unaligned field sizes: the gather's scalar tail), buffer sizes, inserts that wrap the ring more than once,
+    device and pinned-host storage -- sample() through refil_replay_gather equals the reference's fancy indexing bit for bit."""
+    import random
+    rnd = random.Random(1000 + seed)
+    ne = rnd.choice([1, 2, 5, 8, 13, 31, 32, 33, 47, 63, 64])
+    na = rnd.randint(1, ne)
+    ed, A, T1, cap = rnd.randint(1, 37), rnd.randint(2, 19), rnd.randint(1, 23), rnd.randint(3, 17)
+    where = rnd.choice(["device", "device_bytes", "host"])
+    scheme, groups, pre = _scheme(ne=ne, na=na, ed=ed, A=A)
+    kw = dict(device="cuda") if where != "host" else dict(device="cpu", sample_device="cuda")
+    if where == "device_bytes":
+        kw["pack_masks"] = False
+    buf = ReplayBuffer(scheme, groups, cap, T1, preprocess=pre, **kw)
+    ref = ReplayBuffer(scheme, groups, cap, T1, preprocess=pre, device="cpu")          # the reference's path: host storage, fancy indexing
+    tag = 0
+    for _ in range(rnd.randint(2, 6)):
+        n = rnd.randint(1, cap)
+        eps = _episodes(n, T1, 100 * tag, ne=ne, na=na, ed=ed, A=A)
+        tag += 1
+        buf.insert_episode_batch(eps)
+        ref.insert_episode_batch(eps)
+        assert buf.episodes_in_buffer == ref.episodes_in_buffer and buf.buffer_index == ref.buffer_index
+        for _ in range(2):
+            bs = rnd.randint(1, buf.episodes_in_buffer)
+            s0 = rnd.randint(0, 10 ** 6)
+            np.random.seed(s0)
+            got = buf.sample(bs)
+            np.random.seed(s0)
+            want = ref.sample(bs)
+            th.cuda.synchronize()
+            assert got.batch_size == want.batch_size == bs
+            for k, v in want.data.transition_data.items():
+                assert th.equal(got[k].cpu(), v), (k, where, ne, na, ed, A, T1, cap)
+            for k, v in want.data.episode_data.items():
+                assert th.equal(got[k].cpu(), v), k
