@@ -250,9 +250,34 @@ def _attn_ref(q, k, v, masks, heads):
 ])
 @pytest.mark.parametrize("force_valu", [False, True])
 def test_attention_forward_backward(ne, na, heads, hd, variants, force_valu, monkeypatch):
-    import hip_ops
     monkeypatch.setenv("REFIL_ATTN_VALU", "1" if force_valu else "0")   # matrix-core kernel vs generic VALU fallback
-    torch.manual_seed(ne * 100 + na)
+    _attention_case(ne, na, heads, hd, variants, ne * 100 + na)
+
+
+def _attn_fuzz_cases(n, seed=31):
+    import random
+    rnd = random.Random(seed)
+    groups = [[MASK_OBS, MASK_OBS_WITHIN, MASK_OBS_INTERACT], [MASK_ENTITY, MASK_WITHIN, MASK_INTERACT]]
+    out = []
+    for i in range(n):
+        ne = rnd.randint(1, 64)
+        na = rnd.randint(1, min(ne, 32))
+        g = rnd.choice(groups)
+        out.append((ne, na, rnd.choice([1, 2, 3, 4]), rnd.choice([4, 8, 12, 16, 20, 24, 28, 32]), g[:rnd.randint(1, 3)], 7000 + i))
+    return out
+
+
+@pytest.mark.parametrize("ne,na,heads,hd,variants,seed", _attn_fuzz_cases(int(__import__("os").environ.get("REFIL_FUZZ_ATTN_N", "16"))))
+def test_attention_random_shapes(ne, na, heads, hd, variants, seed, monkeypatch):
+    """Attention-core fuzz: any entity / agent count up to 64 / 32, head widths 4..32, 1-3 mask variants, whichever kernel the dispatcher
+    takes (nine matrix-core tile shapes or the vector-ALU kernel), forward and backward against torch autograd."""
+    monkeypatch.delenv("REFIL_ATTN_VALU", raising=False)
+    _attention_case(ne, na, heads, hd, variants, seed)
+
+
+def _attention_case(ne, na, heads, hd, variants, seed):
+    import hip_ops
+    torch.manual_seed(seed)
     B, T1 = 3, 4
     R, w = B * T1, heads * hd
     q = torch.randn(R, na, w, requires_grad=True)
