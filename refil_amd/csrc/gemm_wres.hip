@@ -78,9 +78,41 @@ __device__ inline float4 keep_if(bool in, float4 v) {
 // bytes of LDS of an instantiation: the W slice + the waves' epilogue slabs
 constexpr size_t wres_smem(int tn, int nc, int npass) { return ((size_t)32 * tn * (8 * nc * npass + 4) + (size_t)WR_WAVES * 32 * WR_SLAB_P) * sizeof(float); }
 
+// ---- SPLIT = 6: the fp32 product on the bf16 matrix pipe, without giving up fp32 accuracy --------------------------------------
+// Every fp32 operand is written as hi + mid + lo, three bf16 numbers (8 significant bits each, nearest rounding, the residuals
+// x - hi and x - hi - mid are exact in fp32): the split is exact up to the last bit of the fp32 significand. A product a b is
+// then nine bf16 x bf16 products, each EXACT in the pipe's fp32 accumulate; the three smallest (mid lo, lo mid, lo lo) are below
+// 2^-26 |a b| together -- a quarter of the unit roundoff the fp32 accumulation applies to every partial sum anyway -- and are left
+// out: v_mfma_f32_32x32x16_bf16 x 6 instead of v_mfma_f32_32x32x2_f32 x 8 for the same 16 reduction indices, 192 instead of 512
+// matrix-pipe cycles. (Measured against an fp64 product: tests/test_gpu_ops.py::test_wres_split_accuracy -- the error of the two
+// paths is the same.) W is split once per workgroup while it is staged into LDS (three bf16 planes, 1.5 x the fp32 bytes); the x rows
+// are split in registers right before use, ~5 VALU operations per element, each element feeding 6 TN MFMAs.
+typedef __bf16 wr_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wr_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float wr_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned wr_u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline unsigned wr_pk(float x, float y) { wr_f32x2 v = {x, y}; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wr_bf16x2)); }
+// (x, y) -> packed bf16 pairs hi / mid / lo with x = hi + mid + lo (+ < 2^-25 |x|)
+__device__ inline void wr_split(float x, float y, unsigned& h, unsigned& m, unsigned& l) {
+    h = wr_pk(x, y);
+    x -= __uint_as_float(h << 16); y -= __uint_as_float(h & 0xFFFF0000u);
+    m = wr_pk(x, y);
+    x -= __uint_as_float(m << 16); y -= __uint_as_float(m & 0xFFFF0000u);
+    l = wr_pk(x, y);
+}
+// split layout of the W slice: 3 planes x (32 TN columns) x PB bytes; a column holds, per 16-index super-chunk S and lane half hf,
+// the 8 bf16 of k = 16 S + 8 (e >> 2) + 4 hf + (e & 3), e = 0..7 -- the indices lane half hf holds of chunks 2S and 2S + 1
+constexpr int wres_nse(int nc, int npass) { return npass * ((nc + 1) / 2); }                 // super-chunks
+constexpr int wres_pb(int nc, int npass) { return 32 * wres_nse(nc, npass) + 16; }           // column pitch in bytes (/16 odd)
+constexpr size_t wres_smem_split(int tn, int nc, int npass) { return (size_t)3 * 32 * tn * wres_pb(nc, npass) + (size_t)WR_WAVES * 32 * WR_SLAB_P * sizeof(float); }
+constexpr size_t wres_smem_x(int tn, int nc, int npass, int split) { return split ? wres_smem_split(tn, nc, npass) : wres_smem(tn, nc, npass); }
+// (SPLIT: the double-buffered W planes and the split x pieces cost ~60 registers more: the 256-register cap only for the small shapes)
+constexpr int wres_min_wg(int tn, int nc, int npass, int split) { return wres_smem_x(tn, nc, npass, split) <= 80 * 1024 && (!split || tn * nc * npass < 32) ? 2 : 1; }
+constexpr bool wres_split_ok(int tn, int nc, int npass) { return wres_smem_split(tn, nc, npass) <= 160 * 1024 && (npass == 1 || nc % 2 == 0); }
+
 // (a second workgroup per CU -- and with it the 256-register cap -- only where two W slices fit the CU's 160 KB of LDS)
-template <int TN, int NC, int NPASS, bool BT, int EPI, bool ACC, bool RMASK, bool B2, bool IDX = false>
-__global__ __launch_bounds__(64 * WR_WAVES, (wres_smem(TN, NC, NPASS) <= 80 * 1024 ? 2 : 1)) void gemm_wres_kernel(WresK p) {
+template <int TN, int NC, int NPASS, bool BT, int EPI, bool ACC, bool RMASK, bool B2, bool IDX = false, int SPLIT = 0>
+__global__ __launch_bounds__(64 * WR_WAVES, wres_min_wg(TN, NC, NPASS, SPLIT)) void gemm_wres_kernel(WresK p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lane31 = lane & 31, hf = lane >> 5;
@@ -92,14 +124,17 @@ __global__ __launch_bounds__(64 * WR_WAVES, (wres_smem(TN, NC, NPASS) <= 80 * 10
     float* __restrict__ C = p.C + bz * p.sC;
     const float* __restrict__ AUX = EPI == 1 ? p.aux + bz * p.sC : nullptr;
     float* Ws = lds;
-    float* slab = lds + 32 * TN * KP + wave * 32 * WR_SLAB_P;
+    constexpr int NSE = wres_nse(NC, NPASS), PB = wres_pb(NC, NPASS), PS = 32 * TN * PB;      // (SPLIT) super-chunks, column pitch, plane size [bytes]
+    char* Wb = reinterpret_cast<char*>(lds);
+    float* slab = (SPLIT ? reinterpret_cast<float*>(Wb + 3 * PS) : lds + 32 * TN * KP) + wave * 32 * WR_SLAB_P;
     const int ntiles = IDX ? (*p.rcount + 31) >> 5 : p.ntiles;
     if (IDX && ntiles == 0) return;                    // (uniform: before any barrier)
 
     // ---- stage the W slice (32 TN output columns x 8 NCT reduction indices, zero padded) once; loads batched 8 deep ----
     {
         constexpr int NT = 64 * WR_WAVES, U = 8;
-        constexpr int TOTAL = BT ? 8 * NCT * 8 * TN : 32 * TN * 2 * NCT;          // float4 count
+        constexpr int NCS = SPLIT ? 2 * NSE : NCT;                                // chunks staged (SPLIT: whole super-chunks, zero padded)
+        constexpr int TOTAL = BT ? 8 * NCS * 8 * TN : 32 * TN * 2 * NCS;          // float4 count
         for (int base = 0; base < TOTAL; base += NT * U) {
             float4 v[U];
 #pragma unroll
@@ -110,7 +145,7 @@ __global__ __launch_bounds__(64 * WR_WAVES, (wres_smem(TN, NC, NPASS) <= 80 * 10
                     const bool in = idx < TOTAL && r < p.K && (n0 + o) < p.N;     // N % 4 == 0
                     v[u] = keep_if(in, *reinterpret_cast<const float4*>(W + (long)(in ? r : 0) * p.ldw + (in ? n0 + o : 0)));
                 } else {         // memory [o][r]: 16 bytes along the reduction index
-                    const int n = idx / (2 * NCT), k = (idx - n * (2 * NCT)) * 4;
+                    const int n = idx / (2 * NCS), k = (idx - n * (2 * NCS)) * 4;
                     const bool in = idx < TOTAL && (n0 + n < p.N) && (k < p.K);   // K % 4 == 0
                     v[u] = keep_if(in, *reinterpret_cast<const float4*>(W + (long)(in ? n0 + n : 0) * p.ldw + (in ? k : 0)));
                 }
@@ -119,7 +154,29 @@ __global__ __launch_bounds__(64 * WR_WAVES, (wres_smem(TN, NC, NPASS) <= 80 * 10
             for (int u = 0; u < U; ++u) {
                 const int idx = base + u * NT + tid;
                 if (idx < TOTAL) {
-                    if (BT) {
+                    if (SPLIT) {
+                        unsigned h0, m0, l0, h1, m1, l1;
+                        if (BT) {   // four columns o..o+3 at reduction index r: one bf16 per plane and column
+                            const int r = idx / (8 * TN), o = (idx - r * (8 * TN)) * 4;
+                            wr_split(v[u].x, v[u].y, h0, m0, l0); wr_split(v[u].z, v[u].w, h1, m1, l1);
+                            const int off = (2 * (r >> 4) + ((r >> 2) & 1)) * 16 + 2 * (4 * ((r >> 3) & 1) + (r & 3));
+                            unsigned short* q0 = reinterpret_cast<unsigned short*>(Wb + (o + 0) * PB + off);
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl) {
+                                const unsigned w0 = pl == 0 ? h0 : (pl == 1 ? m0 : l0), w1 = pl == 0 ? h1 : (pl == 1 ? m1 : l1);
+                                unsigned short* q = q0 + pl * (PS / 2);
+                                q[0] = (unsigned short)w0; q[PB / 2] = (unsigned short)(w0 >> 16);
+                                q[2 * (PB / 2)] = (unsigned short)w1; q[3 * (PB / 2)] = (unsigned short)(w1 >> 16);
+                            }
+                        } else {    // four reduction indices k..k+3 of column n: 8 bytes per plane
+                            const int n = idx / (2 * NCS), k = (idx - n * (2 * NCS)) * 4;
+                            wr_split(v[u].x, v[u].y, h0, m0, l0); wr_split(v[u].z, v[u].w, h1, m1, l1);
+                            char* q = Wb + n * PB + (2 * (k >> 4) + ((k >> 2) & 1)) * 16 + 8 * ((k >> 3) & 1);
+                            *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
+                            *reinterpret_cast<uint2*>(q + PS) = make_uint2(m0, m1);
+                            *reinterpret_cast<uint2*>(q + 2 * PS) = make_uint2(l0, l1);
+                        }
+                    } else if (BT) {
                         const int r = idx / (8 * TN), o = (idx - r * (8 * TN)) * 4;
                         Ws[(o + 0) * KP + r] = v[u].x; Ws[(o + 1) * KP + r] = v[u].y;
                         Ws[(o + 2) * KP + r] = v[u].z; Ws[(o + 3) * KP + r] = v[u].w;
@@ -213,42 +270,103 @@ __global__ __launch_bounds__(64 * WR_WAVES, (wres_smem(TN, NC, NPASS) <= 80 * 10
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         WR_TICK(t_top)
-        // W fragments are read one chunk ahead of the MFMAs that use them (LDS latency off the MFMA issue path)
-        float4 bq[2][TN];
+        if constexpr (SPLIT == 0) {
+            // W fragments are read one chunk ahead of the MFMAs that use them (LDS latency off the MFMA issue path)
+            float4 bq[2][TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bq[0][j] = *reinterpret_cast<const float4*>(wb + 32 * j * KP);
+            for (int j = 0; j < TN; ++j) bq[0][j] = *reinterpret_cast<const float4*>(wb + 32 * j * KP);
 #pragma unroll
-        for (int ps_ = 0; ps_ < NPASS; ++ps_) {
+            for (int ps_ = 0; ps_ < NPASS; ++ps_) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int ct = ps_ * NC + c;
-                if (ct + 1 < NCT) {
+                for (int c = 0; c < NC; ++c) {
+                    const int ct = ps_ * NC + c;
+                    if (ct + 1 < NCT) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) bq[(ct + 1) & 1][j] = *reinterpret_cast<const float4*>(wb + 32 * j * KP + 8 * (ct + 1));
+                        for (int j = 0; j < TN; ++j) bq[(ct + 1) & 1][j] = *reinterpret_cast<const float4*>(wb + 32 * j * KP + 8 * (ct + 1));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // (left alone the scheduler sinks these reads to the end of the chunk)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float4 b = bq[ct & 1][j];
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].x, b.x, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].y, b.y, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].z, b.z, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].w, b.w, acc[j], 0, 0, 0);
+                    }
+                    // refill: the second half of this row (two-pass) or the same chunk of the wave's next tile. The
+                    // sched_barriers pin the interleaving: left alone the scheduler sinks all loads below the MFMAs.
+                    __builtin_amdgcn_sched_barrier(0);
+                    // The four chunks that share a 128-byte line of the row are requested TOGETHER, behind the last of them: requested
+                    // one per chunk (1024 matrix-pipe cycles apart, with the other waves' rows in between) the line had left the 32 KB
+                    // vector cache by the time its next quarter was asked for (measured: 71.0 -> 69.3 us alone, -0.7 % of the step)
+                    if ((c & 3) == 3 || c == NC - 1) {
+#pragma unroll
+                        for (int cc = (c & ~3); cc <= c; ++cc) {
+                            if (ps_ + 1 < NPASS) a[cc] = *reinterpret_cast<const float4*>(csrc + min(8 * (ps_ * NC + cc + NC), kmax));
+                            else a[cc] = *reinterpret_cast<const float4*>(nsrc + min(8 * cc, kmax));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);      // (left alone the scheduler sinks these reads to the end of the chunk)
+            }
+        } else {
+            // bf16 x 6 (see wr_split): per 16-index super-chunk and column tile, 3 LDS reads of 16 bytes (the W planes) feed 6 MFMAs;
+            // the planes of the next super-chunk are read while this one's MFMAs run. Products are accumulated smallest first.
+            constexpr int NSP = (NC + 1) / 2;                      // super-chunks per pass
+            const char* wbb = Wb + lane31 * PB + 16 * hf;         // + 32 j PB + 32 s (+ plane PS)
+            wr_u32x4 bq[2][TN][3];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const float4 b = bq[ct & 1][j];
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].x, b.x, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].y, b.y, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].z, b.z, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c].w, b.w, acc[j], 0, 0, 0);
-                }
-                // refill: the second half of this row (two-pass) or the same chunk of the wave's next tile. The
-                // sched_barriers pin the interleaving: left alone the scheduler sinks all loads below the MFMAs.
-                __builtin_amdgcn_sched_barrier(0);
-                // The four chunks that share a 128-byte line of the row are requested TOGETHER, behind the last of them: requested
-                // one per chunk (1024 matrix-pipe cycles apart, with the other waves' rows in between) the line had left the 32 KB
-                // vector cache by the time its next quarter was asked for (measured: 71.0 -> 69.3 us alone, -0.7 % of the step)
-                if ((c & 3) == 3 || c == NC - 1) {
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int cc = (c & ~3); cc <= c; ++cc) {
-                        if (ps_ + 1 < NPASS) a[cc] = *reinterpret_cast<const float4*>(csrc + min(8 * (ps_ * NC + cc + NC), kmax));
-                        else a[cc] = *reinterpret_cast<const float4*>(nsrc + min(8 * cc, kmax));
+                for (int pl = 0; pl < 3; ++pl) bq[0][j][pl] = *reinterpret_cast<const wr_u32x4*>(wbb + pl * PS + 32 * j * PB);
+#pragma unroll
+            for (int ps_ = 0; ps_ < NPASS; ++ps_) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    if ((c & 1) || c == NC - 1) {
+                        const int sc = c >> 1, st_ = ps_ * NSP + sc;
+                        if (st_ + 1 < NSE) {
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                                for (int pl = 0; pl < 3; ++pl)
+                                    bq[(st_ + 1) & 1][j][pl] = *reinterpret_cast<const wr_u32x4*>(wbb + pl * PS + 32 * j * PB + 32 * (st_ + 1));
+                        }
+                        wr_u32x4 ah, am, al;
+                        {
+                            const float4 a0 = a[2 * sc];
+                            float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (2 * sc + 1 < NC) a1 = a[2 * sc + 1 < NC ? 2 * sc + 1 : 0];
+                            unsigned h_[4], m_[4], l_[4];
+                            wr_split(a0.x, a0.y, h_[0], m_[0], l_[0]); wr_split(a0.z, a0.w, h_[1], m_[1], l_[1]);
+                            wr_split(a1.x, a1.y, h_[2], m_[2], l_[2]); wr_split(a1.z, a1.w, h_[3], m_[3], l_[3]);
+                            ah = wr_u32x4{h_[0], h_[1], h_[2], h_[3]}; am = wr_u32x4{m_[0], m_[1], m_[2], m_[3]}; al = wr_u32x4{l_[0], l_[1], l_[2], l_[3]};
+                        }
+                        const wr_bf16x8 Ah = __builtin_bit_cast(wr_bf16x8, ah), Am = __builtin_bit_cast(wr_bf16x8, am), Al = __builtin_bit_cast(wr_bf16x8, al);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const wr_bf16x8 Bh = __builtin_bit_cast(wr_bf16x8, bq[st_ & 1][j][0]), Bm = __builtin_bit_cast(wr_bf16x8, bq[st_ & 1][j][1]),
+                                            Bl = __builtin_bit_cast(wr_bf16x8, bq[st_ & 1][j][2]);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acc[j], 0, 0, 0);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[j], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // refills: as in the fp32 loop (the four chunks of a 128-byte line together, behind the last of them)
+                    if ((c & 3) == 3 || c == NC - 1) {
+#pragma unroll
+                        for (int cc = (c & ~3); cc <= c; ++cc) {
+                            if (ps_ + 1 < NPASS) a[cc] = *reinterpret_cast<const float4*>(csrc + min(8 * (ps_ * NC + cc + NC), kmax));
+                            else a[cc] = *reinterpret_cast<const float4*>(nsrc + min(8 * cc, kmax));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
         WR_TICK(t_mf)
@@ -340,18 +458,31 @@ bool gemm_wres_eligible(const refil_gemm_desc& d) {
     return true;
 }
 
-template <int TN, int NC, int NPASS, bool BT, int EPI, bool ACC, bool RMASK, bool B2 = false, bool IDX = false>
-static int wres_launch_i(const WresK& k, dim3 grid, hipStream_t st) {
-    constexpr size_t smem = wres_smem(TN, NC, NPASS);
+// REFIL_WRES_SPLIT=6 / refil_set_tuning("wres_split", 6): the bf16 x 6 form of the product (see wr_split) wherever its W planes fit the LDS
+static int wres_split_mode() {
+    if (g_tuning.wres_split >= 0) return g_tuning.wres_split == 6 ? 6 : 0;
+    static const int env = [] { const char* e = getenv("REFIL_WRES_SPLIT"); return e && atoi(e) == 6 ? 6 : 0; }();
+    return env;
+}
+template <int TN, int NC, int NPASS, bool BT, int EPI, bool ACC, bool RMASK, bool B2, bool IDX, int SPLIT>
+static int wres_launch_s(const WresK& k, dim3 grid, hipStream_t st) {
+    constexpr size_t smem = wres_smem_x(TN, NC, NPASS, SPLIT);
     static_assert(smem <= 160 * 1024, "W slice + slabs must fit the 160 KB LDS of a CU");
     static bool raised = false;                        // raise the dynamic-LDS cap of this instantiation once
     if (smem > 64 * 1024 && !raised) {
-        REFIL_HIP(hipFuncSetAttribute((const void*)gemm_wres_kernel<TN, NC, NPASS, BT, EPI, ACC, RMASK, B2, IDX>,
+        REFIL_HIP(hipFuncSetAttribute((const void*)gemm_wres_kernel<TN, NC, NPASS, BT, EPI, ACC, RMASK, B2, IDX, SPLIT>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         raised = true;
     }
-    hipLaunchKernelGGL((gemm_wres_kernel<TN, NC, NPASS, BT, EPI, ACC, RMASK, B2, IDX>), grid, dim3(64 * WR_WAVES), smem, st, k);
+    hipLaunchKernelGGL((gemm_wres_kernel<TN, NC, NPASS, BT, EPI, ACC, RMASK, B2, IDX, SPLIT>), grid, dim3(64 * WR_WAVES), smem, st, k);
     return 0;
+}
+template <int TN, int NC, int NPASS, bool BT, int EPI, bool ACC, bool RMASK, bool B2 = false, bool IDX = false>
+static int wres_launch_i(const WresK& k, dim3 grid, hipStream_t st) {
+    if constexpr (wres_split_ok(TN, NC, NPASS)) {
+        if (wres_split_mode() == 6) return wres_launch_s<TN, NC, NPASS, BT, EPI, ACC, RMASK, B2, IDX, 6>(k, grid, st);
+    }
+    return wres_launch_s<TN, NC, NPASS, BT, EPI, ACC, RMASK, B2, IDX, 0>(k, grid, st);
 }
 
 // forward products: K <= 128, one pass

@@ -29,6 +29,9 @@ PARITY_TESTED = {
     "dw4_min_out": (2000,),
     "dw_target": (384, 512),
     "compose_early": (0, 1),
+    # 6: the weight-resident GEMMs compute their fp32 products as six bf16 matrix-pipe products of a 3-way operand split (gemm_wres.hip:
+    # wr_split; fp32-accurate -- tests/test_gpu_ops.py::test_wres_split_accuracy). Never picked by the autotuner: explicit opt-in only.
+    "wres_split": (0, 6),
 }
 # what the first-call autotuner tries, in this order (greedy, one knob at a time)
 CANDIDATES = (("dw4_target", (96,)), ("gru_pd", (2,)), ("dw4_min_out", (2000,)), ("dw_target", (384,)), ("compose_early", (0, 1)))

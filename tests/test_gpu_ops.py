@@ -134,10 +134,52 @@ def test_gemm_dw_stream_rowmaps(N, K, splits):
 
 
 # ---- weight-resident kernel (gemm_wres.hip): taken for M >= 2048, M % 32 == 0, N % 32 == 0, short reductions ----
+@pytest.fixture(params=[0, 6], ids=["fp32", "bf16x6"])
+def wres_mode(request):
+    """Both arithmetic forms of the weight-resident kernel: v_mfma_f32_32x32x2_f32 on the fp32 operands, or the 3-way bf16 split of
+    both operands on v_mfma_f32_32x32x16_bf16 x 6 (refil_set_tuning("wres_split", 6) / REFIL_WRES_SPLIT=6)."""
+    from refil_amd import _lib
+    _lib.check(_lib.lib().refil_set_tuning(b"wres_split", request.param), "refil_set_tuning")
+    yield request.param
+    _lib.check(_lib.lib().refil_set_tuning(b"wres_split", -1), "refil_set_tuning")
+
+
+@pytest.mark.parametrize("M,N,K,bt,scale", [(8192, 128, 128, False, 0.0), (8192, 128, 128, True, 0.0), (4096, 256, 84, False, 0.0),
+                                            (4096, 128, 256, True, 0.0), (8192, 128, 128, False, 2.0), (4096, 64, 200, False, 1.0)])
+def test_wres_split_accuracy(M, N, K, bt, scale):
+    """The bf16 x 6 form is as accurate as the fp32 matrix instruction: both against an fp64 product of the same fp32 operands.
+    scale > 0: operands with a wide dynamic range (x exp(scale N(0,1))), so that the three pieces of a split sit at very different
+    exponents. Bar: rms error <= 1.25 x, max error <= 2 x that of the fp32 path (measured: 0.9-1.05 x)."""
+    import hip_ops
+    from refil_amd import _lib
+    torch.manual_seed(M + N + K + int(bt))
+    x = torch.randn(M, K)
+    W = torch.randn(K, N) / math.sqrt(K) if bt else torch.randn(N, K) / math.sqrt(K)
+    if scale > 0:
+        x = x * torch.exp(scale * torch.randn(M, K))
+        W = W * torch.exp(scale * torch.randn(*W.shape))
+    ref = x.double() @ (W.double() if bt else W.double().t())
+    errs = {}
+    try:
+        for mode in (0, 6):
+            _lib.check(_lib.lib().refil_set_tuning(b"wres_split", mode), "refil_set_tuning")
+            y = torch.full((M, N), float("nan"), device=DEV)
+            if bt:
+                hip_ops.gemm(x.to(DEV), W.to(DEV), y, M, N, K, K, N, N, flags=GEMM_B_OUTC)
+            else:
+                hip_ops.gemm(x.to(DEV), W.to(DEV), y, M, N, K, K, K, N)
+            d = y.cpu().double() - ref
+            errs[mode] = (d.pow(2).mean().sqrt().item(), d.abs().max().item())
+    finally:
+        _lib.check(_lib.lib().refil_set_tuning(b"wres_split", -1), "refil_set_tuning")
+    print(f"fp32 MFMA: rms {errs[0][0]:.3e} max {errs[0][1]:.3e}; bf16 x 6: rms {errs[6][0]:.3e} max {errs[6][1]:.3e}; |ref| rms {ref.pow(2).mean().sqrt().item():.3e}")
+    assert errs[6][0] <= 1.25 * errs[0][0] and errs[6][1] <= 2.0 * errs[0][1], errs
+
+
 @pytest.mark.parametrize("M,N,K,batch", [(4096, 128, 128, 1), (2048 + 64, 256, 128, 2), (6400, 512, 84, 1), (4096, 192, 64, 1),
                                          (4096, 128, 148, 1), (4096, 512, 200, 1), (2048, 64, 256, 2), (4096, 256, 132, 1),
                                          (2560, 64, 128, 1), (3200, 32, 128, 3), (2048, 128, 16, 1), (4096, 96, 40, 1)])
-def test_gemm_wres_forward(M, N, K, batch):
+def test_gemm_wres_forward(M, N, K, batch, wres_mode):
     import hip_ops
     torch.manual_seed(M + N + K)
     x = torch.randn(M, batch * K)
@@ -162,7 +204,7 @@ def test_gemm_wres_forward(M, N, K, batch):
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 128, 128), (2304, 128, 32), (4096, 128, 64), (2560, 64, 96), (4096, 256, 128)])
-def test_gemm_wres_dx(M, N, K):
+def test_gemm_wres_dx(M, N, K, wres_mode):
     """dx[M,N] = dy[M,K] W[K,N]  (N = layer input width, K = layer output width = the reduction)."""
     import hip_ops
     torch.manual_seed(M + N + K + 1)
@@ -177,7 +219,7 @@ def test_gemm_wres_dx(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 128, 256), (2048, 64, 192), (4096, 128, 128), (2560, 128, 64), (2048, 64, 52)])
-def test_gemm_wres_dx_relu_bwd_accum(M, N, K):
+def test_gemm_wres_dx_relu_bwd_accum(M, N, K, wres_mode):
     import hip_ops
     torch.manual_seed(M + N + K + 2)
     na, ne = 4, 8
@@ -442,7 +484,7 @@ def _row_list(M, frac, seed, trash):
 @pytest.mark.parametrize("M,N,K,batch,frac", [(4096, 128, 84, 1, 0.45), (6400, 256, 128, 2, 0.6), (2048, 64, 52, 1, 0.3),
                                               (4096, 128, 148, 1, 0.5), (4096, 512, 196, 1, 0.4),
                                               (4096, 512, 84, 1, 0.0), (4096, 128, 64, 1, 1.0)])
-def test_gemm_wres_forward_row_list(M, N, K, batch, frac):
+def test_gemm_wres_forward_row_list(M, N, K, batch, frac, wres_mode):
     """x W^T over a device-side row list: listed rows are computed, every other row of C stays untouched."""
     import hip_ops
     torch.manual_seed(M + N + K)
@@ -471,7 +513,7 @@ def test_gemm_wres_forward_row_list(M, N, K, batch, frac):
 
 
 @pytest.mark.parametrize("M,N,K,frac", [(4096, 128, 256, 0.45), (2048, 64, 128, 0.5), (4096, 128, 128, 0.7)])
-def test_gemm_wres_dx_relu_bwd_row_list(M, N, K, frac):
+def test_gemm_wres_dx_relu_bwd_row_list(M, N, K, frac, wres_mode):
     import hip_ops
     torch.manual_seed(M + N + K + 5)
     na, ne = 4, 8
