@@ -45,6 +45,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense (MI355X_MICROARCH.md; 2495 measured)
 # BASELINE.json configs. B = episodes per GPU under weak scaling.
 CONFIGS = {
     "cfgT": dict(B=32, T=80, ne=32, d=128, h=128, imagine=True, what="north-star target shape (BASELINE.json north_star / metric)"),
@@ -539,12 +540,26 @@ def main():
         # the projection kernel that executes the most FLOPs per step as well (matrix-core evidence when the dominant kernel is HBM-bound)
         gemm = max((e for e in ents if e["name"].startswith("gemm_") and e["flops"] > 0), key=lambda e: iso.get(e["name"], e)["flops"], default=None)
         gemm_iso = iso.get(gemm["name"], gemm) if gemm else None
+        # The weight-resident GEMMs compute their fp32 products as six bf16 matrix-pipe products of a 3-way operand split (gemm_wres.hip:
+        # wr_split; profiler names ending in ",6>"). `achieved` stays the ALGORITHMIC fp32 FLOPs against the fp32-MFMA roof (what the
+        # reference's arithmetic costs on this part's fp32 matrix instruction); `matrix_pipe` adds what the pipe executes against ITS roof.
+        split6 = (not hbm_bound) and dom["name"].startswith("gemm_wres_kernel") and dom["name"].endswith(",6>")
         roofline = {"kernel": dom["name"], "bound": "hbm" if hbm_bound else "mfma", "achieved": round(ach_iso, 2), "peak": peak,
                     "unit": unit, "frac": round(ach_iso / peak, 4), "traffic": traffic,
-                    "peak_note": "peak = 256 CU x 2.4 GHz x 256 FLOP/clk (MI355X_MICROARCH.md). On real operand data the part clocks to its power "
-                                 "budget: cycle counters inside this kernel give 97.5 % MFMA issue in its main loop, 80 % over the row tile, at an "
-                                 "effective 1.9 GHz (profiles/r04_wres_timing_slab_vs_pipe.txt); the same launch runs 113 TFLOP/s on zeros, 92-103 on "
-                                 "N(0,1) (profiles/r04_gemm_dvfs.txt); DESIGN.md lessons 25-27" if not hbm_bound else None,
+                    "matrix_pipe": None if not split6 else {
+                        "instruction": "v_mfma_f32_32x32x16_bf16 x 6 per 16 reduction indices (both fp32 operands split into three bf16 pieces, the six "
+                                       "largest of the nine piece products, fp32 accumulate: fp32-accurate, tests/test_gpu_ops.py::test_wres_split_accuracy)",
+                        "executed_tflops": round(6.0 * ach_iso, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(6.0 * ach_iso / PEAK_BF16_MFMA_TFLOPS, 4),
+                        "note": "`achieved` / `frac` above: algorithmic fp32 FLOPs (2 M N K of the listed rows) over the launch time against the fp32-MFMA "
+                                "peak -- the roof of the v_mfma_f32_32x32x2_f32 form (REFIL_WRES_SPLIT=0), which this form is allowed to exceed"},
+                    "peak_note": ("peak = 256 CU x 2.4 GHz x 256 FLOP/clk, the fp32 matrix instruction's (MI355X_MICROARCH.md). The launch runs at the clock "
+                                  "the power budget allows: in-kernel cycle counters give 6.7 k cycles of MFMAs (floor 6.1 k) + 2.8 k of epilogue per 32 x 128 "
+                                  "row tile at an effective ~1.6 GHz (profiles/r04_wres_timing_split6.txt); the fp32-instruction form: 16.8 k + 3.5 k at 1.9 GHz "
+                                  "(profiles/r04_wres_timing_slab_vs_pipe.txt); DESIGN.md lessons 25-27, 29" if split6 else
+                                  "peak = 256 CU x 2.4 GHz x 256 FLOP/clk (MI355X_MICROARCH.md). On real operand data the part clocks to its power "
+                                  "budget: cycle counters inside this kernel give 97.5 % MFMA issue in its main loop, 80 % over the row tile, at an "
+                                  "effective 1.9 GHz (profiles/r04_wres_timing_slab_vs_pipe.txt); the same launch runs 113 TFLOP/s on zeros, 92-103 on "
+                                  "N(0,1) (profiles/r04_gemm_dvfs.txt); DESIGN.md lessons 25-27") if not hbm_bound else None,
                     "traffic_unit": f"HBM bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE, {traffic_src})",
                     "hbm_gb_per_step": None if hbm_step is None else round(hbm_step / 1e9, 3),
                     "hbm_gb_per_s_over_step": None if hbm_step is None else round(hbm_step / (ms_per_step * 1e-3) / 1e9, 1),

@@ -25,6 +25,8 @@
 // every place where a load is awaited while a store is in flight degenerates to vmcnt(0) -- see the loop tail.
 #include <string.h>
 
+#include <utility>
+
 #include "bufops.h"
 #include "common.h"
 #include "kernels.h"
@@ -40,6 +42,12 @@ __device__ unsigned long long g_wr_dbg[8192 * 4];
 #else
 #define WR_TICK(acc_)
 #endif
+
+// f(integral_constant<int, 0>) .. f(integral_constant<int, N - 1>): a loop whose index is a constant expression in the body
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 struct WresK {
     const float* A; const float* W; float* C; const float* bias; const uint8_t* rowmask; const float* aux;
@@ -92,6 +100,9 @@ typedef __bf16 wr_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float wr_f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned wr_u32x4 __attribute__((ext_vector_type(4)));
 __device__ inline unsigned wr_pk(float x, float y) { wr_f32x2 v = {x, y}; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wr_bf16x2)); }
+// a - b as ONE scalar v_sub_f32: left to the compiler, the two residuals of a pair are SLP-packed into a v_pk_add_f32, which costs
+// ~13 matrix-pipe cycles beside an MFMA where a plain VALU operation costs none (MI355X_MICROARCH.md, "price of one filler")
+__device__ inline float wr_sub(float a, float b) { float r; asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // (x, y) -> packed bf16 pairs hi / mid / lo with x = hi + mid + lo (+ < 2^-25 |x|)
 __device__ inline void wr_split(float x, float y, unsigned& h, unsigned& m, unsigned& l) {
     h = wr_pk(x, y);
@@ -311,51 +322,79 @@ __global__ __launch_bounds__(64 * WR_WAVES, wres_min_wg(TN, NC, NPASS, SPLIT)) v
             }
         } else {
             // bf16 x 6 (see wr_split): per 16-index super-chunk and column tile, 3 LDS reads of 16 bytes (the W planes) feed 6 MFMAs;
-            // the planes of the next super-chunk are read while this one's MFMAs run. Products are accumulated smallest first.
+            // the planes of the next super-chunk are read, and the x pieces of the next super-chunk are split (~45 VALU operations),
+            // while this one's MFMAs run: the MFMAs go round-robin over the TN accumulators, product by product (smallest first per
+            // accumulator), so two consecutive ones never depend on each other and the fillers between them cost nothing (a filler
+            // between two MFMAs on the SAME accumulator breaks the back-to-back forwarding: DESIGN.md lesson 26).
             constexpr int NSP = (NC + 1) / 2;                      // super-chunks per pass
             const char* wbb = Wb + lane31 * PB + 16 * hf;         // + 32 j PB + 32 s (+ plane PS)
             wr_u32x4 bq[2][TN][3];
+            wr_u32x4 as[2][3];                                    // hi / mid / lo pieces of the x operand, this and the next super-chunk
+            // The split of one super-chunk (8 x values = 4 pairs) as 20 micro-steps (per pair: hi, residual, mid, residual, lo), so that it
+            // can be dealt out in pieces of 1-3 VALU operations behind the MFMAs of the super-chunk before
+            float sx[4], sy[4];
+            unsigned sh[4], sm[4], sl[4];
+            auto split_begin = [&](int sc) {
+                const float4 a0 = a[2 * sc < NC ? 2 * sc : 0];
+                float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (2 * sc + 1 < NC) a1 = a[2 * sc + 1 < NC ? 2 * sc + 1 : 0];
+                sx[0] = a0.x; sy[0] = a0.y; sx[1] = a0.z; sy[1] = a0.w; sx[2] = a1.x; sy[2] = a1.y; sx[3] = a1.z; sy[3] = a1.w;
+            };
+            auto split_micro = [&](auto k_) {
+                constexpr int k = decltype(k_)::value, q = k / 5, t = k % 5;
+                if constexpr (t == 0) sh[q] = wr_pk(sx[q], sy[q]);
+                else if constexpr (t == 1) { sx[q] = wr_sub(sx[q], __uint_as_float(sh[q] << 16)); sy[q] = wr_sub(sy[q], __uint_as_float(sh[q] & 0xFFFF0000u)); }
+                else if constexpr (t == 2) sm[q] = wr_pk(sx[q], sy[q]);
+                else if constexpr (t == 3) { sx[q] = wr_sub(sx[q], __uint_as_float(sm[q] << 16)); sy[q] = wr_sub(sy[q], __uint_as_float(sm[q] & 0xFFFF0000u)); }
+                else sl[q] = wr_pk(sx[q], sy[q]);
+            };
+            auto split_end = [&](wr_u32x4* o) {
+                o[0] = wr_u32x4{sh[0], sh[1], sh[2], sh[3]}; o[1] = wr_u32x4{sm[0], sm[1], sm[2], sm[3]}; o[2] = wr_u32x4{sl[0], sl[1], sl[2], sl[3]};
+            };
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) bq[0][j][pl] = *reinterpret_cast<const wr_u32x4*>(wbb + pl * PS + 32 * j * PB);
+            split_begin(0);
+            static_for<20>(split_micro);
+            split_end(as[0]);
 #pragma unroll
             for (int ps_ = 0; ps_ < NPASS; ++ps_) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                     if ((c & 1) || c == NC - 1) {
                         const int sc = c >> 1, st_ = ps_ * NSP + sc;
-                        if (st_ + 1 < NSE) {
-#pragma unroll
-                            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                                for (int pl = 0; pl < 3; ++pl)
-                                    bq[(st_ + 1) & 1][j][pl] = *reinterpret_cast<const wr_u32x4*>(wbb + pl * PS + 32 * j * PB + 32 * (st_ + 1));
-                        }
-                        wr_u32x4 ah, am, al;
-                        {
-                            const float4 a0 = a[2 * sc];
-                            float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (2 * sc + 1 < NC) a1 = a[2 * sc + 1 < NC ? 2 * sc + 1 : 0];
-                            unsigned h_[4], m_[4], l_[4];
-                            wr_split(a0.x, a0.y, h_[0], m_[0], l_[0]); wr_split(a0.z, a0.w, h_[1], m_[1], l_[1]);
-                            wr_split(a1.x, a1.y, h_[2], m_[2], l_[2]); wr_split(a1.z, a1.w, h_[3], m_[3], l_[3]);
-                            ah = wr_u32x4{h_[0], h_[1], h_[2], h_[3]}; am = wr_u32x4{m_[0], m_[1], m_[2], m_[3]}; al = wr_u32x4{l_[0], l_[1], l_[2], l_[3]};
-                        }
-                        const wr_bf16x8 Ah = __builtin_bit_cast(wr_bf16x8, ah), Am = __builtin_bit_cast(wr_bf16x8, am), Al = __builtin_bit_cast(wr_bf16x8, al);
+                        // the next super-chunk's x pieces: the same pass (its chunks are refilled later), or the next pass once its first
+                        // chunks have been refilled (NC > 4: the refill of chunks 0..3 follows chunk 3); else behind this one's refills
+                        constexpr bool across = NC > 4;
+                        const bool nxt_now = sc + 1 < NSP || (ps_ + 1 < NPASS && across);
+                        constexpr int NG = 6 * TN;                 // MFMAs of a super-chunk = filler slots
                         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            const wr_bf16x8 Bh = __builtin_bit_cast(wr_bf16x8, bq[st_ & 1][j][0]), Bm = __builtin_bit_cast(wr_bf16x8, bq[st_ & 1][j][1]),
-                                            Bl = __builtin_bit_cast(wr_bf16x8, bq[st_ & 1][j][2]);
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm, acc[j], 0, 0, 0);
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc[j], 0, 0, 0);
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc[j], 0, 0, 0);
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acc[j], 0, 0, 0);
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acc[j], 0, 0, 0);
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[j], 0, 0, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                        if (nxt_now) split_begin(sc + 1 < NSP ? sc + 1 : 0);
+                        const wr_bf16x8 Ah = __builtin_bit_cast(wr_bf16x8, as[st_ & 1][0]), Am = __builtin_bit_cast(wr_bf16x8, as[st_ & 1][1]),
+                                        Al = __builtin_bit_cast(wr_bf16x8, as[st_ & 1][2]);
+                        // product order (smallest first; the three of magnitude 2^-16 in the order that frees the W planes early): lo hi,
+                        // hi lo, mid mid, mid hi, hi mid, hi hi. The lo planes of W are dead after the second product and the mid planes after
+                        // the fifth: the next super-chunk's are read right there (the register allocator puts them into the same registers),
+                        // only the hi planes are held twice.
+                        static_for<NG>([&](auto g_) {
+                            constexpr int g = decltype(g_)::value, pr = g / TN, j = g % TN;
+                            constexpr int bpl = pr == 0 ? 0 : (pr == 1 ? 2 : (pr == 2 ? 1 : (pr == 3 ? 0 : (pr == 4 ? 1 : 0))));
+                            const wr_bf16x8 Ap = pr == 0 ? Al : ((pr == 2 || pr == 3) ? Am : Ah);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ap, __builtin_bit_cast(wr_bf16x8, bq[st_ & 1][j][bpl]), acc[j], 0, 0, 0);
+                            // fillers of this MFMA (the sched_barriers pin them here: left alone the scheduler gathers them behind the
+                            // super-chunk's last MFMA): an LDS read of the next planes, a share of the next split
+                            if constexpr (pr == 0 || pr == 2 || pr == 5) {
+                                constexpr int pl = pr == 0 ? 0 : (pr == 2 ? 2 : 1);
+                                if (st_ + 1 < NSE) bq[(st_ + 1) & 1][j][pl] = *reinterpret_cast<const wr_u32x4*>(wbb + pl * PS + 32 * j * PB + 32 * (st_ + 1));
+                            }
+                            if (nxt_now) {
+                                constexpr int k0 = g * 20 / NG, k1 = (g + 1) * 20 / NG;
+                                static_for<k1 - k0>([&](auto d_) { split_micro(std::integral_constant<int, k0 + decltype(d_)::value>{}); });
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        });
+                        if (nxt_now) split_end(as[(st_ + 1) & 1]);
                     }
                     // refills: as in the fp32 loop (the four chunks of a 128-byte line together, behind the last of them)
                     if ((c & 3) == 3 || c == NC - 1) {
@@ -365,6 +404,11 @@ __global__ __launch_bounds__(64 * WR_WAVES, wres_min_wg(TN, NC, NPASS, SPLIT)) v
                             else a[cc] = *reinterpret_cast<const float4*>(nsrc + min(8 * cc, kmax));
                         }
                         __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (c == NC - 1 && ps_ + 1 < NPASS && NC <= 4) {
+                        split_begin(0);
+                        static_for<20>(split_micro);
+                        split_end(as[(ps_ * NSP + (c >> 1) + 1) & 1]);
                     }
                 }
             }
@@ -384,6 +428,23 @@ __global__ __launch_bounds__(64 * WR_WAVES, wres_min_wg(TN, NC, NPASS, SPLIT)) v
         for (int j = 0; j < (ACC ? TN : 0); ++j)
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) asm volatile("" : "+v"(cx[j][ps].x), "+v"(cx[j][ps].y), "+v"(cx[j][ps].z), "+v"(cx[j][ps].w));
+        auto finish = [&](float4 v, int j, int ps) {
+            if (EPI == 0) {
+                v.x += bias4[j].x; v.y += bias4[j].y; v.z += bias4[j].z; v.w += bias4[j].w;
+                if (has_b2) {
+                    const float4 b2 = bias24[B2 ? j : 0];
+                    v.x = fmaf(rsc[ps], b2.x, v.x); v.y = fmaf(rsc[ps], b2.y, v.y);
+                    v.z = fmaf(rsc[ps], b2.z, v.z); v.w = fmaf(rsc[ps], b2.w, v.w);
+                }
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (RMASK) v = keep_if(dead[ps] == 0, v);
+            } else {
+                const float4 x = ax[EPI == 1 ? j : 0][ps];
+                v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f; v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
+                if (ACC) { const float4 o = cx[ACC ? j : 0][ps]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            }
+            return v;
+        };
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -392,24 +453,19 @@ __global__ __launch_bounds__(64 * WR_WAVES, wres_min_wg(TN, NC, NPASS, SPLIT)) v
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
-                float4 v = *reinterpret_cast<const float4*>(slab + (ps * 8 + rsub) * WR_SLAB_P + 4 * c4);
-                if (EPI == 0) {
-                    v.x += bias4[j].x; v.y += bias4[j].y; v.z += bias4[j].z; v.w += bias4[j].w;
-                    if (has_b2) {
-                        const float4 b2 = bias24[B2 ? j : 0];
-                        v.x = fmaf(rsc[ps], b2.x, v.x); v.y = fmaf(rsc[ps], b2.y, v.y);
-                        v.z = fmaf(rsc[ps], b2.z, v.z); v.w = fmaf(rsc[ps], b2.w, v.w);
-                    }
-                    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (RMASK) v = keep_if(dead[ps] == 0, v);
-                } else {
-                    const float4 x = ax[j][ps];
-                    v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f; v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
-                    if (ACC) { const float4 o = cx[j][ps]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-                }
-                outv[j][ps] = v;
+                const float4 v = *reinterpret_cast<const float4*>(slab + (ps * 8 + rsub) * WR_SLAB_P + 4 * c4);
+                // SPLIT (the matrix part of a tile is short, the epilogue a third of it): the transposed rows of ALL column tiles are
+                // requested before any is touched -- a wave's LDS operations execute in order, so tile j + 1 may be written behind the
+                // reads of tile j without waiting for their data: one LDS latency per row tile instead of one per read
+                outv[j][ps] = SPLIT ? v : finish(v, j, ps);
             }
             __builtin_amdgcn_wave_barrier();
+        }
+        if (SPLIT) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) outv[j][ps] = finish(outv[j][ps], j, ps);
         }
         // the stores drain during the next tile's MFMAs; nothing waits on them (the next tile's waits count past them)
 #pragma unroll
@@ -458,10 +514,12 @@ bool gemm_wres_eligible(const refil_gemm_desc& d) {
     return true;
 }
 
-// REFIL_WRES_SPLIT=6 / refil_set_tuning("wres_split", 6): the bf16 x 6 form of the product (see wr_split) wherever its W planes fit the LDS
+// The bf16 x 6 form of the product (see wr_split) is the default wherever its W planes fit the LDS: same accuracy as the fp32 matrix
+// instruction (tests/test_gpu_ops.py::test_wres_split_accuracy), 3/8 of its matrix-pipe cycles. REFIL_WRES_SPLIT=0 /
+// refil_set_tuning("wres_split", 0): the v_mfma_f32_32x32x2_f32 form.
 static int wres_split_mode() {
     if (g_tuning.wres_split >= 0) return g_tuning.wres_split == 6 ? 6 : 0;
-    static const int env = [] { const char* e = getenv("REFIL_WRES_SPLIT"); return e && atoi(e) == 6 ? 6 : 0; }();
+    static const int env = [] { const char* e = getenv("REFIL_WRES_SPLIT"); return e && atoi(e) == 0 ? 0 : 6; }();
     return env;
 }
 template <int TN, int NC, int NPASS, bool BT, int EPI, bool ACC, bool RMASK, bool B2, bool IDX, int SPLIT>
@@ -577,7 +635,7 @@ int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st) {
     // second read is an L2 hit instead of a second trip to HBM.
     if (gy > 1 && gx >= 8) gx &= ~7;
     dim3 grid(gx, gy, gz);
-    // profiler name = the kernel symbol as rocprofv3 prints it (template arguments TN,NC,NPASS,BT,EPI,ACC,RMASK)
+    // profiler name = the kernel symbol as rocprofv3 prints it (template arguments TN,NC,NPASS,BT,EPI,ACC,RMASK,B2,IDX,SPLIT)
     const int nc8 = cdiv(d.K, 8);
     int ncp, npass = 1;
     if (rb) { if (nc8 <= 8) ncp = 8; else if (nc8 <= 16) ncp = 16; else if (nc8 <= 24) { ncp = 12; npass = 2; } else { ncp = 16; npass = 2; } }
@@ -587,8 +645,9 @@ int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st) {
     static thread_local char names[64][64];
     static thread_local int n_names = 0;
     char nm[64];
-    snprintf(nm, sizeof(nm), d.row_index ? "gemm_wres_kernel<%d,%d,%d,%d,%d,%d,%d,%d,1>" : "gemm_wres_kernel<%d,%d,%d,%d,%d,%d,%d,%d>",
-             tn, ncp, npass, bt ? 1 : 0, rb ? 1 : 0, (d.flags & REFIL_GEMM_ACCUM) ? 1 : 0, d.rowmask ? 1 : 0, d.bias2 ? 1 : 0);
+    const bool split = wres_split_mode() == 6 && wres_split_ok(tn, ncp, npass);
+    snprintf(nm, sizeof(nm), "gemm_wres_kernel<%d,%d,%d,%d,%d,%d,%d,%d,%d,%d>", tn, ncp, npass, bt ? 1 : 0, rb ? 1 : 0, (d.flags & REFIL_GEMM_ACCUM) ? 1 : 0,
+             d.rowmask ? 1 : 0, d.bias2 ? 1 : 0, d.row_index ? 1 : 0, split ? 6 : 0);
     const char* pname = nullptr;
     for (int i = 0; i < n_names; ++i)
         if (!strcmp(names[i], nm)) pname = names[i];

@@ -29,8 +29,9 @@ PARITY_TESTED = {
     "dw4_min_out": (2000,),
     "dw_target": (384, 512),
     "compose_early": (0, 1),
-    # 6: the weight-resident GEMMs compute their fp32 products as six bf16 matrix-pipe products of a 3-way operand split (gemm_wres.hip:
-    # wr_split; fp32-accurate -- tests/test_gpu_ops.py::test_wres_split_accuracy). Never picked by the autotuner: explicit opt-in only.
+    # 6 (the built-in default): the weight-resident GEMMs compute their fp32 products as six bf16 matrix-pipe products of a 3-way operand
+    # split (gemm_wres.hip: wr_split; fp32-accurate -- tests/test_gpu_ops.py::test_wres_split_accuracy); 0: the v_mfma_f32_32x32x2_f32 form.
+    # Not an autotuner candidate (the choice changes the arithmetic, not just a launch size).
     "wres_split": (0, 6),
 }
 # what the first-call autotuner tries, in this order (greedy, one knob at a time)
