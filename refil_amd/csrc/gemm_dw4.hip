@@ -26,9 +26,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "bufops.h"
 #include "common.h"
 #include "kernels.h"
 #include "profile.h"
+#include "split.h"
 
 namespace refil {
 
@@ -253,6 +255,229 @@ __global__ __launch_bounds__(256, 1) void gemm_dw4_kernel(Dw4K p) {
     }
 }
 
+// ---- bf16 x 6 form (gemm_wres.hip: wr_split) of the weight gradient for the widest outputs: N = 128, M a multiple of 128 --------
+// A 16-row reduction step of a 32 x 32 output tile is 6 x v_mfma_f32_32x32x16_bf16 (192 matrix-pipe cycles) instead of
+// 8 x v_mfma_f32_32x32x2_f32 (512). The operand layout of that instruction wants, per lane, 8 CONSECUTIVE reduction rows of one
+// output column -- and every element split into three bf16 pieces (~5.5 VALU operations). Done per wave in registers that is
+// 44 (TI + TJ) operations against 6 TI TJ MFMAs: it hides behind the matrix pipe (<= 5 single-issue fillers per MFMA at one wave
+// per SIMD) for 4 x 4 tiles only, which leave no registers for it. Here the split is done ONCE per workgroup and shared through LDS:
+//   * the workgroup (4 waves) owns a 128 TI x 128 output tile and a range of reduction rows; wave w multiplies the tile rows
+//     w TI .. w TI + TI - 1 (TI x 4 MFMA tiles, 64 TI accumulator registers);
+//   * producer role (every thread): unit (column c, half hf) = rows 8 hf .. 8 hf + 7 of one of the 128 TI + 128 operand columns of
+//     the step: 8 dword loads (coalesced along the columns), 20 micro-steps of splitting, three 16-byte LDS writes -- one per
+//     plane, already in MFMA operand layout (column pitch 48 bytes: conflict-free for the writes and the reads). TI + 1 units per
+//     thread and step; the raw rows travel through a 4-deep register ring (3 steps = ~5 k matrix-pipe cycles of prefetch);
+//   * consumer role: 3 (TI + 4) LDS reads of 16 bytes at the head of a step, then 24 TI MFMAs round-robin over the accumulators
+//     (never two in a row on the same one), with the producer work of the NEXT step dealt out behind them, pinned by
+//     sched_barriers (gemm_wres.hip, DESIGN.md lesson 29); one LDS-only barrier per step, two plane buffers;
+//   * rows that do not fill a 64-row period of the ring (the end of the last workgroup's range) go through the fp32 instruction on
+//     the same accumulators; column sums of dy (the bias gradient) are taken from the raw rows by the producers.
+// Partial tiles / column sums have the layout of gemm_dw4_kernel: the same reduction kernels add them up.
+template <int TI> constexpr int dws_ncol() { return 128 * TI + 128; }
+constexpr int DWS_PB = 48, DWS_D = 4;
+template <int TI> constexpr size_t dws_smem() { return (size_t)2 * 3 * dws_ncol<TI>() * DWS_PB + 2 * 128 * TI * sizeof(float); }
+
+template <int TI, bool IDX>
+__global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
+    extern __shared__ __attribute__((aligned(16))) char dws_lds[];
+    constexpr int U = TI + 1, NCOL = dws_ncol<TI>(), PB = DWS_PB, PS = NCOL * PB, BUF = 3 * PS, D = DWS_D, NG = 24 * TI;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave: provably uniform)
+    const int lane31 = lane & 31, hf = lane >> 5;
+    const int bz = blockIdx.z / p.splits, sp = blockIdx.z % p.splits;
+    const int m0 = blockIdx.y * 128 * TI;
+    const float* __restrict__ A = p.A + bz * p.sA;
+    const float* __restrict__ B = p.B + bz * p.sB;
+    const int R = IDX ? *p.rcount : p.R;
+    const int chunk = cdiv(cdiv(R, p.splits), 16 * D) * 16 * D;
+    const int rbeg = min(R, sp * chunk), rend = min(R, rbeg + chunk);
+    const int nper = (rend - rbeg) / (16 * D);                 // whole ring periods (D steps of 16 rows)
+
+    // producer units of this thread: column chunk q = wave U + u of [A columns m0 .. m0 + 128 TI | B columns 0 .. 127]. All requests are
+    // buffer loads (wave-uniform resource + 32-bit byte offset; an offset past the resource returns zeros: steps past the range are
+    // requested and converted like any other and never multiplied) -- and, unlike plain loads through __restrict__ pointers, they stay
+    // where the schedule below puts them
+    const long phys = IDX ? (1L << 24) : (long)R;              // rows the operands may be read at
+    const rsrc_t rsA = mk_rsrc(A, ((phys - 1) * p.lda + p.M) * 4), rsB = mk_rsrc(B, ((phys - 1) * p.ldb + p.N) * 4);
+    const rsrc_t rsI = mk_rsrc(IDX ? p.ridx : nullptr, IDX ? (long)R * 4 : 0);
+    rsrc_t urs[U];
+    unsigned uld4[U], ucol4[U];
+    bool uisa[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int q = wave * U + u;
+        uisa[u] = q < 4 * TI;
+        urs[u] = uisa[u] ? rsA : rsB;
+        uld4[u] = 4u * (uisa[u] ? p.lda : p.ldb);
+        ucol4[u] = 4u * ((uisa[u] ? m0 + 32 * q : 32 * (q - 4 * TI)) + lane31);
+    }
+    char* const wr0 = dws_lds + (32 * wave * U + lane31) * PB + 16 * hf;            // + 32 u PB + plane PS + buffer BUF
+    const char* const rdA = dws_lds + (32 * wave * TI + lane31) * PB + 16 * hf;      // + 32 i PB
+    const char* const rdB = dws_lds + (128 * TI + lane31) * PB + 16 * hf;            // + 32 j PB
+
+    f32x16 acc[TI][4];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float csum[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) csum[u] = 0.f;
+
+    if (nper > 0) {
+        float raw[D][U][8];
+        int ri[2][8];                                           // IDX: list entries of the step whose rows are requested next
+        // list entries / row numbers of step t for this lane's half (8 consecutive positions)
+        auto load_idx = [&](int t, int* o) {
+            const int off = 4 * (rbeg + 16 * t + 8 * hf);
+            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsI, off, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b128(rsI, off + 16, 0, 0);
+            o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+        };
+        auto row_of = [&](int t, int k, const int* idx) -> unsigned { return IDX ? (unsigned)idx[k] : (unsigned)(rbeg + 16 * t + 8 * hf + k); };
+        // (steps past the range are requested through an EMPTY resource: zeros come back, nothing moves -- their column sums add nothing
+        // and their planes are never multiplied; t and nsteps are uniform, the choice is four scalar selects)
+        const int nsteps = nper * D;
+        const rsrc_t rs_none = mk_rsrc(A, 0);
+        auto load_raw = [&](int t, int k, int u, const int* idx, float* o) {
+            const rsrc_t rs = t < nsteps ? urs[u] : rs_none;
+            o[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(__umul24(row_of(t, k, idx), uld4[u]) + ucol4[u]), 0, 0));
+        };
+        // split state of the unit being converted
+        float sx[4], sy[4];
+        unsigned sh[4], sm[4], sl[4];
+        auto split_micro = [&](auto k_, const float* rw, int u) {
+            constexpr int k = decltype(k_)::value, q = k / 5, t = k % 5;
+            if constexpr (t == 0) {
+                sx[q] = rw[2 * q]; sy[q] = rw[2 * q + 1];
+                if (uisa[u]) csum[u] += sx[q] + sy[q];
+                sh[q] = wr_pk(sx[q], sy[q]);
+            } else if constexpr (t == 1) { sx[q] = wr_sub(sx[q], __uint_as_float(sh[q] << 16)); sy[q] = wr_sub(sy[q], __uint_as_float(sh[q] & 0xFFFF0000u)); }
+            else if constexpr (t == 2) sm[q] = wr_pk(sx[q], sy[q]);
+            else if constexpr (t == 3) { sx[q] = wr_sub(sx[q], __uint_as_float(sm[q] << 16)); sy[q] = wr_sub(sy[q], __uint_as_float(sm[q] & 0xFFFF0000u)); }
+            else sl[q] = wr_pk(sx[q], sy[q]);
+        };
+        auto write_planes = [&](int u, int buf) {
+            char* w = wr0 + buf * BUF + 32 * u * PB;
+            *reinterpret_cast<wr_u32x4*>(w) = wr_u32x4{sh[0], sh[1], sh[2], sh[3]};
+            *reinterpret_cast<wr_u32x4*>(w + PS) = wr_u32x4{sm[0], sm[1], sm[2], sm[3]};
+            *reinterpret_cast<wr_u32x4*>(w + 2 * PS) = wr_u32x4{sl[0], sl[1], sl[2], sl[3]};
+        };
+
+        // prologue: rows of steps 0 .. D - 1 requested, step 0 split into buffer 0
+        if (IDX) load_idx(0, ri[0]);
+#pragma unroll
+        for (int t = 0; t < D; ++t) {
+            if (IDX && t + 1 <= D) load_idx(t + 1, ri[(t + 1) & 1]);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) load_raw(t, k, u, ri[t & 1], raw[t][u]);
+        }
+        // (ri[0] now holds the entries of step D)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            static_for<20>([&](auto k_) { split_micro(k_, raw[0][u], u); });
+            write_planes(u, 0);
+        }
+        // everything of the prologue is complete before the ring starts: the waits inside the loop then count its loads exactly
+        __builtin_amdgcn_s_waitcnt(vmcnt_only(0));
+        lds_barrier();
+
+        for (int it = 0; it < nper; ++it) {
+            static_for<D>([&](auto s_) {
+                constexpr int s = decltype(s_)::value;             // step it D + s: multiplies buffer s & 1, converts step + 1 into the other
+                const int step = it * D + s;
+                // operand planes of this step
+                wr_u32x4 ap[TI][3], bp[4][3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) ap[i][pl] = *reinterpret_cast<const wr_u32x4*>(rdA + (s & 1) * BUF + pl * PS + 32 * i * PB);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bp[j][pl] = *reinterpret_cast<const wr_u32x4*>(rdB + (s & 1) * BUF + pl * PS + 32 * j * PB);
+                }
+                // Work dealt out behind the MFMAs, in this order: the list entries of step + D + 1, the row requests of step + D into the ring
+                // slot converted one step EARLIER (slot s: no register dependency on this step's conversions), the conversion of step + 1
+                // (slot s + 1) into the other plane buffer. Items: 1 + 8 U requests, U x (20 micro-steps + 1 write).
+                constexpr int NREQ = 8 * U, NCONV = 21 * U, NW = NREQ + NCONV + 1;
+                // (list entries: ri[s & 1] holds those of step + D -- D is even --, the other set is refilled FIRST, so that the wait for
+                // it at the head of the next step counts past this step's row requests instead of draining them)
+                auto item = [&](auto w_) {
+                    constexpr int w = decltype(w_)::value;
+                    if constexpr (w == 0) {
+                        if (IDX) load_idx(step + D + 1, ri[(s + 1) & 1]);
+                    } else if constexpr (w <= NREQ) {
+                        constexpr int u = (w - 1) / 8, k = (w - 1) % 8;
+                        load_raw(step + D, k, u, ri[s & 1], raw[s][u]);
+                    } else {
+                        constexpr int c = w - NREQ - 1, u = c / 21, k = c % 21;
+                        if constexpr (k < 20) split_micro(std::integral_constant<int, k>{}, raw[(s + 1) % D][u], u);
+                        else write_planes(u, (s + 1) & 1);
+                    }
+                };
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<NG>([&](auto g_) {
+                    constexpr int g = decltype(g_)::value, pr = g / (4 * TI), j = (g / TI) % 4, i = g % TI;
+                    constexpr int apl = pr == 0 ? 2 : ((pr == 2 || pr == 3) ? 1 : 0);            // lo, hi, mid, mid, hi, hi
+                    constexpr int bpl = pr == 0 ? 0 : (pr == 1 ? 2 : (pr == 2 ? 1 : (pr == 3 ? 0 : (pr == 4 ? 1 : 0))));
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wr_bf16x8, ap[i][apl]), __builtin_bit_cast(wr_bf16x8, bp[j][bpl]),
+                                                                        acc[i][j], 0, 0, 0);
+                    constexpr int w0 = g * NW / NG, w1 = (g + 1) * NW / NG;
+                    static_for<w1 - w0>([&](auto d_) { item(std::integral_constant<int, w0 + decltype(d_)::value>{}); });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                lds_barrier();
+            });
+        }
+    }
+
+    // ---- rows past the last whole period: the fp32 instruction on the same accumulators (2 rows per step) ----
+    const int tbeg = rbeg + nper * 16 * D;
+    for (int r2 = tbeg; r2 < rend; r2 += 2) {                    // workgroup-uniform trip count
+        const int r = r2 + hf;
+        const bool ok = r < rend;
+        unsigned rr = ok ? r : rbeg;
+        if (IDX) rr = p.ridx[rr];
+        float va[TI], vb[4];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) { const float v = A[__umul24(rr, (unsigned)p.lda) + m0 + 32 * (wave * TI + i) + lane31]; va[i] = ok ? v : 0.f; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float v = B[__umul24(rr, (unsigned)p.ldb) + 32 * j + lane31]; vb[j] = ok ? v : 0.f; }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[i], vb[j], acc[i][j], 0, 0, 0);
+    }
+
+    // ---- partial tile of this split: partial[(bz * splits + sp)][M][N]; register r of tile (i, j) is the output element
+    //      (row m0 + 32 (wave TI + i) + (r & 3) + 8 (r >> 2) + 4 hf, column 32 j + lane31) ----
+    float* P = p.partial + ((long)bz * p.splits + sp) * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + 32 * (wave * TI + i) + (r & 3) + 8 * (r >> 2) + 4 * hf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) P[(long)m * p.N + 32 * j + lane31] = acc[i][j][r];
+        }
+    if (p.colsum) {
+        // column sums: the producers' sums of the whole periods (two halves per column, fixed order) + the tail rows
+        float* cs = reinterpret_cast<float*>(dws_lds + 2 * BUF);         // [2][128 TI]
+        lds_barrier();
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (uisa[u]) cs[hf * 128 * TI + 32 * (wave * U + u) + lane31] = csum[u];
+        lds_barrier();
+        if (tid < 128 * TI) {
+            float t = cs[tid] + cs[128 * TI + tid];
+            for (int r = tbeg; r < rend; ++r) t += A[__umul24(IDX ? (unsigned)p.ridx[r] : (unsigned)r, (unsigned)p.lda) + m0 + tid];
+            float* CS = p.partial + (long)p.batch * p.splits * p.M * p.N + ((long)bz * p.splits + sp) * p.M;
+            CS[m0 + tid] = t;
+        }
+    }
+}
+
 // wave tile (ti x tj MFMA tiles: the count in [1,4] that wastes the fewest padded rows / columns, the larger on ties) and
 // waves side by side along the output rows
 static void dw4_shape(int M, int N, int& ti, int& tj, int& wmt) {
@@ -339,6 +564,33 @@ static int dw4_launch_t(const Dw4K& k, int wmt, dim3 grid, hipStream_t st) {
     return dw4_launch_w<TI, TJ, 1>(k, grid, st);
 }
 
+// REFIL_DW_SPLIT=0 / refil_set_tuning("dw_split", 0): the fp32-instruction kernel for every shape
+static bool dws_on() {
+    if (g_tuning.dw_split >= 0) return g_tuning.dw_split == 6;
+    static const bool env = [] { const char* e = getenv("REFIL_DW_SPLIT"); return !(e && atoi(e) == 0); }();
+    return env;
+}
+static bool dws_eligible(const refil_gemm_desc& d) {
+    if (!dws_on() || d.N != 128 || (d.M % 128) != 0 || d.a_map.grp || d.b_map.grp) return false;
+    if (d.K < 4096) return false;                                        // (short reductions: all prologue)
+    if (((long)d.K + 64) * d.lda * 4 >= (1L << 31) || ((long)d.K + 64) * d.ldb * 4 >= (1L << 31) || d.lda >= (1 << 22) || d.ldb >= (1 << 22)) return false;
+    if (d.row_index && (reinterpret_cast<uintptr_t>(d.row_index) & 15)) return false;
+    return true;
+}
+template <int TI>
+static int dws_launch_t(const Dw4K& k, dim3 grid, hipStream_t st) {
+    constexpr size_t smem = dws_smem<TI>();
+    static bool raised = false;
+    if (!raised) {
+        REFIL_HIP(hipFuncSetAttribute((const void*)gemm_dws_kernel<TI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        REFIL_HIP(hipFuncSetAttribute((const void*)gemm_dws_kernel<TI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        raised = true;
+    }
+    if (k.ridx) hipLaunchKernelGGL((gemm_dws_kernel<TI, true>), grid, dim3(256), smem, st, k);
+    else hipLaunchKernelGGL((gemm_dws_kernel<TI, false>), grid, dim3(256), smem, st, k);
+    return 0;
+}
+
 int gemm_dw4_launch(const refil_gemm_desc& d, hipStream_t st) {
     Dw4K k;
     k.A = d.A; k.B = d.B; k.partial = d.partial;
@@ -350,6 +602,17 @@ int gemm_dw4_launch(const refil_gemm_desc& d, hipStream_t st) {
     k.amap = mk(d.a_map); k.bmap = mk(d.b_map);
     k.splits = d.splits; k.batch = d.batch; k.colsum = (d.flags & REFIL_GEMM_COLSUM_A) ? 1 : 0;
     k.ridx = d.row_index; k.rcount = d.row_index ? d.row_count : nullptr;
+    if (dws_eligible(d)) {
+        const int ti = (d.M % 256) == 0 ? 2 : 1;
+        dim3 grid(1, d.M / (128 * ti), d.batch * d.splits);
+        const char* pname = ti == 2 ? (d.row_index ? "gemm_dws_kernel<2,1>" : "gemm_dws_kernel<2,0>") : (d.row_index ? "gemm_dws_kernel<1,1>" : "gemm_dws_kernel<1,0>");
+        ProfScope prof(pname, 2.0 * d.M * d.N * d.K * d.batch, 4.0 * d.batch * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N), st,
+                       d.row_index ? d.row_count : nullptr, (double)d.K);
+        const int rc = ti == 2 ? dws_launch_t<2>(k, grid, st) : dws_launch_t<1>(k, grid, st);
+        if (rc) return rc;
+        REFIL_LAUNCH_CHECK();
+        return 0;
+    }
     int ti, tj, wmt;
     dw4_shape(d.M, d.N, ti, tj, wmt);
     dim3 grid(cdiv(d.N, 32 * tj), cdiv(d.M, 32 * ti * wmt), d.batch * d.splits);

@@ -25,12 +25,11 @@
 // every place where a load is awaited while a store is in flight degenerates to vmcnt(0) -- see the loop tail.
 #include <string.h>
 
-#include <utility>
-
 #include "bufops.h"
 #include "common.h"
 #include "kernels.h"
 #include "profile.h"
+#include "split.h"
 
 namespace refil {
 
@@ -42,12 +41,6 @@ __device__ unsigned long long g_wr_dbg[8192 * 4];
 #else
 #define WR_TICK(acc_)
 #endif
-
-// f(integral_constant<int, 0>) .. f(integral_constant<int, N - 1>): a loop whose index is a constant expression in the body
-template <int... Is, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 struct WresK {
     const float* A; const float* W; float* C; const float* bias; const uint8_t* rowmask; const float* aux;
@@ -95,22 +88,6 @@ constexpr size_t wres_smem(int tn, int nc, int npass) { return ((size_t)32 * tn 
 // matrix-pipe cycles. (Measured against an fp64 product: tests/test_gpu_ops.py::test_wres_split_accuracy -- the error of the two
 // paths is the same.) W is split once per workgroup while it is staged into LDS (three bf16 planes, 1.5 x the fp32 bytes); the x rows
 // are split in registers right before use, ~5 VALU operations per element, each element feeding 6 TN MFMAs.
-typedef __bf16 wr_bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 wr_bf16x8 __attribute__((ext_vector_type(8)));
-typedef float wr_f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned wr_u32x4 __attribute__((ext_vector_type(4)));
-__device__ inline unsigned wr_pk(float x, float y) { wr_f32x2 v = {x, y}; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wr_bf16x2)); }
-// a - b as ONE scalar v_sub_f32: left to the compiler, the two residuals of a pair are SLP-packed into a v_pk_add_f32, which costs
-// ~13 matrix-pipe cycles beside an MFMA where a plain VALU operation costs none (MI355X_MICROARCH.md, "price of one filler")
-__device__ inline float wr_sub(float a, float b) { float r; asm("v_sub_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-// (x, y) -> packed bf16 pairs hi / mid / lo with x = hi + mid + lo (+ < 2^-25 |x|)
-__device__ inline void wr_split(float x, float y, unsigned& h, unsigned& m, unsigned& l) {
-    h = wr_pk(x, y);
-    x -= __uint_as_float(h << 16); y -= __uint_as_float(h & 0xFFFF0000u);
-    m = wr_pk(x, y);
-    x -= __uint_as_float(m << 16); y -= __uint_as_float(m & 0xFFFF0000u);
-    l = wr_pk(x, y);
-}
 // split layout of the W slice: 3 planes x (32 TN columns) x PB bytes; a column holds, per 16-index super-chunk S and lane half hf,
 // the 8 bf16 of k = 16 S + 8 (e >> 2) + 4 hf + (e & 3), e = 0..7 -- the indices lane half hf holds of chunks 2S and 2S + 1
 constexpr int wres_nse(int nc, int npass) { return npass * ((nc + 1) / 2); }                 // super-chunks

@@ -1090,6 +1090,7 @@ extern "C" int refil_set_tuning(const char* name, int64_t value) {
     else if (!strcmp(name, "compose_early")) g_tuning.compose_early = value;
     else if (!strcmp(name, "gru_pd")) g_tuning.gru_pd = value;
     else if (!strcmp(name, "wres_split")) g_tuning.wres_split = value;
+    else if (!strcmp(name, "dw_split")) g_tuning.dw_split = value;
     else { set_error("refil_set_tuning: unknown knob '%s'", name); return 1; }
     return 0;
 }

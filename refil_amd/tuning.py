@@ -33,6 +33,8 @@ PARITY_TESTED = {
     # split (gemm_wres.hip: wr_split; fp32-accurate -- tests/test_gpu_ops.py::test_wres_split_accuracy); 0: the v_mfma_f32_32x32x2_f32 form.
     # Not an autotuner candidate (the choice changes the arithmetic, not just a launch size).
     "wres_split": (0, 6),
+    # the same choice for the weight gradients with 128-column outputs (gemm_dw4.hip: gemm_dws_kernel; tests/test_gpu_ops.py::test_gemm_dws_accuracy)
+    "dw_split": (0, 6),
 }
 # what the first-call autotuner tries, in this order (greedy, one knob at a time)
 CANDIDATES = (("dw4_target", (96,)), ("gru_pd", (2,)), ("dw4_min_out", (2000,)), ("dw_target", (384,)), ("compose_early", (0, 1)))

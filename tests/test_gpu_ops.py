@@ -660,11 +660,60 @@ def test_gru_time_bounds(T1, t_last, H, pd, set_tuning):
         assert gi_full[gb, tl + 1:].abs().max().item() == 0.0 if tl + 1 < T1 else True
 
 
+@pytest.fixture(params=[0, 6], ids=["dw_fp32", "dw_bf16x6"])
+def dw_mode(request):
+    """Both arithmetic forms of the large weight gradients (refil_set_tuning("dw_split", .) / REFIL_DW_SPLIT)."""
+    from refil_amd import _lib
+    _lib.check(_lib.lib().refil_set_tuning(b"dw_split", request.param), "refil_set_tuning")
+    yield request.param
+    _lib.check(_lib.lib().refil_set_tuning(b"dw_split", -1), "refil_set_tuning")
+
+
+@pytest.mark.parametrize("Rr,N,batch,splits,frac", [(20000, 256, 1, 24, 0.0), (20000 + 61, 256, 4, 7, 0.45), (9000 + 3, 128, 1, 16, 0.0),
+                                                    (9000 + 130, 128, 2, 5, 0.6), (4096, 384, 1, 2, 0.0), (70000, 256, 1, 96, 0.5)])
+def test_gemm_dws_accuracy(Rr, N, batch, splits, frac):
+    """gemm_dws_kernel (bf16 x 6 weight gradient, 128-column outputs): against an fp64 product, next to the fp32-instruction kernel
+    on the same operands -- rms error <= 2 x, max error <= 3 x the fp32 path's and <= 2e-6 of the result's rms; column sums (bias gradient) to 2e-6 of their scale.
+    Covers whole ring periods, the fp32 tail (row counts that are not multiples of 64), row lists, batches, one and two tile rows."""
+    import hip_ops
+    from refil_amd import _lib
+    torch.manual_seed(Rr + N + batch)
+    K = 128
+    dy = torch.randn(Rr + 8, batch * N) * torch.exp(0.5 * torch.randn(Rr + 8, 1))
+    x = torch.randn(Rr + 8, batch * K)
+    if frac > 0:
+        keep, lst, cnt = _row_list(Rr, frac, N + K, trash=Rr)
+    else:
+        keep, lst, cnt = torch.arange(Rr), None, None
+    ref_w = torch.stack([dy[keep, n * N:(n + 1) * N].double().t() @ x[keep, n * K:(n + 1) * K].double() for n in range(batch)])
+    ref_b = torch.stack([dy[keep, n * N:(n + 1) * N].double().sum(0) for n in range(batch)])
+    errs = {}
+    try:
+        for mode in (0, 6):
+            _lib.check(_lib.lib().refil_set_tuning(b"dw_split", mode), "refil_set_tuning")
+            dW = torch.full((batch, N, K), float("nan"), device=DEV)
+            db = torch.full((batch, N), float("nan"), device=DEV)
+            partial = torch.zeros(batch * splits * (N * K + N), device=DEV)
+            hip_ops.gemm(dy.to(DEV), x.to(DEV), dW, N, K, Rr, batch * N, batch * K, K, flags=GEMM_A_OUTC | GEMM_B_OUTC | GEMM_COLSUM_A,
+                         colsum=db, partial=partial, splits=splits, batch=batch, sA=N, sB=K, sC=N * K, sColsum=N, row_index=lst, row_count=cnt)
+            d = dW.cpu().double() - ref_w
+            errs[mode] = (d.pow(2).mean().sqrt().item(), d.abs().max().item())
+            assert (db.cpu().double() - ref_b).abs().max().item() <= 2e-6 * max(ref_b.abs().max().item(), 1.0) * max(1.0, (len(keep) / 20000) ** 0.5), mode
+    finally:
+        _lib.check(_lib.lib().refil_set_tuning(b"dw_split", -1), "refil_set_tuning")
+    ref_rms = ref_w.pow(2).mean().sqrt().item()
+    print(f"fp32 MFMA: rms {errs[0][0]:.3e} max {errs[0][1]:.3e}; bf16 x 6: rms {errs[6][0]:.3e} max {errs[6][1]:.3e}; |ref| rms {ref_rms:.3e}")
+    # (the products are fp32-accurate; what differs is the length of the accumulation chains -- a workgroup's whole row range in one
+    # accumulator here, a quarter of it per wave in the fp32 kernel: measured 1.0-1.4 x its rms error)
+    assert errs[6][0] <= 2.0 * errs[0][0] and errs[6][1] <= 3.0 * errs[0][1] and errs[6][0] <= 2e-6 * ref_rms, errs
+
+
 @pytest.mark.parametrize("N,K", [(256, 128), (512, 84), (128, 128), (192, 64), (64, 128), (32, 128), (22, 64), (96, 96), (300, 40),
                                  (128, 20), (64, 52)])
 @pytest.mark.parametrize("batch,use_list", [(1, False), (3, False), (1, True)])
-def test_gemm_dw4_tiles(N, K, batch, use_list):
-    """gemm_dw4.hip (every wave-tile shape TI x TJ): dW = dy^T x per batch (+ db), optionally over a row list."""
+def test_gemm_dw4_tiles(N, K, batch, use_list, dw_mode):
+    """gemm_dw4.hip (every wave-tile shape TI x TJ): dW = dy^T x per batch (+ db), optionally over a row list. dw_mode: the fp32
+    instruction everywhere / the bf16 x 6 kernel (gemm_dws_kernel) for the 128-column outputs."""
     import hip_ops
     torch.manual_seed(N * 7 + K + batch)
     Rr, splits = 5000 + 37, 9
