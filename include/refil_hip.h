@@ -459,7 +459,11 @@ int refil_set_overlap(int on);
 /* Schedule knobs that do not change the arithmetic of a step but its launch sizes / launch order (the summation order of the
  * split weight-gradient reductions follows the launch size: results agree to rounding): "dw4_target" / "dw_target" workgroups
  * per 4x4-tile / streamed weight-gradient launch, "dw4_min_out" smallest output taken by the 4x4-tile kernel, "compose_early"
- * 0 / 1, "gru_pd" 2 / 4 steps of prefetch in the 4-row recurrences. value -1 restores the built-in rule (or its environment switch). Process-wide. The best setting depends on the shape
+ * 0 / 1, "gru_pd" 2 / 4 steps of prefetch in the 4-row recurrences. Two knobs choose the matrix instruction of the fp32 products
+ * (same accuracy, different rounding): "wres_split" (projections with a reduction <= 256) and "dw_split" (weight gradients with
+ * 65 .. 128-column outputs): 6 (default) = six bf16 matrix-pipe products of a 3-way operand split with fp32 accumulate,
+ * 0 = v_mfma_f32_32x32x2_f32 (environment: REFIL_WRES_SPLIT / REFIL_DW_SPLIT).
+ * value -1 restores the built-in rule (or its environment switch). Process-wide. The best setting depends on the shape
  * AND on what shares the GPU, so QLearner.train measures the candidates in situ on its first call per shape
  * (refil_amd/learners/q_learner.py: _autotune). No counterpart in the reference. */
 int refil_set_tuning(const char* name, int64_t value);

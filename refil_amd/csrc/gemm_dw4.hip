@@ -23,6 +23,7 @@
 //
 // Row lists (refil_gemm_desc.row_index): the reduction rows come from a device-side list whose length is read from
 // device memory; the indices travel through their own ring, one period ahead of the operand prefetch.
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -273,14 +274,17 @@ __global__ __launch_bounds__(256, 1) void gemm_dw4_kernel(Dw4K p) {
 //   * rows that do not fill a 64-row period of the ring (the end of the last workgroup's range) go through the fp32 instruction on
 //     the same accumulators; column sums of dy (the bias gradient) are taken from the raw rows by the producers.
 // Partial tiles / column sums have the layout of gemm_dw4_kernel: the same reduction kernels add them up.
-template <int TI> constexpr int dws_ncol() { return 128 * TI + 128; }
+// NJ: 32-column tiles of the x operand (N <= 32 NJ; columns past N are requested through an out-of-range offset: zeros). BMAP: the x
+// rows go through a row map (agents' rows inside entity-major storage): physical row = r + (r / grp) (gstride - grp) + off, folded into
+// the request's offset as one extra multiply-add per request plus one v_mul_hi per row.
+constexpr int dws_units(int ti, int nj) { return (4 * ti + nj + 3) / 4; }                       // producer units (32-column chunks) per thread
 constexpr int DWS_PB = 48, DWS_D = 4;
-template <int TI> constexpr size_t dws_smem() { return (size_t)2 * 3 * dws_ncol<TI>() * DWS_PB + 2 * 128 * TI * sizeof(float); }
+constexpr size_t dws_smem(int ti, int nj) { return (size_t)2 * 3 * 128 * dws_units(ti, nj) * DWS_PB + 2 * 128 * ti * sizeof(float); }
 
-template <int TI, bool IDX>
+template <int TI, int NJ, bool IDX, bool BMAP>
 __global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
     extern __shared__ __attribute__((aligned(16))) char dws_lds[];
-    constexpr int U = TI + 1, NCOL = dws_ncol<TI>(), PB = DWS_PB, PS = NCOL * PB, BUF = 3 * PS, D = DWS_D, NG = 24 * TI;
+    constexpr int U = dws_units(TI, NJ), NCOL = 128 * U, PB = DWS_PB, PS = NCOL * PB, BUF = 3 * PS, D = DWS_D, NG = 6 * NJ * TI;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave: provably uniform)
     const int lane31 = lane & 31, hf = lane >> 5;
     const int bz = blockIdx.z / p.splits, sp = blockIdx.z % p.splits;
@@ -297,28 +301,31 @@ __global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
     // requested and converted like any other and never multiplied) -- and, unlike plain loads through __restrict__ pointers, they stay
     // where the schedule below puts them
     const long phys = IDX ? (1L << 24) : (long)R;              // rows the operands may be read at
-    const rsrc_t rsA = mk_rsrc(A, ((phys - 1) * p.lda + p.M) * 4), rsB = mk_rsrc(B, ((phys - 1) * p.ldb + p.N) * 4);
+    const rsrc_t rsA = mk_rsrc(A, ((phys - 1) * p.lda + p.M) * 4), rsB = mk_rsrc(B, (((BMAP ? (1L << 24) : phys) - 1) * p.ldb + p.N) * 4);
     const rsrc_t rsI = mk_rsrc(IDX ? p.ridx : nullptr, IDX ? (long)R * 4 : 0);
+    const rsrc_t rs_none = mk_rsrc(A, 0);
     rsrc_t urs[U];
-    unsigned uld4[U], ucol4[U];
+    unsigned uld4[U], ucol4[U], udelta4[U];
     bool uisa[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int q = wave * U + u;
         uisa[u] = q < 4 * TI;
-        urs[u] = uisa[u] ? rsA : rsB;
+        urs[u] = uisa[u] ? rsA : (q < 4 * TI + NJ ? rsB : rs_none);
         uld4[u] = 4u * (uisa[u] ? p.lda : p.ldb);
-        ucol4[u] = 4u * ((uisa[u] ? m0 + 32 * q : 32 * (q - 4 * TI)) + lane31);
+        const int bcol = 32 * (q - 4 * TI) + lane31;
+        ucol4[u] = uisa[u] ? 4u * (m0 + 32 * q + lane31) : (bcol < p.N ? 4u * bcol + (BMAP ? p.bmap.off * 4u * p.ldb : 0u) : 0x80000000u);
+        udelta4[u] = (BMAP && !uisa[u]) ? (p.bmap.gstride - p.bmap.grp) * 4u * p.ldb : 0u;
     }
     char* const wr0 = dws_lds + (32 * wave * U + lane31) * PB + 16 * hf;            // + 32 u PB + plane PS + buffer BUF
     const char* const rdA = dws_lds + (32 * wave * TI + lane31) * PB + 16 * hf;      // + 32 i PB
-    const char* const rdB = dws_lds + (128 * TI + lane31) * PB + 16 * hf;            // + 32 j PB
+    const char* const rdB = dws_lds + (128 * TI + lane31) * PB + 16 * hf;            // + 32 j PB (chunks 4 TI .. 4 TI + NJ - 1)
 
-    f32x16 acc[TI][4];
+    f32x16 acc[TI][NJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float csum[U];
@@ -338,10 +345,12 @@ __global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
         // (steps past the range are requested through an EMPTY resource: zeros come back, nothing moves -- their column sums add nothing
         // and their planes are never multiplied; t and nsteps are uniform, the choice is four scalar selects)
         const int nsteps = nper * D;
-        const rsrc_t rs_none = mk_rsrc(A, 0);
         auto load_raw = [&](int t, int k, int u, const int* idx, float* o) {
             const rsrc_t rs = t < nsteps ? urs[u] : rs_none;
-            o[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(__umul24(row_of(t, k, idx), uld4[u]) + ucol4[u]), 0, 0));
+            const unsigned r = row_of(t, k, idx);
+            unsigned off = __umul24(r, uld4[u]) + ucol4[u];
+            if (BMAP) off += __umul24(__umulhi(r, p.bmap.magic), udelta4[u]);
+            o[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
         };
         // split state of the unit being converted
         float sx[4], sy[4];
@@ -389,13 +398,13 @@ __global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
                 constexpr int s = decltype(s_)::value;             // step it D + s: multiplies buffer s & 1, converts step + 1 into the other
                 const int step = it * D + s;
                 // operand planes of this step
-                wr_u32x4 ap[TI][3], bp[4][3];
+                wr_u32x4 ap[TI][3], bp[NJ][3];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
                     for (int i = 0; i < TI; ++i) ap[i][pl] = *reinterpret_cast<const wr_u32x4*>(rdA + (s & 1) * BUF + pl * PS + 32 * i * PB);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bp[j][pl] = *reinterpret_cast<const wr_u32x4*>(rdB + (s & 1) * BUF + pl * PS + 32 * j * PB);
+                    for (int j = 0; j < NJ; ++j) bp[j][pl] = *reinterpret_cast<const wr_u32x4*>(rdB + (s & 1) * BUF + pl * PS + 32 * j * PB);
                 }
                 // Work dealt out behind the MFMAs, in this order: the list entries of step + D + 1, the row requests of step + D into the ring
                 // slot converted one step EARLIER (slot s: no register dependency on this step's conversions), the conversion of step + 1
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
                 };
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<NG>([&](auto g_) {
-                    constexpr int g = decltype(g_)::value, pr = g / (4 * TI), j = (g / TI) % 4, i = g % TI;
+                    constexpr int g = decltype(g_)::value, pr = g / (NJ * TI), j = (g / TI) % NJ, i = g % TI;
                     constexpr int apl = pr == 0 ? 2 : ((pr == 2 || pr == 3) ? 1 : 0);            // lo, hi, mid, mid, hi, hi
                     constexpr int bpl = pr == 0 ? 0 : (pr == 1 ? 2 : (pr == 2 ? 1 : (pr == 3 ? 0 : (pr == 4 ? 1 : 0))));
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wr_bf16x8, ap[i][apl]), __builtin_bit_cast(wr_bf16x8, bp[j][bpl]),
@@ -439,15 +448,19 @@ __global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
         const bool ok = r < rend;
         unsigned rr = ok ? r : rbeg;
         if (IDX) rr = p.ridx[rr];
-        float va[TI], vb[4];
+        float va[TI], vb[NJ];
 #pragma unroll
         for (int i = 0; i < TI; ++i) { const float v = A[__umul24(rr, (unsigned)p.lda) + m0 + 32 * (wave * TI + i) + lane31]; va[i] = ok ? v : 0.f; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const float v = B[__umul24(rr, (unsigned)p.ldb) + 32 * j + lane31]; vb[j] = ok ? v : 0.f; }
+        for (int j = 0; j < NJ; ++j) {
+            const bool okb = ok && 32 * j + lane31 < p.N;
+            const float v = B[__umul24(BMAP ? p.bmap(rr) : rr, (unsigned)p.ldb) + (okb ? 32 * j + lane31 : 0)];
+            vb[j] = okb ? v : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[i], vb[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[i], vb[j], acc[i][j], 0, 0, 0);
     }
 
     // ---- partial tile of this split: partial[(bz * splits + sp)][M][N]; register r of tile (i, j) is the output element
@@ -459,7 +472,8 @@ __global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + 32 * (wave * TI + i) + (r & 3) + 8 * (r >> 2) + 4 * hf;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) P[(long)m * p.N + 32 * j + lane31] = acc[i][j][r];
+            for (int j = 0; j < NJ; ++j)
+                if (32 * j + lane31 < p.N) P[(long)m * p.N + 32 * j + lane31] = acc[i][j][r];
         }
     if (p.colsum) {
         // column sums: the producers' sums of the whole periods (two halves per column, fixed order) + the tail rows
@@ -571,23 +585,32 @@ static bool dws_on() {
     return env;
 }
 static bool dws_eligible(const refil_gemm_desc& d) {
-    if (!dws_on() || d.N != 128 || (d.M % 128) != 0 || d.a_map.grp || d.b_map.grp) return false;
+    if (!dws_on() || d.N > 128 || d.N <= 64 || (d.M % 128) != 0 || d.a_map.grp) return false;
     if (d.K < 4096) return false;                                        // (short reductions: all prologue)
     if (((long)d.K + 64) * d.lda * 4 >= (1L << 31) || ((long)d.K + 64) * d.ldb * 4 >= (1L << 31) || d.lda >= (1 << 22) || d.ldb >= (1 << 22)) return false;
+    if (d.b_map.grp) {        // physical row = r + (r / grp) (gstride - grp) + off: multiplier and the furthest offset must fit the 24-bit multiplies / 2 GB
+        const long delta = (long)d.b_map.gstride - d.b_map.grp;
+        const long phys = ((long)d.K + 64) / d.b_map.grp * d.b_map.gstride + d.b_map.grp + d.b_map.off;
+        if (delta < 0 || delta * d.ldb * 4 >= (1L << 24) || phys * d.ldb * 4 >= (1L << 31) || d.b_map.off < 0) return false;
+    }
     if (d.row_index && (reinterpret_cast<uintptr_t>(d.row_index) & 15)) return false;
     return true;
 }
-template <int TI>
-static int dws_launch_t(const Dw4K& k, dim3 grid, hipStream_t st) {
-    constexpr size_t smem = dws_smem<TI>();
+template <int TI, int NJ>
+static int dws_launch_t(const Dw4K& k, bool bmap, dim3 grid, hipStream_t st) {
+    constexpr size_t smem = dws_smem(TI, NJ);
     static bool raised = false;
     if (!raised) {
-        REFIL_HIP(hipFuncSetAttribute((const void*)gemm_dws_kernel<TI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        REFIL_HIP(hipFuncSetAttribute((const void*)gemm_dws_kernel<TI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        REFIL_HIP(hipFuncSetAttribute((const void*)gemm_dws_kernel<TI, NJ, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        REFIL_HIP(hipFuncSetAttribute((const void*)gemm_dws_kernel<TI, NJ, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        REFIL_HIP(hipFuncSetAttribute((const void*)gemm_dws_kernel<TI, NJ, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        REFIL_HIP(hipFuncSetAttribute((const void*)gemm_dws_kernel<TI, NJ, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         raised = true;
     }
-    if (k.ridx) hipLaunchKernelGGL((gemm_dws_kernel<TI, true>), grid, dim3(256), smem, st, k);
-    else hipLaunchKernelGGL((gemm_dws_kernel<TI, false>), grid, dim3(256), smem, st, k);
+    if (k.ridx && bmap) hipLaunchKernelGGL((gemm_dws_kernel<TI, NJ, true, true>), grid, dim3(256), smem, st, k);
+    else if (k.ridx) hipLaunchKernelGGL((gemm_dws_kernel<TI, NJ, true, false>), grid, dim3(256), smem, st, k);
+    else if (bmap) hipLaunchKernelGGL((gemm_dws_kernel<TI, NJ, false, true>), grid, dim3(256), smem, st, k);
+    else hipLaunchKernelGGL((gemm_dws_kernel<TI, NJ, false, false>), grid, dim3(256), smem, st, k);
     return 0;
 }
 
@@ -602,13 +625,27 @@ int gemm_dw4_launch(const refil_gemm_desc& d, hipStream_t st) {
     k.amap = mk(d.a_map); k.bmap = mk(d.b_map);
     k.splits = d.splits; k.batch = d.batch; k.colsum = (d.flags & REFIL_GEMM_COLSUM_A) ? 1 : 0;
     k.ridx = d.row_index; k.rcount = d.row_index ? d.row_count : nullptr;
+    static const bool dbg = getenv("REFIL_DEBUG_DW") != nullptr;
+    if (dbg) fprintf(stderr, "dw4: M=%d N=%d R=%d batch=%d splits=%d lda=%d ldb=%d amap=(%d,%d,%d) bmap=(%d,%d,%d) list=%d colsum=%d dws=%d\n", d.M, d.N, d.K, d.batch,
+                     d.splits, d.lda, d.ldb, d.a_map.grp, (int)d.a_map.gstride, (int)d.a_map.off, d.b_map.grp, (int)d.b_map.gstride, (int)d.b_map.off,
+                     d.row_index ? 1 : 0, (d.flags & REFIL_GEMM_COLSUM_A) ? 1 : 0, dws_eligible(d) ? 1 : 0);
     if (dws_eligible(d)) {
-        const int ti = (d.M % 256) == 0 ? 2 : 1;
+        const int ti = (d.M % 256) == 0 ? 2 : 1, nj = cdiv(d.N, 32);
         dim3 grid(1, d.M / (128 * ti), d.batch * d.splits);
-        const char* pname = ti == 2 ? (d.row_index ? "gemm_dws_kernel<2,1>" : "gemm_dws_kernel<2,0>") : (d.row_index ? "gemm_dws_kernel<1,1>" : "gemm_dws_kernel<1,0>");
+        static thread_local char names[16][40];
+        static thread_local int n_names = 0;
+        char nm[40];
+        snprintf(nm, sizeof(nm), "gemm_dws_kernel<%d,%d,%d,%d>", ti, nj, d.row_index ? 1 : 0, d.b_map.grp ? 1 : 0);
+        const char* pname = nullptr;
+        for (int i = 0; i < n_names; ++i)
+            if (!strcmp(names[i], nm)) pname = names[i];
+        if (!pname && n_names < 16) { strcpy(names[n_names], nm); pname = names[n_names++]; }
+        if (!pname) pname = "gemm_dws_kernel";
         ProfScope prof(pname, 2.0 * d.M * d.N * d.K * d.batch, 4.0 * d.batch * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N), st,
                        d.row_index ? d.row_count : nullptr, (double)d.K);
-        const int rc = ti == 2 ? dws_launch_t<2>(k, grid, st) : dws_launch_t<1>(k, grid, st);
+        const bool bm = d.b_map.grp != 0;
+        const int rc = ti == 2 ? (nj == 4 ? dws_launch_t<2, 4>(k, bm, grid, st) : dws_launch_t<2, 3>(k, bm, grid, st))
+                               : (nj == 4 ? dws_launch_t<1, 4>(k, bm, grid, st) : dws_launch_t<1, 3>(k, bm, grid, st));
         if (rc) return rc;
         REFIL_LAUNCH_CHECK();
         return 0;

@@ -283,6 +283,15 @@ PRODUCTION = {
     "cfg5_ne48_mmm_law_split0": dict(B=32, T=80, ne=48, d=128, imagine=True, A=54, tuned=dict(wres_split=0)),
     "cfg4_shape_split0": dict(B=32, T=150, ne=16, d=128, imagine=False, tuned=dict(wres_split=0)),
     "ne64_split0": dict(B=16, T=40, ne=64, d=128, imagine=True, tuned=dict(wres_split=0)),
+    # dw_split: the same choice for the weight gradients with 65 .. 128-column outputs (gemm_dw4.hip: gemm_dws_kernel, the default);
+    # 0 = the fp32-instruction kernels everywhere. "fp32": both knobs at 0 = round 3's arithmetic.
+    "cfgT_dw0": dict(B=32, T=80, ne=32, d=128, imagine=True, tuned=dict(dw_split=0)),
+    "cfgT_fp32": dict(B=32, T=80, ne=32, d=128, imagine=True, tuned=dict(wres_split=0, dw_split=0)),
+    "cfgT_fp32_tuned": dict(B=32, T=80, ne=32, d=128, imagine=True, tuned=dict(wres_split=0, dw_split=0, dw4_target=96, gru_pd=2)),
+    "cfgT_dense_fp32": dict(B=32, T=80, ne=32, d=128, imagine=True, dense=True, tuned=dict(wres_split=0, dw_split=0)),
+    "cfg2_fp32": dict(B=32, T=80, ne=16, d=64, imagine=True, tuned=dict(wres_split=0, dw_split=0)),
+    "cfg5_ne48_mmm_law_fp32": dict(B=32, T=80, ne=48, d=128, imagine=True, A=54, tuned=dict(wres_split=0, dw_split=0)),
+    "cfg4_shape_dw0": dict(B=32, T=150, ne=16, d=128, imagine=False, tuned=dict(dw_split=0)),
 }
 
 

@@ -669,18 +669,28 @@ def dw_mode(request):
     _lib.check(_lib.lib().refil_set_tuning(b"dw_split", -1), "refil_set_tuning")
 
 
-@pytest.mark.parametrize("Rr,N,batch,splits,frac", [(20000, 256, 1, 24, 0.0), (20000 + 61, 256, 4, 7, 0.45), (9000 + 3, 128, 1, 16, 0.0),
-                                                    (9000 + 130, 128, 2, 5, 0.6), (4096, 384, 1, 2, 0.0), (70000, 256, 1, 96, 0.5)])
-def test_gemm_dws_accuracy(Rr, N, batch, splits, frac):
-    """gemm_dws_kernel (bf16 x 6 weight gradient, 128-column outputs): against an fp64 product, next to the fp32-instruction kernel
-    on the same operands -- rms error <= 2 x, max error <= 3 x the fp32 path's and <= 2e-6 of the result's rms; column sums (bias gradient) to 2e-6 of their scale.
-    Covers whole ring periods, the fp32 tail (row counts that are not multiples of 64), row lists, batches, one and two tile rows."""
+@pytest.mark.parametrize("Rr,N,K,batch,splits,frac,bmap", [
+    (20000, 256, 128, 1, 24, 0.0, None), (20000 + 61, 256, 128, 4, 7, 0.45, None), (9000 + 3, 128, 128, 1, 16, 0.0, None),
+    (9000 + 130, 128, 128, 2, 5, 0.6, None), (4096, 384, 128, 1, 2, 0.0, None), (70000, 256, 128, 1, 96, 0.5, None),
+    (12000 + 7, 512, 84, 1, 12, 0.5, None), (9000, 128, 84, 1, 8, 0.0, None), (8000 + 19, 128, 100, 2, 6, 0.4, None),
+    (12000 + 5, 128, 128, 1, 10, 0.5, (16, 32, 0)), (6000 + 44, 256, 128, 2, 4, 0.0, (16, 32, 0)), (5184, 128, 96, 1, 3, 0.3, (1296, 1312, 0))])
+def test_gemm_dws_accuracy(Rr, N, K, batch, splits, frac, bmap):
+    """gemm_dws_kernel (bf16 x 6 weight gradient, outputs 65 .. 128 columns wide): against an fp64 product, next to the fp32-instruction
+    kernel on the same operands -- rms error <= 2 x, max error <= 3 x the fp32 path's and <= 2e-6 of the result's rms; column sums (bias gradient) to 2e-6 of their scale.
+    Covers whole ring periods, the fp32 tail (row counts that are not multiples of 64), row lists, batches, one and two tile rows, padded
+    column tiles (84 / 96 / 100 columns) and a row map on the x rows (agents' rows in entity-major storage)."""
     import hip_ops
     from refil_amd import _lib
     torch.manual_seed(Rr + N + batch)
-    K = 128
     dy = torch.randn(Rr + 8, batch * N) * torch.exp(0.5 * torch.randn(Rr + 8, 1))
-    x = torch.randn(Rr + 8, batch * K)
+    if bmap:
+        grp, gstride, off = bmap
+        nphys = (Rr + 8) // grp * gstride + grp + off + 8
+        xb = torch.randn(nphys, batch * K)
+        rows = torch.arange(Rr + 8)
+        x = xb[rows + (rows // grp) * (gstride - grp) + off]
+    else:
+        xb = x = torch.randn(Rr + 8, batch * K)
     if frac > 0:
         keep, lst, cnt = _row_list(Rr, frac, N + K, trash=Rr)
     else:
@@ -694,8 +704,9 @@ def test_gemm_dws_accuracy(Rr, N, batch, splits, frac):
             dW = torch.full((batch, N, K), float("nan"), device=DEV)
             db = torch.full((batch, N), float("nan"), device=DEV)
             partial = torch.zeros(batch * splits * (N * K + N), device=DEV)
-            hip_ops.gemm(dy.to(DEV), x.to(DEV), dW, N, K, Rr, batch * N, batch * K, K, flags=GEMM_A_OUTC | GEMM_B_OUTC | GEMM_COLSUM_A,
-                         colsum=db, partial=partial, splits=splits, batch=batch, sA=N, sB=K, sC=N * K, sColsum=N, row_index=lst, row_count=cnt)
+            hip_ops.gemm(dy.to(DEV), xb.to(DEV), dW, N, K, Rr, batch * N, batch * K, K, flags=GEMM_A_OUTC | GEMM_B_OUTC | GEMM_COLSUM_A,
+                         colsum=db, partial=partial, splits=splits, batch=batch, sA=N, sB=K, sC=N * K, sColsum=N, row_index=lst, row_count=cnt,
+                         b_map=bmap or (0, 0, 0))
             d = dW.cpu().double() - ref_w
             errs[mode] = (d.pow(2).mean().sqrt().item(), d.abs().max().item())
             assert (db.cpu().double() - ref_b).abs().max().item() <= 2e-6 * max(ref_b.abs().max().item(), 1.0) * max(1.0, (len(keep) / 20000) ** 0.5), mode
