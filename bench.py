@@ -18,7 +18,10 @@ Prints ONE JSON line (rank 0). Extra objects:
                   once, results written once, rows of live steps) / mean launch duration against 8 TB/s; bound = "mfma"
                   for the projections: achieved = FLOPs the kernel executes per launch (the rows that can influence the
                   loss: the library skips the others) / mean launch duration against 157.3 TFLOP/s (fp32 MFMA,
-                  MI355X_MICROARCH.md). traffic = HBM bytes per launch from a rocprofv3 PMC pass of THIS build handed in
+                  MI355X_MICROARCH.md). The projections compute their fp32 products as six bf16 matrix-pipe products of an
+                  exact 3-way operand split (fp32-accurate; gemm_wres.hip): `frac` stays algorithmic fp32 FLOPs against the
+                  fp32-MFMA roof, `matrix_pipe` adds the executed (6 x) FLOPs against the dense bf16 peak.
+                  traffic = HBM bytes per launch from a rocprofv3 PMC pass of THIS build handed in
                   with --traffic-json (tools/collect_profiles.sh), else null. heaviest_gemm = the same for the GEMM
                   kernel that executes the most FLOPs per step (the matrix-core evidence when the dominant kernel is
                   HBM-bound); every kernel's own rate is in kernels[] (tflops_isolated).
@@ -608,6 +611,13 @@ def main():
             "dense_data": dense, "comm": comm,
             "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": ("fp32 operands, fp32 accumulation, fp32 results everywhere (the reference's arithmetic). Products of the projections: "
+                           + ("six bf16 matrix-pipe products of an EXACT 3-way split of both fp32 operands (the three dropped piece products are below "
+                              "2^-26 of the product), error against fp64 equal to the fp32 matrix instruction's" if os.environ.get("REFIL_WRES_SPLIT", "6") != "0"
+                              else "v_mfma_f32_32x32x2_f32")
+                           + "; large weight gradients: " + ("the same bf16 x 6 form" if os.environ.get("REFIL_DW_SPLIT", "6") != "0" else "v_mfma_f32_32x32x2_f32")
+                           + " (REFIL_WRES_SPLIT=0 REFIL_DW_SPLIT=0: the fp32 instruction everywhere; both forms are compared with the oracle at every "
+                             "production shape, tests/test_gpu_learner.py::PRODUCTION)"),
             "config": {"workload": f"{a.config}: synthetic replay (B={B}/GPU, T={T}, n_entities={dims['ne']}, n_agents={dims['na']}, "
                                    f"d={dims['d']}, hypernet={dims['h']}), {'refil' if W['imagine'] else 'qmix_atten'} learner "
                                    f"({'imagine agent' if W['imagine'] else 'entity_attend_rnn agent'} + flex_qmix), {W['what']}",
