@@ -719,6 +719,34 @@ def test_gemm_dws_accuracy(Rr, N, K, batch, splits, frac, bmap):
     assert errs[6][0] <= 2.0 * errs[0][0] and errs[6][1] <= 3.0 * errs[0][1] and errs[6][0] <= 2e-6 * ref_rms, errs
 
 
+@pytest.mark.parametrize("count", [0, 1, 5, 63, 64, 65, 127, 128, 200, 4 * 64 * 3, 4 * 64 * 3 + 1])
+@pytest.mark.parametrize("N,bmap", [(256, None), (128, (16, 32, 0))])
+def test_gemm_dws_short_lists(count, N, bmap, dw_mode):
+    """Row lists far shorter than the launch was sized for (capacity 6000 rows, 3 splits): empty, shorter than one 16-row step, exactly /
+    just past whole ring periods of a workgroup's range -- the empty-resource requests, the fp32 tail and the column sums at the edges."""
+    import hip_ops
+    torch.manual_seed(count + N)
+    cap, K, splits = 6000, 128, 3
+    dy = torch.randn(cap + 8, N)
+    nphys = (cap + 8) // 16 * 32 + 64 if bmap else cap + 8
+    xb = torch.randn(nphys, K)
+    rows = torch.arange(cap + 8)
+    x = xb[rows + (rows // 16) * 16] if bmap else xb
+    keep = torch.sort(torch.randperm(cap)[:count]).values
+    lst = torch.full(((count + 63) // 64 * 64 + 128,), cap, dtype=torch.int32)
+    lst[:count] = keep.to(torch.int32)
+    cnt = torch.tensor([count], dtype=torch.int32, device=DEV)
+    ref_w = dy[keep].double().t() @ x[keep].double()
+    ref_b = dy[keep].double().sum(0)
+    dW = torch.full((N, K), float("nan"), device=DEV)
+    db = torch.full((N,), float("nan"), device=DEV)
+    partial = torch.zeros(splits * (N * K + N), device=DEV)
+    hip_ops.gemm(dy.to(DEV), xb.to(DEV), dW, N, K, cap, N, K, K, flags=GEMM_A_OUTC | GEMM_B_OUTC | GEMM_COLSUM_A, colsum=db, partial=partial,
+                 splits=splits, row_index=lst.to(DEV), row_count=cnt, b_map=bmap or (0, 0, 0))
+    assert (dW.cpu().double() - ref_w).abs().max().item() <= 5e-5 * max(ref_w.abs().max().item(), 1.0)
+    assert (db.cpu().double() - ref_b).abs().max().item() <= 5e-5 * max(ref_b.abs().max().item(), 1.0)
+
+
 @pytest.mark.parametrize("N,K", [(256, 128), (512, 84), (128, 128), (192, 64), (64, 128), (32, 128), (22, 64), (96, 96), (300, 40),
                                  (128, 20), (64, 52)])
 @pytest.mark.parametrize("batch,use_list", [(1, False), (3, False), (1, True)])
