@@ -401,6 +401,26 @@ int refil_attn_forward(const refil_attn_desc* desc, void* stream);
 int refil_attn_mask_words(const refil_attn_desc* desc, void* mask_words, void* row_bits, void* stream);
 int refil_attn_backward(const refil_attn_desc* desc, void* stream);
 
+/* EntityAttentionLayer forward from the layer's INPUT (attention.py:46-64): in_trans (`query, key, value = in_trans(x).chunk(3)`,
+ * no bias) and the attention core of refil_attn_forward in ONE launch -- Q / K / V never visit HBM unless asked for. The fp32
+ * products of in_trans run as six bf16 matrix-pipe products of an exact 3-way operand split with fp32 accumulate (the "wres_split"
+ * = 6 arithmetic of refil_set_tuning). What the learner step uses for its attention blocks (the target networks of
+ * q_learner.py:111-113,154 store nothing; the live ones keep q_out / k_out / v_out for refil_attn_backward).
+ *   attn   rows, mask variants, O / sO / ldo, t_last, and REQUIRED precomputed mask_words / row_bits (refil_attn_mask_words: the
+ *          dead K/V / Q rows are taken from row_bits); attn.Q / K / V / kv_dead / q_dead are ignored, ldq / ldkv describe the stores
+ *   X      layer input [R*ne, >= w] (leading dimension ldx), w = heads * hd; rows of dead entities are not read
+ *   W_in   in_trans.weight [3w, w] row-major: rows [0,w) -> query, [w,2w) -> key, [2w,3w) -> value
+ *   q_out / k_out / v_out   optional (NULL: not stored): the projections in the layouts of attn.Q / K / V; rows of dead queries /
+ *          keys are not written
+ * Shapes: n_entities <= 32, n_agents <= 16, head dim 16 or 32, w = 64 or 128; others return an error. */
+typedef struct refil_attn_qkv_desc {
+    refil_attn_desc attn;
+    const float* X; int32_t ldx;
+    const float* W_in;
+    float* q_out; float* k_out; float* v_out;
+} refil_attn_qkv_desc;
+int refil_attn_qkv_forward(const refil_attn_qkv_desc* desc, void* stream);
+
 /* Masked entity pooling core of EntityPoolingLayer (attention.py:114-123) under the same mask variants:
  *   O[v][r*na+i][c] = pool_j ( masked_v(i,j) ? 0 : K[r*ne+j][c] ),  pool = mean over ALL ne entities (mode 1) or
  *   max (mode 2; masked entities enter as zeros). K = the in_trans output [R*ne, w] (ldkv), w = heads*hd.

@@ -100,6 +100,11 @@ class AttnDesc(C.Structure):
     ]
 
 
+class AttnQkvDesc(C.Structure):
+    _fields_ = [("attn", AttnDesc), ("X", C.c_void_p), ("ldx", C.c_int32), ("W_in", C.c_void_p),
+                ("q_out", C.c_void_p), ("k_out", C.c_void_p), ("v_out", C.c_void_p)]
+
+
 class GruDesc(C.Structure):
     _fields_ = [
         ("gi", C.c_void_p), ("hsx", C.c_void_p), ("w_hh", C.c_void_p), ("b_hh", C.c_void_p),
@@ -136,6 +141,7 @@ EXPORTS = [
     "refil_learner_row_counts", "refil_attn_mask_words", "refil_set_mixer_grads_hook",
     "refil_oneshot_create", "refil_oneshot_connect", "refil_oneshot_allreduce", "refil_oneshot_status", "refil_oneshot_destroy",
     "refil_allreduce_flat", "refil_pack_mask_bits", "refil_side_stream", "refil_set_tuning", "refil_get_stat",
+    "refil_attn_qkv_forward",
 ]
 IPC_HANDLE_BYTES = 64
 
@@ -180,6 +186,7 @@ def lib():
     L.refil_gemm.argtypes = [C.POINTER(GemmDesc), C.c_void_p]
     L.refil_attn_forward.argtypes = [C.POINTER(AttnDesc), C.c_void_p]
     L.refil_attn_backward.argtypes = [C.POINTER(AttnDesc), C.c_void_p]
+    L.refil_attn_qkv_forward.argtypes = [C.POINTER(AttnQkvDesc), C.c_void_p]
     L.refil_attn_mask_words.argtypes = [C.POINTER(AttnDesc), C.c_void_p, C.c_void_p, C.c_void_p]
     L.refil_pool_forward.argtypes = [C.POINTER(AttnDesc), C.c_int32, C.c_void_p]
     L.refil_pool_backward.argtypes = [C.POINTER(AttnDesc), C.c_int32, C.c_void_p]

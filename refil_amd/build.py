@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["gemm.hip", "gemm_wres.hip", "gemm_dw.hip", "gemm_dw4.hip", "attention.hip", "attention_mfma.hip", "gru.hip", "mixer.hip", "replay.hip", "collective.hip", "learner.hip", "profile.hip"]
+SOURCES = ["gemm.hip", "gemm_wres.hip", "gemm_dw.hip", "gemm_dw4.hip", "attention.hip", "attention_mfma.hip", "attention_qkv.hip", "gru.hip", "mixer.hip", "replay.hip", "collective.hip", "learner.hip", "profile.hip"]
 LIB = os.path.join(HERE, "librefil_hip.so")
 
 

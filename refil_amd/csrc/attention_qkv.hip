@@ -1,0 +1,461 @@
+// EntityAttentionLayer forward from the layer's INPUT: in_trans and the masked multi-head attention core in ONE launch
+// (reference: src/modules/layers/attention.py:46-64 -- `query, key, value = in_trans(x).chunk(3)`, logits, masked softmax, .V,
+// heads merged; the target networks of src/learners/q_learner.py:111-113,154 are never differentiated, so for them Q / K / V
+// exist in registers only).
+//
+// Why. As separate launches the projection writes Q / K / V to HBM and the attention core reads them back: at the north-star
+// shape 250 MB + 45 MB written and 186 MB read per hypernet set and step -- a fifth of the step's HBM traffic -- for values that
+// are consumed once, by the wave that could have produced them.
+//
+// How. A workgroup owns ONE (net, head): its 3 hd rows of in_trans.weight (Wq_h, Wk_h, Wv_h), split once into three bf16 planes
+// (the exact 3-way split of split.h: six bf16 matrix-pipe products with fp32 accumulate = the fp32 product), stay in LDS; its
+// waves walk the live (b,t) rows. The orientation of each product is chosen so that the accumulators ARE the operands of the
+// fp32 16x16x4 core (attention_mfma.hip), lane for lane:
+//     K^T[c][key]   = Wk_h x^T   (A = W fragment, B = x rows)  -> lane (key, c = 16ct+4q+reg): the A operand of S^T = K Q^T
+//     Q^T[c][agent] = Wq_h x^T   (same x registers: the agents are the first entities)  -> the B operand of S^T = K Q^T
+//     V[key][c]     = x Wv_h^T   (A = the SAME x registers, B = W fragment) -> lane (c, key = 16jt+4q+reg): the A operand of O^T = V^T P^T
+// (v_mfma_f32_16x16x32_bf16: A and B fragments have the same lane layout -- index = lane % 16, 8 consecutive reduction indices
+// per lane group -- so one split of an x row serves as A and as B). Nothing but the W planes touches LDS; the x rows stream
+// global -> registers one job ahead; dead rows (refil_attn_desc.kv_dead / t_last) are not fetched. For the live nets the three
+// projections are also stored once, in refil_attn_desc's Q / K / V layouts, for refil_attn_backward.
+#include <stdlib.h>
+#include <string.h>
+
+#include "bufops.h"
+#include "common.h"
+#include "kernels.h"
+#include "profile.h"
+#include "split.h"
+#include "../../include/refil_hip.h"
+
+namespace refil {
+
+constexpr int QKV_MAX_NETS = 8;
+constexpr int QKV_WAVES = 8;
+struct QkvNet {
+    const float* X;      // layer input of this net: entity row (r ne + j) at X + (r ne + j) ldx
+    const float* W;      // in_trans.weight [3w][w], rows [0,w) -> Q, [w,2w) -> K, [2w,3w) -> V
+    float* O;
+    float* Qo; float* Ko; float* Vo;     // optional stores (layouts of refil_attn_desc Q / K / V)
+    int nvar, sum_agents;
+};
+struct QkvM {
+    QkvNet net[QKV_MAX_NETS]; int nnets;
+    int ldx, w, ldq, ldkv, ldo; long sO;
+    int R, T1, ne, na, heads, hd, nvar;
+    const int* t_last;
+    const unsigned long long* mwords; int mw_nvar; const unsigned long long* rbits;
+    float* nact; int zero_dead;
+    int nslices, ngroups, xcd_groups;    // workgroup -> (slice = (net, head), row group); xcd_groups > 0: row groups per XCD (XCD-aware map)
+};
+
+#define MFMA16F(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define MFMA16B(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ inline float q_cross4_sum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+__device__ inline float q_cross4_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
+template <int CTRL>
+__device__ inline float q_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ inline float q_group16_sum(float v) { v += q_dpp<0xB1>(v); v += q_dpp<0x4E>(v); v += q_dpp<0x141>(v); v += q_dpp<0x140>(v); return v; }
+
+// masked softmax of transposed logits (attention_mfma.hip: softmax_T): st[jt][reg] = S^T[key 16jt+4q+reg][agent], in place -> P^T
+template <int NJT>
+__device__ inline void qkv_softmax_T(f32x4 (&st)[NJT], unsigned long long w, int q) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const bool masked = (w >> (16 * jt + 4 * q + reg)) & 1ull;
+            const float v = masked ? -INFINITY : st[jt][reg];
+            st[jt][reg] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = q_cross4_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float e = st[jt][reg] == -INFINITY ? 0.f : __expf(st[jt][reg] - mx);
+            st[jt][reg] = e;
+            sum += e;
+        }
+    sum = q_cross4_sum(sum);
+    const float inv = sum > 0.f ? __builtin_amdgcn_rcpf(sum) : 0.f;     // fully masked row -> 0 (attention.py:60 NaN -> 0)
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) st[jt][reg] *= inv;
+}
+
+__device__ inline unsigned long long q_readlane64(unsigned long long v, int l) {
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l), hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+struct QRow { int r; unsigned long long kdw, qdw, emtw; };
+
+// 8 fp32 values (two float4 of one x row) -> the three bf16x8 pieces hi / mid / lo
+__device__ inline void split8(const float4& a0, const float4& a1, wr_bf16x8 (&o)[3]) {
+    unsigned h[4], m[4], l[4];
+    wr_split(a0.x, a0.y, h[0], m[0], l[0]); wr_split(a0.z, a0.w, h[1], m[1], l[1]);
+    wr_split(a1.x, a1.y, h[2], m[2], l[2]); wr_split(a1.z, a1.w, h[3], m[3], l[3]);
+    o[0] = __builtin_bit_cast(wr_bf16x8, wr_u32x4{h[0], h[1], h[2], h[3]});
+    o[1] = __builtin_bit_cast(wr_bf16x8, wr_u32x4{m[0], m[1], m[2], m[3]});
+    o[2] = __builtin_bit_cast(wr_bf16x8, wr_u32x4{l[0], l[1], l[2], l[3]});
+}
+
+// LDS bytes of an instantiation: the W planes [3 planes][3 matrices (q, k, v)][NCT][NKS][1 KB: lane (c = lane % 16, k group = lane / 16) -> 8 bf16]
+constexpr size_t qkv_plane_bytes(int nct, int nks) { return (size_t)3 * nct * nks * 1024; }
+
+// NJT: 16-entity key tiles (ne <= 16 NJT), NCT: 16-channel tiles of a head (hd = 16 NCT), NKS: 32-index steps of the reduction (w = 32 NKS).
+// n_agents <= 16: the agents' rows are (part of) key tile 0.
+template <int NJT, int NCT, int NKS>
+__global__ __launch_bounds__(64 * QKV_WAVES, 1) void attn_qkv_fwd(QkvM p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_q[];
+    constexpr size_t PSZ = qkv_plane_bytes(NCT, NKS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, q = lane >> 4;
+    int slice, grp;
+    {
+        const int b = blockIdx.x;
+        if (p.xcd_groups > 0) { const int xcd = b & 7, j = b >> 3; slice = j % p.nslices; grp = xcd * p.xcd_groups + j / p.nslices; }
+        else { slice = b % p.nslices; grp = b / p.nslices; }
+    }
+    const int net = slice / p.heads, head = slice - net * p.heads;
+    const QkvNet& n = p.net[net];
+    const int hd = 16 * NCT, w = 32 * NKS;
+    char* planes = smem_q;
+    int* pref = reinterpret_cast<int*>(smem_q + 3 * PSZ);
+
+    // ---- stage this (net, head)'s three weight slices once: split into bf16 planes in fragment order ----
+    {
+        const int w4 = w >> 2, total = 3 * hd * w4;
+        for (int idx = tid; idx < total; idx += 64 * QKV_WAVES) {
+            const int k4 = idx % w4, row = idx / w4, m = row / hd, c = row - m * hd;
+            const float4 v = *reinterpret_cast<const float4*>(n.W + ((long)m * w + head * hd + c) * w + 4 * k4);
+            unsigned h0, m0, l0, h1, m1, l1;
+            wr_split(v.x, v.y, h0, m0, l0); wr_split(v.z, v.w, h1, m1, l1);
+            const int k = 4 * k4, s = k >> 5, qq = (k >> 3) & 3, e = k & 7;
+            char* dst = planes + ((size_t)((m * NCT + (c >> 4)) * NKS + s) << 10) + qq * 256 + (c & 15) * 16 + e * 2;
+            *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(dst + PSZ) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(dst + 2 * PSZ) = make_uint2(l0, l1);
+        }
+    }
+    // ---- live rows: prefix sum of the episodes' live steps (t <= t_last[b]) ----
+    const int nB = p.R / p.T1;
+    int nlive = p.R;
+    if (p.t_last) {
+        if (tid < 64) {
+            int carry = 0;
+            if (tid == 0) pref[0] = 0;
+            for (int base = 0; base < nB; base += 64) {
+                const int j = base + tid;
+                int c = 0;
+                if (j < nB) { c = p.t_last[j] + 1; c = c < 0 ? 0 : (c > p.T1 ? p.T1 : c); }
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(c, d, 64); if (tid >= d) c += o; }
+                if (j < nB) pref[j + 1] = carry + c;
+                carry += __shfl(c, 63, 64);
+            }
+        }
+    }
+    __syncthreads();
+    if (p.t_last) nlive = pref[nB];
+    const int wstride = p.ngroups * QKV_WAVES;
+    const int ord0 = grp * QKV_WAVES + wave;
+    const int njobs = ord0 < nlive ? (nlive - ord0 + wstride - 1) / wstride : 0;
+    if (njobs == 0) return;
+    auto row_of = [&](int k) -> int {           // live ordinal of this wave's k-th job -> row (b,t); wave-uniform
+        int o = ord0 + (k < njobs ? k : njobs - 1) * wstride;
+        if (!p.t_last) return o;
+        int lo = 0, hi = nB;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (pref[mid + 1] <= o) lo = mid + 1; else hi = mid; }
+        return __builtin_amdgcn_readfirstlane(lo * p.T1 + (o - pref[lo]));
+    };
+    const float inv_scale = 1.0f / sqrtf((float)hd);
+    const unsigned long long na_bits = (p.na >= 64) ? ~0ull : ((1ull << p.na) - 1ull);
+    const int col0 = head * hd;
+
+    // operands in flight for the NEXT job: the x rows of every key tile and reduction step, the mask words of this lane's agent
+    float4 xr[NKS][NJT][2];
+    unsigned long long nw[3];
+    auto fetch = [&](const QRow& ri, bool valid) {
+        const rsrc_t rx = mk_rsrc(n.X + (long)ri.r * p.ne * p.ldx, valid ? ((long)(p.ne - 1) * p.ldx + w) * 4 : 0);
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            const int key = 16 * jt + l15;
+            const bool ok = key < p.ne && !((ri.kdw >> key) & 1ull);
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                const int off = (key * p.ldx + 32 * s + 8 * q) * 4;
+                xr[s][jt][0] = buf_ld4(rx, ok ? off : BUF_OOB);
+                xr[s][jt][1] = buf_ld4(rx, ok ? off + 16 : BUF_OOB);
+            }
+        }
+        const rsrc_t rw = mk_rsrc(p.mwords + (long)ri.r * p.mw_nvar * 16, valid ? (long)p.mw_nvar * 16 * 8 : 0);
+#pragma unroll
+        for (int v = 0; v < 3; ++v) nw[v] = buf_ld_u64(rw, v < p.nvar ? (v * 16 + l15) * 8 : BUF_OOB);
+    };
+    // the row words of a row travel one job ahead of its operand fetch, in a vector register (lane l holds word l % 3)
+    auto words_of = [&](int r) -> unsigned long long { return p.rbits[3 * (long)r + lane % 3]; };
+    auto take = [&](int r, unsigned long long wv) -> QRow {
+        QRow x; x.r = r; x.kdw = q_readlane64(wv, 0); x.qdw = q_readlane64(wv, 1); x.emtw = q_readlane64(wv, 2);
+        return x;
+    };
+
+    int r_next = row_of(0);
+    unsigned long long w_next = words_of(r_next);
+    QRow frow = take(r_next, w_next);
+    r_next = row_of(1); w_next = words_of(r_next);
+    fetch(frow, true);
+
+    for (int k = 0; k < njobs; ++k) {
+        const QRow crow = frow;
+        const int r = crow.r;
+        unsigned long long cw[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) cw[v] = nw[v];
+        // ---- in_trans of this row's entities for this head: K^T, V, Q^T tiles on the bf16 pipe (fp32 accumulate) ----
+        f32x4 Kt[NCT][NJT], Vv[NJT][NCT], Qt[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            Qt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) { Kt[ct][jt] = f32x4{0.f, 0.f, 0.f, 0.f}; Vv[jt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+        // product order: smallest first -- (lo, hi), (hi, lo), (mid, mid), (mid, hi), (hi, mid), (hi, hi); planes 0 / 1 / 2 = hi / mid / lo
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            wr_bf16x8 xs[NJT][3];
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) split8(xr[s][jt][0], xr[s][jt][1], xs[jt]);
+            const char* pb = planes + ((size_t)s << 10) + lane * 16;
+            wr_bf16x8 wq[NCT][3], wk[NCT][3];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    wq[ct][pl] = *reinterpret_cast<const wr_bf16x8*>(pb + pl * PSZ + ((size_t)((0 * NCT + ct) * NKS) << 10));
+                    wk[ct][pl] = *reinterpret_cast<const wr_bf16x8*>(pb + pl * PSZ + ((size_t)((1 * NCT + ct) * NKS) << 10));
+                }
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+                    for (int jt = 0; jt < NJT; ++jt) Kt[ct][jt] = MFMA16B(wk[ct][PA[pr]], xs[jt][PB[pr]], Kt[ct][jt]);
+                    Qt[ct] = MFMA16B(wq[ct][PA[pr]], xs[0][PB[pr]], Qt[ct]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            wr_bf16x8 wv[NCT][3];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    wv[ct][pl] = *reinterpret_cast<const wr_bf16x8*>(pb + pl * PSZ + ((size_t)((2 * NCT + ct) * NKS) << 10));
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) Vv[jt][ct] = MFMA16B(xs[jt][PB[pr]], wv[ct][PA[pr]], Vv[jt][ct]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- advance the fetch cursor: the operands of job k+1 are in flight during the core below ----
+        frow = take(r_next, w_next);
+        r_next = row_of(k + 2); w_next = words_of(r_next);
+        fetch(frow, k + 1 < njobs);
+        // queries of inactive / padded agents enter the core as zeros (refil_attn_desc.q_dead: what the separate launches load there)
+        {
+            const bool qz = ((crow.qdw >> l15) & 1ull) || l15 >= p.na;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                if (qz) Qt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // (nact[r] by lane 0 of the row's first slice)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)__popcll(~crow.emtw & na_bits)),
+                                              mk_rsrc(p.nact + r, p.nact && slice == 0 ? 4 : 0), lane == 0 ? 0 : BUF_OOB, 0, 0);
+        // ---- the live nets keep their projections for the backward (layouts of refil_attn_desc Q / K / V) ----
+        {
+            const rsrc_t rk = mk_rsrc(n.Ko + (long)r * p.ne * p.ldkv, n.Ko ? (long)p.ne * p.ldkv * 4 : 0);
+            const rsrc_t rv = mk_rsrc(n.Vo + (long)r * p.ne * p.ldkv, n.Vo ? (long)p.ne * p.ldkv * 4 : 0);
+            const rsrc_t rq = mk_rsrc(n.Qo + (long)r * p.na * p.ldq, n.Qo ? (long)p.na * p.ldq * 4 : 0);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int c = col0 + 16 * ct + 4 * q;
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt) {
+                    const int key = 16 * jt + l15;
+                    const bool ok = key < p.ne && !((crow.kdw >> key) & 1ull);
+                    buf_st4(rk, ok ? (key * p.ldkv + c) * 4 : BUF_OOB, Kt[ct][jt]);
+                }
+                const bool okq = l15 < p.na && !((crow.qdw >> l15) & 1ull);
+                buf_st4(rq, okq ? (l15 * p.ldq + c) * 4 : BUF_OOB, Qt[ct]);
+            }
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int key = 16 * jt + 4 * q + reg;
+                        const bool ok = key < p.ne && !((crow.kdw >> key) & 1ull);
+                        // (__float_as_uint of a copy: __builtin_bit_cast of ONE element of a vector reads element 0 in this clang)
+                        const float vv = Vv[jt][ct][reg];
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vv), rv,
+                                                              ok ? (key * p.ldkv + col0 + 16 * ct + l15) * 4 : BUF_OOB, 0, 0);
+                    }
+        }
+        // ---- attention core (attention_mfma.hip: attn_fwd_pipe), operands straight from the accumulators ----
+        f32x4 stt[NJT];
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) acc = MFMA16F(Kt[ct][jt][reg], Qt[ct][reg], acc);
+            stt[jt] = acc;
+        }
+        f32x4 osum[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) osum[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            f32x4 o[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool on = v < n.nvar;
+            if (on) {
+                f32x4 pt[NJT];
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) pt[jt][reg] = stt[jt][reg] * inv_scale;      // attention.py:54
+                qkv_softmax_T<NJT>(pt, cw[v], q);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+                    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) o[ct] = MFMA16F(Vv[jt][ct][reg], pt[jt][reg], o[ct]);
+                    if (n.sum_agents) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) osum[ct][e] += q_group16_sum(o[ct][e]);
+                    } else if (p.zero_dead && ((crow.emtw >> l15) & 1ull)) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            const rsrc_t ro = mk_rsrc(n.O + v * p.sO + (long)r * p.na * p.ldo, on && !n.sum_agents ? (long)p.na * p.ldo * 4 : 0);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                buf_st4(ro, l15 < p.na ? (l15 * p.ldo + col0 + 16 * ct + 4 * q) * 4 : BUF_OOB, o[ct]);
+        }
+        {
+            const rsrc_t ro = mk_rsrc(n.O + (long)r * p.ldo, n.sum_agents ? (long)p.ldo * 4 : 0);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) buf_st4(ro, l15 == 0 ? (col0 + 16 * ct + 4 * q) * 4 : BUF_OOB, osum[ct]);
+        }
+    }
+}
+
+static int qkv_device_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+
+bool attn_qkv_supported(int ne, int na, int heads, int hd) {
+    const int w = heads * hd;
+    return ne >= 1 && ne <= 32 && na >= 1 && na <= 16 && na <= ne && (hd == 16 || hd == 32) && (w == 64 || w == 128);
+}
+
+template <int NJT, int NCT, int NKS>
+static int qkv_launch_x(QkvM& k, hipStream_t st) {
+    const size_t lds = 3 * qkv_plane_bytes(NCT, NKS) + ((size_t)(k.R / k.T1) + 2) * 4;
+    if (lds > 160 * 1024) return -1;
+    void (*kern)(QkvM) = attn_qkv_fwd<NJT, NCT, NKS>;
+    static bool raised = false;
+    if (!raised) { REFIL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); raised = true; }
+    // one workgroup per CU; workgroup -> (slice, row group). XCD-aware: the heads (and nets) that read the same x rows sit on one
+    // XCD (workgroups are dealt round-robin to the 8 XCDs by block id), so a row comes from HBM once and from that XCD's L2 afterwards
+    const int cus = qkv_device_cus();
+    k.nslices = k.nnets * k.heads;
+    if (cus % 8 == 0 && (cus / 8) % k.nslices == 0) { k.xcd_groups = cus / 8 / k.nslices; k.ngroups = 8 * k.xcd_groups; }
+    else { k.xcd_groups = 0; k.ngroups = cus / k.nslices > 0 ? cus / k.nslices : 1; }
+    const long live_groups = ((long)k.R + QKV_WAVES - 1) / QKV_WAVES;
+    if (!k.xcd_groups && k.ngroups > live_groups) k.ngroups = (int)live_groups;
+    hipLaunchKernelGGL(kern, dim3(k.nslices * k.ngroups), dim3(64 * QKV_WAVES), lds, st, k);
+    REFIL_LAUNCH_CHECK();
+    return 0;
+}
+
+// n attention blocks in one launch (same rows, masks, widths and leading dimensions: attn_mfma_launch_multi's rules); src[i] = the
+// layer input / in_trans weight / optional projection stores of block i. Needs precomputed mask words. -1: shape not instantiated.
+int attn_qkv_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts, const AttnQkvSrc* src, int n, int ldx, hipStream_t st,
+                          float* nact, int zero_dead) {
+    REFIL_CHECK(descs && opts && src && n >= 1 && n <= QKV_MAX_NETS, "refil_attn_qkv: 1..%d nets per launch", QKV_MAX_NETS);
+    const refil_attn_desc& d = descs[0];
+    if (!attn_qkv_supported(d.ne, d.na, d.heads, d.hd)) return -1;
+    REFIL_CHECK(d.mask_words && d.row_bits, "refil_attn_qkv: precomputed mask words required (refil_attn_mask_words)");
+    REFIL_CHECK(d.T1 > 0 && d.R % d.T1 == 0, "refil_attn_qkv: R must be a multiple of T1");
+    const int w = d.heads * d.hd;
+    REFIL_CHECK(ldx % 4 == 0 && d.ldq % 4 == 0 && d.ldkv % 4 == 0 && d.ldo % 4 == 0, "refil_attn_qkv: leading dimensions must be multiples of 4");
+    QkvM k;
+    memset(&k, 0, sizeof(k));
+    k.nnets = n;
+    for (int i = 0; i < n; ++i) {
+        const refil_attn_desc& e = descs[i];
+        REFIL_CHECK(e.R == d.R && e.T1 == d.T1 && e.ne == d.ne && e.na == d.na && e.heads == d.heads && e.hd == d.hd && e.ldq == d.ldq &&
+                    e.ldkv == d.ldkv && e.ldo == d.ldo && e.sO == d.sO && e.t_last == d.t_last && e.mask_words == d.mask_words &&
+                    e.row_bits == d.row_bits, "refil_attn_qkv: nets of one launch must share rows, masks and strides");
+        REFIL_CHECK(i == 0 || e.nvar == 1, "refil_attn_qkv: nets after the first are single-variant under variant 0");
+        REFIL_CHECK(!opts[i].sum_agents || e.nvar == 1, "refil_attn_qkv: the agent-sum output is a single-variant option");
+        REFIL_CHECK(src[i].X && src[i].W && e.O, "refil_attn_qkv: null X / W / O");
+        REFIL_CHECK((reinterpret_cast<uintptr_t>(src[i].X) & 15) == 0 && (reinterpret_cast<uintptr_t>(src[i].W) & 15) == 0, "refil_attn_qkv: X / W must be 16-byte aligned");
+        QkvNet& t = k.net[i];
+        t.X = src[i].X; t.W = src[i].W; t.O = e.O; t.Qo = src[i].Qo; t.Ko = src[i].Ko; t.Vo = src[i].Vo;
+        t.nvar = e.nvar; t.sum_agents = opts[i].sum_agents;
+    }
+    k.ldx = ldx; k.w = w; k.ldq = d.ldq; k.ldkv = d.ldkv; k.ldo = d.ldo; k.sO = d.sO;
+    k.R = d.R; k.T1 = d.T1; k.ne = d.ne; k.na = d.na; k.heads = d.heads; k.hd = d.hd; k.nvar = d.nvar;
+    k.t_last = d.t_last;
+    k.mwords = reinterpret_cast<const unsigned long long*>(d.mask_words); k.rbits = reinterpret_cast<const unsigned long long*>(d.row_bits);
+    k.mw_nvar = d.mask_words_nvar > 0 ? d.mask_words_nvar : d.nvar;
+    REFIL_CHECK(k.mw_nvar >= d.nvar, "refil_attn_qkv: mask_words holds fewer variants than nvar");
+    k.nact = nact; k.zero_dead = zero_dead;
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        flops += (double)d.R * (2.0 * (2.0 * d.ne + d.na) * w * w + (2.0 + 2.0 * descs[i].nvar) * d.heads * d.na * d.ne * d.hd);
+        bytes += 4.0 * d.R * ((double)d.ne * w + (double)descs[i].nvar * d.na * w + (src[i].Ko ? (2.0 * d.ne + d.na) * w : 0.0));
+    }
+    ProfScope prof("attn_qkv_fwd", flops, bytes, st);
+    const int njt = (d.ne + 15) / 16, nct = d.hd / 16, nks = w / 32;
+#define CASE(J, C, S) if (njt == J && nct == C && nks == S) return qkv_launch_x<J, C, S>(k, st)
+    CASE(2, 2, 4); CASE(1, 2, 4); CASE(2, 1, 2); CASE(1, 1, 2); CASE(2, 2, 2); CASE(1, 2, 2); CASE(2, 1, 4); CASE(1, 1, 4);
+#undef CASE
+    return -1;
+}
+
+}  // namespace refil
+
+using namespace refil;
+
+extern "C" int refil_attn_qkv_forward(const refil_attn_qkv_desc* q, void* stream) {
+    REFIL_CHECK(q && q->X && q->W_in, "refil_attn_qkv_forward: null desc / X / W_in");
+    const refil_attn_desc& d = q->attn;
+    REFIL_CHECK(d.nvar >= 1 && d.nvar <= 3, "refil_attn_qkv_forward: nvar must be 1..3");
+    AttnNetOpts o{0, 0};
+    AttnQkvSrc s{q->X, q->W_in, q->q_out, q->k_out, q->v_out};
+    const int rc = attn_qkv_launch_multi(&d, &o, &s, 1, q->ldx, (hipStream_t)stream, nullptr, 0);
+    REFIL_CHECK(rc >= 0, "refil_attn_qkv_forward: shape not instantiated (n_entities <= 32, n_agents <= 16, head dim 16 / 32, width 64 / 128)");
+    return rc;
+}

@@ -499,6 +499,7 @@ static int wres_split_mode() {
     static const int env = [] { const char* e = getenv("REFIL_WRES_SPLIT"); return e && atoi(e) == 0 ? 0 : 6; }();
     return env;
 }
+bool gemm_wres_split_on() { return wres_split_mode() == 6; }
 template <int TN, int NC, int NPASS, bool BT, int EPI, bool ACC, bool RMASK, bool B2, bool IDX, int SPLIT>
 static int wres_launch_s(const WresK& k, dim3 grid, hipStream_t st) {
     constexpr size_t smem = wres_smem_x(TN, NC, NPASS, SPLIT);

@@ -27,12 +27,13 @@ constexpr int RED_MULTI = 28;        // reductions one reduce_multi launch takes
 // launch needed none); the caller runs it later with reduce_multi_launch -- many reductions, one launch
 // Schedule knobs a caller may set at run time (refil_set_tuning: QLearner's first-call autotuner measures them in situ per
 // shape); -1 = the environment switch / built-in rule decides
-struct Tuning { long dw4_target = -1, dw4_min_out = -1, dw_target = -1, compose_early = -1, gru_pd = -1, wres_split = -1, dw_split = -1; };
+struct Tuning { long dw4_target = -1, dw4_min_out = -1, dw_target = -1, compose_early = -1, gru_pd = -1, wres_split = -1, dw_split = -1, attn_qkv = -1; };
 extern Tuning g_tuning;
 int gemm_launch(const refil_gemm_desc& d, hipStream_t st, ReduceK* defer = nullptr);
 int reduce_multi_launch(const ReduceK* r, int n, hipStream_t st);
 // weight-resident kernel for short-reduction forward projections (gemm_wres.hip); gemm_launch dispatches to it
 bool gemm_wres_eligible(const refil_gemm_desc& d);
+bool gemm_wres_split_on();      // the projections run the bf16 x 6 form (refil_set_tuning "wres_split" / REFIL_WRES_SPLIT)
 // streaming weight-gradient kernel (gemm_dw.hip): writes the split partials, gemm_launch runs the reduction
 bool gemm_dw_stream_eligible(const refil_gemm_desc& d);
 int gemm_dw_stream_launch(const refil_gemm_desc& d, hipStream_t st);
@@ -220,6 +221,12 @@ int attn_mask_words_launch(const refil_attn_desc& d, unsigned long long* mwords,
 // several attention blocks that share rows and masks (the hypernets of a mixer) in ONE launch
 struct AttnNetOpts { int sum_agents, bcast_do; };
 int attn_mfma_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts, int n, bool bwd, hipStream_t st, float* nact, int zero_dead);
+
+// attention_qkv.hip: in_trans + attention core in one launch (the layer's input and weight instead of Q / K / V); -1 = shape not instantiated
+struct AttnQkvSrc { const float* X; const float* W; float* Qo; float* Ko; float* Vo; };
+bool attn_qkv_supported(int ne, int na, int heads, int hd);
+int attn_qkv_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts, const AttnQkvSrc* src, int n, int ldx, hipStream_t st,
+                          float* nact, int zero_dead);
 
 int clip_rmsprop_launch(float* params, const float* grads, float* sq, long n, float lr, float alpha, float eps,
                         float wd, float clip, float* stats, float* scratch, hipStream_t st);

@@ -197,6 +197,7 @@ static void carve_hyper(Arena& a, const refil_dims& d, const Sizes& s, int NV, H
 }
 
 enum CarveMode { CARVE_LEARNER, CARVE_AGENT_FWD, CARVE_MIXER_FWD };
+constexpr int QKV_DEFAULT = 15;
 
 static void carve(Arena& a, const refil_dims& d, Work& w, CarveMode mode) {
     const Sizes s = sizes_of(d);
@@ -468,7 +469,12 @@ struct Ctx {
     bool agent_composed, skip_compose;
     int mw_nvar;       // variants per row in w.mw_a / w.mw_h (the step's G; 1 for the target nets' early variant-0 words)
     bool target_same;  // params_target is what the previous call on this workspace saw (refil_batch.target_version)
+    // in_trans + attention core as ONE launch (attention_qkv.hip) for: bit 0 the target hypernets, bit 1 the target agent (neither
+    // stores Q / K / V: q_learner.py:111-113,154 never differentiates them), bit 2 the live hypernets, bit 3 the live agent (Q / K / V
+    // stored once for the backward). REFIL_ATTN_QKV / refil_set_tuning("attn_qkv")
+    int qkv;
 };
+enum { QKV_T_HYPER = 1, QKV_T_AGENT = 2, QKV_L_HYPER = 4, QKV_L_AGENT = 8 };
 
 static int gemm_launch_dw(const Ctx& c, refil_gemm_desc& g, hipStream_t st) {
     DeferredReduce* df = c.defer;
@@ -587,25 +593,29 @@ static int agent_entity_dual(const Ctx& c, const float* Pl, const float* Pt, con
     const refil_dims& d = c.d; const Sizes& s = c.s; const refil_param_layout& L = c.L;
     const int dd = d.d;
     const long dP = Pt - Pl;
+    // in_trans + attention core as one launch (attention_qkv.hip) for the live (Q / K / V stored for the backward) and / or the
+    // target agent (nothing stored); a net that is not fused keeps its projection launches
+    const bool fl = (c.qkv & QKV_L_AGENT) != 0, ft = (c.qkv & QKV_T_AGENT) != 0;
     {
         refil_gemm_desc g = with_rows(linear(c.w.xe, s.Ep, Pl + L.ag_fc1_w, s.E, Pl + L.ag_fc1_b, bl.x1, dd, s.NE, dd, s.E, REFIL_GEMM_RELU), c, rows_ea(c));
         g.batch = 2; g.sA = 0; g.sB = dP; g.sBias = dP; g.sC = bt.x1 - bl.x1;
         RUN(gemm_launch(g, c.st));
     }
-    {
-        refil_gemm_desc g = with_rows(linear(bl.x1, dd, Pl + L.ag_in_w + (long)dd * dd, dd, nullptr, bl.kv, 2 * dd, s.NE, 2 * dd, dd, 0), c, rows_ea(c));
-        g.batch = 2; g.sA = bt.x1 - bl.x1; g.sB = dP; g.sC = bt.kv - bl.kv;
+    const int n0 = fl ? 1 : 0, n1 = ft ? 1 : 2;           // nets [n0, n1) run the separate projections
+    if (n0 < n1) {
+        const AgentBufs& b0 = n0 ? bt : bl; const float* P0 = n0 ? Pt : Pl;
+        refil_gemm_desc g = with_rows(linear(b0.x1, dd, P0 + L.ag_in_w + (long)dd * dd, dd, nullptr, b0.kv, 2 * dd, s.NE, 2 * dd, dd, 0), c, rows_ea(c));
+        g.batch = n1 - n0; g.sA = bt.x1 - bl.x1; g.sB = dP; g.sC = bt.kv - bl.kv;
         RUN(gemm_launch(g, c.st));
-    }
-    {
-        refil_gemm_desc g = linear(bl.x1, dd, Pl + L.ag_in_w, dd, nullptr, bl.q, dd, s.NA, dd, dd, 0);
-        g.a_map = agent_rows(c);
-        g = with_rows(g, c, rows_a(c));
-        g.batch = 2; g.sA = bt.x1 - bl.x1; g.sB = dP; g.sC = bt.q - bl.q;
-        RUN(gemm_launch(g, c.st));
+        refil_gemm_desc q = linear(b0.x1, dd, P0 + L.ag_in_w, dd, nullptr, b0.q, dd, s.NA, dd, dd, 0);
+        q.a_map = agent_rows(c);
+        q = with_rows(q, c, rows_a(c));
+        q.batch = n1 - n0; q.sA = bt.x1 - bl.x1; q.sB = dP; q.sC = bt.q - bl.q;
+        RUN(gemm_launch(q, c.st));
     }
     refil_attn_desc ad[2];
     AttnNetOpts ao[2] = {AttnNetOpts{0, 0}, AttnNetOpts{0, 0}};
+    AttnQkvSrc qs[2];
     for (int n = 0; n < 2; ++n) {
         const AgentBufs& b = n ? bt : bl;
         refil_attn_desc a = attn_base(c, dd);
@@ -615,8 +625,20 @@ static int agent_entity_dual(const Ctx& c, const float* Pl, const float* Pt, con
         a.var[2] = group_code(d, 1, true);
         attn_rows(c, a, false);
         ad[n] = a;
+        qs[n] = AttnQkvSrc{b.x1, (n ? Pt : Pl) + L.ag_in_w, n ? nullptr : b.q, n ? nullptr : b.kv, n ? nullptr : b.kv + dd};
     }
     RUN(stream_after(c.sd, c.mwst, c.st));
+    if (fl || ft) {
+        // (both fused: ONE launch, 2 x heads slices; else the fused net's launch and the other net's attention core)
+        const int f0 = fl ? 0 : 1, nf = (fl && ft) ? 2 : 1;
+        const int rcq = attn_qkv_launch_multi(ad + f0, ao + f0, qs + f0, nf, dd, c.st, nullptr, 1);
+        REFIL_CHECK(rcq >= 0, "refil: fused in_trans + attention shape not instantiated");
+        if (rcq) return rcq;
+        if (fl && ft) return 0;
+        const int rc1 = attn_mfma_launch_ex(ad[fl ? 1 : 0], false, c.st, 0, nullptr, 0, 1);
+        REFIL_CHECK(rc1 >= 0, "refil: agent attention shape not instantiated");
+        return rc1;
+    }
     // the two attention cores: one launch up to 16 entities (launch-bound shapes: cfg2 1.4 % faster), one launch per net
     // above (a second job per wave lengthens every workgroup: cfg-T 1.6 % faster with two launches). REFIL_AGENT_DUAL=2 / 3
     // force two launches / one
@@ -637,9 +659,10 @@ static int agent_entity_dual(const Ctx& c, const float* Pl, const float* Pt, con
 
 // phases: AG_PRE everything up to the GRU input gates, AG_GRU the recurrence, AG_POST fc3 (the learner runs the live and
 // the target agent's recurrences in ONE launch between their PRE and POST parts)
-static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G, const float* h0, int phases = AG_ALL) {
+static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G, const float* h0, int phases = AG_ALL, bool target = false) {
     const refil_dims& d = c.d; const Sizes& s = c.s; const refil_param_layout& L = c.L;
     const int dd = d.d, H = d.H;
+    const bool fused = (c.qkv & (target ? QKV_T_AGENT : QKV_L_AGENT)) != 0;      // in_trans + attention core as one launch
     if (phases & AG_PRE) {
     if (!(phases & AG_NO_ENTITY)) {
     // x1 = relu(fc1(entities))                                       :38
@@ -655,11 +678,13 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
         RUN(pool_launch(a, d.pooling, false, c.st));
     } else {
     // K,V for all entities; Q for the agents only                    attention.py:46-48
+    if (!fused) {
     RUN(gemm_launch(with_rows(linear(b.x1, dd, P + L.ag_in_w + (long)dd * dd, dd, nullptr, b.kv, 2 * dd, s.NE, 2 * dd, dd, 0), c, rows_ea(c)), c.st));
     {
         refil_gemm_desc g = linear(b.x1, dd, P + L.ag_in_w, dd, nullptr, b.q, dd, s.NA, dd, dd, 0);
         g.a_map = agent_rows(c);
         RUN(gemm_launch(with_rows(g, c, rows_a(c)), c.st));
+    }
     }
     {
         refil_attn_desc a = attn_base(c, dd);
@@ -669,7 +694,13 @@ static int agent_forward(const Ctx& c, const float* P, const AgentBufs& b, int G
         a.var[2] = group_code(d, 1, true);
         attn_rows(c, a, false);
         RUN(stream_after(c.sd, c.mwst, c.st));
-        if (c.compose_agent) {
+        if (fused) {
+            const AttnNetOpts ao{0, 0};
+            const AttnQkvSrc qs{b.x1, P + L.ag_in_w, target ? nullptr : b.q, target ? nullptr : b.kv, target ? nullptr : b.kv + dd};
+            const int rc = attn_qkv_launch_multi(&a, &ao, &qs, 1, dd, c.st, nullptr, c.compose_agent ? 1 : 0);
+            REFIL_CHECK(rc >= 0, "refil: fused in_trans + attention shape not instantiated");
+            if (rc) return rc;
+        } else if (c.compose_agent) {
             const int rc = attn_mfma_launch_ex(a, false, c.st, 0, nullptr, 0, 1);      // inactive agents -> exact zeros
             REFIL_CHECK(rc >= 0, "refil: agent attention shape not instantiated");
             if (rc) return rc;
@@ -735,9 +766,14 @@ enum { HY_PRE = 1, HY_ATTN = 2, HY_POST = 4, HY_ALL = 7 };
 // phases: HY_PRE fc1 + K/V/Q projections, HY_ATTN the attention cores, HY_POST the tails. `second` (HY_ATTN only): another set
 // of hypernets under the SAME masks (the target mixer's, single-variant) whose attention cores join this launch -- 8 nets, one
 // launch: a launch's fixed per-row cost (mask words, first operand fetch, ramp) is paid once
-static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int nv0, int phases = HY_ALL, const HyperBufs* second = nullptr) {
+// `target`: these are the target mixer's hypernets (never differentiated: the fused launch stores no Q / K / V for them);
+// `Psecond`: the parameters of `second`'s nets (the fused launch reads in_trans.weight itself)
+static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int nv0, int phases = HY_ALL, const HyperBufs* second = nullptr,
+                         bool target = false, const float* Psecond = nullptr) {
     const refil_dims& d = c.d; const Sizes& s = c.s; const refil_param_layout& L = c.L;
     const int h = d.hyp, M = d.M, nets = s.nets;
+    // in_trans + attention core as one launch (attention_qkv.hip): no K/V / Q projection launches, no Q / K / V round trip
+    const bool fused = (c.qkv & (target ? QKV_T_HYPER : QKV_L_HYPER)) != 0 && (!second || (c.qkv & QKV_T_HYPER));
     // The composed tail maps depend on the parameters alone: built in front of the projections they are off the dependent
     // launches between the attention core and the join of the chains (A/B on one box: cfg-T 1.752 -> 1.742 ms; at 16 entities,
     // where the step is launch-bound rather than saturated, 0.754 -> 0.758: there they stay behind the attention core).
@@ -759,7 +795,7 @@ static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int n
         refil_gemm_desc g = linear(b.x1, nets * h, P + L.mix_in_w, h, P + L.mix_in_w + (long)h * h, b.kv, 2 * h, s.NE, h, h, 0);
         g.batch = nets; g.sA = h; g.sB = L.mix_in_w_stride; g.sBias = L.mix_in_w_stride; g.sC = s.NEa * 2 * h;
         RUN(gemm_launch(g, c.st));
-    } else {
+    } else if (!fused) {
         refil_gemm_desc g = linear(b.x1, nets * h, P + L.mix_in_w + (long)h * h, h, nullptr, b.kv, 2 * h, s.NE, 2 * h, h, 0);
         g.batch = nets; g.sA = h; g.sB = L.mix_in_w_stride; g.sC = s.NEa * 2 * h;
         RUN(gemm_launch(with_rows(g, c, rows_eh(c)), c.st));
@@ -774,12 +810,20 @@ static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int n
         // of a row pipelined), else one launch per net
         refil_attn_desc ad[8];
         AttnNetOpts ao[8];
+        AttnQkvSrc qs[8];
         const int nsets = second ? 2 : 1;
         REFIL_CHECK(nsets * nets <= 8, "refil: too many hypernets for one attention launch");
         for (int set = 0; set < nsets; ++set) {
             const HyperBufs& bb = set == 0 ? b : *second;
             const int nv = set == 0 ? nv0 : 1;
+            const float* Pn = set == 0 ? P : Psecond;
+            const bool store = !(set == 0 ? target : true);      // (a `second` set is the target mixer's)
             for (int n = 0; n < nets; ++n) {
+                if (fused) {
+                    float* kvn = bb.kv + (long)n * s.NEa * 2 * h;
+                    qs[set * nets + n] = AttnQkvSrc{bb.x1 + (long)n * h, Pn + L.mix_in_w + n * L.mix_in_w_stride,
+                                                    store ? bb.q + (long)n * s.NAa * h : nullptr, store ? kvn : nullptr, store ? kvn + h : nullptr};
+                }
                 refil_attn_desc a = attn_base(c, h);
                 attn_rows(c, a, true);
                 a.Q = bb.q + (long)n * s.NAa * h; a.K = bb.kv + (long)n * s.NEa * 2 * h; a.V = a.K + h;
@@ -794,7 +838,11 @@ static int hyper_forward(const Ctx& c, const float* P, const HyperBufs& b, int n
         }
         int rc = -1;
         RUN(stream_after(c.sd, c.mwst, c.st));
-        if (!d.pooling && attn_mfma_supported(d.ne, d.na, h / d.heads))
+        if (fused) {
+            REFIL_CHECK(!second || Psecond, "refil: merged fused hypernet launch needs the second set's parameters");
+            rc = attn_qkv_launch_multi(ad, ao, qs, nsets * nets, nets * h, c.st, c.presum ? c.w.nact : nullptr, 0);
+            REFIL_CHECK(rc >= 0, "refil: fused in_trans + attention shape not instantiated");
+        } else if (!d.pooling && attn_mfma_supported(d.ne, d.na, h / d.heads))
             rc = attn_mfma_launch_multi(ad, ao, nsets * nets, false, c.st, c.presum ? c.w.nact : nullptr, 0);
         if (rc > 0) return rc;
         if (rc < 0) {
@@ -993,6 +1041,7 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
     if (int e = check_dims(*dims)) return e;
     c.d = *dims; c.s = sizes_of(*dims); c.b = *batch; c.st = (hipStream_t)stream;
     c.gst = c.st; c.gpartial = nullptr; c.sd = nullptr; c.mwst = c.st; c.tail_dw = 0; c.tpartial = nullptr; c.defer = nullptr;
+    c.qkv = 0;
     c.same_layout = false; c.slot = 0; c.slot_free = nullptr; c.pre_done = nullptr; c.mw_nvar = c.s.G; c.target_same = false; c.prev = nullptr; c.agent_composed = false; c.skip_compose = false;
     param_layout(c.d, c.L);
     const char* pe = getenv("REFIL_PRESUM");          // read per call: tests compare both paths in one process
@@ -1018,6 +1067,15 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
         // before that the separate pass cost more than it saved there. REFIL_MASKWORDS=0 switches them off)
         c.mwords = mode == CARVE_LEARNER && !(me && me[0] == '0') && !d.pooling && !d.mixer_vdn && !d.mixer_none &&
                    attn_mfma_supported(d.ne, d.na, d.d / d.heads) && attn_mfma_supported(d.ne, d.na, d.hyp / d.heads);
+    }
+    {
+        static const int qkv_env = [] { const char* e = getenv("REFIL_ATTN_QKV"); return e ? atoi(e) : QKV_DEFAULT; }();
+        const refil_dims& d = *dims;
+        int q = g_tuning.attn_qkv >= 0 ? (int)g_tuning.attn_qkv : qkv_env;
+        if (!c.mwords || d.pooling || !gemm_wres_split_on()) q = 0;          // (the fused launch is the bf16 x 6 arithmetic of the projections)
+        if (!attn_qkv_supported(d.ne, d.na, d.heads, d.hyp / d.heads)) q &= ~(QKV_T_HYPER | QKV_L_HYPER);
+        if (d.agent_ff || !attn_qkv_supported(d.ne, d.na, d.heads, d.d / d.heads)) q &= ~(QKV_T_AGENT | QKV_L_AGENT);
+        c.qkv = q;
     }
     REFIL_CHECK(batch->entities && batch->entity_mask, "refil: batch.entities / entity_mask missing");
     REFIL_CHECK(!dims->entity_last_action || batch->actions, "refil: batch.actions missing");
@@ -1091,6 +1149,7 @@ extern "C" int refil_set_tuning(const char* name, int64_t value) {
     else if (!strcmp(name, "gru_pd")) g_tuning.gru_pd = value;
     else if (!strcmp(name, "wres_split")) g_tuning.wres_split = value;
     else if (!strcmp(name, "dw_split")) g_tuning.dw_split = value;
+    else if (!strcmp(name, "attn_qkv")) g_tuning.attn_qkv = value;
     else { set_error("refil_set_tuning: unknown knob '%s'", name); return 1; }
     return 0;
 }
@@ -1278,8 +1337,8 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
             a.nvar = 1; a.var[0] = hyper ? REFIL_MASK_ENTITY : REFIL_MASK_OBS;
             RUN(attn_mask_words_launch(a, hyper ? w.mw_ht : w.mw_at, hyper ? w.rb_ht : w.rb_at, P));
         }
-        if (et_h) RUN(hyper_forward(ce, params_target, w.th, 1));
-        if (et_a) RUN(agent_forward(ce, params_target, w.ta, 1, nullptr, AG_ALL));
+        if (et_h) RUN(hyper_forward(ce, params_target, w.th, 1, HY_ALL, nullptr, true));
+        if (et_a) RUN(agent_forward(ce, params_target, w.ta, 1, nullptr, AG_ALL, true));
         et_done = sd->pool[sd->next_ev];
         sd->next_ev = (sd->next_ev + 1) % 128;
         REFIL_HIP(hipEventRecord(et_done, P));
@@ -1305,21 +1364,22 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         // 3.5 % (cfg2) -- the projections of both mixers in front of it no longer interleave with an attention launch of the
         // other chain; without them (qmix_atten: two symmetric light launches) it wins 2.5 % (cfg4). REFIL_HYPER_MERGE=0/1 forces it
         static const int hy_env = [] { const char* e = getenv("REFIL_HYPER_MERGE"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-        const bool hy_merge = !et_h && (hy_env >= 0 ? hy_env == 1 : nv0 == 1);
+        // (one merged launch is fused for both mixers or for neither)
+        const bool hy_merge = !et_h && (hy_env >= 0 ? hy_env == 1 : nv0 == 1) && ((c.qkv & QKV_T_HYPER) != 0) == ((c.qkv & QKV_L_HYPER) != 0);
         if (hy_merge && 2 * s.nets <= 8 && !d.pooling && attn_mfma_supported(d.ne, d.na, d.hyp / d.heads)) {
             // live and target mixers' hypernets: projections of both, then ONE attention launch for all eight nets, then the tails
             RUN(hyper_forward(ch, params_live, w.lh, nv0, HY_PRE));
             Ctx cht = ch; cht.skip_compose = target_composed;
-            RUN(hyper_forward(cht, params_target, w.th, 1, HY_PRE));
-            RUN(hyper_forward(ch, params_live, w.lh, nv0, HY_ATTN, &w.th));
+            RUN(hyper_forward(cht, params_target, w.th, 1, HY_PRE, nullptr, true));
+            RUN(hyper_forward(ch, params_live, w.lh, nv0, HY_ATTN, &w.th, false, params_target));
             RUN(hyper_forward(ch, params_live, w.lh, nv0, HY_POST));
-            RUN(hyper_forward(cht, params_target, w.th, 1, HY_POST));
+            RUN(hyper_forward(cht, params_target, w.th, 1, HY_POST, nullptr, true));
         } else {
         // the target mixer's hypernets first: A/B on one box -0.2 % (cfg-T) .. -0.7 % (cfg3, cfg5) against live-first -- the live
         // mixer's heavier attention launch (three mask variants) then runs beside the recurrence instead of the agents' GEMMs
         static const bool live_first = [] { const char* e = getenv("REFIL_HYPER_ORDER"); return e && e[0] == '0'; }();
         if (live_first) RUN(hyper_forward(ch, params_live, w.lh, nv0));
-        if (!et_h) { Ctx cht = ch; cht.skip_compose = target_composed; RUN(hyper_forward(cht, params_target, w.th, 1)); }   // target mixer hypernets (et_h: already enqueued)
+        if (!et_h) { Ctx cht = ch; cht.skip_compose = target_composed; RUN(hyper_forward(cht, params_target, w.th, 1, HY_ALL, nullptr, true)); }   // target mixer hypernets (et_h: already enqueued)
         if (!live_first) RUN(hyper_forward(ch, params_live, w.lh, nv0));          // live mixer hypernets
         }
     }
@@ -1366,16 +1426,16 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
         }
         if (dual) RUN(agent_entity_dual(ca, params_live, params_target, w.la, w.ta, G));
         RUN(agent_forward(ca, params_live, w.la, G, nullptr, AG_PRE | (dual ? AG_NO_ENTITY : 0)));
-        if (!et_a) RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_PRE | (dual ? AG_NO_ENTITY : 0)));
+        if (!et_a) RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_PRE | (dual ? AG_NO_ENTITY : 0), true));
         const refil_gru_desc gl = agent_gru_desc(ca, params_live, w.la, G, true), gt = agent_gru_desc(ca, params_target, w.ta, 1, true);
         RUN(gru_forward_launch2(gl, et_a ? nullptr : &gt, ca.st));
         if (!qhead_fused) {
             RUN(agent_forward(ca, params_live, w.la, G, nullptr, AG_POST));
-            if (!et_a) RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_POST));
+            if (!et_a) RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, AG_POST, true));
         }
     } else {
         RUN(agent_forward(ca, params_live, w.la, G, nullptr, qhead_fused ? (AG_PRE | AG_GRU) : AG_ALL));
-        RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, qhead_fused ? (AG_PRE | AG_GRU) : AG_ALL));
+        RUN(agent_forward(ca, params_target, w.ta, 1, nullptr, qhead_fused ? (AG_PRE | AG_GRU) : AG_ALL, true));
     }
     if (et_done) REFIL_HIP(hipStreamWaitEvent(c.st, et_done, 0));      // the early target forward's outputs (agent Q values; hypernets: ev[1] below)
     if (qhead_fused) {

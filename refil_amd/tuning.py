@@ -35,6 +35,10 @@ PARITY_TESTED = {
     "wres_split": (0, 6),
     # the same choice for the weight gradients with 128-column outputs (gemm_dw4.hip: gemm_dws_kernel; tests/test_gpu_ops.py::test_gemm_dws_accuracy)
     "dw_split": (0, 6),
+    # in_trans + attention core as ONE launch (attention_qkv.hip): bit 0 target hypernets, 1 target agent, 2 live hypernets, 3 live agent;
+    # 15 = the built-in default where the shape is instantiated, 0 = the separate launches of rounds 1-4 (same bf16 x 6 arithmetic of the
+    # projections, another summation order: not an autotuner candidate)
+    "attn_qkv": (0, 3, 15),
 }
 # what the first-call autotuner tries, in this order (greedy, one knob at a time)
 CANDIDATES = (("dw4_target", (96,)), ("gru_pd", (2,)), ("dw4_min_out", (2000,)), ("dw_target", (384,)), ("compose_early", (0, 1)))

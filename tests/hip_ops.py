@@ -4,7 +4,7 @@ import ctypes as C
 import torch
 
 from refil_amd import _lib
-from refil_amd._lib import AttnDesc, GemmDesc, GruDesc, RowMap, check, lib, ptr
+from refil_amd._lib import AttnDesc, AttnQkvDesc, GemmDesc, GruDesc, RowMap, check, lib, ptr
 
 
 def _stream():
@@ -58,6 +58,18 @@ def attn_skip(d, t_last=None, kv_dead=None, q_dead=None):
 def attn_forward(d: AttnDesc, O, ldo, sO):
     d.O, d.ldo, d.sO = O.data_ptr(), ldo, sO
     check(lib().refil_attn_forward(C.byref(d), _stream()), "refil_attn_forward")
+
+
+def attn_qkv_forward(d: AttnDesc, X, ldx, W_in, O, ldo, sO, q_out=None, k_out=None, v_out=None):
+    """in_trans + attention core in one launch (refil_attn_qkv_forward); d carries rows / masks / precomputed mask words."""
+    d.O, d.ldo, d.sO = O.data_ptr(), ldo, sO
+    qd = AttnQkvDesc()
+    qd.attn = d
+    qd.X, qd.ldx, qd.W_in = X.data_ptr(), ldx, W_in.data_ptr()
+    qd.q_out = q_out.data_ptr() if q_out is not None else None
+    qd.k_out = k_out.data_ptr() if k_out is not None else None
+    qd.v_out = v_out.data_ptr() if v_out is not None else None
+    check(lib().refil_attn_qkv_forward(C.byref(qd), _stream()), "refil_attn_qkv_forward")
 
 
 def attn_backward(d: AttnDesc, dO, ldo, sO, dQ, dK, dV):

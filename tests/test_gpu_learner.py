@@ -292,6 +292,17 @@ PRODUCTION = {
     "cfg2_fp32": dict(B=32, T=80, ne=16, d=64, imagine=True, tuned=dict(wres_split=0, dw_split=0)),
     "cfg5_ne48_mmm_law_fp32": dict(B=32, T=80, ne=48, d=128, imagine=True, A=54, tuned=dict(wres_split=0, dw_split=0)),
     "cfg4_shape_dw0": dict(B=32, T=150, ne=16, d=128, imagine=False, tuned=dict(dw_split=0)),
+    # attn_qkv: in_trans + attention core as ONE launch (attention_qkv.hip; the default where the shape is instantiated: every case
+    # above with <= 32 entities runs it for all four attention blocks); 0 = projection launches + attention core launch (rounds 1-4),
+    # 3 = the target networks only
+    "cfgT_qkv0": dict(B=32, T=80, ne=32, d=128, imagine=True, tuned=dict(attn_qkv=0)),
+    "cfgT_qkv3": dict(B=32, T=80, ne=32, d=128, imagine=True, tuned=dict(attn_qkv=3)),
+    "cfgT_dense_qkv0": dict(B=32, T=80, ne=32, d=128, imagine=True, dense=True, tuned=dict(attn_qkv=0)),
+    "cfg2_qkv0": dict(B=32, T=80, ne=16, d=64, imagine=True, tuned=dict(attn_qkv=0)),
+    "cfg2_qkv3": dict(B=32, T=80, ne=16, d=64, imagine=True, tuned=dict(attn_qkv=3)),
+    "cfg4_shape_qkv0": dict(B=32, T=150, ne=16, d=128, imagine=False, tuned=dict(attn_qkv=0)),
+    "cfg4_shape_qkv3": dict(B=32, T=150, ne=16, d=128, imagine=False, tuned=dict(attn_qkv=3)),
+    "cfg5_mmm_qkv0": dict(B=32, T=80, ne=16, d=128, imagine=True, na=8, A=22, tuned=dict(attn_qkv=0)),
 }
 
 
@@ -311,7 +322,13 @@ def test_production_size_step_matches_oracle(which):
     if kw.get("H", 64) == 64 and not gm:
         syms += ["lists_kernels", ",1>"]        # ",1>": the row-list instantiations of the GEMM kernels
     for sym in syms:
-        assert sym in names, f"{which}: {sym} did not run (kernels: {sorted(r['kernels'])})"
+        # (the attention forward: the fused in_trans + core launch where it is instantiated, else the core's own launch)
+        assert sym in names or (sym == "attn_fwd_mfma" and "attn_qkv_fwd" in names), f"{which}: {sym} did not run (kernels: {sorted(r['kernels'])})"
+    qkv = (kw.get("tuned") or {}).get("attn_qkv", -1)
+    if not gm and kw["ne"] <= 32 and (kw.get("tuned") or {}).get("wres_split", 6) == 6:
+        assert ("attn_qkv_fwd" in names) == (qkv != 0), f"{which}: fused attention launch expected {qkv != 0} (kernels: {sorted(r['kernels'])})"
+        if qkv in (-1, 15):
+            assert "attn_fwd_mfma" not in names, f"{which}: an attention forward ran unfused"
     assert "attn_fwd_kernel" not in r["kernels"] and "attn_bwd_kernel" not in r["kernels"], "VALU attention fallback taken"
     a2, m2 = dict(agent), dict(mixer)
     torch.set_num_threads(min(16, torch.get_num_threads()))

@@ -852,3 +852,69 @@ def test_attention_persistent_walk(B, T1, ne, na, heads, hd, pre):
     _close(dQ[lq], q.grad[lq], tol=5e-5, what="walk dQ")
     _close(dKV[lk], kv.grad[lk], tol=5e-5, what="walk dKV")
     assert (O[0][~live] == 7.0).all() and (dQ[~lq] == 7.0).all() and (dKV[~lk] == 7.0).all()     # untouched
+
+
+# ------------------------------------------------------------------------------------------------
+# in_trans + attention core in one launch (attention_qkv.hip)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,T1,ne,na,heads,hd,nvar,store", [
+    (24, 40, 32, 16, 4, 32, 3, True), (24, 40, 32, 16, 4, 32, 1, False), (40, 30, 16, 8, 4, 16, 3, True), (5, 7, 20, 7, 4, 32, 2, True),
+    (3, 4, 12, 5, 2, 32, 1, True), (6, 5, 32, 16, 8, 16, 3, False), (4, 6, 9, 9, 4, 16, 1, True), (300, 3, 16, 8, 4, 32, 1, False),
+    (2, 3, 27, 16, 2, 32, 3, True)])
+def test_attention_qkv_forward(B, T1, ne, na, heads, hd, nvar, store):
+    """refil_attn_qkv_forward (layer input + in_trans.weight -> attention output, projections optionally stored) against fp32 torch:
+    ragged episode ends, dead K/V / Q rows holding NaN (never read), up to three mask variants, a strided layer input."""
+    import hip_ops
+    torch.manual_seed(B * 1000 + ne * 10 + hd + nvar)
+    R, w = B * T1, heads * hd
+    variants = [MASK_OBS, MASK_OBS_WITHIN, MASK_OBS_INTERACT][:nvar]
+    x = torch.randn(R, ne, w)
+    W = torch.randn(3 * w, w) / math.sqrt(w)
+    obs = (torch.rand(B, T1, ne, ne) < 0.4).to(torch.uint8)
+    em = torch.zeros(B, T1, ne, dtype=torch.uint8)
+    if na > 2:
+        em[:, :, na - 2:na] = 1
+    if ne > na + 3:
+        em[:, :, ne - 3:] = 1                                          # padded agents / enemies: dead Q and K/V rows
+    em[1::3, T1 // 2:, 0] = 1                                        # an agent dying mid-episode
+    obs = obs | em[:, :, :, None] | em[:, :, None, :]
+    em0 = em[:, 0].contiguous()
+    gb = (torch.rand(B, ne) < 0.5).to(torch.uint8)
+    t_last = torch.randint(-1, T1, (B,), dtype=torch.int32)
+    t_last[0] = T1 - 1
+    if B > 1:
+        t_last[1] = -1
+    live = (torch.arange(T1)[None, :] <= t_last[:, None]).reshape(R)
+    masks = [_masks(c, obs, em, em0, gb, na).reshape(R, na, ne) for c in variants]
+    xz = x * (1 - em.reshape(R, ne, 1).float())                        # dead rows enter as zeros
+    qr = (xz[:, :na] @ W[:w].t()) * (1 - em[:, :, :na].reshape(R, na, 1).float())
+    kr, vr = xz @ W[w:2 * w].t(), xz @ W[2 * w:].t()
+    outs = _attn_ref(qr, kr, vr, masks, heads)
+
+    ldx = 2 * w + 8
+    xd = torch.full((R * ne, ldx), float("nan"))
+    xd[:, w:2 * w] = x.reshape(R * ne, w)
+    xd[em.reshape(R * ne).bool()] = float("nan")                       # garbage where the producer skipped
+    xd = xd.to(DEV)
+    Wd = W.to(DEV)
+    dummy = torch.zeros(4, device=DEV)
+    d = hip_ops.attn_desc(dummy, dummy, dummy, w, 2 * w, R, T1, ne, na, heads, hd, variants, obs_mask=obs.to(DEV),
+                          ent_mask=em.reshape(R, ne).to(DEV), ent_mask0=em0.to(DEV), group_bits=gb.to(DEV))
+    hip_ops.attn_skip(d, t_last.to(DEV), em.reshape(R * ne).to(DEV), em[:, :, :na].reshape(R * na).contiguous().to(DEV))
+    hip_ops.attn_mask_words(d, na)
+    O = torch.full((nvar, R * na, w), 7.0, device=DEV)
+    qo = torch.full((R * na, w), 7.0, device=DEV) if store else None
+    kvo = torch.full((R * ne, 2 * w), 7.0, device=DEV) if store else None
+    hip_ops.attn_qkv_forward(d, xd[:, w:], ldx, Wd, O, w, R * na * w, q_out=qo, k_out=kvo, v_out=kvo[:, w:] if store else None)
+    lq = (live[:, None] & ~em[:, :, :na].reshape(R, na).bool())
+    lk = (live[:, None] & ~em.reshape(R, ne).bool())
+    O = O.cpu().reshape(nvar, R, na, w)
+    for i in range(nvar):
+        _close(O[i][lq], outs[i][lq], what=f"qkv fwd variant {i}")
+    assert (O[0][~live] == 7.0).all()                                  # rows of finished episodes untouched
+    if store:
+        qo, kvo = qo.cpu().reshape(R, na, w), kvo.cpu().reshape(R, ne, 2 * w)
+        _close(qo[lq], qr[lq], tol=3e-6, what="stored Q")
+        _close(kvo[lk][:, :w], kr[lk], tol=3e-6, what="stored K")
+        _close(kvo[lk][:, w:], vr[lk], tol=3e-6, what="stored V")
+        assert (qo[~lq] == 7.0).all() and (kvo[~lk] == 7.0).all()      # dead rows are not written
