@@ -30,6 +30,14 @@
 
 namespace refil {
 
+#ifdef REFIL_QKV_TIMING
+// debug build only (REFIL_EXTRA_FLAGS=-DREFIL_QKV_TIMING; tools/probes/qkv_timing.py): per-wave cycle sums (shader clock) of the job phases
+__device__ unsigned long long g_qkv_dbg[4096 * 8];
+#define QKV_TICK(acc_) { const unsigned long long t1_ = __builtin_readcyclecounter(); acc_ += t1_ - t0_; t0_ = t1_; }
+#else
+#define QKV_TICK(acc_)
+#endif
+
 constexpr int QKV_MAX_NETS = 8;
 constexpr int QKV_WAVES = 8;
 struct QkvNet {
@@ -99,10 +107,18 @@ __device__ inline unsigned long long q_readlane64(unsigned long long v, int l) {
 struct QRow { int r; unsigned long long kdw, qdw, emtw; };
 
 // 8 fp32 values (two float4 of one x row) -> the three bf16x8 pieces hi / mid / lo
+// (residuals as single v_sub_f32: the SLP-packed v_pk_add_f32 costs matrix-pipe cycles beside an MFMA, split.h: wr_sub)
+__device__ inline void split2(float x, float y, unsigned& h, unsigned& m, unsigned& l) {
+    h = wr_pk(x, y);
+    x = wr_sub(x, __uint_as_float(h << 16)); y = wr_sub(y, __uint_as_float(h & 0xFFFF0000u));
+    m = wr_pk(x, y);
+    x = wr_sub(x, __uint_as_float(m << 16)); y = wr_sub(y, __uint_as_float(m & 0xFFFF0000u));
+    l = wr_pk(x, y);
+}
 __device__ inline void split8(const float4& a0, const float4& a1, wr_bf16x8 (&o)[3]) {
     unsigned h[4], m[4], l[4];
-    wr_split(a0.x, a0.y, h[0], m[0], l[0]); wr_split(a0.z, a0.w, h[1], m[1], l[1]);
-    wr_split(a1.x, a1.y, h[2], m[2], l[2]); wr_split(a1.z, a1.w, h[3], m[3], l[3]);
+    split2(a0.x, a0.y, h[0], m[0], l[0]); split2(a0.z, a0.w, h[1], m[1], l[1]);
+    split2(a1.x, a1.y, h[2], m[2], l[2]); split2(a1.z, a1.w, h[3], m[3], l[3]);
     o[0] = __builtin_bit_cast(wr_bf16x8, wr_u32x4{h[0], h[1], h[2], h[3]});
     o[1] = __builtin_bit_cast(wr_bf16x8, wr_u32x4{m[0], m[1], m[2], m[3]});
     o[2] = __builtin_bit_cast(wr_bf16x8, wr_u32x4{l[0], l[1], l[2], l[3]});
@@ -112,13 +128,26 @@ __device__ inline void split8(const float4& a0, const float4& a1, wr_bf16x8 (&o)
 constexpr size_t qkv_plane_bytes(int nct, int nks) { return (size_t)3 * nct * nks * 1024; }
 
 // NJT: 16-entity key tiles (ne <= 16 NJT), NCT: 16-channel tiles of a head (hd = 16 NCT), NKS: 32-index steps of the reduction (w = 32 NKS).
-// n_agents <= 16: the agents' rows are (part of) key tile 0.
-template <int NJT, int NCT, int NKS>
+// n_agents <= 16.
+//
+// Key compaction (NJT > 1). Only the entities that are alive as keys (row_bits: ~kv_dead) take part: they are packed, in entity order,
+// into the first `cnt` tile positions -- the agents, being the first entities, land in tile 0 -- and the dead ones behind them, so a row
+// with <= 16 live entities costs ONE key tile of K^T / V / S^T / P V work instead of two (SC2-law batches: 40-55 % of the rows). The
+// permutation is built per row with one ds_permute (position of every entity: rank among the live / the dead ones) and read back with
+// ds_bpermute: ek = the entity at position 16 jt + lane % 16 (its x row, its K row, as agent: its mask word and its Q / O row),
+// ev = the entities at positions 16 jt + 4 (lane / 16) + reg (their mask bits, their V rows). Attention is invariant under a permutation of
+// the keys; per agent it is a relabelling of the output rows.
+// STORE: some net of the launch keeps its Q / K / V (a launch of target nets only carries no store code at all).
+template <int NJT, int NCT, int NKS, bool STORE>
 __global__ __launch_bounds__(64 * QKV_WAVES, 1) void attn_qkv_fwd(QkvM p) {
     extern __shared__ __attribute__((aligned(16))) char smem_q[];
     constexpr size_t PSZ = qkv_plane_bytes(NCT, NKS);
+    constexpr bool COMPACT = NJT > 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, q = lane >> 4;
+#ifdef REFIL_QKV_TIMING
+    const unsigned long long t_kernel0 = __builtin_readcyclecounter();
+#endif
     int slice, grp;
     {
         const int b = blockIdx.x;
@@ -131,19 +160,30 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void attn_qkv_fwd(QkvM p) {
     char* planes = smem_q;
     int* pref = reinterpret_cast<int*>(smem_q + 3 * PSZ);
 
-    // ---- stage this (net, head)'s three weight slices once: split into bf16 planes in fragment order ----
+    // ---- stage this (net, head)'s three weight slices once: split into bf16 planes in fragment order (loads batched: one memory
+    // latency for the whole slice instead of one per 16 bytes and thread) ----
     {
-        const int w4 = w >> 2, total = 3 * hd * w4;
-        for (int idx = tid; idx < total; idx += 64 * QKV_WAVES) {
-            const int k4 = idx % w4, row = idx / w4, m = row / hd, c = row - m * hd;
-            const float4 v = *reinterpret_cast<const float4*>(n.W + ((long)m * w + head * hd + c) * w + 4 * k4);
-            unsigned h0, m0, l0, h1, m1, l1;
-            wr_split(v.x, v.y, h0, m0, l0); wr_split(v.z, v.w, h1, m1, l1);
-            const int k = 4 * k4, s = k >> 5, qq = (k >> 3) & 3, e = k & 7;
-            char* dst = planes + ((size_t)((m * NCT + (c >> 4)) * NKS + s) << 10) + qq * 256 + (c & 15) * 16 + e * 2;
-            *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(dst + PSZ) = make_uint2(m0, m1);
-            *reinterpret_cast<uint2*>(dst + 2 * PSZ) = make_uint2(l0, l1);
+        constexpr int NTH = 64 * QKV_WAVES, W4 = 8 * NKS, TOTAL = 3 * 16 * NCT * W4, NIT = (TOTAL + NTH - 1) / NTH;
+        float4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * NTH + tid, ic = idx < TOTAL ? idx : 0;
+            const int k4 = ic % W4, row = ic / W4, m = row / hd, c = row - m * hd;
+            v[it] = *reinterpret_cast<const float4*>(n.W + ((long)m * w + head * hd + c) * w + 4 * k4);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = it * NTH + tid;
+            if (idx < TOTAL) {
+                const int k4 = idx % W4, row = idx / W4, m = row / hd, c = row - m * hd;
+                unsigned h0, m0, l0, h1, m1, l1;
+                wr_split(v[it].x, v[it].y, h0, m0, l0); wr_split(v[it].z, v[it].w, h1, m1, l1);
+                const int k = 4 * k4, s = k >> 5, qq = (k >> 3) & 3, e = k & 7;
+                char* dst = planes + ((size_t)((m * NCT + (c >> 4)) * NKS + s) << 10) + qq * 256 + (c & 15) * 16 + e * 2;
+                *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(dst + PSZ) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2*>(dst + 2 * PSZ) = make_uint2(l0, l1);
+            }
         }
     }
     // ---- live rows: prefix sum of the episodes' live steps (t <= t_last[b]) ----
@@ -169,37 +209,82 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void attn_qkv_fwd(QkvM p) {
     const int wstride = p.ngroups * QKV_WAVES;
     const int ord0 = grp * QKV_WAVES + wave;
     const int njobs = ord0 < nlive ? (nlive - ord0 + wstride - 1) / wstride : 0;
+    // the rows of this workgroup's jobs, resolved once (live ordinal -> (b,t) through the prefix sums): rows[wave][job]
+    const int maxjobs = (p.R + wstride - 1) / wstride;
+    int* rows = pref + nB + 2;
+    for (int i = tid; i < QKV_WAVES * maxjobs; i += 64 * QKV_WAVES) {
+        const int wv = i / maxjobs, jb = i - wv * maxjobs;
+        int o = grp * QKV_WAVES + wv + jb * wstride;
+        o = o < nlive ? o : (nlive > 0 ? nlive - 1 : 0);
+        int rr = o;
+        if (p.t_last) {
+            int lo = 0, hi = nB;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (pref[mid + 1] <= o) lo = mid + 1; else hi = mid; }
+            rr = lo * p.T1 + (o - pref[lo]);
+        }
+        rows[i] = rr;
+    }
+    __syncthreads();
     if (njobs == 0) return;
-    auto row_of = [&](int k) -> int {           // live ordinal of this wave's k-th job -> row (b,t); wave-uniform
-        int o = ord0 + (k < njobs ? k : njobs - 1) * wstride;
-        if (!p.t_last) return o;
-        int lo = 0, hi = nB;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (pref[mid + 1] <= o) lo = mid + 1; else hi = mid; }
-        return __builtin_amdgcn_readfirstlane(lo * p.T1 + (o - pref[lo]));
-    };
+    const int* myrows = rows + wave * maxjobs;
+    auto row_of = [&](int k) -> int { return __builtin_amdgcn_readfirstlane(myrows[k < njobs ? k : njobs - 1]); };
     const float inv_scale = 1.0f / sqrtf((float)hd);
     const unsigned long long na_bits = (p.na >= 64) ? ~0ull : ((1ull << p.na) - 1ull);
+    const unsigned long long ne_bits = (p.ne >= 64) ? ~0ull : ((1ull << p.ne) - 1ull);
     const int col0 = head * hd;
 
-    // operands in flight for the NEXT job: the x rows of every key tile and reduction step, the mask words of this lane's agent
+    // the key permutation of a row (see above); identity without compaction
+    struct QMap { int ek[NJT]; unsigned evp[NJT]; int cnt; };
+    auto map_of = [&](unsigned long long kdw) -> QMap {
+        QMap m;
+        if (!COMPACT) {
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt) {
+                m.ek[jt] = 16 * jt + l15;
+                const unsigned e0 = 16 * jt + 4 * q;
+                m.evp[jt] = e0 | ((e0 + 1) << 8) | ((e0 + 2) << 16) | ((e0 + 3) << 24);
+            }
+            m.cnt = 16 * NJT;
+            return m;
+        }
+        const unsigned long long L = ~kdw & ne_bits;
+        m.cnt = __popcll(L);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const bool live = (L >> lane) & 1ull;
+        const int pos = live ? __popcll(L & below) : m.cnt + __popcll(~L & below);
+        const int T = __builtin_amdgcn_ds_permute(pos << 2, lane);          // lane `pos` <- this lane's entity
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt) {
+            m.ek[jt] = __builtin_amdgcn_ds_bpermute((16 * jt + l15) << 2, T);
+            unsigned pk = 0;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) pk |= (unsigned)__builtin_amdgcn_ds_bpermute((16 * jt + 4 * q + reg) << 2, T) << (8 * reg);
+            m.evp[jt] = pk;
+        }
+        return m;
+    };
+
+    // operands in flight for the NEXT job: the x rows of every key tile and reduction step (refilled in place, step by step, as the
+    // current job's projection consumes them: a whole projection + core of flight time), the mask words of this lane's agent
     float4 xr[NKS][NJT][2];
-    unsigned long long nw[3];
-    auto fetch = [&](const QRow& ri, bool valid) {
+    unsigned nw[3];                             // (<= 32 entities: the low half of the 64-bit mask word)
+    auto fetch_x = [&](auto s_, const QRow& ri, const QMap& fm, bool valid) {
+        constexpr int s = decltype(s_)::value;
         const rsrc_t rx = mk_rsrc(n.X + (long)ri.r * p.ne * p.ldx, valid ? ((long)(p.ne - 1) * p.ldx + w) * 4 : 0);
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
-            const int key = 16 * jt + l15;
-            const bool ok = key < p.ne && !((ri.kdw >> key) & 1ull);
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) {
-                const int off = (key * p.ldx + 32 * s + 8 * q) * 4;
-                xr[s][jt][0] = buf_ld4(rx, ok ? off : BUF_OOB);
-                xr[s][jt][1] = buf_ld4(rx, ok ? off + 16 : BUF_OOB);
-            }
+            const int key = fm.ek[jt];
+            // (compacted: the live entities are exactly the first cnt tile positions)
+            const bool ok = COMPACT ? 16 * jt + l15 < fm.cnt : (key < p.ne && !((ri.kdw >> key) & 1ull));
+            const int off = (key * p.ldx + 32 * s + 8 * q) * 4;
+            xr[s][jt][0] = buf_ld4(rx, ok ? off : BUF_OOB);
+            xr[s][jt][1] = buf_ld4(rx, ok ? off + 16 : BUF_OOB);
         }
+    };
+    auto fetch_w = [&](const QRow& ri, const QMap& fm, bool valid) {
         const rsrc_t rw = mk_rsrc(p.mwords + (long)ri.r * p.mw_nvar * 16, valid ? (long)p.mw_nvar * 16 * 8 : 0);
 #pragma unroll
-        for (int v = 0; v < 3; ++v) nw[v] = buf_ld_u64(rw, v < p.nvar ? (v * 16 + l15) * 8 : BUF_OOB);
+        for (int v = 0; v < 3; ++v) nw[v] = __builtin_amdgcn_raw_buffer_load_b32(rw, v < p.nvar && fm.ek[0] < 16 ? (v * 16 + fm.ek[0]) * 8 : BUF_OOB, 0, 0);
     };
     // the row words of a row travel one job ahead of its operand fetch, in a vector register (lane l holds word l % 3)
     auto words_of = [&](int r) -> unsigned long long { return p.rbits[3 * (long)r + lane % 3]; };
@@ -207,161 +292,243 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void attn_qkv_fwd(QkvM p) {
         QRow x; x.r = r; x.kdw = q_readlane64(wv, 0); x.qdw = q_readlane64(wv, 1); x.emtw = q_readlane64(wv, 2);
         return x;
     };
-
     int r_next = row_of(0);
     unsigned long long w_next = words_of(r_next);
     QRow frow = take(r_next, w_next);
+    QMap fmap = map_of(frow.kdw);
     r_next = row_of(1); w_next = words_of(r_next);
-    fetch(frow, true);
+    static_for<NKS>([&](auto s_) { fetch_x(s_, frow, fmap, true); });
+    fetch_w(frow, fmap, true);
+    // The two waves of a SIMD start their jobs in lockstep: both in the projection (sharing the matrix pipe), then both in the store /
+    // core phases (pipe idle). With a static priority the second-dispatched wave takes the pipe for its projection, the other one's runs
+    // behind it -- from then on one wave's projection overlaps the other's stores, softmax and key permutation (cycle counters:
+    // profiles/r05_qkv_timing.txt)
+    if (wave >= QKV_WAVES / 2) __builtin_amdgcn_s_setprio(1);
+
+#ifdef REFIL_QKV_TIMING
+    unsigned long long t_top = 0, t_proj = 0, t_st = 0, t_core = 0, t_pro = 0, t0_ = __builtin_readcyclecounter();
+    const unsigned long long t_begin = t0_;
+#endif
+    // memory operations a job issues BEHIND the fetch of its successor (all buffer stores, the missing ones out of range): the prologue
+    // issues as many dropped stores behind the first fetch, so that the operand wait at the top of the loop is the same count on both
+    // ways into it (vmcnt retires in order and the compiler takes the smaller count of the incoming paths: attention_mfma.hip)
+    constexpr int NSTORE = 1 + (STORE ? NCT * NJT + NCT + 4 * NJT * NCT : 0) + 6 * NCT + NCT;
+    {
+        const rsrc_t none = mk_rsrc(n.O, 0);
+#pragma unroll
+        for (int i = 0; i < NSTORE; ++i) buf_st4(none, BUF_OOB - 16 * i, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
 
     for (int k = 0; k < njobs; ++k) {
         const QRow crow = frow;
+        const QMap cmap = fmap;
         const int r = crow.r;
-        unsigned long long cw[3];
+        // this lane's agent: the entity at tile position lane % 16 of tile 0, when it is an agent that is alive as a query
+        const int agent = cmap.ek[0];
+        const bool agent_ok = l15 < cmap.cnt && agent < p.na && !((crow.qdw >> agent) & 1ull);
+        unsigned cw[3];
 #pragma unroll
-        for (int v = 0; v < 3; ++v) cw[v] = nw[v];
-        // ---- in_trans of this row's entities for this head: K^T, V, Q^T tiles on the bf16 pipe (fp32 accumulate) ----
-        f32x4 Kt[NCT][NJT], Vv[NJT][NCT], Qt[NCT];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            Qt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) { Kt[ct][jt] = f32x4{0.f, 0.f, 0.f, 0.f}; Vv[jt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        }
-        // product order: smallest first -- (lo, hi), (hi, lo), (mid, mid), (mid, hi), (hi, mid), (hi, hi); planes 0 / 1 / 2 = hi / mid / lo
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            wr_bf16x8 xs[NJT][3];
-#pragma unroll
-            for (int jt = 0; jt < NJT; ++jt) split8(xr[s][jt][0], xr[s][jt][1], xs[jt]);
-            const char* pb = planes + ((size_t)s << 10) + lane * 16;
-            wr_bf16x8 wq[NCT][3], wk[NCT][3];
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    wq[ct][pl] = *reinterpret_cast<const wr_bf16x8*>(pb + pl * PSZ + ((size_t)((0 * NCT + ct) * NKS) << 10));
-                    wk[ct][pl] = *reinterpret_cast<const wr_bf16x8*>(pb + pl * PSZ + ((size_t)((1 * NCT + ct) * NKS) << 10));
-                }
-#pragma unroll
-            for (int pr = 0; pr < 6; ++pr)
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-#pragma unroll
-                    for (int jt = 0; jt < NJT; ++jt) Kt[ct][jt] = MFMA16B(wk[ct][PA[pr]], xs[jt][PB[pr]], Kt[ct][jt]);
-                    Qt[ct] = MFMA16B(wq[ct][PA[pr]], xs[0][PB[pr]], Qt[ct]);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-            wr_bf16x8 wv[NCT][3];
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    wv[ct][pl] = *reinterpret_cast<const wr_bf16x8*>(pb + pl * PSZ + ((size_t)((2 * NCT + ct) * NKS) << 10));
-#pragma unroll
-            for (int pr = 0; pr < 6; ++pr)
-#pragma unroll
-                for (int jt = 0; jt < NJT; ++jt)
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) Vv[jt][ct] = MFMA16B(xs[jt][PB[pr]], wv[ct][PA[pr]], Vv[jt][ct]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- advance the fetch cursor: the operands of job k+1 are in flight during the core below ----
+        for (int v = 0; v < 3; ++v) cw[v] = agent_ok ? nw[v] : ~0u;
+        // the row after this one: its words arrived a job ago; its key permutation is built beside the projection below
         frow = take(r_next, w_next);
+        fmap = map_of(frow.kdw);
         r_next = row_of(k + 2); w_next = words_of(r_next);
-        fetch(frow, k + 1 < njobs);
-        // queries of inactive / padded agents enter the core as zeros (refil_attn_desc.q_dead: what the separate launches load there)
-        {
-            const bool qz = ((crow.qdw >> l15) & 1ull) || l15 >= p.na;
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-                if (qz) Qt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        // (nact[r] by lane 0 of the row's first slice)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)__popcll(~crow.emtw & na_bits)),
-                                              mk_rsrc(p.nact + r, p.nact && slice == 0 ? 4 : 0), lane == 0 ? 0 : BUF_OOB, 0, 0);
-        // ---- the live nets keep their projections for the backward (layouts of refil_attn_desc Q / K / V) ----
-        {
-            const rsrc_t rk = mk_rsrc(n.Ko + (long)r * p.ne * p.ldkv, n.Ko ? (long)p.ne * p.ldkv * 4 : 0);
-            const rsrc_t rv = mk_rsrc(n.Vo + (long)r * p.ne * p.ldkv, n.Vo ? (long)p.ne * p.ldkv * 4 : 0);
-            const rsrc_t rq = mk_rsrc(n.Qo + (long)r * p.na * p.ldq, n.Qo ? (long)p.na * p.ldq * 4 : 0);
+        const bool nvalid = k + 1 < njobs;
+        auto job = [&](auto nt_) {
+            constexpr int NT = decltype(nt_)::value;        // key tiles this row needs (1 or NJT)
+            // ---- in_trans of this row's entities for this head: K^T, V, Q^T tiles on the bf16 pipe (fp32 accumulate) ----
+            f32x4 Kt[NCT][NT], Vv[NT][NCT], Qt[NCT];
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
-                const int c = col0 + 16 * ct + 4 * q;
+                Qt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int jt = 0; jt < NJT; ++jt) {
-                    const int key = 16 * jt + l15;
-                    const bool ok = key < p.ne && !((crow.kdw >> key) & 1ull);
-                    buf_st4(rk, ok ? (key * p.ldkv + c) * 4 : BUF_OOB, Kt[ct][jt]);
-                }
-                const bool okq = l15 < p.na && !((crow.qdw >> l15) & 1ull);
-                buf_st4(rq, okq ? (l15 * p.ldq + c) * 4 : BUF_OOB, Qt[ct]);
+                for (int jt = 0; jt < NT; ++jt) { Kt[ct][jt] = f32x4{0.f, 0.f, 0.f, 0.f}; Vv[jt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             }
+            // product order: smallest first -- (lo, hi), (hi, lo), (mid, mid), (mid, hi), (hi, mid), (hi, hi); planes 0 / 1 / 2 = hi / mid / lo
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            QKV_TICK(t_top)
+            static_for<NKS>([&](auto s_) {
+                constexpr int s = decltype(s_)::value;
+                wr_bf16x8 xs[NT][3];
 #pragma unroll
-            for (int jt = 0; jt < NJT; ++jt)
+                for (int jt = 0; jt < NT; ++jt) split8(xr[s][jt][0], xr[s][jt][1], xs[jt]);
+                fetch_x(s_, frow, fmap, nvalid);            // (this step's x registers are free: the next row's come in)
+                const char* pb = planes + ((size_t)s << 10) + lane * 16;
+                // (one matrix's fragments at a time: 12 registers per channel tile instead of 36 -- the 256-register budget of two waves per SIMD)
+                {
+                    wr_bf16x8 wk[NCT][3];
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            wk[ct][pl] = *reinterpret_cast<const wr_bf16x8*>(pb + pl * PSZ + ((size_t)((1 * NCT + ct) * NKS) << 10));
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                            for (int jt = 0; jt < NT; ++jt) Kt[ct][jt] = MFMA16B(wk[ct][PA[pr]], xs[jt][PB[pr]], Kt[ct][jt]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    wr_bf16x8 wq[NCT][3];
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            wq[ct][pl] = *reinterpret_cast<const wr_bf16x8*>(pb + pl * PSZ + ((size_t)((0 * NCT + ct) * NKS) << 10));
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) Qt[ct] = MFMA16B(wq[ct][PA[pr]], xs[0][PB[pr]], Qt[ct]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                wr_bf16x8 wv[NCT][3];
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int key = 16 * jt + 4 * q + reg;
-                        const bool ok = key < p.ne && !((crow.kdw >> key) & 1ull);
-                        // (__float_as_uint of a copy: __builtin_bit_cast of ONE element of a vector reads element 0 in this clang)
-                        const float vv = Vv[jt][ct][reg];
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vv), rv,
-                                                              ok ? (key * p.ldkv + col0 + 16 * ct + l15) * 4 : BUF_OOB, 0, 0);
-                    }
-        }
-        // ---- attention core (attention_mfma.hip: attn_fwd_pipe), operands straight from the accumulators ----
-        f32x4 stt[NJT];
+                    for (int pl = 0; pl < 3; ++pl)
+                        wv[ct][pl] = *reinterpret_cast<const wr_bf16x8*>(pb + pl * PSZ + ((size_t)((2 * NCT + ct) * NKS) << 10));
 #pragma unroll
-        for (int jt = 0; jt < NJT; ++jt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) Vv[jt][ct] = MFMA16B(xs[jt][PB[pr]], wv[ct][PA[pr]], Vv[jt][ct]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            fetch_w(frow, fmap, nvalid);
+            QKV_TICK(t_proj)
+            // queries of inactive agents and of tile positions that hold no agent enter the core as zeros (refil_attn_desc.q_dead)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
+                if (!agent_ok) Qt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // (nact[r] by lane 0 of the row's first slice)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)__popcll(~crow.emtw & na_bits)),
+                                                  mk_rsrc(p.nact + r, p.nact && slice == 0 ? 4 : 0), lane == 0 ? 0 : BUF_OOB, 0, 0);
+            // ---- the live nets keep their projections for the backward (layouts of refil_attn_desc Q / K / V) ----
+            if constexpr (STORE) {
+                const rsrc_t rk = mk_rsrc(n.Ko + (long)r * p.ne * p.ldkv, n.Ko ? (long)p.ne * p.ldkv * 4 : 0);
+                const rsrc_t rv = mk_rsrc(n.Vo + (long)r * p.ne * p.ldkv, n.Vo ? (long)p.ne * p.ldkv * 4 : 0);
+                const rsrc_t rq = mk_rsrc(n.Qo + (long)r * p.na * p.ldq, n.Qo ? (long)p.na * p.ldq * 4 : 0);
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) acc = MFMA16F(Kt[ct][jt][reg], Qt[ct][reg], acc);
-            stt[jt] = acc;
-        }
-        f32x4 osum[NCT];
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const int c = col0 + 16 * ct + 4 * q;
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) osum[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            f32x4 o[NCT];
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const bool on = v < n.nvar;
-            if (on) {
-                f32x4 pt[NJT];
+                    for (int jt = 0; jt < NJT; ++jt) {
+                        const int key = cmap.ek[jt];
+                        const bool ok = jt < NT && (COMPACT ? 16 * jt + l15 < cmap.cnt : (key < p.ne && !((crow.kdw >> key) & 1ull)));
+                        buf_st4(rk, ok ? (key * p.ldkv + c) * 4 : BUF_OOB, Kt[ct][jt < NT ? jt : 0]);
+                    }
+                    buf_st4(rq, agent_ok ? (agent * p.ldq + c) * 4 : BUF_OOB, Qt[ct]);
+                    __builtin_amdgcn_sched_barrier(0);      // (address arithmetic stays beside its store: the compiler otherwise computes all of them first)
+                }
 #pragma unroll
                 for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) pt[jt][reg] = stt[jt][reg] * inv_scale;      // attention.py:54
-                qkv_softmax_T<NJT>(pt, cw[v], q);
+                    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int key = (cmap.evp[jt] >> (8 * reg)) & 0xff;
+                            const bool ok = jt < NT && (COMPACT ? 16 * jt + 4 * q + reg < cmap.cnt : (key < p.ne && !((crow.kdw >> key) & 1ull)));
+                            // (__float_as_uint of a copy: __builtin_bit_cast of ONE element of a vector reads element 0 in this clang)
+                            const float vv = Vv[jt < NT ? jt : 0][ct][reg];
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vv), rv,
+                                                                  ok ? (key * p.ldkv + col0 + 16 * ct + l15) * 4 : BUF_OOB, 0, 0);
+                            if (reg == 3) __builtin_amdgcn_sched_barrier(0);
+                        }
+            }
+            QKV_TICK(t_st)
+            // ---- attention core (attention_mfma.hip: attn_fwd_pipe), operands straight from the accumulators ----
+            f32x4 stt[NT];
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) acc = MFMA16F(Kt[ct][jt][reg], Qt[ct][reg], acc);
+                stt[jt] = acc;
+            }
+            f32x4 osum[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) osum[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                f32x4 o[NCT];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const bool on = v < n.nvar;
+                if (on) {
+                    // masked softmax over the keys of this lane's agent: bit (entity at the tile position) of the agent's mask word
+                    f32x4 pt[NT];
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const bool masked = (cw[v] >> ((cmap.evp[jt] >> (8 * reg)) & 31)) & 1u;
+                            const float x = masked ? -INFINITY : stt[jt][reg] * inv_scale;      // attention.py:54-57
+                            pt[jt][reg] = x;
+                            mx = fmaxf(mx, x);
+                        }
+                    mx = q_cross4_max(mx);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const float e = pt[jt][reg] == -INFINITY ? 0.f : __expf(pt[jt][reg] - mx);
+                            pt[jt][reg] = e;
+                            sum += e;
+                        }
+                    sum = q_cross4_sum(sum);
+                    const float inv = sum > 0.f ? __builtin_amdgcn_rcpf(sum) : 0.f;     // fully masked row -> 0 (attention.py:60 NaN -> 0)
+#pragma unroll
+                    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) pt[jt][reg] *= inv;
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+                        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) o[ct] = MFMA16F(Vv[jt][ct][reg], pt[jt][reg], o[ct]);
+                        if (n.sum_agents) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) osum[ct][e] += q_group16_sum(o[ct][e]);
+                        }
+                    }
+                }
+                // rows of the agents that are alive as queries; the others (inactive agents) read as exact zeros: the layer's post-mask
+                // (attention.py:66-67) for the callers that ask for it (zero_dead), a defined value for the rest (refil_attn_desc: discarded)
+                const rsrc_t ro = mk_rsrc(n.O + v * p.sO + (long)r * p.na * p.ldo, on && !n.sum_agents ? (long)p.na * p.ldo * 4 : 0);
+                const bool zrow = l15 < p.na && ((crow.qdw >> l15) & 1ull);
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
-#pragma unroll
-                    for (int jt = 0; jt < NJT; ++jt)
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) o[ct] = MFMA16F(Vv[jt][ct][reg], pt[jt][reg], o[ct]);
-                    if (n.sum_agents) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) osum[ct][e] += q_group16_sum(o[ct][e]);
-                    } else if (p.zero_dead && ((crow.emtw >> l15) & 1ull)) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    buf_st4(ro, agent_ok ? (agent * p.ldo + col0 + 16 * ct + 4 * q) * 4 : BUF_OOB, o[ct]);
+                    buf_st4(ro, zrow ? (l15 * p.ldo + col0 + 16 * ct + 4 * q) * 4 : BUF_OOB, f32x4{0.f, 0.f, 0.f, 0.f});
                 }
             }
-            const rsrc_t ro = mk_rsrc(n.O + v * p.sO + (long)r * p.na * p.ldo, on && !n.sum_agents ? (long)p.na * p.ldo * 4 : 0);
+            {
+                const rsrc_t ro = mk_rsrc(n.O + (long)r * p.ldo, n.sum_agents ? (long)p.ldo * 4 : 0);
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-                buf_st4(ro, l15 < p.na ? (l15 * p.ldo + col0 + 16 * ct + 4 * q) * 4 : BUF_OOB, o[ct]);
-        }
-        {
-            const rsrc_t ro = mk_rsrc(n.O + (long)r * p.ldo, n.sum_agents ? (long)p.ldo * 4 : 0);
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) buf_st4(ro, l15 == 0 ? (col0 + 16 * ct + 4 * q) * 4 : BUF_OOB, osum[ct]);
+                for (int ct = 0; ct < NCT; ++ct) buf_st4(ro, l15 == 0 ? (col0 + 16 * ct + 4 * q) * 4 : BUF_OOB, osum[ct]);
+            }
+            QKV_TICK(t_core)
+        };
+        if (COMPACT && cmap.cnt <= 16) job(std::integral_constant<int, 1>{});
+        else job(std::integral_constant<int, NJT>{});
+    }
+#ifdef REFIL_QKV_TIMING
+    if (lane == 0) {
+        const int wi = blockIdx.x * QKV_WAVES + wave;
+        if (wi < 4096) {
+            unsigned long long* o = g_qkv_dbg + 8 * wi;
+            o[0] = t_top; o[1] = t_proj; o[2] = t_st; o[3] = t_core; o[4] = njobs; o[5] = __builtin_readcyclecounter() - t_begin; o[6] = t_begin - t_kernel0; o[7] = 0;
         }
     }
+#endif
 }
 
 static int qkv_device_cus() {
@@ -380,11 +547,11 @@ bool attn_qkv_supported(int ne, int na, int heads, int hd) {
 
 template <int NJT, int NCT, int NKS>
 static int qkv_launch_x(QkvM& k, hipStream_t st) {
-    const size_t lds = 3 * qkv_plane_bytes(NCT, NKS) + ((size_t)(k.R / k.T1) + 2) * 4;
-    if (lds > 160 * 1024) return -1;
-    void (*kern)(QkvM) = attn_qkv_fwd<NJT, NCT, NKS>;
-    static bool raised = false;
-    if (!raised) { REFIL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); raised = true; }
+    bool store = false;
+    for (int i = 0; i < k.nnets; ++i) store |= k.net[i].Ko != nullptr || k.net[i].Vo != nullptr || k.net[i].Qo != nullptr;
+    void (*kern)(QkvM) = store ? attn_qkv_fwd<NJT, NCT, NKS, true> : attn_qkv_fwd<NJT, NCT, NKS, false>;
+    static bool raised[2] = {false, false};
+    if (!raised[store]) { REFIL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); raised[store] = true; }
     // one workgroup per CU; workgroup -> (slice, row group). XCD-aware: the heads (and nets) that read the same x rows sit on one
     // XCD (workgroups are dealt round-robin to the 8 XCDs by block id), so a row comes from HBM once and from that XCD's L2 afterwards
     const int cus = qkv_device_cus();
@@ -393,6 +560,10 @@ static int qkv_launch_x(QkvM& k, hipStream_t st) {
     else { k.xcd_groups = 0; k.ngroups = cus / k.nslices > 0 ? cus / k.nslices : 1; }
     const long live_groups = ((long)k.R + QKV_WAVES - 1) / QKV_WAVES;
     if (!k.xcd_groups && k.ngroups > live_groups) k.ngroups = (int)live_groups;
+    // LDS: the W planes, the live-step prefix sums [B + 2], the workgroup's row table [waves][jobs per wave]
+    const long wstride = (long)k.ngroups * QKV_WAVES, maxjobs = (k.R + wstride - 1) / wstride;
+    const size_t lds = 3 * qkv_plane_bytes(NCT, NKS) + ((size_t)(k.R / k.T1) + 2 + QKV_WAVES * maxjobs) * 4;
+    if (lds > 160 * 1024) return -1;
     hipLaunchKernelGGL(kern, dim3(k.nslices * k.ngroups), dim3(64 * QKV_WAVES), lds, st, k);
     REFIL_LAUNCH_CHECK();
     return 0;
@@ -448,6 +619,12 @@ int attn_qkv_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts,
 }  // namespace refil
 
 using namespace refil;
+
+#ifdef REFIL_QKV_TIMING
+extern "C" int refil_debug_qkv_timing(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(refil::g_qkv_dbg), (size_t)n * 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int refil_attn_qkv_forward(const refil_attn_qkv_desc* q, void* stream) {
     REFIL_CHECK(q && q->X && q->W_in, "refil_attn_qkv_forward: null desc / X / W_in");
