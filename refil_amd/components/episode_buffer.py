@@ -344,10 +344,7 @@ class ReplayBuffer(EpisodeBatch):
             raise IndexError(f"episode ids must lie in [0, {self.buffer_size})")
         nfields = len(self.data.transition_data) + len(self.data.episode_data) + len(self._packed)
         if nfields > _lib.MAX_GATHER_FIELDS:            # (more scheme keys than one gather launch takes: the reference's path)
-            out = self[ep_ids]
-            if self.sample_device is not None:
-                out.to(self.sample_device)
-            return out
+            return self[ep_ids]
         early = os.environ.get("REFIL_EARLY") != "0" and os.environ.get("REFIL_HIPGRAPH") != "1"
         return self._gather_on(ep_ids, n, early, self.device)
 
@@ -366,8 +363,16 @@ class ReplayBuffer(EpisodeBatch):
         runtime (cfg-T 2.28 -> 3.15 ms per step, cfg2 0.93 -> 2.25; DESIGN.md lesson 23), and on one of the step's four streams
         the gather sits in front of that stream's chain whichever one it is."""
         import ctypes  # noqa: F401
+        from .. import _lib
         dev = self.sample_device
         ep_ids = np.ascontiguousarray(self._draw(n), dtype=np.int64)
+        if ep_ids.size and (ep_ids.min() < 0 or ep_ids.max() >= self.buffer_size):
+            raise IndexError(f"episode ids must lie in [0, {self.buffer_size})")
+        if len(self.data.transition_data) + len(self.data.episode_data) + len(self._packed) > _lib.MAX_GATHER_FIELDS:
+            # more scheme keys than one gather launch takes: the reference's path (host-side indexing, then the copy to the device)
+            out = self[ep_ids]
+            out.to(dev)
+            return out
         early = os.environ.get("REFIL_EARLY") != "0" and os.environ.get("REFIL_HIPGRAPH") != "1"
         with th.cuda.device(dev):
             out = self._gather_on(ep_ids, n, early, dev)

@@ -32,11 +32,14 @@ class BasicMAC:
         elif type(t) is int:
             t, int_t = slice(t, t + 1), True
         agent_inputs = self._build_inputs(ep_batch, t)
+        groups = None
         if kwargs.get("imagine", False):
             agent_outs, self.hidden_states, groups = self.agent(agent_inputs, self.hidden_states, **kwargs)
-            return agent_outs, groups
-        agent_outs, self.hidden_states = self.agent(agent_inputs, self.hidden_states)
-        return agent_outs.squeeze(1) if int_t else agent_outs
+        else:
+            agent_outs, self.hidden_states = self.agent(agent_inputs, self.hidden_states)
+        if int_t:                                           # (a single step returns the outputs alone, imagined or not)
+            return agent_outs.squeeze(1)
+        return (agent_outs, groups) if kwargs.get("imagine", False) else agent_outs
 
     def init_hidden(self, batch_size):
         self.hidden_states = self.agent.init_hidden().unsqueeze(0).expand(batch_size, self.n_agents, -1)

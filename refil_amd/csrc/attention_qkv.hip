@@ -55,6 +55,7 @@ struct QkvM {
     const unsigned long long* mwords; int mw_nvar; const unsigned long long* rbits;
     float* nact; int zero_dead;
     int nslices, ngroups, xcd_groups;    // workgroup -> (slice = (net, head), row group); xcd_groups > 0: row groups per XCD (XCD-aware map)
+    int stagger;                         // how the two waves of a SIMD are kept out of phase: 0 nothing, 1 static priority, 2 a delayed start (REFIL_QKV_STAGGER)
 };
 
 #define MFMA16F(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -299,11 +300,13 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void attn_qkv_fwd(QkvM p) {
     r_next = row_of(1); w_next = words_of(r_next);
     static_for<NKS>([&](auto s_) { fetch_x(s_, frow, fmap, true); });
     fetch_w(frow, fmap, true);
-    // The two waves of a SIMD start their jobs in lockstep: both in the projection (sharing the matrix pipe), then both in the store /
-    // core phases (pipe idle). With a static priority the second-dispatched wave takes the pipe for its projection, the other one's runs
-    // behind it -- from then on one wave's projection overlaps the other's stores, softmax and key permutation (cycle counters:
-    // profiles/r05_qkv_timing.txt)
-    if (wave >= QKV_WAVES / 2) __builtin_amdgcn_s_setprio(1);
+    // The two waves of a SIMD start their jobs in lockstep. Keeping them out of phase -- a static priority for the second-dispatched wave
+    // or a delayed start -- was measured and changes nothing (the matrix pipe is ~83 % busy either way: profiles/r05_qkv_timing.txt,
+    // r05_qkv_stagger.txt), and a raised priority takes issue slots from the OTHER chain's kernels on the same SIMD: off by default
+    if (wave >= QKV_WAVES / 2) {
+        if (p.stagger == 1) __builtin_amdgcn_s_setprio(1);
+        else if (p.stagger >= 2) { for (int i = 0; i < 24 * (p.stagger - 1); ++i) __builtin_amdgcn_s_sleep(2); }       // (~128 cycles per s_sleep 2)
+    }
 
 #ifdef REFIL_QKV_TIMING
     unsigned long long t_top = 0, t_proj = 0, t_st = 0, t_core = 0, t_pro = 0, t0_ = __builtin_readcyclecounter();
@@ -558,6 +561,8 @@ static int qkv_launch_x(QkvM& k, hipStream_t st) {
     k.nslices = k.nnets * k.heads;
     if (cus % 8 == 0 && (cus / 8) % k.nslices == 0) { k.xcd_groups = cus / 8 / k.nslices; k.ngroups = 8 * k.xcd_groups; }
     else { k.xcd_groups = 0; k.ngroups = cus / k.nslices > 0 ? cus / k.nslices : 1; }
+    static const int stagger_env = [] { const char* e = getenv("REFIL_QKV_STAGGER"); return e ? atoi(e) : 0; }();
+    k.stagger = stagger_env;
     const long live_groups = ((long)k.R + QKV_WAVES - 1) / QKV_WAVES;
     if (!k.xcd_groups && k.ngroups > live_groups) k.ngroups = (int)live_groups;
     // LDS: the W planes, the live-step prefix sums [B + 2], the workgroup's row table [waves][jobs per wave]

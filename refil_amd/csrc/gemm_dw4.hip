@@ -504,6 +504,10 @@ static void dw4_shape(int M, int N, int& ti, int& tj, int& wmt) {
         return best;
     };
     ti = pick(M); tj = pick(N);
+    // (4 x 4 tiles = 256 accumulators: with the ring and the column sums beside them the 512-entry register file spills 32-139
+    // registers -- code-object metadata, round 4 -- so a 128 x 128 wave tile is walked as two 128 x 64 ones; only the fp32-instruction
+    // form of these gradients gets here, the bf16 x 6 kernel takes them by default)
+    if (ti * tj == 16) tj = 2;
     const int mt = cdiv(M, 32 * ti);
     wmt = (mt >= 4 && ti == 4) ? 4 : ((mt >= 2 && ti >= 2) ? 2 : 1);       // (only these (ti, wmt) pairs are instantiated)
 }
@@ -667,7 +671,7 @@ int gemm_dw4_launch(const refil_gemm_desc& d, hipStream_t st) {
     int rc = 1;
 #define CASE(I, J) if (ti == I && tj == J) rc = dw4_launch_t<I, J>(k, wmt, grid, st)
     CASE(1, 1); CASE(1, 2); CASE(1, 3); CASE(1, 4); CASE(2, 1); CASE(2, 2); CASE(2, 3); CASE(2, 4);
-    CASE(3, 1); CASE(3, 2); CASE(3, 3); CASE(3, 4); CASE(4, 1); CASE(4, 2); CASE(4, 3); CASE(4, 4);
+    CASE(3, 1); CASE(3, 2); CASE(3, 3); CASE(3, 4); CASE(4, 1); CASE(4, 2); CASE(4, 3);
 #undef CASE
     if (rc) return rc;
     REFIL_LAUNCH_CHECK();

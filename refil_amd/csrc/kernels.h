@@ -228,6 +228,8 @@ bool attn_qkv_supported(int ne, int na, int heads, int hd);
 int attn_qkv_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts, const AttnQkvSrc* src, int n, int ldx, hipStream_t st,
                           float* nact, int zero_dead);
 
+// device view of the calling thread's sticky error word of the one-launch row lists on the current device (learner.hip), or NULL
+const int* lists_error_word_dev();
 int clip_rmsprop_launch(float* params, const float* grads, float* sq, long n, float lr, float alpha, float eps,
                         float wd, float clip, float* stats, float* scratch, hipStream_t st);
 

@@ -532,6 +532,14 @@ static int* row_hints() {
     return g_hint[dev];
 }
 
+const int* lists_error_word_dev() {
+    // (only once a learner step has created the words: the optimiser alone never allocates them)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES || !g_hint[dev]) { (void)hipGetLastError(); return nullptr; }
+    const int* h = row_hints_dev();
+    return h ? h + 8 : nullptr;
+}
+
 struct RowList { const int* idx; const int* cnt; int which; };      // which: index into the counts array (= the hint slot)
 static refil_gemm_desc with_rows(refil_gemm_desc g, const Ctx& c, RowList l) {
     if (c.lists) {
@@ -1186,6 +1194,8 @@ static int learner_forward_backward(const refil_dims* dims, const refil_batch* b
     REFIL_CHECK(batch->obs_mask && batch->actions && batch->avail_actions && batch->reward && batch->terminated && batch->filled,
                 "refil_learner_forward_backward: incomplete batch");
     REFIL_CHECK(dims->gt_factors >= 0 && dims->gt_factors <= 2, "refil: gt_factors must be 0, 1 or 2");
+    REFIL_CHECK(batch->t_limit == 0 || (batch->t_limit >= 2 && batch->t_limit <= dims->T1), "refil_learner_forward_backward: t_limit %d outside [2, T1 = %d] (0 = none)",
+                batch->t_limit, dims->T1);
     REFIL_CHECK(!dims->imagine || batch->group_bits || dims->gt_factors == 1, "refil_learner_forward_backward: group_bits required when imagine=1");
     REFIL_CHECK(!(dims->gt_factors || dims->gt_obs_mask) || batch->gt_mask, "refil_learner_forward_backward: gt_mask required by gt_factors / gt_obs_mask");
     const refil_dims& d = c.d; const Sizes& s = c.s; const refil_param_layout& L = c.L; Work& w = c.w;

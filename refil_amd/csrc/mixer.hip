@@ -1502,9 +1502,16 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, floa
 }
 
 __global__ __launch_bounds__(256) void rmsprop_kernel(float* p, const float* g, float* sq, long n, float lr, float alpha,
-                                                      float eps, float wd, float clip, float* stats, const float* partial) {
+                                                      float eps, float wd, float clip, float* stats, const float* partial, const int* step_failed) {
     __shared__ float red[4];
     __shared__ float s_scale;
+    // the one-launch row-list kernel of THIS step gave up waiting for its grid (lists_fused_kernel: a partitioned / CU-masked device, or
+    // another process holding the CUs beyond the time-out): its lists were incomplete and so are these gradients -- the step is dropped
+    // (parameters and square_avg untouched, grad_norm = NaN); the host reports the sticky error at the next call (lists_launch)
+    if (step_failed && *reinterpret_cast<const volatile int*>(step_failed)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) stats[REFIL_STAT_GRAD_NORM] = __int_as_float(0x7fc00000);
+        return;
+    }
     float s = partial[threadIdx.x];   // OPT_BLOCKS == blockDim
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -1531,12 +1538,13 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(float* p, const float* g, 
 
 int clip_rmsprop_launch(float* params, const float* grads, float* sq, long n, float lr, float alpha, float eps,
                         float wd, float clip, float* stats, float* scratch, hipStream_t st) {
+    const int* step_failed = lists_error_word_dev();
     ProfScope prof_sumsq_kernel("sumsq_kernel", 0.0, 0.0, st);
     hipLaunchKernelGGL(sumsq_kernel, dim3(OPT_BLOCKS), dim3(256), 0, st, grads, n, scratch);
     REFIL_LAUNCH_CHECK();
     const int blocks = (int)min((long)1024, cdivl(n, 256));
     ProfScope prof_rmsprop_kernel("rmsprop_kernel", 0.0, 0.0, st);
-    hipLaunchKernelGGL(rmsprop_kernel, dim3(blocks), dim3(256), 0, st, params, grads, sq, n, lr, alpha, eps, wd, clip, stats, scratch);
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(blocks), dim3(256), 0, st, params, grads, sq, n, lr, alpha, eps, wd, clip, stats, scratch, step_failed);
     REFIL_LAUNCH_CHECK();
     return 0;
 }

@@ -143,8 +143,13 @@ class QLearner:
     def _apply_tuning(setting):
         if QLearner._APPLIED[0] == setting:
             return
+        # the autotuner's own knobs are reset to their defaults when the setting does not name them; the arithmetic-form / kernel-choice
+        # knobs (wres_split, dw_split, attn_qkv: never candidates) are left as the caller set them -- refil_set_tuning("wres_split", 0)
+        # before the first train() is the documented way to compare with earlier builds
+        own = {k for k, _ in tuning.CANDIDATES}
         for k in tuning.PARITY_TESTED:
-            _lib.check(_lib.lib().refil_set_tuning(k.encode(), int(setting.get(k, -1))), "refil_set_tuning")
+            if k in own or k in setting:
+                _lib.check(_lib.lib().refil_set_tuning(k.encode(), int(setting.get(k, -1))), "refil_set_tuning")
         QLearner._APPLIED[0] = dict(setting)
 
     def tuning_chosen(self):
@@ -230,7 +235,9 @@ class QLearner:
         # layout, the early prologue / early target forward and the tuner's bucket -- stays the same from step to step.
         # REFIL_UNTRIM=0: train on the view as given.
         t_limit = 0
+        # (REFIL_HIPGRAPH=1: the captured step does not carry t_limit -- the view is trained as given)
         while (getattr(batch, "_untrimmed", None) is not None and os.environ.get("REFIL_UNTRIM") != "0" and
+               os.environ.get("REFIL_HIPGRAPH") != "1" and
                args.mixer != "lin_flex_qmix"):         # (lin_flex_qmix logs ingroup_prop as a mean over ALL (b,t) of the batch it was given)
             t_limit = t_limit or batch.max_seq_length  # (refil_batch.t_limit: the transitions the view cut off stay cut off)
             batch = batch._untrimmed
@@ -317,10 +324,21 @@ class QLearner:
 
     def _tv(self):
         """refil_batch.target_version: changes whenever the target parameters may have been rewritten -- the explicit counter of
-        _update_targets / load_models plus torch's in-place version counter of the flat buffer (load_state_dict and any other
-        write through the parameter views bumps it). Unchanged since the previous call = the library may run the target nets'
-        forward early, beside the end of the previous step."""
-        return ((self._target_epoch + 1) << 32) | (self.flat_target._version & 0xFFFFFFFF)
+        _update_targets / load_models plus torch's in-place version counters of the flat buffer AND of every target parameter.
+        (FlatParamModule.adopt binds a parameter with `p.data = view`, which gives the Parameter a version counter of its own:
+        target_mixer.load_state_dict(...) / target_mac.load_state(...) bump the parameters' counters, not the flat buffer's.)
+        Unchanged since the previous call = the library may run the target nets' forward early, beside the end of the
+        previous step, and keep their composed maps."""
+        key = (id(self.target_mac), id(self._tmix))
+        got = self.__dict__.get("_target_params")
+        if got is None or got[0] != key:
+            got = (key, list(self.target_mac.parameters()) + list(self._tmix.parameters()))
+            self._target_params = got
+        ps = got[1]
+        v = self.flat_target._version
+        for p in ps:
+            v += p._version
+        return ((self._target_epoch + 1) << 32) | (v & 0xFFFFFFFF)
 
     def _optimiser_step(self):
         a = self.args

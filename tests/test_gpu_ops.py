@@ -149,7 +149,7 @@ def wres_mode(request):
 def test_wres_split_accuracy(M, N, K, bt, scale):
     """The bf16 x 6 form is as accurate as the fp32 matrix instruction: both against an fp64 product of the same fp32 operands.
     scale > 0: operands with a wide dynamic range (x exp(scale N(0,1))), so that the three pieces of a split sit at very different
-    exponents. Bar: rms error <= 1.25 x, max error <= 2 x that of the fp32 path (measured: 0.9-1.05 x)."""
+    exponents. Bar: rms error <= 1.1 x, max error <= 1.5 x that of the fp32 path (measured: 0.9-1.05 x rms)."""
     import hip_ops
     from refil_amd import _lib
     torch.manual_seed(M + N + K + int(bt))
@@ -173,7 +173,56 @@ def test_wres_split_accuracy(M, N, K, bt, scale):
     finally:
         _lib.check(_lib.lib().refil_set_tuning(b"wres_split", -1), "refil_set_tuning")
     print(f"fp32 MFMA: rms {errs[0][0]:.3e} max {errs[0][1]:.3e}; bf16 x 6: rms {errs[6][0]:.3e} max {errs[6][1]:.3e}; |ref| rms {ref.pow(2).mean().sqrt().item():.3e}")
-    assert errs[6][0] <= 1.25 * errs[0][0] and errs[6][1] <= 2.0 * errs[0][1], errs
+    assert errs[6][0] <= 1.1 * errs[0][0] and errs[6][1] <= 1.5 * errs[0][1], errs
+
+
+def test_wres_split_edge_operands():
+    """Non-finite, huge, tiny and subnormal operands through refil_gemm in both arithmetic forms (include/refil_hip.h
+    refil_set_tuning): (1) a row holding such an operand never disturbs the OTHER rows (bit for bit); (2) Inf / NaN operands give a
+    non-finite result in both forms -- the split form NaN where the fp32 instruction gives Inf (x - bf16(x) = Inf - Inf); (3) |x| >= 3.3962e38
+    (half-way between bf16's largest finite value and 2^128: the top 0.2 % of the fp32 range) rounds its hi piece to Inf in the split
+    form where the fp32 instruction may still give a finite value: the one documented difference; (4) tiny / subnormal operands give finite results within the fp32 unit roundoff of
+    the row's scale + the flush-to-zero floor of a subnormal piece."""
+    import hip_ops
+    from refil_amd import _lib
+    torch.manual_seed(11)
+    M, N, K = 4096, 128, 128
+    x = torch.randn(M, K)
+    W = torch.randn(N, K) / math.sqrt(K)
+    special = {3: float("inf"), 40: float("-inf"), 77: float("nan"), 130: 3.4e38, 131: -3.3965e38, 200: 3.395e38, 260: 1e-38, 261: 1.2e-38,
+               300: 1e-41, 301: -3e-44, 350: 1e30, 351: 1e-30}
+    xs = x.clone()
+    for r, v in special.items():
+        xs[r, 5] = v
+    xs[400, :] = 1e-39 * torch.randn(K)              # a whole row of subnormals
+    special[400] = None
+    clean = torch.ones(M, dtype=torch.bool)
+    clean[list(special)] = False
+    ref = xs.double() @ W.double().t()
+    out = {}
+    try:
+        for mode in (0, 6):
+            _lib.check(_lib.lib().refil_set_tuning(b"wres_split", mode), "refil_set_tuning")
+            ya = torch.full((M, N), 5.0, device=DEV); yb = torch.full((M, N), 5.0, device=DEV)
+            hip_ops.gemm(x.to(DEV), W.to(DEV), ya, M, N, K, K, K, N)
+            hip_ops.gemm(xs.to(DEV), W.to(DEV), yb, M, N, K, K, K, N)
+            ya, yb = ya.cpu(), yb.cpu()
+            assert torch.equal(ya[clean], yb[clean]), "a special operand in one row changed another row"
+            out[mode] = yb
+    finally:
+        _lib.check(_lib.lib().refil_set_tuning(b"wres_split", -1), "refil_set_tuning")
+    for mode in (0, 6):
+        y = out[mode]
+        for r in (3, 40, 77):
+            assert not torch.isfinite(y[r]).any(), f"form {mode}: Inf / NaN operand in row {r} gave a finite result"
+        for r in (200, 350, 351, 260, 261, 300, 301, 400):              # finite in both forms, to fp32 accuracy of the row's scale
+            assert torch.isfinite(y[r]).all(), f"form {mode}: row {r} not finite"
+            scale = (xs[r].abs().double() @ W.abs().double().t())
+            err = (y[r].double() - ref[r]).abs()
+            assert (err <= 4e-7 * scale + 1e-37).all(), f"form {mode}: row {r} max err {err.max().item():.3e} (scale {scale.max().item():.3e})"
+    assert torch.isinf(out[0][3]).all() and torch.isnan(out[6][3]).all()            # Inf: fp32 instruction Inf, split form NaN
+    assert torch.isfinite(out[0][130]).all() and not torch.isfinite(out[6][130]).any()     # 3.4e38: rounds to Inf in bf16
+    assert torch.isfinite(out[0][131]).all() and not torch.isfinite(out[6][131]).any()
 
 
 @pytest.mark.parametrize("M,N,K,batch", [(4096, 128, 128, 1), (2048 + 64, 256, 128, 2), (6400, 512, 84, 1), (4096, 192, 64, 1),
