@@ -13,18 +13,16 @@ summed over all GPUs); --scaling strong fixes the GLOBAL batch (--global-batch, 
 Prints ONE JSON line (rank 0). Extra objects:
   roofline     -- the kernel symbol with the largest isolated GPU time per step, timed with HIP events on the launch
                   stream by the library's profiler right after the timed region (events are kept out of the timed
-                  region itself so they cannot perturb `value`). bound = "hbm" for the attention cores / recurrences /
-                  mixing kernels (below the 19.7 FLOP/B ridge): achieved = algorithmic bytes per launch (operands read
-                  once, results written once, rows of live steps) / mean launch duration against 8 TB/s; bound = "mfma"
-                  for the projections: achieved = FLOPs the kernel executes per launch (the rows that can influence the
-                  loss: the library skips the others) / mean launch duration against 157.3 TFLOP/s (fp32 MFMA,
-                  MI355X_MICROARCH.md). The projections compute their fp32 products as six bf16 matrix-pipe products of an
-                  exact 3-way operand split (fp32-accurate; gemm_wres.hip): `frac` stays algorithmic fp32 FLOPs against the
-                  fp32-MFMA roof, `matrix_pipe` adds the executed (6 x) FLOPs against the dense bf16 peak.
-                  traffic = HBM bytes per launch from a rocprofv3 PMC pass of THIS build handed in
-                  with --traffic-json (tools/collect_profiles.sh), else null. heaviest_gemm = the same for the GEMM
-                  kernel that executes the most FLOPs per step (the matrix-core evidence when the dominant kernel is
-                  HBM-bound); every kernel's own rate is in kernels[] (tflops_isolated).
+                  region itself so they cannot perturb `value`). Every kernel is priced against BOTH roofs it can hit and
+                  `bound` names the one that binds (the larger floor): the matrix pipe it ISSUES on -- fp32 products computed as
+                  six bf16 matrix-pipe products of an exact 3-way operand split (gemm_wres / gemm_dws / the in_trans part of
+                  attn_qkv_fwd; refil_profile_entry.flops_bf16x6) are priced at 2500 / 6 = 416.7 TFLOP/s of fp32 work, the rest at the
+                  fp32 matrix instruction's 157.3 TFLOP/s -- and HBM at 8 TB/s with the bytes the launch really moved (rocprofv3 PMC:
+                  2 * FETCH_SIZE + WRITE_SIZE, collected by bench.py itself or handed in with --traffic-json; without them the
+                  algorithmic bytes). `frac` = that floor / measured time; `frac_vs_fp32_instruction` keeps the round-1..4 figure
+                  (algorithmic fp32 FLOPs / time / 157.3 TFLOP/s: a comparison with the fp32 instruction, which the split form may
+                  exceed). achieved / peak / unit are in the binding roof's unit (hbm: algorithmic bytes per launch / time). Every
+                  kernels[] row carries bound, mfma_frac and hbm_frac.
   cpu_baseline -- oracle/refil_oracle.py (a fixture-pinned CPU port of the reference learner) timed on this box's host
                   cores on a bounded sample of the same workload (N=1, rank 0 only).
 """
@@ -49,6 +47,8 @@ import torch.distributed as dist
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense (MI355X_MICROARCH.md; 2495 measured)
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0      # fp32 products computed as six bf16 matrix-pipe products: 416.7 TFLOP/s of fp32 work
+PEAK_HBM_GBS = 8000.0
 # BASELINE.json configs. B = episodes per GPU under weak scaling.
 CONFIGS = {
     "cfgT": dict(B=32, T=80, ne=32, d=128, h=128, imagine=True, what="north-star target shape (BASELINE.json north_star / metric)"),
@@ -178,6 +178,27 @@ def build(dims, imagine, B, T, seed, device, shard=None, dense=False, fresh=0, h
         batch.ready_event.record()
     learner._bench_episode_batch = episode_batch           # (bench.py's second, densified timed region builds its batch with it)
     return args, batch, learner, data, buffer
+
+
+def gpu_state(index):
+    """clock / power / temperature of the device right after the timed region (rocm-smi; box-to-box spread of the headline is ~5 %: the
+    line carries the state it was measured in). None when rocm-smi is not available."""
+    import shutil
+    import subprocess
+    if shutil.which("rocm-smi") is None:
+        return None
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(index), "--showclocks", "--showpower", "--showtemp", "--json"], stdout=subprocess.PIPE,
+                           stderr=subprocess.DEVNULL, timeout=20)
+        card = next(iter(json.loads(r.stdout.decode()).values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "power", "temperature (sensor junction)", "temperature (sensor edge)")):
+                keep[k] = v
+        return keep or None
+    except Exception:
+        return None
 
 
 def cpu_model():
@@ -372,8 +393,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step_loss():
+        """the loss of the step just taken from the (all-reduced) stat sums: (1 - lmbda) sum(td^2) / sum(mask) + lmbda sum(td_im^2) / sum(mask)"""
+        st = learner.grads[learner._n:learner._n + _lib.REFIL_NSTAT].double().cpu()
+        q = st[_lib.STAT_TD_SQ] / st[_lib.STAT_MASK_SUM]
+        return float((1 - args.lmbda) * q + args.lmbda * st[_lib.STAT_IM_TD_SQ] / st[_lib.STAT_MASK_SUM]) if W["imagine"] else float(q)
+
+    def replica_checksum():
+        """bit-level checksums of the live parameters and the RMSprop state (int32 views summed in int64)"""
+        return torch.stack([learner.flat_live.view(torch.int32).to(torch.int64).sum(), learner.square_avg.view(torch.int32).to(torch.int64).sum()])
+
+    loss_step0 = None
     for i in range(a.warmup):
         step(i)
+        if i == 0:              # (outside the timed region) the job's first loss: under strong scaling it equals the single-process loss of the
+            torch.cuda.synchronize()     # same global batch up to summation order -- a first multi-GPU run can be checked against an N = 1 line
+            loss_step0 = step_loss()
     barrier()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
@@ -410,9 +445,22 @@ def main():
             ver = ".".join(str(x) for x in torch.cuda.nccl.version())
         except Exception:
             ver = None
+        # Self-validation of a multi-GPU run: the replicas must still be bit-identical after the timed steps (one all-reduce(SUM) of
+        # [grads | stats], the global sum(mask) applied by the optimiser kernel: no parameter broadcast ever happens) -- checked on bit-level
+        # checksums of the live parameters and the RMSprop state, gathered over the job's own process group; a divergence is an error
+        cs = replica_checksum()
+        gathered = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(gathered, cs)
+        identical = all(torch.equal(g, gathered[0]) for g in gathered)
         comm = {"bytes": gb.numel() * 4, "allreduce_us_per_step": round(ce0.elapsed_time(ce1) * 100.0, 1), "backend": backend,
                 "nccl_version": ver, "algorithm": os.environ.get("REFIL_ALLREDUCE", "backend all_reduce(SUM), one collective per step"),
-                "buckets": os.environ.get("REFIL_DP_BUCKETS") == "1"}
+                "buckets": os.environ.get("REFIL_DP_BUCKETS") == "1",
+                "ranks": dist.get_world_size(), "replicas_identical": bool(identical),
+                "replica_checksums": [int(x) for x in gathered[0].tolist()], "loss_step0": loss_step0,
+                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
+        if not identical:
+            raise SystemExit(f"bench.py: the data-parallel replicas diverged after {a.warmup + a.steps} steps (rank {rank}: {cs.tolist()} vs rank 0: "
+                             f"{gathered[0].tolist()}) -- the line would not be a valid measurement")
     # a second, short timed region on the DENSIFIED batch (no padding, full-length episodes: nothing for the row lists to skip),
     # so that the headline cannot be read as a dense rate
     dense = None
@@ -498,7 +546,7 @@ def main():
         iso_total = sum(x["total_ms"] for x in iso.values()) / nprof
         dom = next((e for e in ents if e["flops"] > 0), ents[0])            # dominant kernel (largest isolated time per step)
         dom_iso = iso.get(dom["name"], dom)
-        traffic, hbm_step, traffic_src = None, None, "not collected in this run"
+        traffic, hbm_step, traffic_src, tr = None, None, "not collected in this run", None
         if a.traffic_json:
             tj = json.load(open(a.traffic_json))
             traffic = tj["kernels"].get(dom["name"], {}).get("hbm_bytes_per_launch")
@@ -512,57 +560,75 @@ def main():
         # report every (b,t) row and skip the finished steps inside the kernel -- scaled by the live-step fraction here
         live_frac = rows["live_steps"] / max(rows["steps"], 1) if rows["lists"] else 1.0
         executed_flops = sum(x["flops"] * (live_frac if n.startswith("attn_") else 1.0) for n, x in iso.items()) / nprof
-        # which roof bounds it: the projections are matrix-core work; the attention cores / recurrences / mixing kernels move
-        # far more bytes per FLOP than the 157 TFLOP/s : 8 TB/s ridge (19.7 FLOP/B) -- HBM. Row-list GEMMs report the FLOPs /
-        # bytes of the rows they process; the attention launches skip finished steps: scaled by the live-step fraction.
-        hbm_bound = dom["name"].split("<")[0] in ("attn_fwd_mfma", "attn_bwd_mfma", "attn_fwd_kernel", "attn_bwd_kernel", "gru_fwd_kernel",
-                                                   "gru_bwd_kernel", "mix_fwd_kernel", "mix_bwd_kernel", "reduce_partials_kernel")
-        live = 1.0
-        if dom["name"].startswith("attn_"):
-            # attention launches: the profiler's bytes are the dense (all rows) operand + result sizes. The kernels move data
-            # for the K / V rows and the query rows that can influence the loss only (row lists); one symbol covers the agent
-            # launch (1 net) and the hypernet launch (4 nets): K/V-side bytes scale with the listed entity rows, Q-side bytes
-            # with the active agent rows (fractions of the dense rows, finished steps included)
-            if rows["lists"]:
-                f_e = (rows["entity_rows_agent"] + 4.0 * rows["entity_rows_hyper"]) / (5.0 * max(rows["entity_rows"], 1))
-                f_a = rows["agent_rows"] / max(rows["all_agent_rows"], 1)
-                bwd = "bwd" in dom["name"]
-                w_e, w_a = (4.0 * dims["ne"], 3.0 * dims["na"]) if bwd else (2.0 * dims["ne"], 2.0 * dims["na"])
-                live = (w_e * f_e + w_a * f_a) / (w_e + w_a)
-            else:
-                live = rows["live_steps"] / max(rows["steps"], 1)
+        # Both roofs per kernel (see the module docstring): the matrix pipe(s) the kernel issues on and HBM with the measured bytes.
+        # Row-list GEMMs report the FLOPs / bytes of the rows they process; the attention launches report every (b,t) row and skip
+        # the finished steps inside the kernel: scaled by the live-step fraction here.
+        per_launch_pmc = tr["per_launch"] if tr else (
+            {k: v.get("hbm_bytes_per_launch") for k, v in json.load(open(a.traffic_json))["kernels"].items()} if a.traffic_json else {})
+
+        def attn_bytes_scale(name):
+            # attention launches: the profiler's bytes are the dense (all rows) operand + result sizes. The kernels move data for the
+            # K / V rows and the query rows that can influence the loss only; one symbol covers the agent launch (1 net) and the
+            # hypernet launch (4 nets): K/V-side bytes scale with the listed entity rows, Q-side bytes with the active agent rows
+            if not name.startswith("attn_"):
+                return 1.0
+            if not rows["lists"]:
+                return rows["live_steps"] / max(rows["steps"], 1)
+            f_e = (rows["entity_rows_agent"] + 4.0 * rows["entity_rows_hyper"]) / (5.0 * max(rows["entity_rows"], 1))
+            f_a = rows["agent_rows"] / max(rows["all_agent_rows"], 1)
+            w_e, w_a = (4.0 * dims["ne"], 3.0 * dims["na"]) if "bwd" in name else (2.0 * dims["ne"], 2.0 * dims["na"])
+            return (w_e * f_e + w_a * f_a) / (w_e + w_a)
+
+        def price(name, x):
+            """roofs of kernel `name` from its isolated profile entry x: seconds per launch it cannot beat on the matrix pipes / on HBM"""
+            t = 1e-3 * x["total_ms"] / x["launches"]
+            fsc = live_frac if name.startswith("attn_") else 1.0
+            fl, fs = fsc * x["flops"] / x["launches"], fsc * x.get("flops_bf16x6", 0.0) / x["launches"]
+            t_mfma = fs / (PEAK_SPLIT_TFLOPS * 1e12) + (fl - fs) / (PEAK_FP32_MFMA_TFLOPS * 1e12)
+            alg_bytes = attn_bytes_scale(name) * x["bytes"] / x["launches"]
+            pmc = per_launch_pmc.get(name)
+            t_hbm = (pmc if pmc else alg_bytes) / (PEAK_HBM_GBS * 1e9)
+            return {"t": t, "flops": fl, "flops_bf16x6": fs, "t_mfma": t_mfma, "t_hbm": t_hbm, "alg_bytes": alg_bytes, "pmc_bytes": pmc,
+                    "bound": "hbm" if t_hbm > t_mfma else "mfma"}
+
+        for k in kernels:
+            x = iso.get(k["name"])
+            if x and x["launches"]:
+                pr = price(k["name"], x)
+                k["bound"] = pr["bound"]
+                k["mfma_frac"] = round(pr["t_mfma"] / pr["t"], 4)
+                k["hbm_frac"] = round(pr["t_hbm"] / pr["t"], 4)
+                k["hbm_bytes_per_launch"] = pr["pmc_bytes"] if pr["pmc_bytes"] else None
+        pd = price(dom["name"], dom_iso)
+        t_situ = 1e-3 * dom["total_ms"] / dom["launches"]
+        hbm_bound = pd["bound"] == "hbm"
         if hbm_bound:
-            per_launch = live * dom_iso["bytes"] / dom_iso["launches"]
-            ach_iso = per_launch / (1e-3 * dom_iso["total_ms"] / dom_iso["launches"]) / 1e9
-            ach_situ = per_launch / (1e-3 * dom["total_ms"] / dom["launches"]) / 1e9
-            peak, unit = 8000.0, "GB/s"
+            ach_iso, ach_situ = pd["alg_bytes"] / pd["t"] / 1e9, pd["alg_bytes"] / t_situ / 1e9
+            peak, unit = PEAK_HBM_GBS, "GB/s"
         else:
-            ach_iso = dom_iso["flops"] / (dom_iso["total_ms"] * 1e-3) / 1e12
-            ach_situ = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-            peak, unit = PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
+            # the roof of the mix of matrix instructions this kernel issues, in TFLOP/s of algorithmic fp32 work
+            peak = pd["flops"] / pd["t_mfma"] / 1e12 if pd["t_mfma"] > 0 else PEAK_FP32_MFMA_TFLOPS
+            ach_iso, ach_situ = pd["flops"] / pd["t"] / 1e12, pd["flops"] / t_situ / 1e12
+            unit = "TFLOP/s"
+        live = attn_bytes_scale(dom["name"])
         # the projection kernel that executes the most FLOPs per step as well (matrix-core evidence when the dominant kernel is HBM-bound)
         gemm = max((e for e in ents if e["name"].startswith("gemm_") and e["flops"] > 0), key=lambda e: iso.get(e["name"], e)["flops"], default=None)
         gemm_iso = iso.get(gemm["name"], gemm) if gemm else None
-        # The weight-resident GEMMs compute their fp32 products as six bf16 matrix-pipe products of a 3-way operand split (gemm_wres.hip:
-        # wr_split; profiler names ending in ",6>"). `achieved` stays the ALGORITHMIC fp32 FLOPs against the fp32-MFMA roof (what the
-        # reference's arithmetic costs on this part's fp32 matrix instruction); `matrix_pipe` adds what the pipe executes against ITS roof.
-        split6 = (not hbm_bound) and dom["name"].startswith("gemm_wres_kernel") and dom["name"].endswith(",6>")
-        roofline = {"kernel": dom["name"], "bound": "hbm" if hbm_bound else "mfma", "achieved": round(ach_iso, 2), "peak": peak,
-                    "unit": unit, "frac": round(ach_iso / peak, 4), "traffic": traffic,
-                    "matrix_pipe": None if not split6 else {
-                        "instruction": "v_mfma_f32_32x32x16_bf16 x 6 per 16 reduction indices (both fp32 operands split into three bf16 pieces, the six "
-                                       "largest of the nine piece products, fp32 accumulate: fp32-accurate, tests/test_gpu_ops.py::test_wres_split_accuracy)",
-                        "executed_tflops": round(6.0 * ach_iso, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(6.0 * ach_iso / PEAK_BF16_MFMA_TFLOPS, 4),
-                        "note": "`achieved` / `frac` above: algorithmic fp32 FLOPs (2 M N K of the listed rows) over the launch time against the fp32-MFMA "
-                                "peak -- the roof of the v_mfma_f32_32x32x2_f32 form (REFIL_WRES_SPLIT=0), which this form is allowed to exceed"},
-                    "peak_note": ("peak = 256 CU x 2.4 GHz x 256 FLOP/clk, the fp32 matrix instruction's (MI355X_MICROARCH.md). The launch runs at the clock "
-                                  "the power budget allows: in-kernel cycle counters give 6.7 k cycles of MFMAs (floor 6.1 k) + 2.8 k of epilogue per 32 x 128 "
-                                  "row tile at an effective ~1.6 GHz (profiles/r04_wres_timing_split6.txt); the fp32-instruction form: 16.8 k + 3.5 k at 1.9 GHz "
-                                  "(profiles/r04_wres_timing_slab_vs_pipe.txt); DESIGN.md lessons 25-27, 29" if split6 else
-                                  "peak = 256 CU x 2.4 GHz x 256 FLOP/clk (MI355X_MICROARCH.md). On real operand data the part clocks to its power "
-                                  "budget: cycle counters inside this kernel give 97.5 % MFMA issue in its main loop, 80 % over the row tile, at an "
-                                  "effective 1.9 GHz (profiles/r04_wres_timing_slab_vs_pipe.txt); the same launch runs 113 TFLOP/s on zeros, 92-103 on "
-                                  "N(0,1) (profiles/r04_gemm_dvfs.txt); DESIGN.md lessons 25-27") if not hbm_bound else None,
+        pg = price(gemm["name"], gemm_iso) if gemm else None
+        # matrix-pipe floor of the whole step: every kernel's FLOPs priced on the pipe it issues them on
+        step_mfma_floor = sum(price(n, x)["t_mfma"] * x["launches"] for n, x in iso.items() if x["launches"]) / nprof
+        roofline = {"kernel": dom["name"], "bound": pd["bound"], "achieved": round(ach_iso, 2), "peak": round(peak, 1),
+                    "unit": unit, "frac": round(max(pd["t_mfma"], pd["t_hbm"]) / pd["t"], 4), "traffic": traffic,
+                    "mfma_frac": round(pd["t_mfma"] / pd["t"], 4), "hbm_frac": round(pd["t_hbm"] / pd["t"], 4),
+                    "frac_vs_fp32_instruction": round(pd["flops"] / pd["t"] / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "roofs": {"fp32_mfma_tflops": PEAK_FP32_MFMA_TFLOPS, "bf16x6_tflops_of_fp32_work": round(PEAK_SPLIT_TFLOPS, 1), "hbm_gbs": PEAK_HBM_GBS,
+                              "flops_per_launch": pd["flops"], "flops_per_launch_on_bf16x6": pd["flops_bf16x6"],
+                              "mfma_floor_us": round(pd["t_mfma"] * 1e6, 2), "hbm_floor_us": round(pd["t_hbm"] * 1e6, 2),
+                              "hbm_bytes_used": "rocprofv3 PMC" if pd["pmc_bytes"] else "algorithmic (no PMC pass in this run)",
+                              "note": "bound = the larger floor; frac = that floor / the measured launch time. fp32 products issued as six bf16 "
+                                      "matrix-pipe products of an exact 3-way operand split (fp32-accurate: tests/test_gpu_ops.py::test_wres_split_accuracy) "
+                                      "are priced at the dense bf16 peak / 6, everything else at the fp32 matrix instruction's peak; "
+                                      "frac_vs_fp32_instruction = the rounds 1-4 figure, which this form may exceed"},
                     "traffic_unit": f"HBM bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE, {traffic_src})",
                     "hbm_gb_per_step": None if hbm_step is None else round(hbm_step / 1e9, 3),
                     "hbm_gb_per_s_over_step": None if hbm_step is None else round(hbm_step / (ms_per_step * 1e-3) / 1e9, 1),
@@ -572,10 +638,14 @@ def main():
                     "algorithmic_bytes_per_launch": round(live * dom_iso["bytes"] / dom_iso["launches"]),
                     "achieved_in_situ": round(ach_situ, 2), "frac_in_situ": round(ach_situ / peak, 4),
                     "heaviest_gemm": None if not gemm else {
-                        "kernel": gemm["name"], "bound": "mfma", "launches_per_step": gemm["launches"] // nprof,
-                        "achieved": round(gemm_iso["flops"] / (gemm_iso["total_ms"] * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(gemm_iso["flops"] / (gemm_iso["total_ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                        "avg_launch_us": round(1e3 * gemm_iso["total_ms"] / gemm_iso["launches"], 2)},
+                        "kernel": gemm["name"], "bound": pg["bound"], "launches_per_step": gemm["launches"] // nprof,
+                        "achieved_tflops": round(pg["flops"] / pg["t"] / 1e12, 2), "frac": round(max(pg["t_mfma"], pg["t_hbm"]) / pg["t"], 4),
+                        "mfma_frac": round(pg["t_mfma"] / pg["t"], 4), "hbm_frac": round(pg["t_hbm"] / pg["t"], 4),
+                        "frac_vs_fp32_instruction": round(pg["flops"] / pg["t"] / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "avg_launch_us": round(pg["t"] * 1e6, 2)},
+                    "step_mfma_floor_ms": round(step_mfma_floor * 1e3, 3),
+                    "step_frac_of_matrix_roof": round(step_mfma_floor / (ms_per_step * 1e-3), 4),
+                    "step_frac_of_hbm_roof": None if hbm_step is None else round(hbm_step / (PEAK_HBM_GBS * 1e9) / (ms_per_step * 1e-3), 4),
                     "launches_per_step": dom["launches"] // nprof,
                     "avg_launch_us": round(1e3 * dom_iso["total_ms"] / dom_iso["launches"], 2),
                     "avg_launch_us_in_situ": round(1e3 * dom["total_ms"] / dom["launches"], 2),
@@ -592,7 +662,9 @@ def main():
                                 "with the other stream's kernels, a lower bound on kernel quality. `step_frac_executed` = FLOPs the step's launches "
                                 "EXECUTE (profiler, listed rows) / step time / peak -- the honest step-level fraction; `step_frac_dense_equivalent` = the "
                                 "DENSE algorithmic FLOPs of SURVEY.md section 8d / step time / peak (work the row lists and the algebra of DESIGN.md "
-                                "section 5 remove still counts there: a speed-up figure against the dense schedule, not a utilisation)"}
+                                "section 5 remove still counts there: a speed-up figure against the dense schedule, not a utilisation). "
+                                "`step_frac_of_matrix_roof` = the executed FLOPs priced on the pipes they are issued on (bf16 x 6 products at 416.7, the rest at "
+                                "157.3 TFLOP/s) / step time; `step_frac_of_hbm_roof` = PMC bytes per step / 8 TB/s / step time"}
     if world > 1:
         dist.barrier()
 
@@ -606,6 +678,7 @@ def main():
             "metric": "learner transitions/sec (B x T per full QLearner.train step)", "value": round(value, 1),
             "unit": "transitions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 3), "median_ms_per_step": round(statistics.median(per_step), 3),
+            "min_ms_per_step": round(min(per_step), 3), "loss_step0": loss_step0, "gpu_state": gpu_state(local_rank),
             "host_enqueue_ms_per_step": round(host_enqueue / a.steps * 1e3, 3), "higher_is_better": True, "scaling": a.scaling,
             "filled_transitions_per_s": round(mask_sum * a.steps / elapsed, 1),
             "dense_data": dense, "comm": comm,

@@ -465,8 +465,10 @@ typedef struct refil_profile_entry {
     char name[96];          /* kernel symbol, e.g. "gemm_kernel<2,2,2,2,false,false>"             */
     int64_t launches;
     double total_ms;
-    double flops;
+    double flops;           /* algorithmic fp32 FLOPs (2 m n k per product)                                 */
     double bytes;
+    double flops_bf16x6;    /* the part of `flops` the kernel computes as six bf16 matrix-pipe products of an exact 3-way
+                               operand split (roof: the dense bf16 peak / 6); the rest runs the fp32 matrix instructions */
 } refil_profile_entry;
 int refil_profile_enable(int on);
 int refil_profile_collect(refil_profile_entry* out, int max_entries);

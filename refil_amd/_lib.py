@@ -128,7 +128,7 @@ GRADS_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
 
 class ProfileEntry(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double), ("flops", C.c_double),
-                ("bytes", C.c_double)]
+                ("bytes", C.c_double), ("flops_bf16x6", C.c_double)]
 
 
 # every symbol include/refil_hip.h declares (tests/test_abi.py checks the library exports them all)
@@ -222,13 +222,13 @@ def profile_enable(on: bool):
 
 
 def profile_collect():
-    """[{name, launches, total_ms, flops, bytes}] aggregated per kernel symbol since profile_enable(True)."""
+    """[{name, launches, total_ms, flops, bytes, flops_bf16x6}] aggregated per kernel symbol since profile_enable(True)."""
     buf = (ProfileEntry * 64)()
     n = lib().refil_profile_collect(buf, 64)
     if n > 0:
         check(n, "refil_profile_collect")
     return [dict(name=buf[i].name.decode(), launches=buf[i].launches, total_ms=buf[i].total_ms, flops=buf[i].flops,
-                 bytes=buf[i].bytes) for i in range(-n)]
+                 bytes=buf[i].bytes, flops_bf16x6=buf[i].flops_bf16x6) for i in range(-n)]
 
 
 def check(rc: int, what: str):

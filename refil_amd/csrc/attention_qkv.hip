@@ -608,12 +608,16 @@ int attn_qkv_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts,
     k.mw_nvar = d.mask_words_nvar > 0 ? d.mask_words_nvar : d.nvar;
     REFIL_CHECK(k.mw_nvar >= d.nvar, "refil_attn_qkv: mask_words holds fewer variants than nvar");
     k.nact = nact; k.zero_dead = zero_dead;
-    double flops = 0.0, bytes = 0.0;
+    // algorithmic work of the launch (all rows; the callers scale by the live fraction): in_trans on the bf16 pipe (x 6), the core on the
+    // fp32 matrix instruction; bytes: the layer input read once, the outputs (and the kept projections) written once
+    double flops = 0.0, bytes = 0.0, fsplit = 0.0;
     for (int i = 0; i < n; ++i) {
-        flops += (double)d.R * (2.0 * (2.0 * d.ne + d.na) * w * w + (2.0 + 2.0 * descs[i].nvar) * d.heads * d.na * d.ne * d.hd);
+        const double proj = (double)d.R * 2.0 * (2.0 * d.ne + d.na) * w * w;
+        fsplit += proj;
+        flops += proj + (double)d.R * (2.0 + 2.0 * descs[i].nvar) * d.heads * d.na * d.ne * d.hd;
         bytes += 4.0 * d.R * ((double)d.ne * w + (double)descs[i].nvar * d.na * w + (src[i].Ko ? (2.0 * d.ne + d.na) * w : 0.0));
     }
-    ProfScope prof("attn_qkv_fwd", flops, bytes, st);
+    ProfScope prof("attn_qkv_fwd", flops, bytes, st, nullptr, 0.0, fsplit);
     const int njt = (d.ne + 15) / 16, nct = d.hd / 16, nks = w / 32;
 #define CASE(J, C, S) if (njt == J && nct == C && nks == S) return qkv_launch_x<J, C, S>(k, st)
     CASE(2, 2, 4); CASE(1, 2, 4); CASE(2, 1, 2); CASE(1, 1, 2); CASE(2, 2, 2); CASE(1, 2, 2); CASE(2, 1, 4); CASE(1, 1, 4);

@@ -646,7 +646,7 @@ int gemm_dw4_launch(const refil_gemm_desc& d, hipStream_t st) {
         if (!pname && n_names < 16) { strcpy(names[n_names], nm); pname = names[n_names++]; }
         if (!pname) pname = "gemm_dws_kernel";
         ProfScope prof(pname, 2.0 * d.M * d.N * d.K * d.batch, 4.0 * d.batch * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N), st,
-                       d.row_index ? d.row_count : nullptr, (double)d.K);
+                       d.row_index ? d.row_count : nullptr, (double)d.K, 2.0 * d.M * d.N * d.K * d.batch);
         const bool bm = d.b_map.grp != 0;
         const int rc = ti == 2 ? (nj == 4 ? dws_launch_t<2, 4>(k, bm, grid, st) : dws_launch_t<2, 3>(k, bm, grid, st))
                                : (nj == 4 ? dws_launch_t<1, 4>(k, bm, grid, st) : dws_launch_t<1, 3>(k, bm, grid, st));

@@ -633,7 +633,7 @@ int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st) {
     if (!pname) pname = "gemm_wres_kernel";
     ProfScope prof(pname, 2.0 * d.M * d.N * d.K * d.batch,
                    4.0 * d.batch * ((double)d.M * d.K + (double)d.N * d.K + (double)d.M * d.N * (rb ? ((d.flags & REFIL_GEMM_ACCUM) ? 3.0 : 2.0) : 1.0)), st,
-                   d.row_index ? d.row_count : nullptr, (double)d.M);
+                   d.row_index ? d.row_count : nullptr, (double)d.M, split ? 2.0 * d.M * d.N * d.K * d.batch : 0.0);
     int rc;
     if (rb) rc = wres_launch_rbwd(k, (d.flags & REFIL_GEMM_ACCUM) != 0, grid, st);
     else if (bt) rc = tn == 4 ? wres_launch_bwd<4>(k, grid, st) : (tn == 2 ? wres_launch_bwd<2>(k, grid, st) : wres_launch_bwd<1>(k, grid, st));

@@ -1491,8 +1491,12 @@ int sum_launch(const float* x, long n, float* out, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 constexpr int OPT_BLOCKS = 256;
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, float* partial) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, float* partial, const int* step_failed) {
     __shared__ float red[4];
+    // (the sticky error word of the one-launch row lists lives in pinned HOST memory: ONE lane reads it over PCIe and leaves a copy
+    // behind the partial sums for the optimiser kernel -- every workgroup of that kernel reading the host word itself cost 0.3 ms)
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        reinterpret_cast<int*>(partial)[OPT_BLOCKS] = step_failed ? *reinterpret_cast<const volatile int*>(step_failed) : 0;
     float s = 0.f;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) s = fmaf(g[i], g[i], s);
     s = wave_sum(s);
@@ -1502,13 +1506,13 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, floa
 }
 
 __global__ __launch_bounds__(256) void rmsprop_kernel(float* p, const float* g, float* sq, long n, float lr, float alpha,
-                                                      float eps, float wd, float clip, float* stats, const float* partial, const int* step_failed) {
+                                                      float eps, float wd, float clip, float* stats, const float* partial) {
     __shared__ float red[4];
     __shared__ float s_scale;
     // the one-launch row-list kernel of THIS step gave up waiting for its grid (lists_fused_kernel: a partitioned / CU-masked device, or
     // another process holding the CUs beyond the time-out): its lists were incomplete and so are these gradients -- the step is dropped
     // (parameters and square_avg untouched, grad_norm = NaN); the host reports the sticky error at the next call (lists_launch)
-    if (step_failed && *reinterpret_cast<const volatile int*>(step_failed)) {
+    if (reinterpret_cast<const int*>(partial)[OPT_BLOCKS]) {
         if (blockIdx.x == 0 && threadIdx.x == 0) stats[REFIL_STAT_GRAD_NORM] = __int_as_float(0x7fc00000);
         return;
     }
@@ -1540,11 +1544,11 @@ int clip_rmsprop_launch(float* params, const float* grads, float* sq, long n, fl
                         float wd, float clip, float* stats, float* scratch, hipStream_t st) {
     const int* step_failed = lists_error_word_dev();
     ProfScope prof_sumsq_kernel("sumsq_kernel", 0.0, 0.0, st);
-    hipLaunchKernelGGL(sumsq_kernel, dim3(OPT_BLOCKS), dim3(256), 0, st, grads, n, scratch);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(OPT_BLOCKS), dim3(256), 0, st, grads, n, scratch, step_failed);
     REFIL_LAUNCH_CHECK();
     const int blocks = (int)min((long)1024, cdivl(n, 256));
     ProfScope prof_rmsprop_kernel("rmsprop_kernel", 0.0, 0.0, st);
-    hipLaunchKernelGGL(rmsprop_kernel, dim3(blocks), dim3(256), 0, st, params, grads, sq, n, lr, alpha, eps, wd, clip, stats, scratch, step_failed);
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(blocks), dim3(256), 0, st, params, grads, sq, n, lr, alpha, eps, wd, clip, stats, scratch);
     REFIL_LAUNCH_CHECK();
     return 0;
 }

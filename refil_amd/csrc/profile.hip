@@ -13,14 +13,14 @@
 
 namespace refil {
 
-struct Rec { const char* name; double flops, bytes; hipEvent_t e0, e1; const int* rows_dev; double rows_max; hipStream_t st; };
+struct Rec { const char* name; double flops, bytes; hipEvent_t e0, e1; const int* rows_dev; double rows_max; hipStream_t st; double flops_split; };
 static bool g_on = false;
 static std::vector<Rec> g_recs;
 
 bool prof_enabled() { return g_on; }
 
-void prof_begin(const char* kernel, double flops, double bytes, hipStream_t st, const int* rows_dev, double rows_max) {
-    Rec r{kernel, flops, bytes, nullptr, nullptr, rows_dev, rows_max, st};
+void prof_begin(const char* kernel, double flops, double bytes, hipStream_t st, const int* rows_dev, double rows_max, double flops_split) {
+    Rec r{kernel, flops, bytes, nullptr, nullptr, rows_dev, rows_max, st, flops_split};
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
     hipEventRecord(r.e0, st);
     g_recs.push_back(r);
@@ -68,7 +68,7 @@ extern "C" int refil_profile_collect(refil_profile_entry* out, int max_entries) 
             if (hipMemcpy(&n, r.rows_dev, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) scale = n / r.rows_max;
             else (void)hipGetLastError();
         }
-        e.launches += 1; e.total_ms += ms; e.flops += scale * r.flops; e.bytes += scale * r.bytes;
+        e.launches += 1; e.total_ms += ms; e.flops += scale * r.flops; e.bytes += scale * r.bytes; e.flops_bf16x6 += scale * r.flops_split;
     }
     int n = 0;
     for (auto& kv : agg) {

@@ -32,10 +32,10 @@ def test_struct_sizes_match_header():
     import subprocess
     import tempfile
     from refil_amd import _lib
-    src = '#include "refil_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",' \
+    src = '#include "refil_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",' \
           'sizeof(refil_dims),sizeof(refil_param_layout),sizeof(refil_batch),sizeof(refil_debug_out),' \
           'sizeof(refil_gemm_desc),sizeof(refil_attn_desc),sizeof(refil_gru_desc),sizeof(refil_opt_hyper),' \
-          'sizeof(refil_gather_field));return 0;}\n'
+          'sizeof(refil_gather_field),sizeof(refil_profile_entry),sizeof(refil_attn_qkv_desc));return 0;}\n'
     with tempfile.TemporaryDirectory() as td:
         c = os.path.join(td, "s.c")
         open(c, "w").write(src)
@@ -43,7 +43,7 @@ def test_struct_sizes_match_header():
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
     mine = [C.sizeof(t) for t in (_lib.Dims, _lib.ParamLayout, _lib.Batch, _lib.DebugOut, _lib.GemmDesc, _lib.AttnDesc,
-                                  _lib.GruDesc, _lib.OptHyper, _lib.GatherField)]
+                                  _lib.GruDesc, _lib.OptHyper, _lib.GatherField, _lib.ProfileEntry, _lib.AttnQkvDesc)]
     assert sizes == mine
 
 

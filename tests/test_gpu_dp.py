@@ -142,6 +142,34 @@ def test_bench_two_ranks_control_flow():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 64
     assert out["roofline"]["frac"] > 0 and out["value"] > 0
+    # the self-validation of a multi-GPU line: the replicas are still bit-identical after the timed steps, the process group's own size,
+    # the first step's (all-reduced) loss
+    comm = out["comm"]
+    assert comm["replicas_identical"] is True and comm["ranks"] == 2 and len(comm["replica_checksums"]) == 2
+    assert comm["loss_step0"] is not None and comm["loss_step0"] > 0 and out["loss_step0"] == comm["loss_step0"]
+    assert out["roofline"]["bound"] in ("hbm", "mfma") and all("hbm_frac" in k and "mfma_frac" in k for k in out["kernels"])
+
+
+def test_bench_strong_scaling_loss_equals_single_process():
+    """bench.py --scaling strong over 2 ranks (one GPU, gloo) against the same global batch in one process: the first step's loss -- the
+    quantity a first multi-GPU run is checked with -- agrees to the summation order of the all-reduced stat sums."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--config", "cfg2", "--steps", "2", "--warmup", "1", "--scaling", "strong", "--global-batch", "16", "--no-cpu-baseline", "--no-profile", "--no-traffic"]
+    env = dict(os.environ, REFIL_BENCH_ONE_GPU="1", REFIL_AUTOTUNE="0")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                        env=env, cwd=root, capture_output=True, text=True, timeout=500)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, env=dict(os.environ, REFIL_AUTOTUNE="0"),
+                        cwd=root, capture_output=True, text=True, timeout=500)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    o2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
+    o1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    assert o2["comm"]["replicas_identical"] is True
+    assert abs(o2["loss_step0"] - o1["loss_step0"]) <= 1e-5 * abs(o1["loss_step0"]), (o1["loss_step0"], o2["loss_step0"])
 
 
 def _oneshot_worker(rank, world, port, q):

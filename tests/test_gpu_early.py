@@ -257,3 +257,34 @@ def test_max_t_filled_trim_trains_through_the_parent(monkeypatch):
         lb.flat_live.copy_(la.flat_live); lb.square_avg.copy_(la.square_avg); lb.flat_target.copy_(la.flat_target)
     # la kept its layout: every step after the first took the early prologue; lb's layout changed every step: none did
     assert _lib.get_stat("learner_steps") - s0 == 12 and _lib.get_stat("early_prologue_steps") - e0 == 5
+
+
+def test_out_of_band_target_writes_are_seen(monkeypatch):
+    """target_mixer.load_state_dict / target_mac.load_state between two train() calls (no _update_targets, no load_models): the target
+    parameters' own version counters change, so the next step neither runs the target forward early nor reuses the composed target maps
+    of the previous call. Learner A relies on that detection, learner B bumps the explicit epoch: bit-identical parameters."""
+    import bench
+    monkeypatch.delenv("REFIL_EARLY", raising=False)
+    monkeypatch.setenv("REFIL_EARLY_TARGET", "1")
+    W = dict(bench.CONFIGS["cfg2"])
+    dims = bench.workload_dims(W)
+    dev = torch.device("cuda", 0)
+    _, b1, la, _, _ = bench.build(dims, W["imagine"], 8, W["T"], seed=100, device=dev)
+    _, b2, lb, _, _ = bench.build(dims, W["imagine"], 8, W["T"], seed=100, device=dev)
+    la._check_flat(); lb._check_flat()
+    torch.manual_seed(5)
+    new_mix = {k: torch.randn_like(v) * 0.1 for k, v in la.target_mixer.state_dict().items()}
+    new_agent = {k: torch.randn_like(v) * 0.1 for k, v in la.target_mac.agent.state_dict().items()}
+    for i in range(8):
+        if i == 4:                                  # (steps 1-3 ran with the early target forward: the cached state is warm)
+            v0 = la._tv()
+            for l in (la, lb):
+                l.target_mixer.load_state_dict(new_mix)
+                l.target_mac.agent.load_state_dict(new_agent)
+            assert la._tv() != v0, "the target parameters were rewritten: the version must change"
+            lb._target_epoch += 1
+        la.train(b1, t_env=0, episode_num=i)
+        lb.train(b2, t_env=0, episode_num=i)
+        torch.cuda.synchronize()
+        assert torch.equal(la.flat_target, lb.flat_target)
+        assert torch.equal(la.flat_live, lb.flat_live), f"step {i}: max |d| = {(la.flat_live - lb.flat_live).abs().max().item():.3e}"
