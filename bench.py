@@ -299,7 +299,8 @@ def collect_traffic(argv_cfg, timeout_s=240, tuning=None):
             f = F[k][0] / max(F[k][1], 1) if k in F else 0.0
             w = Wr[k][0] / max(Wr[k][1], 1) if k in Wr else 0.0
             per[k] = round(2 * f + w)
-        return {"per_launch": per, "hbm_bytes_per_step": total / steps_prof}
+        launches = {k: max(F[k][1] if k in F else 0, Wr[k][1] if k in Wr else 0) for k in per}
+        return {"per_launch": per, "launches": launches, "hbm_bytes_per_step": total / steps_prof, "steps": steps_prof}
     except Exception:
         return None
     finally:
@@ -629,6 +630,10 @@ def main():
                                       "matrix-pipe products of an exact 3-way operand split (fp32-accurate: tests/test_gpu_ops.py::test_wres_split_accuracy) "
                                       "are priced at the dense bf16 peak / 6, everything else at the fp32 matrix instruction's peak; "
                                       "frac_vs_fp32_instruction = the rounds 1-4 figure, which this form may exceed"},
+                    "traffic_by_kernel_mb_per_step": None if not tr else {
+                        k: round(v * tr["launches"].get(k, 0) / tr["steps"] / 1e6, 1) for k, v in sorted(
+                            tr["per_launch"].items(), key=lambda kv: -kv[1] * tr["launches"].get(kv[0], 0))[:24]
+                        if "<" not in k or k in {x["name"] for x in ents} or k.split("<")[0] not in {x["name"].split("<")[0] for x in ents}},
                     "traffic_unit": f"HBM bytes/launch (rocprofv3 PMC 2*FETCH_SIZE+WRITE_SIZE, {traffic_src})",
                     "hbm_gb_per_step": None if hbm_step is None else round(hbm_step / 1e9, 3),
                     "hbm_gb_per_s_over_step": None if hbm_step is None else round(hbm_step / (ms_per_step * 1e-3) / 1e9, 1),

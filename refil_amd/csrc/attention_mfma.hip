@@ -612,8 +612,16 @@ __global__ __launch_bounds__(256) void attn_fwd_pipe(AttnM p) {
     }
 }
 
+#ifdef REFIL_ATTN_TIMING
+// debug build only (tools/probes/attn_sched.py): when every workgroup of the LAST attn_bwd_pipe launch started and ended (100 MHz wall clock)
+__device__ unsigned long long g_attn_dbg[4096 * 2];
+#endif
+
 template <int NJT, int NAT, int NCT, bool PRE>
 __global__ __launch_bounds__(256, (NJT <= 2 && NAT == 1) ? 2 : 1) void attn_bwd_pipe(AttnM p) {
+#ifdef REFIL_ATTN_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 4096) { g_attn_dbg[2 * blockIdx.x] = wall_clock64(); g_attn_dbg[2 * blockIdx.x + 1] = 0; }
+#endif
     using S = PipeShape<NJT, NAT, NCT>;
     constexpr int KP = S::KP, AP = S::AP, C4 = S::C4, pd = S::PD, TP = S::TP;
     constexpr int NW = (3 * AP + 63) / 64;
@@ -792,6 +800,10 @@ __global__ __launch_bounds__(256, (NJT <= 2 && NAT == 1) ? 2 : 1) void attn_bwd_
             }
         __builtin_amdgcn_wave_barrier();                   // (the next job's operands overwrite the wave's LDS tiles)
     }
+#ifdef REFIL_ATTN_TIMING
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_attn_dbg[2 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1056,3 +1068,9 @@ int attn_mfma_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts
 }
 
 }  // namespace refil
+
+#ifdef REFIL_ATTN_TIMING
+extern "C" int refil_debug_attn_timing(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(refil::g_attn_dbg), (size_t)n * 2 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -593,6 +593,19 @@ int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st) {
     const bool bt = d.flags & REFIL_GEMM_B_OUTC, rb = d.flags & REFIL_GEMM_RELU_BWD;
     int tn = (d.N % 128 == 0) ? 4 : ((d.N % 64 == 0) ? 2 : 1);
     if (rb) tn = 2;                                   // relu'(aux) (+ C) operands of a tile live in registers too
+    // chunk counts of the instantiation this shape takes (wres_launch_fwd / _bwd / _rbwd)
+    const int nc8 = cdiv(d.K, 8);
+    int ncp, npass = 1;
+    if (rb) { if (nc8 <= 8) ncp = 8; else if (nc8 <= 16) ncp = 16; else if (nc8 <= 24) { ncp = 12; npass = 2; } else { ncp = 16; npass = 2; } }
+    else if (bt) ncp = nc8 <= 4 ? 4 : (nc8 <= 8 ? 8 : 16);
+    else if (nc8 <= 16) ncp = nc8 <= 4 ? 4 : (nc8 <= 8 ? 8 : (nc8 <= 11 ? 11 : 16));
+    else { ncp = nc8 <= 24 ? 12 : 16; npass = 2; }
+    // The bf16 x 6 form keeps THREE planes of the W slice in LDS: a 128-column slice of a long reduction (the fc1 layers of wide entity
+    // feature vectors: K = 164 at 48 entities -> 153 KB + slabs) does not fit where a 64-column one does. Two narrower column blocks on the
+    // bf16 pipe beat one wide one on the fp32 instruction (cfg5: 96 -> see profiles/r05_cfg5_fc1_split.txt); the x rows' second read is an L2 hit
+    // (column blocks of the same rows share an XCD, below)
+    if (wres_split_mode() == 6 && !rb)               // (the dX-through-ReLU launches exist as 64-column tiles only)
+        while (tn > 1 && !wres_split_ok(tn, ncp, npass) && wres_split_ok(tn / 2, ncp, npass)) tn >>= 1;
     static const int n_cu = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); n = 256; }
@@ -614,12 +627,6 @@ int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st) {
     if (gy > 1 && gx >= 8) gx &= ~7;
     dim3 grid(gx, gy, gz);
     // profiler name = the kernel symbol as rocprofv3 prints it (template arguments TN,NC,NPASS,BT,EPI,ACC,RMASK,B2,IDX,SPLIT)
-    const int nc8 = cdiv(d.K, 8);
-    int ncp, npass = 1;
-    if (rb) { if (nc8 <= 8) ncp = 8; else if (nc8 <= 16) ncp = 16; else if (nc8 <= 24) { ncp = 12; npass = 2; } else { ncp = 16; npass = 2; } }
-    else if (bt) ncp = nc8 <= 4 ? 4 : (nc8 <= 8 ? 8 : 16);
-    else if (nc8 <= 16) ncp = nc8 <= 4 ? 4 : (nc8 <= 8 ? 8 : (nc8 <= 11 ? 11 : 16));
-    else { ncp = nc8 <= 24 ? 12 : 16; npass = 2; }
     static thread_local char names[64][64];
     static thread_local int n_names = 0;
     char nm[64];
