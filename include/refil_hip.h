@@ -484,7 +484,12 @@ int refil_set_overlap(int on);
  * 0 / 1, "gru_pd" 2 / 4 steps of prefetch in the 4-row recurrences. Two knobs choose the matrix instruction of the fp32 products
  * (same accuracy, different rounding): "wres_split" (projections with a reduction <= 256) and "dw_split" (weight gradients with
  * 65 .. 128-column outputs): 6 (default) = six bf16 matrix-pipe products of a 3-way operand split with fp32 accumulate,
- * 0 = v_mfma_f32_32x32x2_f32 (environment: REFIL_WRES_SPLIT / REFIL_DW_SPLIT).
+ * 0 = v_mfma_f32_32x32x2_f32 (environment: REFIL_WRES_SPLIT / REFIL_DW_SPLIT). Operand range of the split form: an Inf operand gives NaN
+ * (x - bf16(x) = Inf - Inf) where the fp32 instruction gives Inf, |x| >= 3.3962e38 rounds its leading piece to Inf; everything else,
+ * subnormals included, behaves as the fp32 instruction does (tests/test_gpu_ops.py::test_wres_split_edge_operands).
+ * "attn_qkv": which attention blocks of the learner step run in_trans + attention core as ONE launch (refil_attn_qkv_forward's kernel):
+ * bit 0 target hypernets, 1 target agent, 2 live hypernets, 3 live agent; default 15 where the shape is instantiated and "wres_split"
+ * is 6; 0 = the projection launches + attention-core launch (environment: REFIL_ATTN_QKV).
  * value -1 restores the built-in rule (or its environment switch). Process-wide. The best setting depends on the shape
  * AND on what shares the GPU, so QLearner.train measures the candidates in situ on its first call per shape
  * (refil_amd/learners/q_learner.py: _autotune). No counterpart in the reference. */

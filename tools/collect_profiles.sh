@@ -6,7 +6,7 @@
 #   3b. the same step without a tracer (HIP events of the library profiler)                 -> gpurun_out/<tag>_timeline_untraced.txt
 #   4. the bench line of every BASELINE.json config (cfgT with the CPU baseline and the PMC traffic of step 2)
 # Copy the summaries into profiles/ afterwards (tools/pmc_summarize.py folds step 2).
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -64,4 +64,7 @@ python bench.py --fresh-batches 8 --host-buffer --no-cpu-baseline --no-traffic >
 # what the fp32 matrix pipes sustain on real operand data (DVFS): bare MFMA streams, and the dominant projection on random / zero data
 hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_dvfs_probe.hip -o /tmp/mfma_dvfs_probe 2>/dev/null && /tmp/mfma_dvfs_probe > $OUT/${TAG}_mfma_dvfs_probe.txt 2>&1
 python tools/gemm_bench.py 50 dvfs 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_gemm_dvfs.txt
+# round 5: the fused in_trans + attention launch against the launches it replaces (microbench), and the step with it switched off
+(python tools/qkv_bench.py; python tools/qkv_bench.py --store --nvar 3; python tools/qkv_bench.py --dense; python tools/qkv_bench.py --cfg2) 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_qkv_bench.txt
+REFIL_ATTN_QKV=0 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_cfgT_qkv0.json 2> /dev/null
 ls -la $OUT | grep ${TAG}_
