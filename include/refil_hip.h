@@ -479,8 +479,8 @@ int refil_profile_collect(refil_profile_entry* out, int max_entries);
 int refil_set_overlap(int on);
 
 /* Schedule knobs that do not change the arithmetic of a step but its launch sizes / launch order (the summation order of the
- * split weight-gradient reductions follows the launch size: results agree to rounding): "dw4_target" / "dw_target" workgroups
- * per 4x4-tile / streamed weight-gradient launch, "dw4_min_out" smallest output taken by the 4x4-tile kernel, "compose_early"
+ * split weight-gradient reductions follows the launch size: results agree to rounding): "dw4_target" / "dw_target" / "dws_target" workgroups
+ * per 4x4-tile / streamed / bf16 x 6 weight-gradient launch, "dw4_min_out" smallest output taken by the 4x4-tile kernel, "compose_early"
  * 0 / 1, "gru_pd" 2 / 4 steps of prefetch in the 4-row recurrences. Two knobs choose the matrix instruction of the fp32 products
  * (same accuracy, different rounding): "wres_split" (projections with a reduction <= 256) and "dw_split" (weight gradients with
  * 65 .. 128-column outputs): 6 (default) = six bf16 matrix-pipe products of a 3-way operand split with fp32 accumulate,

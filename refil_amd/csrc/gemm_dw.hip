@@ -214,6 +214,10 @@ int gemm_dw_stream_launch(const refil_gemm_desc& d, hipStream_t st) {
     k.splits = d.splits; k.batch = d.batch; k.colsum = (d.flags & REFIL_GEMM_COLSUM_A) ? 1 : 0;
     k.ridx = d.row_index; k.rcount = d.row_index ? d.row_count : nullptr;
     const bool idx = d.row_index != nullptr;
+    static const bool dbg = getenv("REFIL_DEBUG_DW") != nullptr;
+    if (dbg) fprintf(stderr, "dw_stream: M=%d N=%d R=%d batch=%d splits=%d lda=%d ldb=%d amap=(%d,%d,%d) bmap=(%d,%d,%d) list=%d colsum=%d\n", d.M, d.N, d.K, d.batch,
+                     d.splits, d.lda, d.ldb, d.a_map.grp, (int)d.a_map.gstride, (int)d.a_map.off, d.b_map.grp, (int)d.b_map.gstride, (int)d.b_map.off,
+                     idx ? 1 : 0, (d.flags & REFIL_GEMM_COLSUM_A) ? 1 : 0);
     const bool wide = d.N > 64, tall = d.M >= 256;
     // wide + tall: 8 waves cover 256 x 128 of the output so that x (the B operand) is read once per workgroup -- two
     // 128-row workgroups would land on different XCDs and each fetch its own copy from HBM

@@ -278,13 +278,21 @@ __global__ __launch_bounds__(256, 1) void gemm_dw4_kernel(Dw4K p) {
 // rows go through a row map (agents' rows inside entity-major storage): physical row = r + (r / grp) (gstride - grp) + off, folded into
 // the request's offset as one extra multiply-add per request plus one v_mul_hi per row.
 constexpr int dws_units(int ti, int nj) { return (4 * ti + nj + 3) / 4; }                       // producer units (32-column chunks) per thread
-constexpr int DWS_PB = 48, DWS_D = 4;
+#ifndef DWS_DEPTH
+#define DWS_DEPTH 4
+#endif
+#ifndef DWS_PERIOD
+#define DWS_PERIOD 4
+#endif
+// ring depth D (steps of 16 rows requested ahead) and steps per trip of the main loop P (a multiple of D, even: two plane buffers)
+constexpr int DWS_PB = 48, DWS_D = DWS_DEPTH, DWS_P = DWS_PERIOD;
+static_assert(DWS_P % DWS_D == 0 && DWS_P % 2 == 0 && DWS_D >= 3, "gemm_dws_kernel: period must be an even multiple of the ring depth");
 constexpr size_t dws_smem(int ti, int nj) { return (size_t)2 * 3 * 128 * dws_units(ti, nj) * DWS_PB + 2 * 128 * ti * sizeof(float); }
 
 template <int TI, int NJ, bool IDX, bool BMAP>
 __global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
     extern __shared__ __attribute__((aligned(16))) char dws_lds[];
-    constexpr int U = dws_units(TI, NJ), NCOL = 128 * U, PB = DWS_PB, PS = NCOL * PB, BUF = 3 * PS, D = DWS_D, NG = 6 * NJ * TI;
+    constexpr int U = dws_units(TI, NJ), NCOL = 128 * U, PB = DWS_PB, PS = NCOL * PB, BUF = 3 * PS, D = DWS_D, PER = DWS_P, NG = 6 * NJ * TI;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave: provably uniform)
     const int lane31 = lane & 31, hf = lane >> 5;
     const int bz = blockIdx.z / p.splits, sp = blockIdx.z % p.splits;
@@ -292,9 +300,9 @@ __global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
     const float* __restrict__ A = p.A + bz * p.sA;
     const float* __restrict__ B = p.B + bz * p.sB;
     const int R = IDX ? *p.rcount : p.R;
-    const int chunk = cdiv(cdiv(R, p.splits), 16 * D) * 16 * D;
+    const int chunk = cdiv(cdiv(R, p.splits), 16 * PER) * 16 * PER;
     const int rbeg = min(R, sp * chunk), rend = min(R, rbeg + chunk);
-    const int nper = (rend - rbeg) / (16 * D);                 // whole ring periods (D steps of 16 rows)
+    const int nper = (rend - rbeg) / (16 * PER);                 // whole periods (P steps of 16 rows)
 
     // producer units of this thread: column chunk q = wave U + u of [A columns m0 .. m0 + 128 TI | B columns 0 .. 127]. All requests are
     // buffer loads (wave-uniform resource + 32-bit byte offset; an offset past the resource returns zeros: steps past the range are
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
 
     if (nper > 0) {
         float raw[D][U][8];
-        int ri[2][8];                                           // IDX: list entries of the step whose rows are requested next
+        int ri[D][8];                                           // IDX: list entries of the steps whose rows are requested next (set = step % D)
         // list entries / row numbers of step t for this lane's half (8 consecutive positions)
         auto load_idx = [&](int t, int* o) {
             const int off = 4 * (rbeg + 16 * t + 8 * hf);
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
         auto row_of = [&](int t, int k, const int* idx) -> unsigned { return IDX ? (unsigned)idx[k] : (unsigned)(rbeg + 16 * t + 8 * hf + k); };
         // (steps past the range are requested through an EMPTY resource: zeros come back, nothing moves -- their column sums add nothing
         // and their planes are never multiplied; t and nsteps are uniform, the choice is four scalar selects)
-        const int nsteps = nper * D;
+        const int nsteps = nper * PER;
         auto load_raw = [&](int t, int k, int u, const int* idx, float* o) {
             const rsrc_t rs = t < nsteps ? urs[u] : rs_none;
             const unsigned r = row_of(t, k, idx);
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
         float sx[4], sy[4];
         unsigned sh[4], sm[4], sl[4];
         auto split_micro = [&](auto k_, const float* rw, int u) {
-            constexpr int k = decltype(k_)::value, q = k / 5, t = k % 5;
+            constexpr int k = decltype(k_)::value, q = k % 4, t = k / 4;      // (the four pairs' chains interleaved: consecutive micro-steps are independent)
             if constexpr (t == 0) {
                 sx[q] = rw[2 * q]; sy[q] = rw[2 * q + 1];
                 if (uisa[u]) csum[u] += sx[q] + sy[q];
@@ -374,16 +382,15 @@ __global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
         };
 
         // prologue: rows of steps 0 .. D - 1 requested, step 0 split into buffer 0
-        if (IDX) load_idx(0, ri[0]);
 #pragma unroll
         for (int t = 0; t < D; ++t) {
-            if (IDX && t + 1 <= D) load_idx(t + 1, ri[(t + 1) & 1]);
+            if (IDX) load_idx(t, ri[t]);
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) load_raw(t, k, u, ri[t & 1], raw[t][u]);
+                for (int k = 0; k < 8; ++k) load_raw(t, k, u, ri[t], raw[t][u]);
         }
-        // (ri[0] now holds the entries of step D)
+        if (IDX) { load_idx(D, ri[0]); load_idx(D + 1, ri[1]); }     // (entries of steps D, D + 1: requested two steps ahead of their rows)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             static_for<20>([&](auto k_) { split_micro(k_, raw[0][u], u); });
@@ -394,9 +401,9 @@ __global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
         lds_barrier();
 
         for (int it = 0; it < nper; ++it) {
-            static_for<D>([&](auto s_) {
-                constexpr int s = decltype(s_)::value;             // step it D + s: multiplies buffer s & 1, converts step + 1 into the other
-                const int step = it * D + s;
+            static_for<PER>([&](auto s_) {
+                constexpr int s = decltype(s_)::value;             // step it PER + s: multiplies buffer s & 1, converts step + 1 into the other
+                const int step = it * PER + s;
                 // operand planes of this step
                 wr_u32x4 ap[TI][3], bp[NJ][3];
 #pragma unroll
@@ -410,19 +417,24 @@ __global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
                 // slot converted one step EARLIER (slot s: no register dependency on this step's conversions), the conversion of step + 1
                 // (slot s + 1) into the other plane buffer. Items: 1 + 8 U requests, U x (20 micro-steps + 1 write).
                 constexpr int NREQ = 8 * U, NCONV = 21 * U, NW = NREQ + NCONV + 1;
-                // (list entries: ri[s & 1] holds those of step + D -- D is even --, the other set is refilled FIRST, so that the wait for
-                // it at the head of the next step counts past this step's row requests instead of draining them)
+                // (list entries: set s holds those of step + D, requested TWO steps ago: the wait for them counts past the row requests
+                // of the two steps in between instead of draining them -- the 6-bit vmcnt holds ~2.4 steps of requests)
                 auto item = [&](auto w_) {
                     constexpr int w = decltype(w_)::value;
                     if constexpr (w == 0) {
-                        if (IDX) load_idx(step + D + 1, ri[(s + 1) & 1]);
+                        if (IDX) load_idx(step + D + 2, ri[(s + 2) % D]);
                     } else if constexpr (w <= NREQ) {
                         constexpr int u = (w - 1) / 8, k = (w - 1) % 8;
-                        load_raw(step + D, k, u, ri[s & 1], raw[s][u]);
+                        load_raw(step + D, k, u, ri[s % D], raw[s % D][u]);
                     } else {
+#ifndef DWS_DEBUG_NO_CONV
                         constexpr int c = w - NREQ - 1, u = c / 21, k = c % 21;
                         if constexpr (k < 20) split_micro(std::integral_constant<int, k>{}, raw[(s + 1) % D][u], u);
                         else write_planes(u, (s + 1) & 1);
+#else
+                        constexpr int c = w - NREQ - 1, u = c / 21, k = c % 21;      // (timing probe: the rows are consumed, nothing is converted)
+                        if constexpr (k == 0) csum[u] += raw[(s + 1) % D][u][0] + raw[(s + 1) % D][u][7];
+#endif
                     }
                 };
                 __builtin_amdgcn_sched_barrier(0);
@@ -430,8 +442,12 @@ __global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
                     constexpr int g = decltype(g_)::value, pr = g / (NJ * TI), j = (g / TI) % NJ, i = g % TI;
                     constexpr int apl = pr == 0 ? 2 : ((pr == 2 || pr == 3) ? 1 : 0);            // lo, hi, mid, mid, hi, hi
                     constexpr int bpl = pr == 0 ? 0 : (pr == 1 ? 2 : (pr == 2 ? 1 : (pr == 3 ? 0 : (pr == 4 ? 1 : 0))));
+#ifndef DWS_DEBUG_NO_MFMA
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wr_bf16x8, ap[i][apl]), __builtin_bit_cast(wr_bf16x8, bp[j][bpl]),
                                                                         acc[i][j], 0, 0, 0);
+#else
+                    if (g < TI * NJ) acc[i][j][0] += __uint_as_float(ap[i][apl][0] ^ bp[j][bpl][0]);      // (timing probe)
+#endif
                     constexpr int w0 = g * NW / NG, w1 = (g + 1) * NW / NG;
                     static_for<w1 - w0>([&](auto d_) { item(std::integral_constant<int, w0 + decltype(d_)::value>{}); });
                     __builtin_amdgcn_sched_barrier(0);
@@ -442,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void gemm_dws_kernel(Dw4K p) {
     }
 
     // ---- rows past the last whole period: the fp32 instruction on the same accumulators (2 rows per step) ----
-    const int tbeg = rbeg + nper * 16 * D;
+    const int tbeg = rbeg + nper * 16 * PER;
     for (int r2 = tbeg; r2 < rend; r2 += 2) {                    // workgroup-uniform trip count
         const int r = r2 + hf;
         const bool ok = r < rend;
@@ -550,11 +566,28 @@ bool gemm_dw4_eligible(const refil_gemm_desc& d) {
     return true;
 }
 
-// reduction splits of the dw4 kernel for an [M, N] output: one workgroup per CU (the LDS reduction buffer allows no more)
-int gemm_dw4_splits(int M, int N, int batch, long R) {
+static bool dws_eligible(const refil_gemm_desc& d);
+
+// reduction splits of a weight-gradient launch (d.M x d.N outputs, d.K rows, d.batch nets): workgroups = tiles x splits
+int gemm_dw4_splits(const refil_gemm_desc& d) {
+    const long R = d.K;
+    if (dws_eligible(d)) {
+        // the bf16 x 6 kernel: one workgroup per 128 ti x (<= 128) output tile and split. Alone on the GPU (tools/dws_bench.py) the four
+        // hypernets' K / V gradient takes 192 us on 64 workgroups, 119 on 128, 93 on 256 -- a workgroup's pace (1.1 us per 16-row step) is
+        // its own instruction stream's, not the memory system's: cache-resident operands change nothing. Inside the step the order is the
+        // other way round (tools/sweep.sh, one box, profiles/r05_dws_target.txt): 64 workgroups 1.406 ms, 128 1.415, 192 1.423, 256 1.426 --
+        // these launches run beside three other streams, what they cost the step is their CU-time, and the narrow launch leaves the other
+        // CUs to the chains. REFIL_DWS_TARGET / refil_set_tuning("dws_target") = the workgroups a launch aims for
+        const int ti = (d.M % 256) == 0 ? 2 : 1;
+        const long tiles = (long)(d.M / (128 * ti)) * d.batch;
+        static const long target = [] { const char* e = getenv("REFIL_DWS_TARGET"); return e ? atol(e) : 64L; }();
+        long splits = max(2L, (g_tuning.dws_target > 0 ? g_tuning.dws_target : target) / tiles);
+        splits = min(splits, max(2L, R / 1024));          // >= 1024 rows (16 ring periods) per workgroup
+        return (int)splits;
+    }
     int ti, tj, wmt;
-    dw4_shape(M, N, ti, tj, wmt);
-    const long tiles = (long)cdiv(M, 32 * ti * wmt) * cdiv(N, 32 * tj) * batch;
+    dw4_shape(d.M, d.N, ti, tj, wmt);
+    const long tiles = (long)cdiv(d.M, 32 * ti * wmt) * cdiv(d.N, 32 * tj) * d.batch;
     // (swept with the step's four streams running, tools/sweep.sh: 128 workgroups beat one per CU by 1 % of the step, 64 lose 5 %)
     static const long target = [] { const char* e = getenv("REFIL_DW4_TARGET"); return e ? atol(e) : 128L; }();
     long splits = max(2L, (g_tuning.dw4_target > 0 ? g_tuning.dw4_target : target) / tiles);

@@ -27,7 +27,7 @@ constexpr int RED_MULTI = 28;        // reductions one reduce_multi launch takes
 // launch needed none); the caller runs it later with reduce_multi_launch -- many reductions, one launch
 // Schedule knobs a caller may set at run time (refil_set_tuning: QLearner's first-call autotuner measures them in situ per
 // shape); -1 = the environment switch / built-in rule decides
-struct Tuning { long dw4_target = -1, dw4_min_out = -1, dw_target = -1, compose_early = -1, gru_pd = -1, wres_split = -1, dw_split = -1, attn_qkv = -1; };
+struct Tuning { long dw4_target = -1, dw4_min_out = -1, dw_target = -1, compose_early = -1, gru_pd = -1, wres_split = -1, dw_split = -1, attn_qkv = -1, dws_target = -1; };
 extern Tuning g_tuning;
 int gemm_launch(const refil_gemm_desc& d, hipStream_t st, ReduceK* defer = nullptr);
 int reduce_multi_launch(const ReduceK* r, int n, hipStream_t st);
@@ -41,7 +41,7 @@ int gemm_wres_launch(const refil_gemm_desc& d, hipStream_t st);
 // second-generation weight-gradient kernel (gemm_dw4.hip): 4 x 4 MFMA tiles per wave, in-workgroup split reduction
 bool gemm_dw4_enabled();
 bool gemm_dw4_eligible(const refil_gemm_desc& d);
-int gemm_dw4_splits(int M, int N, int batch, long R);
+int gemm_dw4_splits(const refil_gemm_desc& d);
 int gemm_dw4_launch(const refil_gemm_desc& d, hipStream_t st);
 int attn_forward_launch(const refil_attn_desc& d, hipStream_t st);
 int attn_backward_launch(const refil_attn_desc& d, hipStream_t st);

@@ -321,7 +321,7 @@ static refil_gemm_desc linear_dw(const float* dy, int lddy, const float* x, int 
     g.colsum = db; g.partial = partial; g.batch = batch;
     g.splits = 2;
     if (gemm_dw4_enabled() && gemm_dw4_eligible(g)) {            // gemm_dw4.hip: one workgroup per CU
-        g.splits = gemm_dw4_splits(N, K, batch, R);
+        g.splits = gemm_dw4_splits(g);
         while (g.splits > 2 && (long)batch * g.splits * ((long)N * K + N) > PARTIAL_FLOATS) --g.splits;
         return g;
     }
@@ -1151,6 +1151,7 @@ extern "C" int refil_set_mixer_grads_hook(refil_grads_hook hook, void* user) {
 extern "C" int refil_set_tuning(const char* name, int64_t value) {
     REFIL_CHECK(name, "refil_set_tuning: null name");
     if (!strcmp(name, "dw4_target")) g_tuning.dw4_target = value;
+    else if (!strcmp(name, "dws_target")) g_tuning.dws_target = value;
     else if (!strcmp(name, "dw4_min_out")) g_tuning.dw4_min_out = value;
     else if (!strcmp(name, "dw_target")) g_tuning.dw_target = value;
     else if (!strcmp(name, "compose_early")) g_tuning.compose_early = value;

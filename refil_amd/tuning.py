@@ -25,6 +25,9 @@ import os
 # knob -> values with parity coverage (-1 / absent = the built-in default, always covered)
 PARITY_TESTED = {
     "dw4_target": (96, 128),
+    # workgroups a bf16 x 6 weight-gradient launch (gemm_dws_kernel) aims for: 64 = the built-in default (inside the step the narrow launch wins:
+    # profiles/r05_dws_target.txt), 128 / 256 are faster alone on the GPU. Not an autotuner candidate.
+    "dws_target": (64, 128, 256),
     "gru_pd": (2, 4),
     "dw4_min_out": (2000,),
     "dw_target": (384, 512),

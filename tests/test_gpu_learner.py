@@ -285,6 +285,8 @@ PRODUCTION = {
     "ne64_split0": dict(B=16, T=40, ne=64, d=128, imagine=True, tuned=dict(wres_split=0)),
     # dw_split: the same choice for the weight gradients with 65 .. 128-column outputs (gemm_dw4.hip: gemm_dws_kernel, the default);
     # 0 = the fp32-instruction kernels everywhere. "fp32": both knobs at 0 = round 3's arithmetic.
+    "cfgT_dws128": dict(B=32, T=80, ne=32, d=128, imagine=True, tuned=dict(dws_target=128)),
+    "cfgT_dws256_tuned": dict(B=32, T=80, ne=32, d=128, imagine=True, tuned=dict(dws_target=256, dw4_target=96, gru_pd=2)),
     "cfgT_dw0": dict(B=32, T=80, ne=32, d=128, imagine=True, tuned=dict(dw_split=0)),
     "cfgT_fp32": dict(B=32, T=80, ne=32, d=128, imagine=True, tuned=dict(wres_split=0, dw_split=0)),
     "cfgT_fp32_tuned": dict(B=32, T=80, ne=32, d=128, imagine=True, tuned=dict(wres_split=0, dw_split=0, dw4_target=96, gru_pd=2)),

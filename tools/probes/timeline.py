@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="cfgT")
 ap.add_argument("--out", default="gpurun_out/timeline.txt")
+ap.add_argument("--batch", type=int, default=0, help="episodes instead of the config's (small shards)")
 a = ap.parse_args()
 raw = a.out + ".raw"
 os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
@@ -19,6 +20,8 @@ import bench  # noqa: E402
 from refil_amd import _lib  # noqa: E402
 
 W = dict(bench.CONFIGS[a.config])
+if a.batch:
+    W["B"] = a.batch
 dims = bench.workload_dims(W)
 args, batch, learner, data, _ = bench.build(dims, W["imagine"], W["B"], W["T"], seed=100, device=torch.device("cuda:0"))
 for i in range(8):
