@@ -622,6 +622,10 @@ static bool dws_on() {
     return env;
 }
 static bool dws_eligible(const refil_gemm_desc& d) {
+    // (outputs 65 .. 128 columns wide. Two column tiles -- 33 .. 64 columns: the recurrent / tail layers, cfg2's in_trans -- were built and
+    // measured in round 5 (tools/dws_bench.py "thin" shapes, profiles/r05_dws_target.txt): 12 TI MFMAs per step leave the launch bound by
+    // the 3-way split, and the fp32-instruction kernels are as fast or faster there: 256 x 52: 48 vs 58 us on 64 workgroups but 49 vs 39
+    // on 128; 128 x 64 x 4 nets: 51 vs 44 us)
     if (!dws_on() || d.N > 128 || d.N <= 64 || (d.M % 128) != 0 || d.a_map.grp) return false;
     if (d.K < 4096) return false;                                        // (short reductions: all prologue)
     if (((long)d.K + 64) * d.lda * 4 >= (1L << 31) || ((long)d.K + 64) * d.ldb * 4 >= (1L << 31) || d.lda >= (1 << 22) || d.ldb >= (1 << 22)) return false;

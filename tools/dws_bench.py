@@ -44,7 +44,8 @@ def main():
     lsta, cnta = lsta.to(dev), torch.tensor([na_], dtype=torch.int32, device=dev)
     print(f"entity rows {R}, listed {n}; agent rows {ra}, listed {na_}")
     shapes = [("K/V, 4 hypernets", 256, 128, 4, R, lst, cnt, n, None), ("K/V, agent", 256, 128, 1, R, lst, cnt, n, None),
-              ("Q, 4 hypernets", 128, 128, 4, ra, lsta, cnta, na_, (na, ne, 0)), ("Q, agent", 128, 128, 1, ra, lsta, cnta, na_, (na, ne, 0))]
+              ("Q, 4 hypernets", 128, 128, 4, ra, lsta, cnta, na_, (na, ne, 0)), ("Q, agent", 128, 128, 1, ra, lsta, cnta, na_, (na, ne, 0)),
+              ("thin 128x64", 128, 64, 1, R, lst, cnt, n, None), ("thin 256x52", 256, 52, 1, R, lst, cnt, n, None), ("thin 128x64 x4", 128, 64, 4, R, lst, cnt, n, None)]
     for name, N, K, batch, rows, l, c, nl, bmap in shapes:
         if a.only not in name:
             continue
