@@ -112,8 +112,23 @@ __device__ inline float dpp_rot(float v) {
 __device__ inline float quad4_sum(float v) { v += dpp_rot<0x124>(v); v += dpp_rot<0x128>(v); return v; }   // row_ror:4, row_ror:8
 __device__ inline float pick4(const f32x4& v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3])); }
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
+#ifndef GRU_NACC
+#define GRU_NACC 2          // accumulators per gate in the 4-row forward recurrence (2 or 4)
+#endif
+#ifndef GRU_NACC_BWD
+#define GRU_NACC_BWD 3      // accumulators of the 4-row backward recurrence (3, 6 or 12)
+#endif
 
 // VALU: the recurrent product on the vector ALUs (packed FMAs) instead of the matrix cores -- see gru_valu_enabled()
+#ifdef REFIL_GRU_TIMING
+// debug build only (REFIL_EXTRA_FLAGS=-DREFIL_GRU_TIMING; tools/probes/gru_timing.py): cycle sums (shader clock) of a step's phases in
+// workgroup 0 / wave 0 of the LAST gru_fwd4 launch: [0] wait for the step's inputs, [1] LDS reads + recurrent product, [2] k-slice sums,
+// [3] gates, [4] stores + barrier, [5] steps
+__device__ unsigned long long g_gru_dbg[8];
+#define GRU_STAMP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); dbg_acc[i] += t_ - dbg_t; dbg_t = t_; } while (0)
+#else
+#define GRU_STAMP(i) do { } while (0)
+#endif
 template <bool SAVE, int GH, bool VALU = false, int PD_ = REFIL_GRU_PD>
 __global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
     constexpr int HP = GH + 4, KS = VALU ? GH : GH / 4;    // KS: reduction indices per lane (MFMA: per k slice)
@@ -181,6 +196,9 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
     // loads re-read the last step, its stores carry the dropped offset) and skips the arithmetic behind a uniform branch that
     // contains none -- one back edge, no exit from the middle of the unrolled body, every path with the same operation count:
     // the s_waitcnt in front of a slot's use then counts exactly the PD steps of loads and stores issued behind it.
+#ifdef REFIL_GRU_TIMING
+    unsigned long long dbg_acc[6] = {0, 0, 0, 0, 0, 0}, dbg_t = __builtin_readcyclecounter();
+#endif
     for (int t0 = 0; t0 < tend; t0 += PD) {
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
@@ -194,6 +212,7 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
             float gcur[3];
 #pragma unroll
             for (int g = 0; g < 3; ++g) { asm volatile("" : "+v"(gq[u][g])); gcur[g] = gq[u][g]; }
+            GRU_STAMP(0);
             {   // refill the slot with step t + PD (past the end: the last step again -- no branch around the loads)
                 const unsigned o = go + (unsigned)min(t + PD, tlast) * gi_step;
 #pragma unroll
@@ -231,20 +250,31 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
                     const float4 v = *reinterpret_cast<const float4*>(hb + j * HP + KS * ks + 4 * s4);
                     a[4 * s4] = v.x; a[4 * s4 + 1] = v.y; a[4 * s4 + 2] = v.z; a[4 * s4 + 3] = v.w;
                 }
-                f32x4 acc[3][2];                           // two accumulators per gate: dependent chains half as long
+                f32x4 acc[3][GRU_NACC];                    // GRU_NACC accumulators per gate: dependent chains that much shorter
 #pragma unroll
-                for (int g = 0; g < 3; ++g) { acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = acc[g][0]; }
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int i = 0; i < GRU_NACC; ++i) acc[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < KS; ++s)
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) acc[g][s & 1] = MFMA4(a[s], bw[g][s], acc[g][s & 1]);
+                    for (int g = 0; g < 3; ++g) acc[g][s % GRU_NACC] = MFMA4(a[s], bw[g][s], acc[g][s % GRU_NACC]);
+#ifdef REFIL_GRU_TIMING
+                asm volatile("s_nop 0" :: "v"(acc[0][0][0]), "v"(acc[1][GRU_NACC - 1][0]), "v"(acc[2][0][0]), "v"(acc[2][GRU_NACC - 1][0]));
+                GRU_STAMP(1);
+#endif
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
                     f32x4 v = acc[g][0] + acc[g][1];
+                    if (GRU_NACC == 4) v = v + (acc[g][2] + acc[g][3]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = quad4_sum(v[i]);
                     pre[g] = pick4(v, ks);                 // (row ks, column c): the element this lane owns
                 }
+#ifdef REFIL_GRU_TIMING
+                asm volatile("s_nop 0" :: "v"(pre[0]), "v"(pre[1]), "v"(pre[2]));
+                GRU_STAMP(2);
+#endif
                 }
                 rg = fast_sigmoid(gcur[0] + pre[0] + bhr);
                 zg = fast_sigmoid(gcur[1] + pre[1] + bhz);
@@ -252,14 +282,26 @@ __global__ __launch_bounds__(4 * GH) void gru_fwd4_kernel(GruK2 p2) {
                 ng = fast_tanh(gcur[2] + rg * gh);
                 hold = (1.0f - zg) * ng + zg * hold;
                 hn[ks * HP + c] = hold;
+#ifdef REFIL_GRU_TIMING
+                asm volatile("s_nop 0" :: "v"(hold));
+                GRU_STAMP(3);
+#endif
             }
             const unsigned hod = live ? ho : GRU_BUF_DROP, sod = live ? so : GRU_BUF_DROP;
             stb32(rs_h, hod, hold);
             if (SAVE) { stb32(rs_r, sod, rg); stb32(rs_z, sod, zg); stb32(rs_n, sod, ng); stb32(rs_g, sod, gh); }   // (no save buffers: zero-sized resources)
             ho += st_step; so += st_step;
             if (live) lds_barrier();                       // (not __syncthreads(): its fence would drain the step's stores -- common.h)
+#ifdef REFIL_GRU_TIMING
+            GRU_STAMP(4);
+            dbg_acc[5] += live ? 1 : 0;
+#endif
         }
     }
+#ifdef REFIL_GRU_TIMING
+    if (blockIdx.x == 0 && tid == 0)
+        for (int i = 0; i < 6; ++i) g_gru_dbg[i] = dbg_acc[i];
+#endif
 }
 
 // BPTT on 4-row tiles: lane (cg, ks, j) owns element (row ks, column c) of the tile. For t = T1-1 .. 0:
@@ -372,18 +414,21 @@ __global__ __launch_bounds__(4 * GH) void gru_bwd4_kernel(GruK p) {
                     const f32x2 t2 = (b0 + b1) + (b2 + b3);
                     carry = dhz + (t2[0] + t2[1]);
                 } else {
-                f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+                f32x4 aa[GRU_NACC_BWD];
+#pragma unroll
+                for (int i = 0; i < GRU_NACC_BWD; ++i) aa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < KS; s += 12) {
                     const float4 v0 = *reinterpret_cast<const float4*>(gw + j * GP + KS * ks + s);
                     const float4 v1 = *reinterpret_cast<const float4*>(gw + j * GP + KS * ks + s + 4);
                     const float4 v2 = *reinterpret_cast<const float4*>(gw + j * GP + KS * ks + s + 8);
-                    a0 = MFMA4(v0.x, bw[s], a0); a1 = MFMA4(v0.y, bw[s + 1], a1); a2 = MFMA4(v0.z, bw[s + 2], a2);
-                    a0 = MFMA4(v0.w, bw[s + 3], a0); a1 = MFMA4(v1.x, bw[s + 4], a1); a2 = MFMA4(v1.y, bw[s + 5], a2);
-                    a0 = MFMA4(v1.z, bw[s + 6], a0); a1 = MFMA4(v1.w, bw[s + 7], a1); a2 = MFMA4(v2.x, bw[s + 8], a2);
-                    a0 = MFMA4(v2.y, bw[s + 9], a0); a1 = MFMA4(v2.z, bw[s + 10], a1); a2 = MFMA4(v2.w, bw[s + 11], a2);
+                    const float av[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) aa[(s + e) % GRU_NACC_BWD] = MFMA4(av[e], bw[s + e], aa[(s + e) % GRU_NACC_BWD]);
                 }
-                f32x4 v = a0 + a1 + a2;
+                f32x4 v = aa[0] + aa[1] + aa[2];
+                if (GRU_NACC_BWD >= 6) v = v + (aa[3 % GRU_NACC_BWD] + aa[4 % GRU_NACC_BWD] + aa[5 % GRU_NACC_BWD]);
+                if (GRU_NACC_BWD == 12) v = v + ((aa[6 % GRU_NACC_BWD] + aa[7 % GRU_NACC_BWD] + aa[8 % GRU_NACC_BWD]) + (aa[9 % GRU_NACC_BWD] + aa[10 % GRU_NACC_BWD] + aa[11 % GRU_NACC_BWD]));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = quad4_sum(v[i]);
                 carry = dhz + pick4(v, ks);
@@ -797,3 +842,9 @@ extern "C" int refil_gru_backward(const refil_gru_desc* desc, void* stream) {
     REFIL_CHECK(desc, "refil_gru_backward: null desc");
     return refil::gru_backward_launch(*desc, (hipStream_t)stream);
 }
+
+#ifdef REFIL_GRU_TIMING
+extern "C" int refil_debug_gru_timing(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(refil::g_gru_dbg), 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
