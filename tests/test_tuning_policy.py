@@ -29,6 +29,9 @@ def test_only_parity_tested_values_pass():
     assert tuning.parse_env("dw4_target=96,gru_pd=2") == {"dw4_target": 96, "gru_pd": 2}
     with pytest.raises(ValueError):
         tuning.parse_env("dw4_target=77")
+    assert tuning.check({"dws_target": 128}) and tuning.check({"dws_target": 64, "attn_qkv": 3})
+    with pytest.raises(ValueError):
+        tuning.check({"dws_target": 32})                     # (measured, slower, and without a parity case)
     for knob, values in tuning.CANDIDATES:                   # what the tuner tries is inside what the tests cover
         assert all(v in tuning.PARITY_TESTED[knob] for v in values)
 
