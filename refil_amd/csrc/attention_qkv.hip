@@ -548,6 +548,25 @@ bool attn_qkv_supported(int ne, int na, int heads, int hd) {
     return ne >= 1 && ne <= 32 && na >= 1 && na <= 16 && na <= ne && (hd == 16 || hd == 32) && (w == 64 || w == 128);
 }
 
+// workgroup grid of a launch over `nslices` (net, head) slices and R rows, and its LDS bytes: the W planes, the live-step prefix sums
+// [B + 2], the workgroup's row table [waves][jobs per wave]
+static size_t qkv_grid_lds(int nslices, long R, int T1, size_t plane_bytes, int& xcd_groups, int& ngroups) {
+    const int cus = qkv_device_cus();
+    if (cus % 8 == 0 && (cus / 8) % nslices == 0) { xcd_groups = cus / 8 / nslices; ngroups = 8 * xcd_groups; }
+    else { xcd_groups = 0; ngroups = cus / nslices > 0 ? cus / nslices : 1; }
+    const long live_groups = (R + QKV_WAVES - 1) / QKV_WAVES;
+    if (!xcd_groups && ngroups > live_groups) ngroups = (int)live_groups;
+    const long wstride = (long)ngroups * QKV_WAVES, maxjobs = (R + wstride - 1) / wstride;
+    return plane_bytes + ((size_t)(R / T1) + 2 + QKV_WAVES * maxjobs) * 4;
+}
+// does a launch of `nnets` blocks over R rows fit the LDS (the row table grows with R / workgroups per slice)? The learner asks before it
+// decides for the fused launch; beyond it the separate projection / attention launches run
+bool attn_qkv_fits(int heads, int hd, long R, int T1, int nnets) {
+    int xg = 0, ng = 0;
+    const size_t planes = 3 * qkv_plane_bytes(hd / 16, heads * hd / 32);
+    return T1 > 0 && nnets >= 1 && nnets <= QKV_MAX_NETS && qkv_grid_lds(nnets * heads, R, T1, planes, xg, ng) <= 160 * 1024;
+}
+
 template <int NJT, int NCT, int NKS>
 static int qkv_launch_x(QkvM& k, hipStream_t st) {
     bool store = false;
@@ -557,17 +576,10 @@ static int qkv_launch_x(QkvM& k, hipStream_t st) {
     if (!raised[store]) { REFIL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); raised[store] = true; }
     // one workgroup per CU; workgroup -> (slice, row group). XCD-aware: the heads (and nets) that read the same x rows sit on one
     // XCD (workgroups are dealt round-robin to the 8 XCDs by block id), so a row comes from HBM once and from that XCD's L2 afterwards
-    const int cus = qkv_device_cus();
     k.nslices = k.nnets * k.heads;
-    if (cus % 8 == 0 && (cus / 8) % k.nslices == 0) { k.xcd_groups = cus / 8 / k.nslices; k.ngroups = 8 * k.xcd_groups; }
-    else { k.xcd_groups = 0; k.ngroups = cus / k.nslices > 0 ? cus / k.nslices : 1; }
     static const int stagger_env = [] { const char* e = getenv("REFIL_QKV_STAGGER"); return e ? atoi(e) : 0; }();
     k.stagger = stagger_env;
-    const long live_groups = ((long)k.R + QKV_WAVES - 1) / QKV_WAVES;
-    if (!k.xcd_groups && k.ngroups > live_groups) k.ngroups = (int)live_groups;
-    // LDS: the W planes, the live-step prefix sums [B + 2], the workgroup's row table [waves][jobs per wave]
-    const long wstride = (long)k.ngroups * QKV_WAVES, maxjobs = (k.R + wstride - 1) / wstride;
-    const size_t lds = 3 * qkv_plane_bytes(NCT, NKS) + ((size_t)(k.R / k.T1) + 2 + QKV_WAVES * maxjobs) * 4;
+    const size_t lds = qkv_grid_lds(k.nslices, k.R, k.T1, 3 * qkv_plane_bytes(NCT, NKS), k.xcd_groups, k.ngroups);
     if (lds > 160 * 1024) return -1;
     hipLaunchKernelGGL(kern, dim3(k.nslices * k.ngroups), dim3(64 * QKV_WAVES), lds, st, k);
     REFIL_LAUNCH_CHECK();

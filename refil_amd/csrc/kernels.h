@@ -225,6 +225,7 @@ int attn_mfma_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts
 // attention_qkv.hip: in_trans + attention core in one launch (the layer's input and weight instead of Q / K / V); -1 = shape not instantiated
 struct AttnQkvSrc { const float* X; const float* W; float* Qo; float* Ko; float* Vo; };
 bool attn_qkv_supported(int ne, int na, int heads, int hd);
+bool attn_qkv_fits(int heads, int hd, long R, int T1, int nnets);
 int attn_qkv_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts, const AttnQkvSrc* src, int n, int ldx, hipStream_t st,
                           float* nact, int zero_dead);
 

@@ -1083,6 +1083,11 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
         if (!c.mwords || d.pooling || !gemm_wres_split_on()) q = 0;          // (the fused launch is the bf16 x 6 arithmetic of the projections)
         if (!attn_qkv_supported(d.ne, d.na, d.heads, d.hyp / d.heads)) q &= ~(QKV_T_HYPER | QKV_L_HYPER);
         if (d.agent_ff || !attn_qkv_supported(d.ne, d.na, d.heads, d.d / d.heads)) q &= ~(QKV_T_AGENT | QKV_L_AGENT);
+        // (the fused launch keeps a row table in LDS that grows with B T1 / workgroups per slice: beyond ~350 k rows per 16 slices the
+        // separate launches take over -- sized for the widest launch a chain can issue: both hypernet sets merged, both agents)
+        const long Rq = (long)d.B * d.T1;
+        if ((q & (QKV_T_HYPER | QKV_L_HYPER)) && !attn_qkv_fits(d.heads, d.hyp / d.heads, Rq, d.T1, 2 * sizes_of(d).nets)) q &= ~(QKV_T_HYPER | QKV_L_HYPER);
+        if ((q & (QKV_T_AGENT | QKV_L_AGENT)) && !attn_qkv_fits(d.heads, d.d / d.heads, Rq, d.T1, 2)) q &= ~(QKV_T_AGENT | QKV_L_AGENT);
         c.qkv = q;
     }
     REFIL_CHECK(batch->entities && batch->entity_mask, "refil: batch.entities / entity_mask missing");
