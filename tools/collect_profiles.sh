@@ -67,4 +67,8 @@ python tools/gemm_bench.py 50 dvfs 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_gemm_
 # round 5: the fused in_trans + attention launch against the launches it replaces (microbench), and the step with it switched off
 (python tools/qkv_bench.py; python tools/qkv_bench.py --store --nvar 3; python tools/qkv_bench.py --dense; python tools/qkv_bench.py --cfg2) 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_qkv_bench.txt
 REFIL_ATTN_QKV=0 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_cfgT_qkv0.json 2> /dev/null
+# round 5: the bf16 x 6 weight gradient alone on the GPU for a sweep of workgroup counts (profiles/r05_dws_target.txt part 1), the host's
+# cost of one call on an idle queue
+python tools/dws_bench.py --splits 16,32,64,128 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_dws_bench.txt
+for a in "cfg2" "cfgT 4" "cfgT"; do python tools/probes/host_cost.py $a 2>&1 | grep -v amdgpu.ids; done > $OUT/${TAG}_host_cost.txt
 ls -la $OUT | grep ${TAG}_
