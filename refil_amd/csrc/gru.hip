@@ -74,7 +74,8 @@ __device__ inline void stb32(rsrc_t rs, unsigned byte_off, float v) {
 // A recurrence is a chain of T1 dependent steps per row tile; what bounds it is the time of ONE step on ONE CU, not
 // throughput (128 sixteen-row tiles leave half of the 256 CUs idle). With v_mfma_f32_16x16x4_f32 a tile cannot have fewer
 // than 16 rows, i.e. 48 MFMAs (1536 cycles) per step and SIMD. v_mfma_f32_4x4x1_16b_f32 computes 16 independent 4x4 outer
-// products per instruction at the same FLOP rate (8 cycles; tools/probes/mfma4_probe.hip: layout and rate), so a tile of FOUR
+// products per instruction at the same FLOP rate (8 cycles of the pipe with two waves feeding a SIMD -- tools/probes/mfma4_probe.hip: layout
+// and rate; ONE wave issues them every ~20 cycles whatever the accumulator chains: profiles/r05_gru_timing.txt), so a tile of FOUR
 // rows works: block (cg, ks) = lane / 4 of wave w multiplies the 4 rows (A: lane % 4 = row) by the 4 hidden columns
 // 16 w + 4 cg + (lane % 4) over the k slice ks (a quarter of the reduction: the k order is free), 3 gates x H/4 instructions
 // = 384 cycles per step instead of 1536, on four times as many workgroups (every CU gets two). The four k-slice partials of
