@@ -101,6 +101,68 @@ __global__ __launch_bounds__(256) void gru_bf16_steps(const float* __restrict__ 
     }
 }
 
+// Variant 2: the PRODUCER splits. The lane that computes h_t(row q, col) splits that one value and writes its three bf16 pieces into
+// LDS planes [plane][row][H] (2-byte stores); the A fragments of the next step are then three 16-byte LDS reads per k-step with no
+// arithmetic between the barrier and the first MFMA (variant 1 splits 16 values per lane on the dependent path: ~90 operations).
+constexpr int HPB = H + 8;                          // bf16 elements per plane row (144 bytes: the four rows start in different banks)
+__global__ __launch_bounds__(256) void gru_bf16_steps_planes(const float* __restrict__ gi, const float* __restrict__ w_hh, const float* __restrict__ b_hh,
+                                                             float* __restrict__ hs, int T) {
+    __shared__ __attribute__((aligned(16))) unsigned short hpl[2][3][ROWS * HPB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c16 = lane & 15, q = lane >> 4;
+    const int col = 16 * wave + c16;
+    u32x4 bw[3][2][3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float* wr = w_hh + (long)(g * H + col) * H + 32 * ks + 8 * q;
+            split8(*reinterpret_cast<const float4*>(wr), *reinterpret_cast<const float4*>(wr + 4), bw[g][ks]);
+        }
+    const float bhr = b_hh[col], bhz = b_hh[H + col], bhn = b_hh[2 * H + col];
+    const long tile = blockIdx.x;
+    const float* gt = gi + tile * T * ROWS * 3 * H + (long)q * 3 * H + col;
+    float* ht = hs + tile * (T + 1) * ROWS * H + (long)q * H + col;
+    float hold = ht[0];
+    auto publish = [&](int buf, float x) {
+        unsigned h, m, l;
+        split2(x, 0.f, h, m, l);                    // (the low half of each packed pair is x's piece)
+        hpl[buf][0][q * HPB + col] = (unsigned short)h; hpl[buf][1][q * HPB + col] = (unsigned short)m; hpl[buf][2][q * HPB + col] = (unsigned short)l;
+    };
+    publish(0, hold);
+    __syncthreads();
+    float g0 = gt[0], g1 = gt[H], g2 = gt[2 * H];
+    for (int t = 0; t < T; ++t) {
+        const int tn = t + 1 < T ? t + 1 : t;
+        const float n0 = gt[(long)tn * ROWS * 3 * H], n1 = gt[(long)tn * ROWS * 3 * H + H], n2 = gt[(long)tn * ROWS * 3 * H + 2 * H];
+        u32x4 ah[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                ah[ks][pl] = *reinterpret_cast<const u32x4*>(&hpl[t & 1][pl][(c16 >> 2) * HPB + 32 * ks + 8 * q]);
+        f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[ks][PA[p]]), __builtin_bit_cast(bf16x8, bw[g][ks][PB[p]]), acc[g], 0, 0, 0);
+        const float rg = sigm(g0 + acc[0][0] + bhr);
+        const float zg = sigm(g1 + acc[1][0] + bhz);
+        const float ng = tanh_(g2 + rg * (acc[2][0] + bhn));
+        hold = (1.0f - zg) * ng + zg * hold;
+        publish((t + 1) & 1, hold);
+        ht[(long)(t + 1) * ROWS * H] = hold;
+        g0 = n0; g1 = n1; g2 = n2;
+        __syncthreads();
+    }
+}
+
+typedef void (*kern_t)(const float*, const float*, const float*, float*, int);
+
 int main() {
     const int T = 81, tiles = 384, check_tiles = 4;
     std::vector<float> gi((size_t)tiles * T * ROWS * 3 * H), whh(3 * H * H), bhh(3 * H), hs((size_t)tiles * (T + 1) * ROWS * H, 0.f);
@@ -115,7 +177,12 @@ int main() {
     hipMalloc(&dgi, gi.size() * 4); hipMalloc(&dw, whh.size() * 4); hipMalloc(&db, bhh.size() * 4); hipMalloc(&dhs, hs.size() * 4);
     hipMemcpy(dgi, gi.data(), gi.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dw, whh.data(), whh.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(db, bhh.data(), bhh.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dhs, hs.data(), hs.size() * 4, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(gru_bf16_steps, dim3(tiles), dim3(256), 0, 0, dgi, dw, db, dhs, T);
+    const kern_t kerns[2] = {gru_bf16_steps, gru_bf16_steps_planes};
+    const char* names[2] = {"consumer splits h (16 values per lane and step)", "producer splits h (bf16 planes in LDS)"};
+    for (int kv = 0; kv < 2; ++kv) {
+    printf("-- %s\n", names[kv]);
+    hipMemcpy(dhs, hs.data(), hs.size() * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(kerns[kv], dim3(tiles), dim3(256), 0, 0, dgi, dw, db, dhs, T);
     hipDeviceSynchronize();
     std::vector<float> out(hs.size());
     hipMemcpy(out.data(), dhs, hs.size() * 4, hipMemcpyDeviceToHost);
@@ -146,9 +213,10 @@ int main() {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipMemcpy(dhs, hs.data(), hs.size() * 4, hipMemcpyHostToDevice);
     hipEventRecord(e0);
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(gru_bf16_steps, dim3(tiles), dim3(256), 0, 0, dgi, dw, db, dhs, T);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kerns[kv], dim3(tiles), dim3(256), 0, 0, dgi, dw, db, dhs, T);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%d tiles x %d steps: %.1f us per launch = %.0f ns per dependent step (gru_fwd4_kernel at this shape: 92.9 us = 1146 ns)\n", tiles, T, ms * 100.0, ms * 1e5 / T);
+    }
     return 0;
 }
