@@ -1,0 +1,369 @@
+// TEST INFRASTRUCTURE -- CPU wavefront emulator runtime behind tests/emu/include/hip/hip_runtime.h (see the header there).
+//
+// Execution model. A kernel launch runs at once (streams are host-order queues). Its workgroups are handed to a pool of OS threads
+// (EMU_THREADS, default 16; a grid of up to that many workgroups is co-resident, which is what the kernels with inter-workgroup spin
+// barriers are promised by the occupancy gate they apply: emulated device = EMU_CUS compute units x 2 workgroups). Inside a
+// workgroup every lane is a fiber with its own stack; lanes run one at a time until they reach a wave collective (MFMA, shuffle, DPP,
+// permute, readlane, ballot, wave_barrier ...), a workgroup barrier, a spin-wait yield, or the end of the kernel. A collective completes
+// when every lane of the wave that has not exited has arrived; if no lane of the workgroup can run and a wave is only partly there
+// (a collective in divergent control flow), the lanes that did arrive complete it among themselves, as the hardware's EXEC mask would.
+#include <hip/hip_runtime.h>
+
+#include <pthread.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <time.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+extern "C" void emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size emu_switch, .-emu_switch
+)");
+
+namespace emu {
+
+thread_local const LaneIds* cur_lane_ids = nullptr;
+thread_local const BlockIds* cur_block_ids = nullptr;
+thread_local void* cur_dyn_smem = nullptr;
+
+namespace {
+
+constexpr size_t STACK_BYTES = 512 * 1024;
+enum State { READY, WAIT_WAVE, WAIT_BLOCK, SPIN, DONE };
+
+struct Wave {
+    alignas(64) unsigned char tab[2][64 * XS];
+    unsigned long long arrived = 0, alive = 0, part[2] = {0, 0};
+    int gen = 0;
+};
+struct Block;
+struct Lane {
+    LaneIds ids;
+    void* sp = nullptr;
+    State state = READY;
+    int wait_gen = 0;
+    Wave* wave = nullptr;
+    Block* blk = nullptr;
+};
+struct Block {
+    BlockIds ids;
+    std::vector<Lane> lanes;
+    std::vector<Wave> waves;
+    int bar_gen = 0, bar_count = 0, alive = 0;
+    void* sched_sp = nullptr;
+    KernelCall call;
+    const char* name;
+};
+
+thread_local Lane* cur = nullptr;
+thread_local Block* cur_blk = nullptr;
+thread_local std::vector<char*>* stacks = nullptr;
+
+char* stack_of(size_t i) {
+    if (!stacks) stacks = new std::vector<char*>();
+    while (stacks->size() <= i) {
+        void* p = mmap(nullptr, STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (p == MAP_FAILED) { perror("emu: mmap of a lane stack"); abort(); }
+        stacks->push_back(static_cast<char*>(p));
+    }
+    return (*stacks)[i];
+}
+
+void to_sched() {
+    Lane* me = cur;
+    emu_switch(&me->sp, cur_blk->sched_sp);
+}
+void complete(Wave* w) {
+    w->part[w->gen & 1] = w->arrived;
+    w->arrived = 0;
+    w->gen++;
+}
+
+[[noreturn]] void lane_exit() {
+    Lane* me = cur;
+    Block* b = cur_blk;
+    Wave* w = me->wave;
+    me->state = DONE;
+    w->alive &= ~(1ull << me->ids.lane);
+    if (w->arrived && w->arrived == w->alive) complete(w);
+    b->alive--;
+    if (b->bar_count > 0 && b->bar_count == b->alive) { b->bar_count = 0; b->bar_gen++; }
+    to_sched();
+    abort();
+}
+extern "C" void emu_lane_entry() {
+    cur_blk->call.run(cur_blk->call.ctx);
+    lane_exit();
+}
+
+void run_block(Block& b) {
+    cur_blk = &b;
+    cur_block_ids = &b.ids;
+    const size_t n = b.lanes.size();
+    for (size_t i = 0; i < n; ++i) {
+        char* top = stack_of(i) + STACK_BYTES;
+        void** sp = reinterpret_cast<void**>(top);
+        *--sp = nullptr;                                        // (keeps the entry's frame 16-byte aligned as after a call)
+        *--sp = reinterpret_cast<void*>(&emu_lane_entry);
+        for (int r = 0; r < 6; ++r) *--sp = nullptr;
+        b.lanes[i].sp = sp;
+    }
+    long idle_spins = 0;
+    while (b.alive > 0) {
+        bool progressed = false, spinning = false;
+        for (size_t i = 0; i < n; ++i) {
+            Lane& l = b.lanes[i];
+            bool run = false;
+            switch (l.state) {
+                case READY: run = true; break;
+                case WAIT_WAVE: run = l.wave->gen != l.wait_gen; break;
+                case WAIT_BLOCK: run = b.bar_gen != l.wait_gen; break;
+                case SPIN: run = true; spinning = true; break;
+                case DONE: break;
+            }
+            if (!run) continue;
+            if (l.state != SPIN) progressed = true;
+            l.state = READY;
+            cur = &l;
+            cur_lane_ids = &l.ids;
+            emu_switch(&b.sched_sp, l.sp);
+        }
+        if (progressed) { idle_spins = 0; continue; }
+        if (b.alive == 0) break;
+        if (spinning && ++idle_spins < 2000000) { sched_yield(); continue; }
+        // nobody can run: a collective reached by part of a wave completes among the lanes that are there
+        bool released = false;
+        for (Wave& w : b.waves)
+            if (w.arrived) { complete(&w); released = true; }
+        if (released) continue;
+        if (b.bar_count > 0) { b.bar_count = 0; b.bar_gen++; continue; }
+        fprintf(stderr, "emu: deadlock in kernel %s, workgroup %u (%d lanes alive)\n", b.name, b.ids.bid.x, b.alive);
+        abort();
+    }
+    cur = nullptr;
+    cur_lane_ids = nullptr;
+}
+
+// ---- worker pool ----
+struct Job {
+    dim3 grid, block;
+    size_t shmem;
+    const char* name;
+    KernelCall call;
+    std::atomic<long> next{0};
+    long total = 0;
+};
+// (never destroyed: the detached workers wait on them until the process ends)
+std::mutex& mu = *new std::mutex();
+std::condition_variable& cv_work = *new std::condition_variable();
+std::condition_variable& cv_done = *new std::condition_variable();
+Job* job = nullptr;
+long job_seq = 0;
+int workers_busy = 0;
+std::vector<std::thread>* pool = nullptr;
+
+void work_on(Job& j) {
+    const unsigned nthreads = j.block.x * j.block.y * j.block.z;
+    const unsigned nwaves = (nthreads + 63) / 64;
+    char* dyn = nullptr;
+    if (j.shmem) {
+        if (posix_memalign(reinterpret_cast<void**>(&dyn), 64, j.shmem)) abort();
+    }
+    for (;;) {
+        const long idx = j.next.fetch_add(1);
+        if (idx >= j.total) break;
+        Block b;
+        b.ids.gdim = Idx{j.grid.x, j.grid.y, j.grid.z};
+        b.ids.bdim = Idx{j.block.x, j.block.y, j.block.z};
+        b.ids.bid = Idx{(unsigned)(idx % j.grid.x), (unsigned)(idx / j.grid.x % j.grid.y), (unsigned)(idx / ((long)j.grid.x * j.grid.y))};
+        b.call = j.call;
+        b.name = j.name;
+        b.lanes.resize(nthreads);
+        b.waves.resize(nwaves);
+        b.alive = (int)nthreads;
+        for (unsigned t = 0; t < nthreads; ++t) {
+            Lane& l = b.lanes[t];
+            l.ids.tid = Idx{t % j.block.x, t / j.block.x % j.block.y, t / (j.block.x * j.block.y)};
+            l.ids.lane = (int)(t & 63);
+            l.wave = &b.waves[t >> 6];
+            l.blk = &b;
+            l.wave->alive |= 1ull << (t & 63);
+        }
+        if (dyn) memset(dyn, 0xFF, j.shmem);          // LDS holds garbage at the start of a workgroup: NaNs / -1 here
+        cur_dyn_smem = dyn;
+        run_block(b);
+    }
+    free(dyn);
+}
+
+void worker_main() {
+    long seen = 0;
+    for (;;) {
+        Job* j;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_work.wait(lk, [&] { return job_seq != seen; });
+            seen = job_seq;
+            j = job;
+        }
+        if (j) work_on(*j);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (--workers_busy == 0) cv_done.notify_all();
+        }
+    }
+}
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+int pool_size() {
+    static const int n = [] { int v = env_int("EMU_THREADS", 16); return v < 1 ? 1 : v; }();
+    return n;
+}
+std::mutex& launch_mu = *new std::mutex();     // one launch at a time (the host API is callable from several threads)
+
+}  // namespace
+
+Xchg xchg(const void* mine, int nbytes) {
+    Lane* me = cur;
+    Wave* w = me->wave;
+    const int par = w->gen & 1, mygen = w->gen;
+    if (nbytes) memcpy(w->tab[par] + XS * me->ids.lane, mine, (size_t)nbytes);
+    w->arrived |= 1ull << me->ids.lane;
+    if (w->arrived == w->alive) complete(w);
+    else { me->state = WAIT_WAVE; me->wait_gen = mygen; to_sched(); }
+    return Xchg{w->tab[par], w->part[par]};
+}
+void wave_sync() { xchg(nullptr, 0); }
+void block_sync() {
+    Lane* me = cur;
+    Block* b = cur_blk;
+    const int mygen = b->bar_gen;
+    if (++b->bar_count == b->alive) { b->bar_count = 0; b->bar_gen++; }
+    else { me->state = WAIT_BLOCK; me->wait_gen = mygen; to_sched(); }
+}
+void lane_yield() {
+    cur->state = SPIN;
+    to_sched();
+}
+unsigned long long wall_ticks() {
+    // 100 MHz on the hardware; the emulator is orders of magnitude slower than the GPU, so its clock runs 1000 x slower too
+    // (the kernels' wall-clock time-outs then scale with the emulation)
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ((unsigned long long)ts.tv_sec * 1000000000ull + (unsigned long long)ts.tv_nsec) / 10000ull;
+}
+
+void launch(dim3 grid, dim3 block, size_t shmem, const char* name, KernelCall call) {
+    std::lock_guard<std::mutex> lg(launch_mu);
+    Job j;
+    j.grid = grid; j.block = block; j.shmem = shmem; j.name = name; j.call = call;
+    j.total = (long)grid.x * grid.y * grid.z;
+    if (j.total <= 0 || block.x * block.y * block.z == 0) return;
+    if (env_int("EMU_TRACE", 0)) fprintf(stderr, "emu: launch %s grid %u x %u x %u block %u lds %zu\n", name, grid.x, grid.y, grid.z, block.x * block.y * block.z, shmem);
+    const int n = pool_size();
+    std::unique_lock<std::mutex> lk(mu);
+    if (!pool) {
+        pool = new std::vector<std::thread>();
+        for (int i = 0; i < n; ++i) { pool->emplace_back(worker_main); pool->back().detach(); }
+    }
+    job = &j;
+    workers_busy = n;
+    ++job_seq;
+    cv_work.notify_all();
+    cv_done.wait(lk, [&] { return workers_busy == 0; });
+    job = nullptr;
+}
+
+}  // namespace emu
+
+// ---------------------------------------------------------------- host API ----
+struct emuStream { int id; };
+struct emuEvent { double t_ms; };
+
+static double now_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+const char* hipGetErrorString(hipError_t e) {
+    switch (e) {
+        case hipSuccess: return "success";
+        case hipErrorInvalidValue: return "invalid value";
+        case hipErrorOutOfMemory: return "out of memory";
+        case hipErrorNotSupported: return "not supported by the CPU emulator";
+        default: return "error";
+    }
+}
+hipError_t hipGetLastError() { return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) {
+    if (a == hipDeviceAttributeMultiprocessorCount) { *v = emu::env_int("EMU_CUS", 8); return hipSuccess; }
+    *v = 0;
+    return hipErrorInvalidValue;
+}
+hipError_t hipDeviceSynchronize() { return hipSuccess; }
+hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
+hipError_t hipMalloc(void** p, size_t n) { return posix_memalign(p, 256, n ? n : 1) ? hipErrorOutOfMemory : hipSuccess; }
+hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyFromSymbol(void* d, const void* sym, size_t n, size_t off, hipMemcpyKind) { memcpy(d, static_cast<const char*>(sym) + off, n); return hipSuccess; }
+hipError_t hipMemcpyToSymbol(const void* sym, const void* s, size_t n, size_t off, hipMemcpyKind) { memcpy(const_cast<char*>(static_cast<const char*>(sym)) + off, s, n); return hipSuccess; }
+hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t) {
+    for (size_t r = 0; r < height; ++r) memmove(static_cast<char*>(d) + r * dpitch, static_cast<const char*>(s) + r * spitch, width);
+    return hipSuccess;
+}
+hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static std::atomic<int> g_stream_ids{1};
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = new emuStream{g_stream_ids++}; return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreateWithPriority(s, 0, 0); }
+hipError_t hipStreamCreate(hipStream_t* s) { return hipStreamCreateWithPriority(s, 0, 0); }
+hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st) { *st = hipStreamCaptureStatusNone; return hipSuccess; }
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { if (g) *g = nullptr; return hipErrorNotSupported; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = new emuEvent{0.0}; return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { if (e) e->t_ms = now_ms(); return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t_ms - a->t_ms); return hipSuccess; }
+hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t*, void*) { return hipErrorNotSupported; }
+hipError_t hipIpcOpenMemHandle(void**, hipIpcMemHandle_t, unsigned) { return hipErrorNotSupported; }
+hipError_t hipIpcCloseMemHandle(void*) { return hipErrorNotSupported; }

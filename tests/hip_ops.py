@@ -121,8 +121,9 @@ def gru_backward(d):
 def attn_mask_words(d: AttnDesc, na):
     """precompute the mask words of desc's variants (refil_attn_mask_words) and attach them to the desc"""
     na_pad = (na + 15) // 16 * 16
-    mw = torch.zeros(d.R * d.nvar * na_pad, dtype=torch.int64, device="cuda")
-    rb = torch.zeros(d.R * 3, dtype=torch.int64, device="cuda")
+    dev = d._keep[0].device       # (the tensors the desc was built from: the GPU in the gpu tier, host memory under tests/emu)
+    mw = torch.zeros(d.R * d.nvar * na_pad, dtype=torch.int64, device=dev)
+    rb = torch.zeros(d.R * 3, dtype=torch.int64, device=dev)
     check(lib().refil_attn_mask_words(C.byref(d), ptr(mw), ptr(rb), _stream()), "refil_attn_mask_words")
     d._keep += [mw, rb]
     d.mask_words, d.row_bits, d.mask_words_nvar = mw.data_ptr(), rb.data_ptr(), d.nvar
