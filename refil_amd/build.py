@@ -14,7 +14,7 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "refil_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "refil_hip.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -35,7 +35,12 @@ def build(force=False, verbose=True):
         if p.returncode != 0:
             sys.stderr.write(out.decode())
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
+    # The dynamic symbol table holds the C ABI of include/refil_hip.h and nothing else: the launchers' C++ symbols and the kernel
+    # handles stay local to the library (a linker version script: no object file is compiled differently for it).
+    vs = os.path.join(HERE, "build", "exports.map")
+    with open(vs, "w") as fh:
+        fh.write("{ global: refil_*; local: *; };\n")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={vs}", "-o", LIB] + objs + ["-ldl"]
     subprocess.check_call(cmd)
     if verbose:
         print(f"built {LIB}")

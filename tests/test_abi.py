@@ -27,6 +27,16 @@ def test_header_symbols_are_exported(L):
         assert hasattr(L, name), f"{name} declared in refil_hip.h but not exported"
 
 
+def test_library_exports_the_header_and_nothing_else(L):
+    """The dynamic symbol table of librefil_hip.so is exactly the C ABI of include/refil_hip.h (no C++ launcher symbols, no kernel
+    handles: refil_amd/build.py links with a version script)."""
+    import subprocess
+    from refil_amd import _lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    assert exported == set(_lib.EXPORTS), sorted(exported ^ set(_lib.EXPORTS))[:20]
+
+
 def test_struct_sizes_match_header():
     """ctypes mirrors must have the C sizes (computed from the header with the host compiler)."""
     import subprocess
