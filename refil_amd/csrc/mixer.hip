@@ -497,7 +497,11 @@ int lists_launch(const ListArgs& a0, hipStream_t st) {
     }
     if (a.err_host && *reinterpret_cast<const volatile int*>(a.err_host)) {
         set_error("refil: the one-launch row-list kernel timed out waiting for its grid (the device could not hold all %d workgroups "
-                  "at once: partitioned / CU-masked GPU?). The row lists of that step were incomplete; set REFIL_LISTS_FUSED=0", a.B * nsub);
+                  "at once: partitioned / CU-masked GPU?). The row lists of that step were incomplete and the optimiser dropped every step "
+                  "since (parameters untouched, grad_norm NaN); set REFIL_LISTS_FUSED=0", a.B * nsub);
+        // reported once: the word is cleared with the report, so that optimiser calls after it (this learner's under another setting, or
+        // any other refil_clip_rmsprop_step on the device) are no longer dropped for a failure their caller has been told about
+        *const_cast<volatile int*>(reinterpret_cast<const volatile int*>(a.err_host)) = 0;
         return 3;
     }
     // (other streams' workgroups occupy CUs too, but they drain: the exchange only needs this grid to FIT)

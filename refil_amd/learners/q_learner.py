@@ -139,17 +139,22 @@ class QLearner:
     _APPLIED = [None]
     _MEASURED = [0]      # buckets measured by this process
 
+    _NAMED = [frozenset()]   # non-candidate knobs the applied setting named: set by this module, so this module takes them back
+
     @staticmethod
     def _apply_tuning(setting):
         if QLearner._APPLIED[0] == setting:
             return
         # the autotuner's own knobs are reset to their defaults when the setting does not name them; the arithmetic-form / kernel-choice
-        # knobs (wres_split, dw_split, attn_qkv: never candidates) are left as the caller set them -- refil_set_tuning("wres_split", 0)
-        # before the first train() is the documented way to compare with earlier builds
+        # knobs (wres_split, dw_split, attn_qkv, dws_target: never candidates) are left as the CALLER set them -- refil_set_tuning("wres_split", 0)
+        # before the first train() is the documented way to compare with earlier builds -- unless an earlier setting
+        # of THIS module named one (a REFIL_AUTOTUNE string or cache entry with attn_qkv=0): that value goes back to the default with
+        # the setting that brought it, so tuning_chosen() is what the library runs
         own = {k for k, _ in tuning.CANDIDATES}
         for k in tuning.PARITY_TESTED:
-            if k in own or k in setting:
+            if k in own or k in setting or k in QLearner._NAMED[0]:
                 _lib.check(_lib.lib().refil_set_tuning(k.encode(), int(setting.get(k, -1))), "refil_set_tuning")
+        QLearner._NAMED[0] = frozenset(k for k in setting if k not in own)
         QLearner._APPLIED[0] = dict(setting)
 
     def tuning_chosen(self):
@@ -305,6 +310,7 @@ class QLearner:
         if t_env - self.log_stats_t >= args.learner_log_interval:
             st = self.grads[self._n:].tolist()                         # the only host sync, on log steps
             msum = st[_lib.STAT_MASK_SUM]
+            self._check_step_not_dropped(st)
             q_loss = st[_lib.STAT_TD_SQ] / msum
             if dims.imagine:
                 im_loss = st[_lib.STAT_IM_TD_SQ] / msum
@@ -321,6 +327,18 @@ class QLearner:
             self.logger.log_stat("q_taken_mean", st[_lib.STAT_QTOT_SUM] / (msum * args.n_agents), t_env)    # :194 quirk kept
             self.logger.log_stat("target_mean", st[_lib.STAT_TARGET_SUM] / (msum * args.n_agents), t_env)
             self.log_stats_t = t_env
+
+    @staticmethod
+    def _check_step_not_dropped(st):
+        """The optimiser kernel drops a step whose one-launch row lists timed out (mixer.hip: rmsprop_kernel): parameters untouched,
+        grad_norm = NaN while the loss statistics of the forward pass are finite. Training on with frozen parameters would be silent
+        -- the reference cannot get there --, so the log step that sees that signature raises. (A NaN loss is a diverged run, which the
+        reference logs as it is: not this.)"""
+        import math
+        if math.isnan(st[_lib.STAT_GRAD_NORM]) and math.isfinite(st[_lib.STAT_TD_SQ]) and math.isfinite(st[_lib.STAT_MASK_SUM]):
+            raise RuntimeError("refil: the optimiser dropped this step (grad_norm is NaN, the loss is finite): the one-launch row-list "
+                               "kernel timed out waiting for its grid on this device (partitioned / CU-masked GPU, or another process "
+                               "holding the compute units). Set REFIL_LISTS_FUSED=0; the next library call reports the same.")
 
     def _tv(self):
         """refil_batch.target_version: changes whenever the target parameters may have been rewritten -- the explicit counter of

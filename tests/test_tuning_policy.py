@@ -45,3 +45,44 @@ def test_autotune_is_opt_in(monkeypatch):
     assert tuning.mode() == "measure"
     monkeypatch.setenv("REFIL_AUTOTUNE", "gru_pd=2")
     assert tuning.mode() == {"gru_pd": 2}
+
+
+def test_apply_tuning_takes_back_the_non_candidate_knobs_it_set(monkeypatch):
+    """A setting that names a non-candidate knob (attn_qkv, wres_split ...: REFIL_AUTOTUNE strings / cache entries may) must not leak
+    it into later settings that do not; a value the CALLER set through refil_set_tuning is never touched."""
+    from refil_amd.learners.q_learner import QLearner
+    state, calls = {}, []
+
+    class FakeLib:
+        def refil_set_tuning(self, name, value):
+            calls.append((name.decode(), int(value)))
+            state[name.decode()] = int(value)
+            return 0
+
+    monkeypatch.setattr(_lib, "lib", lambda: FakeLib())
+    monkeypatch.setattr(QLearner, "_APPLIED", [None])
+    monkeypatch.setattr(QLearner, "_NAMED", [frozenset()])
+    state["wres_split"] = 0                                   # the caller's own choice, made before the first train()
+    QLearner._apply_tuning({"gru_pd": 2, "attn_qkv": 0})
+    assert state["attn_qkv"] == 0 and state["gru_pd"] == 2 and state["wres_split"] == 0
+    assert "wres_split" not in [k for k, _ in calls]
+    QLearner._apply_tuning({"dw4_target": 96})                # another bucket's setting: it does not name attn_qkv
+    assert state["attn_qkv"] == -1 and state["gru_pd"] == -1 and state["dw4_target"] == 96 and state["wres_split"] == 0
+    assert QLearner._APPLIED[0] == {"dw4_target": 96}
+    calls.clear()
+    QLearner._apply_tuning({"dw4_target": 96})                # unchanged: no calls
+    assert calls == []
+    QLearner._apply_tuning({})
+    assert "attn_qkv" not in [k for k, _ in calls] and state["dw4_target"] == -1
+
+
+def test_a_dropped_step_is_not_logged_as_training():
+    """grad_norm NaN with a finite loss = the optimiser kernel dropped the step (row-list time-out): the log step raises; a NaN loss is
+    a diverged run and is logged like the reference logs it."""
+    from refil_amd.learners.q_learner import QLearner
+    st = [100.0, 3.0, 2.0, 5.0, 1.0, 1.0, float("nan"), 0.0]
+    with pytest.raises(RuntimeError, match="REFIL_LISTS_FUSED=0"):
+        QLearner._check_step_not_dropped(st)
+    st[_lib.STAT_GRAD_NORM] = 0.7
+    QLearner._check_step_not_dropped(st)
+    QLearner._check_step_not_dropped([100.0, float("nan"), 2.0, 5.0, 1.0, 1.0, float("nan"), 0.0])
