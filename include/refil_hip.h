@@ -412,7 +412,12 @@ int refil_attn_backward(const refil_attn_desc* desc, void* stream);
  *   W_in   in_trans.weight [3w, w] row-major: rows [0,w) -> query, [w,2w) -> key, [2w,3w) -> value
  *   q_out / k_out / v_out   optional (NULL: not stored): the projections in the layouts of attn.Q / K / V; rows of dead queries /
  *          keys are not written
- * Shapes: n_entities <= 32, n_agents <= 16, head dim 16 or 32, w = 64 or 128; others return an error. */
+ * Row bits: an agent that row_bits marks alive as a QUERY is treated as alive as a key as well (its x row is read -- the query is
+ * projected from the registers the key and the value come from --, its K / V rows are written when stores are asked for, and it is
+ * attended to unless the mask words exclude it). The learner's row lists only produce rows where query-alive implies key-alive.
+ * Shapes: n_entities <= 48, n_agents <= 32, head dim 16 or 32, w = 64 or 128; with more than 32 entities or more than 16 agents:
+ * head dim 32 at w = 128 or head dim 16 at w = 64. Others, and launches whose row table does not fit the LDS
+ * (about B*T1 > 350 k rows per 16 (net, head) slices on 256 CUs), return an error. */
 typedef struct refil_attn_qkv_desc {
     refil_attn_desc attn;
     const float* X; int32_t ldx;
@@ -489,7 +494,10 @@ int refil_set_overlap(int on);
  * subnormals included, behaves as the fp32 instruction does (tests/test_gpu_ops.py::test_wres_split_edge_operands).
  * "attn_qkv": which attention blocks of the learner step run in_trans + attention core as ONE launch (refil_attn_qkv_forward's kernel):
  * bit 0 target hypernets, 1 target agent, 2 live hypernets, 3 live agent; default 15 where the shape is instantiated and "wres_split"
- * is 6; 0 = the projection launches + attention-core launch (environment: REFIL_ATTN_QKV).
+ * is 6; 0 = the projection launches + attention-core launch (environment: REFIL_ATTN_QKV). "attn_qkv_wide": 1 = the same for more than
+ * 32 entities / 16 agents (three key tiles / two agent tiles, one wave per SIMD; parity-tested, not yet timed: default 0; environment:
+ * REFIL_ATTN_QKV_WIDE). "qkv_lds_budget": bytes of LDS a fused launch may use (default / <= 0: 160 KB) -- lowers the point at which the
+ * learner falls back to the separate launches (tests).
  * value -1 restores the built-in rule (or its environment switch). Process-wide. The best setting depends on the shape
  * AND on what shares the GPU, so QLearner.train measures the candidates in situ on its first call per shape
  * (refil_amd/learners/q_learner.py: _autotune). No counterpart in the reference. */

@@ -21,6 +21,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <type_traits>
+
 #include "bufops.h"
 #include "common.h"
 #include "kernels.h"
@@ -39,7 +42,8 @@ __device__ unsigned long long g_qkv_dbg[4096 * 8];
 #endif
 
 constexpr int QKV_MAX_NETS = 8;
-constexpr int QKV_WAVES = 8;
+// waves per workgroup of an instantiation: a third key tile or a second agent tile needs more than the 256 registers of two waves per SIMD
+constexpr int qkv_waves(int njt, int nat) { return njt + nat >= 4 ? 4 : 8; }
 struct QkvNet {
     const float* X;      // layer input of this net: entity row (r ne + j) at X + (r ne + j) ldx
     const float* W;      // in_trans.weight [3w][w], rows [0,w) -> Q, [w,2w) -> K, [2w,3w) -> V
@@ -128,8 +132,10 @@ __device__ inline void split8(const float4& a0, const float4& a1, wr_bf16x8 (&o)
 // LDS bytes of an instantiation: the W planes [3 planes][3 matrices (q, k, v)][NCT][NKS][1 KB: lane (c = lane % 16, k group = lane / 16) -> 8 bf16]
 constexpr size_t qkv_plane_bytes(int nct, int nks) { return (size_t)3 * nct * nks * 1024; }
 
-// NJT: 16-entity key tiles (ne <= 16 NJT), NCT: 16-channel tiles of a head (hd = 16 NCT), NKS: 32-index steps of the reduction (w = 32 NKS).
-// n_agents <= 16.
+// NJT: 16-entity key tiles (ne <= 16 NJT, up to 3), NCT: 16-channel tiles of a head (hd = 16 NCT), NKS: 32-index steps of the reduction
+// (w = 32 NKS), NAT: 16-agent query tiles (n_agents <= 16 NAT <= 16 NJT; the agents are the first entities, so the queries of agent tile
+// `at` are projected from the x registers of key tile `at`). Three key tiles hold 96 registers of x rows in flight alone: the forms with a
+// third key tile or a second agent tile run four waves per workgroup (one per SIMD, 512 registers), the others eight.
 //
 // Key compaction (NJT > 1). Only the entities that are alive as keys (row_bits: ~kv_dead) take part: they are packed, in entity order,
 // into the first `cnt` tile positions -- the agents, being the first entities, land in tile 0 -- and the dead ones behind them, so a row
@@ -139,11 +145,16 @@ constexpr size_t qkv_plane_bytes(int nct, int nks) { return (size_t)3 * nct * nk
 // ev = the entities at positions 16 jt + 4 (lane / 16) + reg (their mask bits, their V rows). Attention is invariant under a permutation of
 // the keys; per agent it is a relabelling of the output rows.
 // STORE: some net of the launch keeps its Q / K / V (a launch of target nets only carries no store code at all).
-template <int NJT, int NCT, int NKS, bool STORE>
-__global__ __launch_bounds__(64 * QKV_WAVES, 1) void attn_qkv_fwd(QkvM p) {
+template <int NJT, int NCT, int NKS, bool STORE, int NAT>
+__global__ __launch_bounds__(64 * qkv_waves(NJT, NAT), 1) void attn_qkv_fwd(QkvM p) {
     extern __shared__ __attribute__((aligned(16))) char smem_q[];
+    static_assert(NAT >= 1 && NAT <= NJT && NJT <= 3, "agent tiles are key tiles");
+    constexpr int QKV_WAVES = qkv_waves(NJT, NAT);
+    constexpr int NAP = 16 * NAT;                // agents per row of the mask-word table (refil_attn_mask_words pads to 16)
     constexpr size_t PSZ = qkv_plane_bytes(NCT, NKS);
     constexpr bool COMPACT = NJT > 1;
+    // (<= 32 entities: the low half of the 64-bit mask word is all a lane needs)
+    using mw_t = std::conditional_t<(NJT > 2), unsigned long long, unsigned>;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, q = lane >> 4;
 #ifdef REFIL_QKV_TIMING
@@ -268,7 +279,7 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void attn_qkv_fwd(QkvM p) {
     // operands in flight for the NEXT job: the x rows of every key tile and reduction step (refilled in place, step by step, as the
     // current job's projection consumes them: a whole projection + core of flight time), the mask words of this lane's agent
     float4 xr[NKS][NJT][2];
-    unsigned nw[3];                             // (<= 32 entities: the low half of the 64-bit mask word)
+    mw_t nw[3][NAT];
     auto fetch_x = [&](auto s_, const QRow& ri, const QMap& fm, bool valid) {
         constexpr int s = decltype(s_)::value;
         const rsrc_t rx = mk_rsrc(n.X + (long)ri.r * p.ne * p.ldx, valid ? ((long)(p.ne - 1) * p.ldx + w) * 4 : 0);
@@ -283,14 +294,24 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void attn_qkv_fwd(QkvM p) {
         }
     };
     auto fetch_w = [&](const QRow& ri, const QMap& fm, bool valid) {
-        const rsrc_t rw = mk_rsrc(p.mwords + (long)ri.r * p.mw_nvar * 16, valid ? (long)p.mw_nvar * 16 * 8 : 0);
+        const rsrc_t rw = mk_rsrc(p.mwords + (long)ri.r * p.mw_nvar * NAP, valid ? (long)p.mw_nvar * NAP * 8 : 0);
 #pragma unroll
-        for (int v = 0; v < 3; ++v) nw[v] = __builtin_amdgcn_raw_buffer_load_b32(rw, v < p.nvar && fm.ek[0] < 16 ? (v * 16 + fm.ek[0]) * 8 : BUF_OOB, 0, 0);
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int at = 0; at < NAT; ++at) {
+                const int off = v < p.nvar && fm.ek[at] < NAP ? (v * NAP + fm.ek[at]) * 8 : BUF_OOB;
+                if constexpr (NJT > 2) nw[v][at] = buf_ld_u64(rw, off);
+                else nw[v][at] = __builtin_amdgcn_raw_buffer_load_b32(rw, off, 0, 0);
+            }
     };
     // the row words of a row travel one job ahead of its operand fetch, in a vector register (lane l holds word l % 3)
     auto words_of = [&](int r) -> unsigned long long { return p.rbits[3 * (long)r + lane % 3]; };
     auto take = [&](int r, unsigned long long wv) -> QRow {
         QRow x; x.r = r; x.kdw = q_readlane64(wv, 0); x.qdw = q_readlane64(wv, 1); x.emtw = q_readlane64(wv, 2);
+        // an agent that is alive as a query needs its x row (Q^T comes from the same registers as K^T / V) whatever row_bits says about
+        // it as a key: it is fetched, projected and -- unless its mask bits exclude it -- attended to like a live key
+        // (refil_hip.h, refil_attn_qkv_forward; the learner's row lists never produce such a row)
+        x.kdw &= x.qdw | ~na_bits;
         return x;
     };
     int r_next = row_of(0);
@@ -315,7 +336,7 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void attn_qkv_fwd(QkvM p) {
     // memory operations a job issues BEHIND the fetch of its successor (all buffer stores, the missing ones out of range): the prologue
     // issues as many dropped stores behind the first fetch, so that the operand wait at the top of the loop is the same count on both
     // ways into it (vmcnt retires in order and the compiler takes the smaller count of the incoming paths: attention_mfma.hip)
-    constexpr int NSTORE = 1 + (STORE ? NCT * NJT + NCT + 4 * NJT * NCT : 0) + 6 * NCT + NCT;
+    constexpr int NSTORE = 1 + (STORE ? NCT * NJT + NCT * NAT + 4 * NJT * NCT : 0) + 6 * NCT * NAT + NCT;
     {
         const rsrc_t none = mk_rsrc(n.O, 0);
 #pragma unroll
@@ -326,24 +347,31 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void attn_qkv_fwd(QkvM p) {
         const QRow crow = frow;
         const QMap cmap = fmap;
         const int r = crow.r;
-        // this lane's agent: the entity at tile position lane % 16 of tile 0, when it is an agent that is alive as a query
-        const int agent = cmap.ek[0];
-        const bool agent_ok = l15 < cmap.cnt && agent < p.na && !((crow.qdw >> agent) & 1ull);
-        unsigned cw[3];
+        // this lane's agent of agent tile `at`: the entity at tile position lane % 16 of key tile `at`, when it is an agent that is alive
+        // as a query (the live agents, being the first entities, sit in the first positions: all of them within the first NAT tiles)
+        bool agent_ok[NAT];
+        mw_t cw[3][NAT];
 #pragma unroll
-        for (int v = 0; v < 3; ++v) cw[v] = agent_ok ? nw[v] : ~0u;
+        for (int at = 0; at < NAT; ++at) {
+            const int agent = cmap.ek[at];
+            agent_ok[at] = 16 * at + l15 < cmap.cnt && agent < p.na && !((crow.qdw >> agent) & 1ull);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) cw[v][at] = agent_ok[at] ? nw[v][at] : ~(mw_t)0;
+        }
         // the row after this one: its words arrived a job ago; its key permutation is built beside the projection below
         frow = take(r_next, w_next);
         fmap = map_of(frow.kdw);
         r_next = row_of(k + 2); w_next = words_of(r_next);
         const bool nvalid = k + 1 < njobs;
         auto job = [&](auto nt_) {
-            constexpr int NT = decltype(nt_)::value;        // key tiles this row needs (1 or NJT)
+            constexpr int NT = decltype(nt_)::value;        // key tiles this row needs (1 .. NJT)
+            constexpr int NA = NAT < NT ? NAT : NT;         // agent tiles this row needs (its live agents sit within its live positions)
             // ---- in_trans of this row's entities for this head: K^T, V, Q^T tiles on the bf16 pipe (fp32 accumulate) ----
-            f32x4 Kt[NCT][NT], Vv[NT][NCT], Qt[NCT];
+            f32x4 Kt[NCT][NT], Vv[NT][NCT], Qt[NCT][NA];
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
-                Qt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int at = 0; at < NA; ++at) Qt[ct][at] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int jt = 0; jt < NT; ++jt) { Kt[ct][jt] = f32x4{0.f, 0.f, 0.f, 0.f}; Vv[jt][ct] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             }
@@ -383,7 +411,9 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void attn_qkv_fwd(QkvM p) {
 #pragma unroll
                     for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct) Qt[ct] = MFMA16B(wq[ct][PA[pr]], xs[0][PB[pr]], Qt[ct]);
+                        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                            for (int at = 0; at < NA; ++at) Qt[ct][at] = MFMA16B(wq[ct][PA[pr]], xs[at][PB[pr]], Qt[ct][at]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 wr_bf16x8 wv[NCT][3];
@@ -405,7 +435,9 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void attn_qkv_fwd(QkvM p) {
             // queries of inactive agents and of tile positions that hold no agent enter the core as zeros (refil_attn_desc.q_dead)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
-                if (!agent_ok) Qt[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int at = 0; at < NA; ++at)
+                    if (!agent_ok[at]) Qt[ct][at] = f32x4{0.f, 0.f, 0.f, 0.f};
             // (nact[r] by lane 0 of the row's first slice)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)__popcll(~crow.emtw & na_bits)),
                                                   mk_rsrc(p.nact + r, p.nact && slice == 0 ? 4 : 0), lane == 0 ? 0 : BUF_OOB, 0, 0);
@@ -423,7 +455,9 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void attn_qkv_fwd(QkvM p) {
                         const bool ok = jt < NT && (COMPACT ? 16 * jt + l15 < cmap.cnt : (key < p.ne && !((crow.kdw >> key) & 1ull)));
                         buf_st4(rk, ok ? (key * p.ldkv + c) * 4 : BUF_OOB, Kt[ct][jt < NT ? jt : 0]);
                     }
-                    buf_st4(rq, agent_ok ? (agent * p.ldq + c) * 4 : BUF_OOB, Qt[ct]);
+#pragma unroll
+                    for (int at = 0; at < NAT; ++at)
+                        buf_st4(rq, at < NA && agent_ok[at] ? (cmap.ek[at] * p.ldq + c) * 4 : BUF_OOB, Qt[ct][at < NA ? at : 0]);
                     __builtin_amdgcn_sched_barrier(0);      // (address arithmetic stays beside its store: the compiler otherwise computes all of them first)
                 }
 #pragma unroll
@@ -443,74 +477,83 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void attn_qkv_fwd(QkvM p) {
             }
             QKV_TICK(t_st)
             // ---- attention core (attention_mfma.hip: attn_fwd_pipe), operands straight from the accumulators ----
-            f32x4 stt[NT];
+            f32x4 stt[NT][NA];
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct)
+                for (int at = 0; at < NA; ++at) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) acc = MFMA16F(Kt[ct][jt][reg], Qt[ct][reg], acc);
-                stt[jt] = acc;
-            }
+                    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) acc = MFMA16F(Kt[ct][jt][reg], Qt[ct][at][reg], acc);
+                    stt[jt][at] = acc;
+                }
             f32x4 osum[NCT];
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) osum[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
-                f32x4 o[NCT];
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
                 const bool on = v < n.nvar;
-                if (on) {
-                    // masked softmax over the keys of this lane's agent: bit (entity at the tile position) of the agent's mask word
-                    f32x4 pt[NT];
-                    float mx = -INFINITY;
-#pragma unroll
-                    for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) {
-                            const bool masked = (cw[v] >> ((cmap.evp[jt] >> (8 * reg)) & 31)) & 1u;
-                            const float x = masked ? -INFINITY : stt[jt][reg] * inv_scale;      // attention.py:54-57
-                            pt[jt][reg] = x;
-                            mx = fmaxf(mx, x);
-                        }
-                    mx = q_cross4_max(mx);
-                    float sum = 0.f;
-#pragma unroll
-                    for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) {
-                            const float e = pt[jt][reg] == -INFINITY ? 0.f : __expf(pt[jt][reg] - mx);
-                            pt[jt][reg] = e;
-                            sum += e;
-                        }
-                    sum = q_cross4_sum(sum);
-                    const float inv = sum > 0.f ? __builtin_amdgcn_rcpf(sum) : 0.f;     // fully masked row -> 0 (attention.py:60 NaN -> 0)
-#pragma unroll
-                    for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) pt[jt][reg] *= inv;
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) {
-#pragma unroll
-                        for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-                            for (int reg = 0; reg < 4; ++reg) o[ct] = MFMA16F(Vv[jt][ct][reg], pt[jt][reg], o[ct]);
-                        if (n.sum_agents) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) osum[ct][e] += q_group16_sum(o[ct][e]);
-                        }
-                    }
-                }
                 // rows of the agents that are alive as queries; the others (inactive agents) read as exact zeros: the layer's post-mask
                 // (attention.py:66-67) for the callers that ask for it (zero_dead), a defined value for the rest (refil_attn_desc: discarded)
                 const rsrc_t ro = mk_rsrc(n.O + v * p.sO + (long)r * p.na * p.ldo, on && !n.sum_agents ? (long)p.na * p.ldo * 4 : 0);
-                const bool zrow = l15 < p.na && ((crow.qdw >> l15) & 1ull);
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) {
-                    buf_st4(ro, agent_ok ? (agent * p.ldo + col0 + 16 * ct + 4 * q) * 4 : BUF_OOB, o[ct]);
-                    buf_st4(ro, zrow ? (l15 * p.ldo + col0 + 16 * ct + 4 * q) * 4 : BUF_OOB, f32x4{0.f, 0.f, 0.f, 0.f});
+                for (int at = 0; at < NAT; ++at) {
+                    constexpr int ZA = NA - 1;      // (index clamp for the agent tiles a short row does not have: no code is generated for them)
+                    const int ax = at < NA ? at : ZA;
+                    f32x4 o[NCT];
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) o[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (on && at < NA) {
+                        // masked softmax over the keys of this lane's agent: bit (entity at the tile position) of the agent's mask word
+                        f32x4 pt[NT];
+                        float mx = -INFINITY;
+#pragma unroll
+                        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) {
+                                const bool masked = (cw[v][ax] >> ((cmap.evp[jt] >> (8 * reg)) & (NJT > 2 ? 63 : 31))) & (mw_t)1;
+                                const float x = masked ? -INFINITY : stt[jt][ax][reg] * inv_scale;      // attention.py:54-57
+                                pt[jt][reg] = x;
+                                mx = fmaxf(mx, x);
+                            }
+                        mx = q_cross4_max(mx);
+                        float sum = 0.f;
+#pragma unroll
+                        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) {
+                                const float e = pt[jt][reg] == -INFINITY ? 0.f : __expf(pt[jt][reg] - mx);
+                                pt[jt][reg] = e;
+                                sum += e;
+                            }
+                        sum = q_cross4_sum(sum);
+                        const float inv = sum > 0.f ? __builtin_amdgcn_rcpf(sum) : 0.f;     // fully masked row -> 0 (attention.py:60 NaN -> 0)
+#pragma unroll
+                        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) pt[jt][reg] *= inv;
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+                            for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+                                for (int reg = 0; reg < 4; ++reg) o[ct] = MFMA16F(Vv[jt][ct][reg], pt[jt][reg], o[ct]);
+                            if (n.sum_agents) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) osum[ct][e] += q_group16_sum(o[ct][e]);
+                            }
+                        }
+                    }
+                    const int idx = 16 * at + l15;
+                    const bool zrow = idx < p.na && ((crow.qdw >> idx) & 1ull);
+                    const bool orow = at < NA && agent_ok[ax];
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        buf_st4(ro, orow ? (cmap.ek[ax] * p.ldo + col0 + 16 * ct + 4 * q) * 4 : BUF_OOB, o[ct]);
+                        buf_st4(ro, zrow ? (idx * p.ldo + col0 + 16 * ct + 4 * q) * 4 : BUF_OOB, f32x4{0.f, 0.f, 0.f, 0.f});
+                    }
                 }
             }
             {
@@ -521,6 +564,7 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void attn_qkv_fwd(QkvM p) {
             QKV_TICK(t_core)
         };
         if (COMPACT && cmap.cnt <= 16) job(std::integral_constant<int, 1>{});
+        else if (NJT > 2 && cmap.cnt <= 32) job(std::integral_constant<int, (NJT > 2 ? 2 : NJT)>{});
         else job(std::integral_constant<int, NJT>{});
     }
 #ifdef REFIL_QKV_TIMING
@@ -534,54 +578,82 @@ __global__ __launch_bounds__(64 * QKV_WAVES, 1) void attn_qkv_fwd(QkvM p) {
 #endif
 }
 
+constexpr int QKV_MAX_DEV = 16;
+static int qkv_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= QKV_MAX_DEV) { (void)hipGetLastError(); dev = 0; }
+    return dev;
+}
+// compute units of the CURRENT device (a process may drive several): asked once per device
 static int qkv_device_cus() {
-    static const int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
-    return n;
+    static std::atomic<int> cus[QKV_MAX_DEV];
+    const int dev = qkv_device();
+    int v = cus[dev].load(std::memory_order_relaxed);
+    if (v <= 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 256; }
+        cus[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
 }
 
+// LDS a launch may ask for: 160 KB (one workgroup per CU). refil_set_tuning("qkv_lds_budget", bytes) lowers it -- the tests' way to reach
+// the learner's fall-back to the separate projection / attention launches without a 350 k-row batch
+static std::atomic<long> g_qkv_lds_budget{160 * 1024};
+void attn_qkv_set_lds_budget(long bytes) { g_qkv_lds_budget.store(bytes > 0 && bytes < 160 * 1024 ? bytes : 160 * 1024, std::memory_order_relaxed); }
+
+static bool qkv_wide_instantiated(int nct, int nks) { return (nct == 2 && nks == 4) || (nct == 1 && nks == 2); }
 bool attn_qkv_supported(int ne, int na, int heads, int hd) {
     const int w = heads * hd;
-    return ne >= 1 && ne <= 32 && na >= 1 && na <= 16 && na <= ne && (hd == 16 || hd == 32) && (w == 64 || w == 128);
+    if (!(ne >= 1 && ne <= 48 && na >= 1 && na <= 32 && na <= ne && (hd == 16 || hd == 32) && (w == 64 || w == 128))) return false;
+    const int njt = (ne + 15) / 16, nat = (na + 15) / 16;
+    if (nat > njt) return false;
+    // (<= 32 entities / <= 16 agents: every head dim / width combination; the wide forms: head dim 32 at width 128, 16 at 64)
+    return (njt <= 2 && nat == 1) || qkv_wide_instantiated(hd / 16, w / 32);
 }
+// more than two key tiles or a second agent tile: instantiated and tested, but never timed on a GPU -- the learner takes these only when asked
+bool attn_qkv_wide(int ne, int na) { return ne > 32 || na > 16; }
 
 // workgroup grid of a launch over `nslices` (net, head) slices and R rows, and its LDS bytes: the W planes, the live-step prefix sums
 // [B + 2], the workgroup's row table [waves][jobs per wave]
-static size_t qkv_grid_lds(int nslices, long R, int T1, size_t plane_bytes, int& xcd_groups, int& ngroups) {
+static size_t qkv_grid_lds(int nslices, long R, int T1, size_t plane_bytes, int waves, int& xcd_groups, int& ngroups) {
     const int cus = qkv_device_cus();
     if (cus % 8 == 0 && (cus / 8) % nslices == 0) { xcd_groups = cus / 8 / nslices; ngroups = 8 * xcd_groups; }
     else { xcd_groups = 0; ngroups = cus / nslices > 0 ? cus / nslices : 1; }
-    const long live_groups = (R + QKV_WAVES - 1) / QKV_WAVES;
+    const long live_groups = (R + waves - 1) / waves;
     if (!xcd_groups && ngroups > live_groups) ngroups = (int)live_groups;
-    const long wstride = (long)ngroups * QKV_WAVES, maxjobs = (R + wstride - 1) / wstride;
-    return plane_bytes + ((size_t)(R / T1) + 2 + QKV_WAVES * maxjobs) * 4;
+    const long wstride = (long)ngroups * waves, maxjobs = (R + wstride - 1) / wstride;
+    return plane_bytes + ((size_t)(R / T1) + 2 + waves * maxjobs) * 4;
 }
 // does a launch of `nnets` blocks over R rows fit the LDS (the row table grows with R / workgroups per slice)? The learner asks before it
-// decides for the fused launch; beyond it the separate projection / attention launches run
-bool attn_qkv_fits(int heads, int hd, long R, int T1, int nnets) {
+// decides for the fused launch; beyond it the separate projection / attention launches run. Same sizing function, same device, same
+// budget as the launcher: the two cannot disagree.
+bool attn_qkv_fits(int ne, int na, int heads, int hd, long R, int T1, int nnets) {
     int xg = 0, ng = 0;
     const size_t planes = 3 * qkv_plane_bytes(hd / 16, heads * hd / 32);
-    return T1 > 0 && nnets >= 1 && nnets <= QKV_MAX_NETS && qkv_grid_lds(nnets * heads, R, T1, planes, xg, ng) <= 160 * 1024;
+    return T1 > 0 && nnets >= 1 && nnets <= QKV_MAX_NETS &&
+           qkv_grid_lds(nnets * heads, R, T1, planes, qkv_waves((ne + 15) / 16, (na + 15) / 16), xg, ng) <= (size_t)g_qkv_lds_budget.load(std::memory_order_relaxed);
 }
 
-template <int NJT, int NCT, int NKS>
+template <int NJT, int NCT, int NKS, int NAT>
 static int qkv_launch_x(QkvM& k, hipStream_t st) {
     bool store = false;
     for (int i = 0; i < k.nnets; ++i) store |= k.net[i].Ko != nullptr || k.net[i].Vo != nullptr || k.net[i].Qo != nullptr;
-    void (*kern)(QkvM) = store ? attn_qkv_fwd<NJT, NCT, NKS, true> : attn_qkv_fwd<NJT, NCT, NKS, false>;
-    static bool raised[2] = {false, false};
-    if (!raised[store]) { REFIL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); raised[store] = true; }
+    void (*kern)(QkvM) = store ? attn_qkv_fwd<NJT, NCT, NKS, true, NAT> : attn_qkv_fwd<NJT, NCT, NKS, false, NAT>;
+    // (per device: the attribute belongs to the device's copy of the function; a repeated call is harmless, a missed one is not)
+    static std::atomic<bool> raised[QKV_MAX_DEV][2];
+    const int dev = qkv_device();
+    if (!raised[dev][store].load(std::memory_order_relaxed)) {
+        REFIL_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        raised[dev][store].store(true, std::memory_order_relaxed);
+    }
     // one workgroup per CU; workgroup -> (slice, row group). XCD-aware: the heads (and nets) that read the same x rows sit on one
     // XCD (workgroups are dealt round-robin to the 8 XCDs by block id), so a row comes from HBM once and from that XCD's L2 afterwards
     k.nslices = k.nnets * k.heads;
     static const int stagger_env = [] { const char* e = getenv("REFIL_QKV_STAGGER"); return e ? atoi(e) : 0; }();
     k.stagger = stagger_env;
-    const size_t lds = qkv_grid_lds(k.nslices, k.R, k.T1, 3 * qkv_plane_bytes(NCT, NKS), k.xcd_groups, k.ngroups);
-    if (lds > 160 * 1024) return -1;
-    hipLaunchKernelGGL(kern, dim3(k.nslices * k.ngroups), dim3(64 * QKV_WAVES), lds, st, k);
+    const size_t lds = qkv_grid_lds(k.nslices, k.R, k.T1, 3 * qkv_plane_bytes(NCT, NKS), qkv_waves(NJT, NAT), k.xcd_groups, k.ngroups);
+    if (lds > (size_t)g_qkv_lds_budget.load(std::memory_order_relaxed)) return -1;
+    hipLaunchKernelGGL(kern, dim3(k.nslices * k.ngroups), dim3(64 * qkv_waves(NJT, NAT)), lds, st, k);
     REFIL_LAUNCH_CHECK();
     return 0;
 }
@@ -630,9 +702,11 @@ int attn_qkv_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts,
         bytes += 4.0 * d.R * ((double)d.ne * w + (double)descs[i].nvar * d.na * w + (src[i].Ko ? (2.0 * d.ne + d.na) * w : 0.0));
     }
     ProfScope prof("attn_qkv_fwd", flops, bytes, st, nullptr, 0.0, fsplit);
-    const int njt = (d.ne + 15) / 16, nct = d.hd / 16, nks = w / 32;
-#define CASE(J, C, S) if (njt == J && nct == C && nks == S) return qkv_launch_x<J, C, S>(k, st)
-    CASE(2, 2, 4); CASE(1, 2, 4); CASE(2, 1, 2); CASE(1, 1, 2); CASE(2, 2, 2); CASE(1, 2, 2); CASE(2, 1, 4); CASE(1, 1, 4);
+    const int njt = (d.ne + 15) / 16, nct = d.hd / 16, nks = w / 32, nat = (d.na + 15) / 16;
+#define CASE(J, C, S, A) if (njt == J && nct == C && nks == S && nat == A) return qkv_launch_x<J, C, S, A>(k, st)
+    CASE(2, 2, 4, 1); CASE(1, 2, 4, 1); CASE(2, 1, 2, 1); CASE(1, 1, 2, 1); CASE(2, 2, 2, 1); CASE(1, 2, 2, 1); CASE(2, 1, 4, 1); CASE(1, 1, 4, 1);
+    // > 32 entities / > 16 agents (BASELINE configs[4]: 48 entities, 24 agents)
+    CASE(3, 2, 4, 2); CASE(3, 2, 4, 1); CASE(2, 2, 4, 2); CASE(3, 1, 2, 2); CASE(3, 1, 2, 1); CASE(2, 1, 2, 2);
 #undef CASE
     return -1;
 }
@@ -654,6 +728,7 @@ extern "C" int refil_attn_qkv_forward(const refil_attn_qkv_desc* q, void* stream
     AttnNetOpts o{0, 0};
     AttnQkvSrc s{q->X, q->W_in, q->q_out, q->k_out, q->v_out};
     const int rc = attn_qkv_launch_multi(&d, &o, &s, 1, q->ldx, (hipStream_t)stream, nullptr, 0);
-    REFIL_CHECK(rc >= 0, "refil_attn_qkv_forward: shape not instantiated (n_entities <= 32, n_agents <= 16, head dim 16 / 32, width 64 / 128)");
+    REFIL_CHECK(rc >= 0, "refil_attn_qkv_forward: shape not instantiated (n_entities <= 48, n_agents <= 32, head dim 16 / 32, width 64 / 128; more than "
+                         "32 entities or 16 agents: head dim 32 at width 128 or 16 at 64) or the launch's row table exceeds the LDS");
     return rc;
 }

@@ -27,7 +27,7 @@ constexpr int RED_MULTI = 28;        // reductions one reduce_multi launch takes
 // launch needed none); the caller runs it later with reduce_multi_launch -- many reductions, one launch
 // Schedule knobs a caller may set at run time (refil_set_tuning: QLearner's first-call autotuner measures them in situ per
 // shape); -1 = the environment switch / built-in rule decides
-struct Tuning { long dw4_target = -1, dw4_min_out = -1, dw_target = -1, compose_early = -1, gru_pd = -1, wres_split = -1, dw_split = -1, attn_qkv = -1, dws_target = -1; };
+struct Tuning { long dw4_target = -1, dw4_min_out = -1, dw_target = -1, compose_early = -1, gru_pd = -1, wres_split = -1, dw_split = -1, attn_qkv = -1, dws_target = -1, attn_qkv_wide = -1; };
 extern Tuning g_tuning;
 int gemm_launch(const refil_gemm_desc& d, hipStream_t st, ReduceK* defer = nullptr);
 int reduce_multi_launch(const ReduceK* r, int n, hipStream_t st);
@@ -225,7 +225,9 @@ int attn_mfma_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts
 // attention_qkv.hip: in_trans + attention core in one launch (the layer's input and weight instead of Q / K / V); -1 = shape not instantiated
 struct AttnQkvSrc { const float* X; const float* W; float* Qo; float* Ko; float* Vo; };
 bool attn_qkv_supported(int ne, int na, int heads, int hd);
-bool attn_qkv_fits(int heads, int hd, long R, int T1, int nnets);
+bool attn_qkv_wide(int ne, int na);
+bool attn_qkv_fits(int ne, int na, int heads, int hd, long R, int T1, int nnets);
+void attn_qkv_set_lds_budget(long bytes);
 int attn_qkv_launch_multi(const refil_attn_desc* descs, const AttnNetOpts* opts, const AttnQkvSrc* src, int n, int ldx, hipStream_t st,
                           float* nact, int zero_dead);
 

@@ -1083,11 +1083,16 @@ static int make_ctx(Ctx& c, const refil_dims* dims, const refil_batch* batch, vo
         if (!c.mwords || d.pooling || !gemm_wres_split_on()) q = 0;          // (the fused launch is the bf16 x 6 arithmetic of the projections)
         if (!attn_qkv_supported(d.ne, d.na, d.heads, d.hyp / d.heads)) q &= ~(QKV_T_HYPER | QKV_L_HYPER);
         if (d.agent_ff || !attn_qkv_supported(d.ne, d.na, d.heads, d.d / d.heads)) q &= ~(QKV_T_AGENT | QKV_L_AGENT);
+        // more than 32 entities or 16 agents (BASELINE configs[4]): the three-key-tile / two-agent-tile forms are parity-tested but were
+        // never timed on a GPU (round 6 had none): the separate launches stay the default there; REFIL_ATTN_QKV_WIDE=1 /
+        // refil_set_tuning("attn_qkv_wide", 1) takes the fused launch
+        static const int wide_env = [] { const char* e = getenv("REFIL_ATTN_QKV_WIDE"); return e ? atoi(e) : 0; }();
+        if (attn_qkv_wide(d.ne, d.na) && !(g_tuning.attn_qkv_wide >= 0 ? g_tuning.attn_qkv_wide == 1 : wide_env == 1)) q = 0;
         // (the fused launch keeps a row table in LDS that grows with B T1 / workgroups per slice: beyond ~350 k rows per 16 slices the
         // separate launches take over -- sized for the widest launch a chain can issue: both hypernet sets merged, both agents)
         const long Rq = (long)d.B * d.T1;
-        if ((q & (QKV_T_HYPER | QKV_L_HYPER)) && !attn_qkv_fits(d.heads, d.hyp / d.heads, Rq, d.T1, 2 * sizes_of(d).nets)) q &= ~(QKV_T_HYPER | QKV_L_HYPER);
-        if ((q & (QKV_T_AGENT | QKV_L_AGENT)) && !attn_qkv_fits(d.heads, d.d / d.heads, Rq, d.T1, 2)) q &= ~(QKV_T_AGENT | QKV_L_AGENT);
+        if ((q & (QKV_T_HYPER | QKV_L_HYPER)) && !attn_qkv_fits(d.ne, d.na, d.heads, d.hyp / d.heads, Rq, d.T1, 2 * sizes_of(d).nets)) q &= ~(QKV_T_HYPER | QKV_L_HYPER);
+        if ((q & (QKV_T_AGENT | QKV_L_AGENT)) && !attn_qkv_fits(d.ne, d.na, d.heads, d.d / d.heads, Rq, d.T1, 2)) q &= ~(QKV_T_AGENT | QKV_L_AGENT);
         c.qkv = q;
     }
     REFIL_CHECK(batch->entities && batch->entity_mask, "refil: batch.entities / entity_mask missing");
@@ -1164,6 +1169,8 @@ extern "C" int refil_set_tuning(const char* name, int64_t value) {
     else if (!strcmp(name, "wres_split")) g_tuning.wres_split = value;
     else if (!strcmp(name, "dw_split")) g_tuning.dw_split = value;
     else if (!strcmp(name, "attn_qkv")) g_tuning.attn_qkv = value;
+    else if (!strcmp(name, "attn_qkv_wide")) g_tuning.attn_qkv_wide = value;
+    else if (!strcmp(name, "qkv_lds_budget")) attn_qkv_set_lds_budget((long)value);      // (bytes; <= 0: the device's 160 KB)
     else { set_error("refil_set_tuning: unknown knob '%s'", name); return 1; }
     return 0;
 }

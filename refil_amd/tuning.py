@@ -42,6 +42,10 @@ PARITY_TESTED = {
     # 15 = the built-in default where the shape is instantiated, 0 = the separate launches of rounds 1-4 (same bf16 x 6 arithmetic of the
     # projections, another summation order: not an autotuner candidate)
     "attn_qkv": (0, 3, 15),
+    # the same launch for more than 32 entities / 16 agents (three key tiles / two agent tiles, one wave per SIMD): 1 = take it. Parity-tested
+    # (tests/test_gpu_learner.py::test_wide_fused_attention_step_matches_oracle, PRODUCTION["cfg5_ne48*_qkvwide"]) but built in a round without
+    # a GPU: off by default until it has been timed against the three launches it replaces. Not an autotuner candidate.
+    "attn_qkv_wide": (0, 1),
 }
 # what the first-call autotuner tries, in this order (greedy, one knob at a time)
 CANDIDATES = (("dw4_target", (96,)), ("gru_pd", (2,)), ("dw4_min_out", (2000,)), ("dw_target", (384,)), ("compose_early", (0, 1)))

@@ -217,8 +217,51 @@ def test_degenerate_episodes_match_oracle(B, T, ne, d):
     _assert_step_matches_oracle(cfg, batch, bits, agent, mixer, tagent, tmixer, True)
 
 
-def _assert_step_matches_oracle(cfg, batch, bits, agent, mixer, tagent, tmixer, imagine):
-    r = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer)
+@pytest.mark.parametrize("B,T,ne,na,d,imagine", [(4, 8, 48, None, 128, True), (3, 6, 40, 12, 128, True), (3, 5, 32, 24, 128, True), (3, 6, 48, 20, 128, False)])
+def test_wide_fused_attention_step_matches_oracle(B, T, ne, na, d, imagine):
+    """More than 32 entities or 16 agents with refil_set_tuning("attn_qkv_wide", 1): in_trans + attention core of all four attention
+    blocks as ONE launch on the three-key-tile / two-agent-tile instantiations (attention_qkv.hip; BASELINE configs[4] is 48 entities,
+    24 agents), against the oracle -- every output, every gradient, the post-step parameters."""
+    cfg, batch, bits, agent, mixer, tagent, tmixer = _oracle_case(B, T, ne, seed=600 + ne, imagine=imagine, d=d, h=d, na=na)
+    _assert_step_matches_oracle(cfg, batch, bits, agent, mixer, tagent, tmixer, imagine, tuned=dict(attn_qkv_wide=1), expect_kernel="attn_qkv_fwd",
+                                forbid_kernel="attn_fwd_mfma")
+
+
+@pytest.mark.parametrize("B,T,ne,d", [(4, 10, 32, 128), (5, 9, 16, 64)])
+def test_fused_attention_lds_fallback_is_bit_identical(B, T, ne, d):
+    """The fused in_trans + attention launch keeps a row table in LDS that grows with B T1; the learner asks attn_qkv_fits() and runs the
+    separate projection / attention launches beyond it. The fall-back is reached here through refil_set_tuning("qkv_lds_budget", bytes)
+    instead of a 350 k-row batch: no fused launch runs, nothing fails at launch time, and the step is bit-identical to attn_qkv = 0."""
+    from refil_amd import _lib
+    cfg, batch, bits, agent, mixer, tagent, tmixer = _oracle_case(B, T, ne, seed=77, imagine=True, d=d, h=d)
+    base = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, profile=True)
+    assert "attn_qkv_fwd" in base["kernels"]
+    sep = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, profile=True, tuned=dict(attn_qkv=0))
+    assert "attn_qkv_fwd" not in sep["kernels"]
+    _lib.check(_lib.lib().refil_set_tuning(b"qkv_lds_budget", 8 * 1024), "refil_set_tuning")      # smaller than any launch's W planes
+    try:
+        low = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, profile=True)
+    finally:
+        _lib.check(_lib.lib().refil_set_tuning(b"qkv_lds_budget", -1), "refil_set_tuning")
+    assert "attn_qkv_fwd" not in low["kernels"] and "attn_fwd_mfma" in " ".join(low["kernels"])
+    for k in sep["grads"]:
+        assert torch.equal(low["grads"][k], sep["grads"][k]), k
+        assert torch.equal(low["post"][k], sep["post"][k]), k
+    for k in sep["out"]:
+        assert torch.equal(low["out"][k], sep["out"][k]), k
+    assert torch.equal(low["stats"], sep["stats"])
+    again = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, profile=True)          # the budget is back: fused again
+    assert "attn_qkv_fwd" in again["kernels"]
+    for k in base["grads"]:
+        assert torch.equal(again["grads"][k], base["grads"][k]), k
+
+
+def _assert_step_matches_oracle(cfg, batch, bits, agent, mixer, tagent, tmixer, imagine, tuned=None, expect_kernel=None, forbid_kernel=None):
+    r = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, tuned=tuned, profile=expect_kernel is not None)
+    if expect_kernel is not None:
+        names = " ".join(r["kernels"])
+        assert expect_kernel in names, f"{expect_kernel} did not run (kernels: {sorted(r['kernels'])})"
+        assert forbid_kernel is None or forbid_kernel not in names, f"{forbid_kernel} ran (kernels: {sorted(r['kernels'])})"
     a2, m2 = dict(agent), dict(mixer)
     out, grads, gnorm = orc.train_step(cfg, a2, m2, tagent, tmixer, batch, bits)
     o, st = r["out"], r["stats"]
@@ -305,6 +348,10 @@ PRODUCTION = {
     "cfg4_shape_qkv0": dict(B=32, T=150, ne=16, d=128, imagine=False, tuned=dict(attn_qkv=0)),
     "cfg4_shape_qkv3": dict(B=32, T=150, ne=16, d=128, imagine=False, tuned=dict(attn_qkv=3)),
     "cfg5_mmm_qkv0": dict(B=32, T=80, ne=16, d=128, imagine=True, na=8, A=22, tuned=dict(attn_qkv=0)),
+    # attn_qkv_wide: the fused launch for more than 32 entities / 16 agents (three key tiles, two agent tiles; round 6, opt-in: never timed)
+    "cfg5_ne48_qkvwide": dict(B=32, T=80, ne=48, d=128, imagine=True, tuned=dict(attn_qkv_wide=1)),
+    "cfg5_ne48_mmm_law_qkvwide": dict(B=32, T=80, ne=48, d=128, imagine=True, A=54, tuned=dict(attn_qkv_wide=1)),
+    "cfg5_ne48_mmm_law_qkvwide_tuned": dict(B=32, T=80, ne=48, d=128, imagine=True, A=54, tuned=dict(attn_qkv_wide=1, dw4_min_out=2000, gru_pd=2)),
 }
 
 
@@ -327,6 +374,11 @@ def test_production_size_step_matches_oracle(which):
         # (the attention forward: the fused in_trans + core launch where it is instantiated, else the core's own launch)
         assert sym in names or (sym == "attn_fwd_mfma" and "attn_qkv_fwd" in names), f"{which}: {sym} did not run (kernels: {sorted(r['kernels'])})"
     qkv = (kw.get("tuned") or {}).get("attn_qkv", -1)
+    wide = (kw.get("tuned") or {}).get("attn_qkv_wide", -1) == 1       # > 32 entities / > 16 agents take the fused launch only when asked
+    if not gm and kw["ne"] > 32:
+        assert ("attn_qkv_fwd" in names) == wide, f"{which}: fused attention launch expected {wide} (kernels: {sorted(r['kernels'])})"
+        if wide:
+            assert "attn_fwd_mfma" not in names, f"{which}: an attention forward ran unfused"
     if not gm and kw["ne"] <= 32 and (kw.get("tuned") or {}).get("wres_split", 6) == 6:
         assert ("attn_qkv_fwd" in names) == (qkv != 0), f"{which}: fused attention launch expected {qkv != 0} (kernels: {sorted(r['kernels'])})"
         if qkv in (-1, 15):

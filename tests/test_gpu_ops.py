@@ -909,7 +909,10 @@ def test_attention_persistent_walk(B, T1, ne, na, heads, hd, pre):
 @pytest.mark.parametrize("B,T1,ne,na,heads,hd,nvar,store", [
     (24, 40, 32, 16, 4, 32, 3, True), (24, 40, 32, 16, 4, 32, 1, False), (40, 30, 16, 8, 4, 16, 3, True), (5, 7, 20, 7, 4, 32, 2, True),
     (3, 4, 12, 5, 2, 32, 1, True), (6, 5, 32, 16, 8, 16, 3, False), (4, 6, 9, 9, 4, 16, 1, True), (300, 3, 16, 8, 4, 32, 1, False),
-    (2, 3, 27, 16, 2, 32, 3, True)])
+    (2, 3, 27, 16, 2, 32, 3, True),
+    # more than 32 entities / 16 agents (three key tiles, two agent tiles, 64-bit mask words; BASELINE configs[4] is 48 / 24):
+    (12, 20, 48, 24, 4, 32, 3, True), (4, 6, 40, 12, 4, 32, 2, True), (5, 5, 32, 24, 4, 32, 3, True), (3, 4, 48, 32, 4, 16, 1, False),
+    (6, 5, 30, 20, 4, 16, 3, True), (4, 5, 36, 9, 4, 16, 2, True), (40, 3, 48, 24, 4, 32, 1, False)])
 def test_attention_qkv_forward(B, T1, ne, na, heads, hd, nvar, store):
     """refil_attn_qkv_forward (layer input + in_trans.weight -> attention output, projections optionally stored) against fp32 torch:
     ragged episode ends, dead K/V / Q rows holding NaN (never read), up to three mask variants, a strided layer input."""
@@ -967,3 +970,47 @@ def test_attention_qkv_forward(B, T1, ne, na, heads, hd, nvar, store):
         _close(kvo[lk][:, :w], kr[lk], tol=3e-6, what="stored K")
         _close(kvo[lk][:, w:], vr[lk], tol=3e-6, what="stored V")
         assert (qo[~lq] == 7.0).all() and (kvo[~lk] == 7.0).all()      # dead rows are not written
+
+
+@pytest.mark.parametrize("ne,na,heads,hd", [(12, 6, 4, 16), (32, 16, 4, 32), (48, 24, 4, 32)])
+def test_attention_qkv_query_alive_but_dead_as_key(ne, na, heads, hd):
+    """refil_attn_qkv_forward with an agent that row_bits marks alive as a QUERY and dead as a KEY (and that every mask excludes as a
+    key): its x row is fetched all the same -- Q^T is projected from the registers K^T / V come from -- and its output row equals the
+    reference's. (The learner's row lists never produce such a row; the separate refil_attn_forward takes Q from a buffer.)"""
+    import hip_ops
+    torch.manual_seed(ne + hd)
+    B, T1, nvar = 3, 4, 2
+    R, w = B * T1, heads * hd
+    variants = [MASK_OBS, MASK_OBS_WITHIN]
+    x = torch.randn(R, ne, w)
+    W = torch.randn(3 * w, w) / math.sqrt(w)
+    em = torch.zeros(B, T1, ne, dtype=torch.uint8)
+    em[:, :, ne - 2:] = 1
+    obs = (torch.rand(B, T1, ne, ne) < 0.3).to(torch.uint8)
+    obs = obs | em[:, :, :, None] | em[:, :, None, :]
+    odd = 1                                                      # the agent nobody observes (not even itself): dead as a key, alive as a query
+    obs[:, :, :, odd] = 1
+    em0 = em[:, 0].contiguous()
+    gb = (torch.rand(B, ne) < 0.5).to(torch.uint8)
+    kv_dead = em.clone()
+    kv_dead[:, :, odd] = 1
+    masks = [_masks(c, obs, em, em0, gb, na).reshape(R, na, ne) for c in variants]
+    xz = x * (1 - em.reshape(R, ne, 1).float())
+    qr = xz[:, :na] @ W[:w].t()
+    kr, vr = xz @ W[w:2 * w].t(), xz @ W[2 * w:].t()
+    outs = _attn_ref(qr, kr, vr, masks, heads)
+    xd = x.reshape(R * ne, w).clone()
+    xd[em.reshape(R * ne).bool()] = float("nan")
+    xd = xd.to(DEV)
+    dummy = torch.zeros(4, device=DEV)
+    d = hip_ops.attn_desc(dummy, dummy, dummy, w, 2 * w, R, T1, ne, na, heads, hd, variants, obs_mask=obs.to(DEV),
+                          ent_mask=em.reshape(R, ne).to(DEV), ent_mask0=em0.to(DEV), group_bits=gb.to(DEV))
+    hip_ops.attn_skip(d, None, kv_dead.reshape(R * ne).to(DEV), em[:, :, :na].reshape(R * na).contiguous().to(DEV))
+    hip_ops.attn_mask_words(d, na)
+    O = torch.full((nvar, R * na, w), 7.0, device=DEV)
+    hip_ops.attn_qkv_forward(d, xd, w, W.to(DEV), O, w, R * na * w)
+    O = O.cpu().reshape(nvar, R, na, w)
+    lq = ~em[:, :, :na].reshape(R, na).bool()
+    for i in range(nvar):
+        _close(O[i][lq], outs[i][lq], what=f"variant {i}")
+        assert torch.isfinite(O[i]).all()
