@@ -83,6 +83,50 @@ def algorithmic_flops(B, T, ne, na, E, A, d, h, H, M, G):
     return la_f + la_b + ta_f + sum(f + b for f, b in lm) + sum(f for f, _ in tm)
 
 
+def qkv_useful_fraction(rows, ne, na):
+    """Share of the FLOPs credited to the fused in_trans + attention launch (attention_qkv.hip) that falls on entity rows which can
+    influence the loss. The launch is credited, per live (b,t) row, with the projections of ALL ne entities / na agents and the full
+    na x ne core (SURVEY.md section 8d's per-row figure): it computes whole 16-entity tiles, where the row-list GEMMs it replaced ran
+    exactly the listed rows. `rows` = LearnerEngine.row_counts(): listed entity rows of the agent nets / the hypernets, active agent
+    rows, live steps. One symbol covers the agent launches (1 of 5 nets) and the hypernet launches (4 of 5): weighted like that.
+    Projections: 2 na w^2 (Q) + 4 ne w^2 (K, V) per row; core: ~ na ne w per variant -- the projections dominate (w >= 64), the core's
+    na ne product scales with both live fractions."""
+    live_rows_e = max(rows["live_steps"] * ne, 1)
+    live_rows_a = max(rows["live_steps"] * na, 1)
+    f_a = min(1.0, rows["agent_rows"] / live_rows_a)
+    out = 0.0
+    for share, listed in ((0.2, rows["entity_rows_agent"]), (0.8, rows["entity_rows_hyper"])):
+        f_e = min(1.0, listed / live_rows_e)
+        out += share * (2.0 * na * f_a + 4.0 * ne * f_e) / (2.0 * na + 4.0 * ne)
+    return out
+
+
+def replica_checksum_of(flat_live, square_avg):
+    """bit-level checksums of the live parameters and the RMSprop state (int32 views summed in int64)"""
+    return torch.stack([flat_live.view(torch.int32).to(torch.int64).sum(), square_avg.view(torch.int32).to(torch.int64).sum()])
+
+
+def validate_replicas(cs, world):
+    """Self-validation of a multi-GPU run (after the timed region): every rank's checksums gathered over the job's own process group;
+    the replicas must be bit-identical (one all-reduce(SUM) of [grads | stats] and the global sum(mask) in the optimiser kernel keep them
+    so: no parameter broadcast ever happens). Returns (identical, checksums of rank 0, all ranks' checksums). Backend-agnostic: the 2-rank
+    gloo test of the CPU tier runs this very function (tests/test_dp_gloo.py)."""
+    gathered = [torch.zeros_like(cs) for _ in range(world)]
+    dist.all_gather(gathered, cs)
+    identical = all(torch.equal(g, gathered[0]) for g in gathered)
+    return bool(identical), [int(x) for x in gathered[0].tolist()], [[int(x) for x in g.tolist()] for g in gathered]
+
+
+def comm_record(n_floats, allreduce_us, backend, nccl_version, identical, checksums, loss_step0):
+    """the `comm` object of an N > 1 bench line"""
+    return {"bytes": n_floats * 4, "allreduce_us_per_step": allreduce_us, "backend": backend,
+            "nccl_version": nccl_version, "algorithm": os.environ.get("REFIL_ALLREDUCE", "backend all_reduce(SUM), one collective per step"),
+            "buckets": os.environ.get("REFIL_DP_BUCKETS") == "1",
+            "ranks": dist.get_world_size(), "replicas_identical": bool(identical),
+            "replica_checksums": checksums, "loss_step0": loss_step0,
+            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
+
+
 def workload_dims(W):
     """Network / environment sizes of a CONFIGS entry (the SC2 shape law of refil_amd.synthetic for its entity count)."""
     from refil_amd.synthetic import sc2_shape_law
@@ -401,8 +445,7 @@ def main():
         return float((1 - args.lmbda) * q + args.lmbda * st[_lib.STAT_IM_TD_SQ] / st[_lib.STAT_MASK_SUM]) if W["imagine"] else float(q)
 
     def replica_checksum():
-        """bit-level checksums of the live parameters and the RMSprop state (int32 views summed in int64)"""
-        return torch.stack([learner.flat_live.view(torch.int32).to(torch.int64).sum(), learner.square_avg.view(torch.int32).to(torch.int64).sum()])
+        return replica_checksum_of(learner.flat_live, learner.square_avg)
 
     loss_step0 = None
     for i in range(a.warmup):
@@ -450,18 +493,11 @@ def main():
         # [grads | stats], the global sum(mask) applied by the optimiser kernel: no parameter broadcast ever happens) -- checked on bit-level
         # checksums of the live parameters and the RMSprop state, gathered over the job's own process group; a divergence is an error
         cs = replica_checksum()
-        gathered = [torch.zeros_like(cs) for _ in range(world)]
-        dist.all_gather(gathered, cs)
-        identical = all(torch.equal(g, gathered[0]) for g in gathered)
-        comm = {"bytes": gb.numel() * 4, "allreduce_us_per_step": round(ce0.elapsed_time(ce1) * 100.0, 1), "backend": backend,
-                "nccl_version": ver, "algorithm": os.environ.get("REFIL_ALLREDUCE", "backend all_reduce(SUM), one collective per step"),
-                "buckets": os.environ.get("REFIL_DP_BUCKETS") == "1",
-                "ranks": dist.get_world_size(), "replicas_identical": bool(identical),
-                "replica_checksums": [int(x) for x in gathered[0].tolist()], "loss_step0": loss_step0,
-                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
+        identical, cs0, _ = validate_replicas(cs, world)
+        comm = comm_record(gb.numel(), round(ce0.elapsed_time(ce1) * 100.0, 1), backend, ver, identical, cs0, loss_step0)
         if not identical:
             raise SystemExit(f"bench.py: the data-parallel replicas diverged after {a.warmup + a.steps} steps (rank {rank}: {cs.tolist()} vs rank 0: "
-                             f"{gathered[0].tolist()}) -- the line would not be a valid measurement")
+                             f"{cs0}) -- the line would not be a valid measurement")
     # a second, short timed region on the DENSIFIED batch (no padding, full-length episodes: nothing for the row lists to skip),
     # so that the headline cannot be read as a dense rate
     dense = None
@@ -600,6 +636,13 @@ def main():
                 k["mfma_frac"] = round(pr["t_mfma"] / pr["t"], 4)
                 k["hbm_frac"] = round(pr["t_hbm"] / pr["t"], 4)
                 k["hbm_bytes_per_launch"] = pr["pmc_bytes"] if pr["pmc_bytes"] else None
+                if k["name"].startswith("attn_qkv") and rows["lists"]:
+                    # credited FLOPs include the dead entity slots of the 16-entity tiles: the fraction on rows that matter, and the roof
+                    # fraction counted on those alone
+                    u = qkv_useful_fraction(rows, dims["ne"], dims["na"])
+                    k["useful_flops_frac"] = round(u, 4)
+                    k["useful_flops_per_launch"] = round(pr["flops"] * u)
+                    k["mfma_frac_useful"] = round(pr["t_mfma"] * u / pr["t"], 4)
         pd = price(dom["name"], dom_iso)
         t_situ = 1e-3 * dom["total_ms"] / dom["launches"]
         hbm_bound = pd["bound"] == "hbm"
@@ -622,6 +665,10 @@ def main():
                     "unit": unit, "frac": round(max(pd["t_mfma"], pd["t_hbm"]) / pd["t"], 4), "traffic": traffic,
                     "mfma_frac": round(pd["t_mfma"] / pd["t"], 4), "hbm_frac": round(pd["t_hbm"] / pd["t"], 4),
                     "frac_vs_fp32_instruction": round(pd["flops"] / pd["t"] / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    # the fused in_trans + attention launch is credited with whole 16-entity tiles; on the entity rows that can influence the loss:
+                    "useful_flops_frac": round(qkv_useful_fraction(rows, dims["ne"], dims["na"]), 4) if dom["name"].startswith("attn_qkv") and rows["lists"] else None,
+                    "frac_useful": round(max(pd["t_mfma"] * qkv_useful_fraction(rows, dims["ne"], dims["na"]), pd["t_hbm"]) / pd["t"], 4)
+                    if dom["name"].startswith("attn_qkv") and rows["lists"] else None,
                     "roofs": {"fp32_mfma_tflops": PEAK_FP32_MFMA_TFLOPS, "bf16x6_tflops_of_fp32_work": round(PEAK_SPLIT_TFLOPS, 1), "hbm_gbs": PEAK_HBM_GBS,
                               "flops_per_launch": pd["flops"], "flops_per_launch_on_bf16x6": pd["flops_bf16x6"],
                               "mfma_floor_us": round(pd["t_mfma"] * 1e6, 2), "hbm_floor_us": round(pd["t_hbm"] * 1e6, 2),

@@ -95,3 +95,46 @@ def test_shard_helpers_cover_the_batch_exactly():
     for k, v in batch.items():
         assert torch.equal(torch.cat([p[k] for p in parts]), v)
     assert torch.equal(torch.cat([dp.shard_bits(bits, r, 2) for r in range(2)]), bits)
+
+
+def _validate_worker(rank, world, port, q, diverge):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    torch.manual_seed(3)
+    live, sq = torch.randn(1000), torch.rand(1000)
+    if diverge and rank == 1:
+        live.view(torch.int32)[17] ^= 1                      # one mantissa bit of one parameter on one rank
+    cs = bench.replica_checksum_of(live, sq)
+    identical, cs0, allcs = bench.validate_replicas(cs, world)
+    rec = bench.comm_record(1008, 12.5, "gloo", None, identical, cs0, 0.25)
+    q.put((rank, identical, allcs, rec))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("diverge", [False, True])
+def test_bench_replica_validation_two_ranks(diverge):
+    """bench.py's self-validation of an N > 1 line (the `comm` object: replicas_identical, replica_checksums, ranks, hw_queues) on two gloo
+    ranks: identical replicas pass; ONE flipped mantissa bit on one rank is seen by every rank (bench.py then exits instead of printing)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_validate_worker, args=(r, 2, port, q, diverge)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, identical, allcs, rec in got:
+        assert identical == (not diverge)
+        assert len(allcs) == 2 and (allcs[0] == allcs[1]) == (not diverge)
+        assert rec["replicas_identical"] == (not diverge) and rec["ranks"] == 2 and rec["hw_queues"] == "8"
+        assert rec["replica_checksums"] == allcs[0] and rec["bytes"] == 4032 and rec["loss_step0"] == 0.25

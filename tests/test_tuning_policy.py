@@ -86,3 +86,17 @@ def test_a_dropped_step_is_not_logged_as_training():
     st[_lib.STAT_GRAD_NORM] = 0.7
     QLearner._check_step_not_dropped(st)
     QLearner._check_step_not_dropped([100.0, float("nan"), 2.0, 5.0, 1.0, 1.0, float("nan"), 0.0])
+
+
+def test_bench_useful_fraction_of_the_fused_attention_launch():
+    """bench.py prints, beside the FLOPs credited to attn_qkv_fwd (whole 16-entity tiles), the share on entity rows that can influence
+    the loss: 1 on dense data, ~0.57 at the round-5 cfg-T row counts (profiles/r05_qkv_bench.txt: 34 162 of 60 416 live entity slots)."""
+    import bench
+    ne, na, steps = 32, 16, 2592
+    dense = dict(live_steps=steps, entity_rows_agent=steps * ne, entity_rows_hyper=steps * ne, agent_rows=steps * na)
+    assert bench.qkv_useful_fraction(dense, ne, na) == pytest.approx(1.0)
+    live = 1888
+    r05 = dict(live_steps=live, entity_rows_agent=int(0.38 * steps * ne), entity_rows_hyper=int(0.49 * steps * ne), agent_rows=int(0.48 * steps * na))
+    u = bench.qkv_useful_fraction(r05, ne, na)
+    assert 0.5 < u < 0.75
+    assert bench.qkv_useful_fraction(dict(live_steps=live, entity_rows_agent=0, entity_rows_hyper=0, agent_rows=0), ne, na) == 0.0
