@@ -311,19 +311,18 @@ static refil_gemm_desc linear_dx(const float* dy, int lddy, const float* W, int 
     g.M = (int)M; g.N = K; g.K = N; g.flags = flags | REFIL_GEMM_B_OUTC;
     return g;
 }
-// dW[N,K] = dy[R,N]^T x[R,K]; db[N] = colsum(dy)  (reduction over the R rows, split deterministically)
-static refil_gemm_desc linear_dw(const float* dy, int lddy, const float* x, int ldx, float* dW, int lddw, float* db,
-                                 long R, int N, int K, float* partial, int batch) {
-    refil_gemm_desc g = G0();
-    g.A = dy; g.lda = lddy; g.B = x; g.ldb = ldx; g.C = dW; g.ldc = lddw;
-    g.M = N; g.N = K; g.K = (int)R;
-    g.flags = REFIL_GEMM_A_OUTC | REFIL_GEMM_B_OUTC | (db ? REFIL_GEMM_COLSUM_A : 0);
-    g.colsum = db; g.partial = partial; g.batch = batch;
+// reduction splits of a weight-gradient launch (g.M x g.N outputs, g.K rows, g.batch nets). The count follows the kernel that will take the
+// launch (4x4-tile / bf16 x 6 / streamed), and which one does depends on the row maps and the row list the caller attaches AFTER
+// linear_dw(): the rule runs once on the bare descriptor and again on the final one (gemm_launch_dw) -- same rule, so a descriptor whose
+// kernel did not change keeps its count, and one whose maps turned a kernel away gets the count that kernel's sweep chose
+static void dw_size_splits(refil_gemm_desc& g) {
+    const int N = g.M, K = g.N, batch = g.batch;
+    const long R = g.K;
     g.splits = 2;
     if (gemm_dw4_enabled() && gemm_dw4_eligible(g)) {            // gemm_dw4.hip: one workgroup per CU
         g.splits = gemm_dw4_splits(g);
         while (g.splits > 2 && (long)batch * g.splits * ((long)N * K + N) > PARTIAL_FLOATS) --g.splits;
-        return g;
+        return;
     }
     const int bn = K > 64 ? 128 : (K > 32 ? 64 : 32);
     const long tiles = (long)cdiv(N, 128) * cdiv(K, bn) * batch;
@@ -336,6 +335,17 @@ static refil_gemm_desc linear_dw(const float* dy, int lddy, const float* x, int 
     splits = max(splits, 1L);
     while (splits > 1 && (long)batch * splits * ((long)N * K + N) > PARTIAL_FLOATS) --splits;
     g.splits = (int)splits;
+}
+
+// dW[N,K] = dy[R,N]^T x[R,K]; db[N] = colsum(dy)  (reduction over the R rows, split deterministically)
+static refil_gemm_desc linear_dw(const float* dy, int lddy, const float* x, int ldx, float* dW, int lddw, float* db,
+                                 long R, int N, int K, float* partial, int batch) {
+    refil_gemm_desc g = G0();
+    g.A = dy; g.lda = lddy; g.B = x; g.ldb = ldx; g.C = dW; g.ldc = lddw;
+    g.M = N; g.N = K; g.K = (int)R;
+    g.flags = REFIL_GEMM_A_OUTC | REFIL_GEMM_B_OUTC | (db ? REFIL_GEMM_COLSUM_A : 0);
+    g.colsum = db; g.partial = partial; g.batch = batch;
+    dw_size_splits(g);
     return g;
 }
 
@@ -477,6 +487,7 @@ struct Ctx {
 enum { QKV_T_HYPER = 1, QKV_T_AGENT = 2, QKV_L_HYPER = 4, QKV_L_AGENT = 8 };
 
 static int gemm_launch_dw(const Ctx& c, refil_gemm_desc& g, hipStream_t st) {
+    dw_size_splits(g);              // (the descriptor is final here: row maps and row list attached)
     DeferredReduce* df = c.defer;
     if (df && g.splits > 1 && df->n < 64 && !(g.flags & REFIL_GEMM_ACCUM) && g.C >= df->lo && g.C < df->hi &&
         (!g.colsum || (g.colsum >= df->lo && g.colsum < df->hi))) {
