@@ -9,6 +9,8 @@
 // (a collective in divergent control flow), the lanes that did arrive complete it among themselves, as the hardware's EXEC mask would.
 #include <hip/hip_runtime.h>
 
+#include <cxxabi.h>
+#include <dlfcn.h>
 #include <pthread.h>
 #include <sched.h>
 #include <sys/mman.h>
@@ -16,7 +18,9 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <map>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -49,6 +53,7 @@ namespace emu {
 thread_local const LaneIds* cur_lane_ids = nullptr;
 thread_local const BlockIds* cur_block_ids = nullptr;
 thread_local void* cur_dyn_smem = nullptr;
+thread_local unsigned long long counters[C_N] = {};
 
 namespace {
 
@@ -176,7 +181,11 @@ struct Job {
     KernelCall call;
     std::atomic<long> next{0};
     long total = 0;
+    std::atomic<unsigned long long> counts[C_N];
 };
+struct KernelCounts { unsigned long long launches = 0, workgroups = 0, c[C_N] = {}; };
+std::map<std::string, KernelCounts>& kernel_counts = *new std::map<std::string, KernelCounts>();
+std::mutex& counts_mu = *new std::mutex();
 // (never destroyed: the detached workers wait on them until the process ends)
 std::mutex& mu = *new std::mutex();
 std::condition_variable& cv_work = *new std::condition_variable();
@@ -218,6 +227,23 @@ void work_on(Job& j) {
         run_block(b);
     }
     free(dyn);
+    for (int i = 0; i < C_N; ++i) { j.counts[i].fetch_add(counters[i]); counters[i] = 0; }
+}
+
+std::string kernel_name(const void* fn, const char* text) {
+    Dl_info info;
+    if (fn && dladdr(fn, &info) && info.dli_sname) {
+        int status = 0;
+        char* d = abi::__cxa_demangle(info.dli_sname, nullptr, nullptr, &status);
+        std::string out = status == 0 && d ? d : info.dli_sname;
+        free(d);
+        const size_t paren = out.rfind('(');                 // drop the parameter list and the namespace
+        if (paren != std::string::npos) out.resize(paren);
+        if (out.rfind("void ", 0) == 0) out.erase(0, 5);
+        if (out.rfind("refil::", 0) == 0) out.erase(0, 7);
+        return out;
+    }
+    return text;
 }
 
 void worker_main() {
@@ -279,9 +305,10 @@ unsigned long long wall_ticks() {
     return ((unsigned long long)ts.tv_sec * 1000000000ull + (unsigned long long)ts.tv_nsec) / 10000ull;
 }
 
-void launch(dim3 grid, dim3 block, size_t shmem, const char* name, KernelCall call) {
+void launch(dim3 grid, dim3 block, size_t shmem, const char* name, const void* fn, KernelCall call) {
     std::lock_guard<std::mutex> lg(launch_mu);
     Job j;
+    for (int i = 0; i < C_N; ++i) j.counts[i].store(0);
     j.grid = grid; j.block = block; j.shmem = shmem; j.name = name; j.call = call;
     j.total = (long)grid.x * grid.y * grid.z;
     if (j.total <= 0 || block.x * block.y * block.z == 0) return;
@@ -298,9 +325,33 @@ void launch(dim3 grid, dim3 block, size_t shmem, const char* name, KernelCall ca
     cv_work.notify_all();
     cv_done.wait(lk, [&] { return workers_busy == 0; });
     job = nullptr;
+    lk.unlock();
+    static const bool counting = env_int("EMU_COUNT", 0) != 0;
+    if (counting) {
+        std::lock_guard<std::mutex> cg(counts_mu);
+        KernelCounts& kc = kernel_counts[kernel_name(fn, name)];
+        kc.launches++;
+        kc.workgroups += (unsigned long long)j.total;
+        for (int i = 0; i < C_N; ++i) kc.c[i] += j.counts[i].load();
+    }
 }
 
 }  // namespace emu
+
+// EMU_COUNT=1: per kernel instantiation -- launches, workgroups, wave-level matrix instructions by type, raw-buffer bytes -- as text lines
+// "name launches workgroups mfma_32x32x2_f32 mfma_16x16x4_f32 mfma_4x4x1_f32 mfma_16x16x32_bf16 mfma_32x32x16_bf16 buf_load_bytes buf_store_bytes"
+extern "C" int emu_counters_dump(char* buf, int n, int reset) {
+    std::lock_guard<std::mutex> cg(emu::counts_mu);
+    std::string out;
+    for (auto& kv : emu::kernel_counts) {
+        out += kv.first + "\t" + std::to_string(kv.second.launches) + "\t" + std::to_string(kv.second.workgroups);
+        for (int i = 0; i < emu::C_N; ++i) out += "\t" + std::to_string(kv.second.c[i]);
+        out += "\n";
+    }
+    if (reset) emu::kernel_counts.clear();
+    if (buf && n > 0) { strncpy(buf, out.c_str(), (size_t)n - 1); buf[n - 1] = 0; }
+    return (int)out.size() + 1;
+}
 
 // ---------------------------------------------------------------- host API ----
 struct emuStream { int id; };

@@ -77,6 +77,11 @@ unsigned long long wall_ticks();
 
 struct rsrc { char* base; long bytes; };
 
+// executed-work counters (per kernel instantiation; read with emu_counters_dump): wave-level matrix instructions by type, bytes moved by
+// the raw buffer instructions (in-range dwords only; plain pointer accesses are not seen)
+enum Counter { C_MFMA_32x32x2_F32, C_MFMA_16x16x4_F32, C_MFMA_4x4x1_F32, C_MFMA_16x16x32_BF16, C_MFMA_32x32x16_BF16, C_BUF_LOAD_BYTES, C_BUF_STORE_BYTES, C_N };
+extern thread_local unsigned long long counters[C_N];
+
 }  // namespace emu
 
 #define threadIdx (emu::lane_ids().tid)
@@ -203,6 +208,7 @@ static inline v16f mfma_32x32x2f32(float a, float b, v16f c, int, int, int) {
     const float ab[2] = {a, b};
     const Xchg e = xchg(ab, 8);
     const int l = lane_ids().lane, j = l & 31;
+    if (l == __builtin_ctzll(e.mask)) counters[C_MFMA_32x32x2_F32]++;
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
         float acc = c[r];
@@ -220,6 +226,7 @@ static inline v4f mfma_16x16x4f32(float a, float b, v4f c, int, int, int) {
     const float ab[2] = {a, b};
     const Xchg e = xchg(ab, 8);
     const int l = lane_ids().lane, j = l & 15;
+    if (l == __builtin_ctzll(e.mask)) counters[C_MFMA_16x16x4_F32]++;
     for (int r = 0; r < 4; ++r) {
         const int i = 4 * (l >> 4) + r;
         float acc = c[r];
@@ -237,6 +244,7 @@ static inline v4f mfma_4x4x1f32(float a, float b, v4f c, int, int, int) {
     const float ab[2] = {a, b};
     const Xchg e = xchg(ab, 8);
     const int l = lane_ids().lane;
+    if (l == __builtin_ctzll(e.mask)) counters[C_MFMA_4x4x1_F32]++;
     for (int i = 0; i < 4; ++i) {
         float A[2];
         memcpy(A, e.tab + XS * (4 * (l / 4) + i), 8);
@@ -254,6 +262,7 @@ static inline v4f mfma_16x16x32_bf16(v8bf a, v8bf b, v4f c, int, int, int) {
     memcpy(ab, &a, 16); memcpy(ab + 16, &b, 16);
     const Xchg e = xchg(ab, 32);
     const int l = lane_ids().lane, j = l & 15;
+    if (l == __builtin_ctzll(e.mask)) counters[C_MFMA_16x16x32_BF16]++;
     for (int r = 0; r < 4; ++r) {
         const int i = 4 * (l >> 4) + r;
         // (bf16 products are exact; the instruction's 32-term dot product is modelled as exact with ONE rounding into the accumulator --
@@ -271,6 +280,7 @@ static inline v16f mfma_32x32x16_bf16(v8bf a, v8bf b, v16f c, int, int, int) {
     memcpy(ab, &a, 16); memcpy(ab + 16, &b, 16);
     const Xchg e = xchg(ab, 32);
     const int l = lane_ids().lane, j = l & 31;
+    if (l == __builtin_ctzll(e.mask)) counters[C_MFMA_32x32x16_BF16]++;
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
         double acc = 0.0;
@@ -288,14 +298,14 @@ static inline void buf_load(rsrc rs, int voff, int soff, unsigned* out) {
     const long o = (long)(unsigned)voff + (long)(unsigned)soff;
     for (int d = 0; d < NDW; ++d) {
         out[d] = 0;
-        if (o + 4 * d + 4 <= rs.bytes) memcpy(&out[d], rs.base + o + 4 * d, 4);
+        if (o + 4 * d + 4 <= rs.bytes) { memcpy(&out[d], rs.base + o + 4 * d, 4); counters[C_BUF_LOAD_BYTES] += 4; }
     }
 }
 template <int NDW>
 static inline void buf_store(rsrc rs, int voff, int soff, const unsigned* in) {
     const long o = (long)(unsigned)voff + (long)(unsigned)soff;
     for (int d = 0; d < NDW; ++d)
-        if (o + 4 * d + 4 <= rs.bytes) memcpy(rs.base + o + 4 * d, &in[d], 4);
+        if (o + 4 * d + 4 <= rs.bytes) { memcpy(rs.base + o + 4 * d, &in[d], 4); counters[C_BUF_STORE_BYTES] += 4; }
 }
 typedef unsigned u32x4_gcc __attribute__((vector_size(16)));
 typedef unsigned u32x2_gcc __attribute__((vector_size(8)));
@@ -393,9 +403,11 @@ hipError_t hipDeviceGetAttribute(int*, hipDeviceAttribute_t, int);
 hipError_t hipDeviceSynchronize();
 hipError_t hipDeviceGetStreamPriorityRange(int*, int*);
 hipError_t hipMalloc(void**, size_t);
+template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), n); }
 hipError_t hipExtMallocWithFlags(void**, size_t, unsigned);
 hipError_t hipFree(void*);
 hipError_t hipHostMalloc(void**, size_t, unsigned = 0);
+template <class T> static inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipHostMalloc(reinterpret_cast<void**>(p), n, f); }
 hipError_t hipHostFree(void*);
 hipError_t hipHostGetDevicePointer(void**, void*, unsigned);
 hipError_t hipMemcpy(void*, const void*, size_t, hipMemcpyKind);
@@ -429,7 +441,7 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F,
 
 namespace emu {
 struct KernelCall { void (*run)(void*); void* ctx; };
-void launch(dim3 grid, dim3 block, size_t shmem, const char* name, KernelCall call);
+void launch(dim3 grid, dim3 block, size_t shmem, const char* name, const void* fn, KernelCall call);
 
 template <class F, class... A>
 struct Bound {
@@ -439,7 +451,7 @@ struct Bound {
 template <class F, class... A>
 static inline void launch_bound(dim3 grid, dim3 block, size_t shmem, const char* name, F f, A&&... a) {
     Bound<F, A...> b{f, std::tuple<std::decay_t<A>...>(std::forward<A>(a)...)};
-    launch(grid, block, shmem, name, KernelCall{&Bound<F, A...>::run, &b});
+    launch(grid, block, shmem, name, reinterpret_cast<const void*>(f), KernelCall{&Bound<F, A...>::run, &b});
 }
 }  // namespace emu
 
