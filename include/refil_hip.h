@@ -412,6 +412,8 @@ int refil_attn_backward(const refil_attn_desc* desc, void* stream);
  *   W_in   in_trans.weight [3w, w] row-major: rows [0,w) -> query, [w,2w) -> key, [2w,3w) -> value
  *   q_out / k_out / v_out   optional (NULL: not stored): the projections in the layouts of attn.Q / K / V; rows of dead queries /
  *          keys are not written
+ * Dead keys keep refil_attn_desc's meaning: a K / V row that row_bits marks dead is a ZERO row -- where a mask variant leaves it visible it
+ * takes part in the softmax with logit 0 and value 0, whether or not the key compaction computes its tile.
  * Row bits: an agent that row_bits marks alive as a QUERY is treated as alive as a key as well (its x row is read -- the query is
  * projected from the registers the key and the value come from --, its K / V rows are written when stores are asked for, and it is
  * attended to unless the mask words exclude it). The learner's row lists only produce rows where query-alive implies key-alive.

@@ -246,7 +246,10 @@ __global__ __launch_bounds__(64 * qkv_waves(NJT, NAT), 1) void attn_qkv_fwd(QkvM
     const int col0 = head * hd;
 
     // the key permutation of a row (see above); identity without compaction
-    struct QMap { int ek[NJT]; unsigned evp[NJT]; int cnt; };
+    // dropped: the entities a short row leaves outside its key tiles (all of them dead as keys). A dead K / V row is a ZERO row, not an
+    // absent one (refil_attn_desc.kv_dead): where a mask leaves such a key visible it still counts in the softmax -- logit 0, value 0 --,
+    // which the core adds in closed form. (The learner's row lists mark a key dead only when every mask hides it: nothing to add there.)
+    struct QMap { int ek[NJT]; unsigned evp[NJT]; int cnt; mw_t dropped; };
     auto map_of = [&](unsigned long long kdw) -> QMap {
         QMap m;
         if (!COMPACT) {
@@ -257,6 +260,7 @@ __global__ __launch_bounds__(64 * qkv_waves(NJT, NAT), 1) void attn_qkv_fwd(QkvM
                 m.evp[jt] = e0 | ((e0 + 1) << 8) | ((e0 + 2) << 16) | ((e0 + 3) << 24);
             }
             m.cnt = 16 * NJT;
+            m.dropped = 0;
             return m;
         }
         const unsigned long long L = ~kdw & ne_bits;
@@ -264,6 +268,8 @@ __global__ __launch_bounds__(64 * qkv_waves(NJT, NAT), 1) void attn_qkv_fwd(QkvM
         const unsigned long long below = (1ull << lane) - 1ull;
         const bool live = (L >> lane) & 1ull;
         const int pos = live ? __popcll(L & below) : m.cnt + __popcll(~L & below);
+        const int ntiles = m.cnt <= 16 ? 1 : (NJT > 2 && m.cnt <= 32 ? 2 : NJT);      // (the job's dispatch below)
+        m.dropped = (mw_t)__ballot(lane < p.ne && pos >= 16 * ntiles);
         const int T = __builtin_amdgcn_ds_permute(pos << 2, lane);          // lane `pos` <- this lane's entity
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
@@ -519,6 +525,9 @@ __global__ __launch_bounds__(64 * qkv_waves(NJT, NAT), 1) void attn_qkv_fwd(QkvM
                                 mx = fmaxf(mx, x);
                             }
                         mx = q_cross4_max(mx);
+                        // visible zero rows outside the tiles: logit 0 each
+                        const int nd = NJT > 2 ? __popcll(~cw[v][ax] & cmap.dropped) : __popc((unsigned)(~cw[v][ax] & cmap.dropped));
+                        if (nd) mx = fmaxf(mx, 0.f);
                         float sum = 0.f;
 #pragma unroll
                         for (int jt = 0; jt < NT; ++jt)
@@ -529,6 +538,7 @@ __global__ __launch_bounds__(64 * qkv_waves(NJT, NAT), 1) void attn_qkv_fwd(QkvM
                                 sum += e;
                             }
                         sum = q_cross4_sum(sum);
+                        if (nd) sum += (float)nd * __expf(0.f - mx);
                         const float inv = sum > 0.f ? __builtin_amdgcn_rcpf(sum) : 0.f;     // fully masked row -> 0 (attention.py:60 NaN -> 0)
 #pragma unroll
                         for (int jt = 0; jt < NT; ++jt)

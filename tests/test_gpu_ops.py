@@ -1014,3 +1014,79 @@ def test_attention_qkv_query_alive_but_dead_as_key(ne, na, heads, hd):
     for i in range(nvar):
         _close(O[i][lq], outs[i][lq], what=f"variant {i}")
         assert torch.isfinite(O[i]).all()
+
+
+def _qkv_fuzz_cases(n, seed=606):
+    import random
+    rnd = random.Random(seed)
+    out = []
+    for i in range(n):
+        heads, hd = rnd.choice([(4, 32), (4, 32), (4, 16), (8, 16), (2, 32)])       # w = 128 or 64
+        wide_ok = (hd, heads * hd) in ((32, 128), (16, 64))
+        ne = rnd.randint(1, 48 if wide_ok else 32)
+        na = rnd.randint(1, min(ne, 32 if wide_ok else 16))
+        out.append((rnd.randint(1, 7), rnd.randint(1, 9), ne, na, heads, hd, rnd.randint(1, 3), rnd.random() < 0.5, rnd.choice([0.0, 0.15, 0.5, 0.85]),
+                    9000 + i))
+    return out
+
+
+@pytest.mark.parametrize("B,T1,ne,na,heads,hd,nvar,store,dead,seed", _qkv_fuzz_cases(int(__import__("os").environ.get("REFIL_FUZZ_QKV_N", "12")),
+                                                                                          int(__import__("os").environ.get("REFIL_FUZZ_QKV_SEED", "606"))))
+def test_attention_qkv_random_shapes(B, T1, ne, na, heads, hd, nvar, store, dead, seed):
+    """Fuzz of the fused in_trans + attention launch: any entity / agent count its instantiations take (one to three key tiles, one or two
+    agent tiles), RANDOM dead entities at every density (so the key compaction sees every fill of its tiles, including rows with no live
+    entity and rows where only agents / only non-agents live), ragged episode ends, 1-3 mask variants, stores on / off, against fp32 torch.
+    Half the cases use the entity / within / interact masks, which leave keys VISIBLE that are dead at this step (the imagined groups are
+    drawn on the first step's entity mask, entity_rnn_agent.py:94-101): a dead K / V row is a zero row that still counts in the softmax,
+    also when the compaction leaves it outside the computed tiles (found by this fuzz, seed 606 case 7: the first version dropped them)."""
+    import hip_ops
+    torch.manual_seed(seed)
+    R, w = B * T1, heads * hd
+    groups = [[MASK_OBS, MASK_OBS_WITHIN, MASK_OBS_INTERACT], [MASK_ENTITY, MASK_WITHIN, MASK_INTERACT]]
+    variants = groups[seed % 2][:nvar]
+    x = torch.randn(R, ne, w)
+    W = torch.randn(3 * w, w) / math.sqrt(w)
+    em = (torch.rand(B, T1, ne) < dead).to(torch.uint8)
+    if B > 1:
+        em[1] = 1                                                      # an episode with every entity inactive
+    obs = (torch.rand(B, T1, ne, ne) < 0.4).to(torch.uint8)
+    obs = obs | em[:, :, :, None] | em[:, :, None, :]
+    em0 = em[:, 0].contiguous()
+    gb = (torch.rand(B, ne) < 0.5).to(torch.uint8)
+    t_last = torch.randint(-1, T1, (B,), dtype=torch.int32)
+    t_last[0] = T1 - 1
+    live = (torch.arange(T1)[None, :] <= t_last[:, None]).reshape(R)
+    masks = [_masks(c, obs, em, em0, gb, na).reshape(R, na, ne) for c in variants]
+    xz = x * (1 - em.reshape(R, ne, 1).float())
+    qr = (xz[:, :na] @ W[:w].t()) * (1 - em[:, :, :na].reshape(R, na, 1).float())
+    kr, vr = xz @ W[w:2 * w].t(), xz @ W[2 * w:].t()
+    outs = _attn_ref(qr, kr, vr, masks, heads)
+    xd = x.reshape(R * ne, w).clone()
+    xd[em.reshape(R * ne).bool()] = float("nan")
+    xd, Wd = xd.to(DEV), W.to(DEV)
+    dummy = torch.zeros(4, device=DEV)
+    d = hip_ops.attn_desc(dummy, dummy, dummy, w, 2 * w, R, T1, ne, na, heads, hd, variants, obs_mask=obs.to(DEV),
+                          ent_mask=em.reshape(R, ne).to(DEV), ent_mask0=em0.to(DEV), group_bits=gb.to(DEV))
+    hip_ops.attn_skip(d, t_last.to(DEV), em.reshape(R * ne).to(DEV), em[:, :, :na].reshape(R * na).contiguous().to(DEV))
+    hip_ops.attn_mask_words(d, na)
+    O = torch.full((nvar, R * na, w), 7.0, device=DEV)
+    qo = torch.full((R * na, w), 7.0, device=DEV) if store else None
+    kvo = torch.full((R * ne, 2 * w), 7.0, device=DEV) if store else None
+    hip_ops.attn_qkv_forward(d, xd, w, Wd, O, w, R * na * w, q_out=qo, k_out=kvo, v_out=kvo[:, w:] if store else None)
+    lq = (live[:, None] & ~em[:, :, :na].reshape(R, na).bool())
+    lk = (live[:, None] & ~em.reshape(R, ne).bool())
+    O = O.cpu().reshape(nvar, R, na, w)
+    for i in range(nvar):
+        if lq.any():
+            _close(O[i][lq], outs[i][lq], what=f"qkv fuzz variant {i}")
+        dq = live[:, None] & em[:, :, :na].reshape(R, na).bool()
+        assert (O[i][dq] == 0).all(), "rows of inactive agents of a live step read as exact zeros"
+    assert (O[0][~live] == 7.0).all()
+    if store:
+        qo, kvo = qo.cpu().reshape(R, na, w), kvo.cpu().reshape(R, ne, 2 * w)
+        if lq.any():
+            _close(qo[lq], qr[lq], tol=3e-6, what="stored Q")
+        if lk.any():
+            _close(kvo[lk][:, :w], kr[lk], tol=3e-6, what="stored K")
+            _close(kvo[lk][:, w:], vr[lk], tol=3e-6, what="stored V")
+        assert (qo[~lq] == 7.0).all() and (kvo[~lk] == 7.0).all()
