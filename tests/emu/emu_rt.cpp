@@ -60,10 +60,20 @@ namespace {
 constexpr size_t STACK_BYTES = 512 * 1024;
 enum State { READY, WAIT_WAVE, WAIT_BLOCK, SPIN, DONE };
 
+// one completed collective: what its lanes published, kept until every one of them has entered its NEXT collective (or left the kernel)
+struct Result {
+    alignas(64) unsigned char tab[64 * XS];
+    unsigned long long part = 0;
+    int refs = 0;
+};
 struct Wave {
-    alignas(64) unsigned char tab[2][64 * XS];
-    unsigned long long arrived = 0, alive = 0, part[2] = {0, 0};
+    alignas(64) unsigned char tab[64 * XS];     // what the waiting lanes have published
+    unsigned long long arrived = 0, alive = 0, released = 0;
+    const void* site[64] = {};                  // where (return address of the wrapper's call) each waiting lane entered its collective
+    Result* res[64] = {};                       // the result a lane was released with
+    std::vector<Result*> pool;
     int gen = 0;
+    ~Wave() { for (Result* r : pool) delete r; }
 };
 struct Block;
 struct Lane {
@@ -102,10 +112,48 @@ void to_sched() {
     Lane* me = cur;
     emu_switch(&me->sp, cur_blk->sched_sp);
 }
-void complete(Wave* w) {
-    w->part[w->gen & 1] = w->arrived;
-    w->arrived = 0;
+Result* result_get(Wave* w) {
+    for (Result* r : w->pool)
+        if (r->refs == 0) return r;
+    w->pool.push_back(new Result());
+    return w->pool.back();
+}
+void release_group(Wave* w, unsigned long long group) {
+    Result* r = result_get(w);
+    r->part = group;
+    r->refs = __builtin_popcountll(group);
+    for (unsigned long long m = group; m; m &= m - 1) {
+        const int l = __builtin_ctzll(m);
+        memcpy(r->tab + XS * l, w->tab + XS * l, XS);
+        w->res[l] = r;
+    }
+    w->released |= group;
+    w->arrived &= ~group;
     w->gen++;
+}
+unsigned long long group_at(const Wave* w, const void* site) {
+    unsigned long long g = 0;
+    for (unsigned long long m = w->arrived; m; m &= m - 1) {
+        const int l = __builtin_ctzll(m);
+        if (w->site[l] == site) g |= 1ull << l;
+    }
+    return g;
+}
+// Called when every lane of the wave that is still in the kernel waits in a collective, or when nothing in the workgroup can run and
+// part of a wave does (the rest waits at the workgroup barrier or spins). Lanes at DIFFERENT call sites are in different instructions
+// (an if / else with a shuffle in each arm, lanes that left a loop early): the hardware issues them one after the other under disjoint
+// EXEC masks, in its structured order -- then-arm, else-arm, join; a loop body before the loop's exit --, which the code address
+// approximates: the group at the lowest call site completes among its own lanes; the others keep waiting for the lanes it sets free to
+// join them (reconvergence). One call site = the whole wave in the common case.
+bool complete_earliest(Wave* w) {
+    if (!w->arrived) return false;
+    const void* first = nullptr;
+    for (unsigned long long m = w->arrived; m; m &= m - 1) {
+        const void* st = w->site[__builtin_ctzll(m)];
+        if (!first || st < first) first = st;
+    }
+    release_group(w, group_at(w, first));
+    return true;
 }
 
 [[noreturn]] void lane_exit() {
@@ -113,8 +161,9 @@ void complete(Wave* w) {
     Block* b = cur_blk;
     Wave* w = me->wave;
     me->state = DONE;
+    if (w->res[me->ids.lane]) { w->res[me->ids.lane]->refs--; w->res[me->ids.lane] = nullptr; }
     w->alive &= ~(1ull << me->ids.lane);
-    if (w->arrived && w->arrived == w->alive) complete(w);
+    if (w->arrived && w->arrived == w->alive) complete_earliest(w);
     b->alive--;
     if (b->bar_count > 0 && b->bar_count == b->alive) { b->bar_count = 0; b->bar_gen++; }
     to_sched();
@@ -145,7 +194,7 @@ void run_block(Block& b) {
             bool run = false;
             switch (l.state) {
                 case READY: run = true; break;
-                case WAIT_WAVE: run = l.wave->gen != l.wait_gen; break;
+                case WAIT_WAVE: run = (l.wave->released >> l.ids.lane) & 1ull; break;
                 case WAIT_BLOCK: run = b.bar_gen != l.wait_gen; break;
                 case SPIN: run = true; spinning = true; break;
                 case DONE: break;
@@ -163,7 +212,7 @@ void run_block(Block& b) {
         // nobody can run: a collective reached by part of a wave completes among the lanes that are there
         bool released = false;
         for (Wave& w : b.waves)
-            if (w.arrived) { complete(&w); released = true; }
+            if (complete_earliest(&w)) released = true;
         if (released) continue;
         if (b.bar_count > 0) { b.bar_count = 0; b.bar_gen++; continue; }
         fprintf(stderr, "emu: deadlock in kernel %s, workgroup %u (%d lanes alive)\n", b.name, b.ids.bid.x, b.alive);
@@ -275,17 +324,20 @@ std::mutex& launch_mu = *new std::mutex();     // one launch at a time (the host
 
 }  // namespace
 
-Xchg xchg(const void* mine, int nbytes) {
+__attribute__((noinline)) Xchg xchg(const void* mine, int nbytes) {
     Lane* me = cur;
     Wave* w = me->wave;
-    const int par = w->gen & 1, mygen = w->gen;
-    if (nbytes) memcpy(w->tab[par] + XS * me->ids.lane, mine, (size_t)nbytes);
-    w->arrived |= 1ull << me->ids.lane;
-    if (w->arrived == w->alive) complete(w);
-    else { me->state = WAIT_WAVE; me->wait_gen = mygen; to_sched(); }
-    return Xchg{w->tab[par], w->part[par]};
+    const int lane = me->ids.lane;
+    const unsigned long long bit = 1ull << lane;
+    if (w->res[lane]) { w->res[lane]->refs--; w->res[lane] = nullptr; }        // (the previous collective's result has been read)
+    if (nbytes) memcpy(w->tab + XS * lane, mine, (size_t)nbytes);
+    w->site[lane] = __builtin_return_address(0);
+    w->arrived |= bit;
+    if (w->arrived == w->alive) complete_earliest(w);
+    if (!(w->released & bit)) { me->state = WAIT_WAVE; to_sched(); }
+    w->released &= ~bit;
+    return Xchg{w->res[lane]->tab, w->res[lane]->part};
 }
-void wave_sync() { xchg(nullptr, 0); }
 void block_sync() {
     Lane* me = cur;
     Block* b = cur_blk;

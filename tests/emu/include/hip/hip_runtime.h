@@ -68,8 +68,7 @@ static inline const LaneIds& lane_ids() { return *cur_lane_ids; }
 static inline const BlockIds& block_ids() { return *cur_block_ids; }
 
 struct Xchg { const unsigned char* tab; unsigned long long mask; };   // tab + XS * l = what lane l published; mask = participating lanes
-Xchg xchg(const void* mine, int nbytes);
-void wave_sync();
+Xchg xchg(const void* mine, int nbytes);      // (never inlined: its return address identifies the collective's call site)
 void block_sync();
 void lane_yield();           // a spin-wait iteration: lets the other lanes of the workgroup (and the OS) run
 static inline void* dyn_smem() { return cur_dyn_smem; }      // the workgroup's dynamic LDS allocation
@@ -118,9 +117,9 @@ static inline void __syncthreads() { emu::block_sync(); }
 // A wave executes in lockstep on the hardware; here its lanes are fibers that run one after the other between two collectives. Every
 // point where the kernels tell the COMPILER that lanes exchange data (wave_barrier around same-wave LDS traffic, explicit waitcnts,
 // scheduling barriers) is therefore a real wave-level rendezvous in the emulator.
-#define __builtin_amdgcn_wave_barrier() emu::wave_sync()
-#define __builtin_amdgcn_s_waitcnt(x) emu::wave_sync()
-#define __builtin_amdgcn_sched_barrier(x) emu::wave_sync()
+#define __builtin_amdgcn_wave_barrier() ((void)emu::xchg(nullptr, 0))
+#define __builtin_amdgcn_s_waitcnt(x) ((void)emu::xchg(nullptr, 0))
+#define __builtin_amdgcn_sched_barrier(x) ((void)emu::xchg(nullptr, 0))
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) emu::lane_yield()
@@ -137,20 +136,21 @@ static inline T lane_get(const Xchg& e, int l) { T v; memcpy(&v, e.tab + XS * l,
 static inline bool lane_on(const Xchg& e, int l) { return (e.mask >> l) & 1ull; }
 
 template <class T>
-static inline T shfl_from(T v, int src) {
+__attribute__((always_inline)) static inline T shfl_from(T v, int src) {
     static_assert(sizeof(T) <= XS, "payload");
     const Xchg e = xchg(&v, sizeof(T));
-    return lane_on(e, src) ? lane_get<T>(e, src) : v;
+    if (!lane_on(e, src)) { T z; memset(&z, 0, sizeof(T)); return z; }      // (HIP's shuffles are ds_bpermute: a disabled source lane reads as 0)
+    return lane_get<T>(e, src);
 }
-static inline int readfirstlane(int v) {
+__attribute__((always_inline)) static inline int readfirstlane(int v) {
     const Xchg e = xchg(&v, 4);
     return lane_get<int>(e, __builtin_ctzll(e.mask));
 }
-static inline int readlane(int v, int l) {
+__attribute__((always_inline)) static inline int readlane(int v, int l) {
     const Xchg e = xchg(&v, 4);
     return lane_get<int>(e, l & 63);
 }
-static inline unsigned long long ballot(bool p) {
+__attribute__((always_inline)) static inline unsigned long long ballot(bool p) {
     const unsigned char b = p ? 1 : 0;
     const Xchg e = xchg(&b, 1);
     unsigned long long m = 0;
@@ -174,7 +174,7 @@ static inline int dpp_src(int l, int ctrl) {
     fprintf(stderr, "emu: DPP control 0x%x not emulated\n", ctrl);
     abort();
 }
-static inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+__attribute__((always_inline)) static inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     const int l = lane_ids().lane;
     const Xchg e = xchg(&src, 4);
     if (!((row_mask >> (l >> 4)) & 1) || !((bank_mask >> ((l >> 2) & 3)) & 1)) return old;
@@ -183,12 +183,12 @@ static inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_
     return lane_get<int>(e, s);
 }
 // ds_bpermute_b32: lane l reads the data of lane (addr / 4) % 64;  ds_permute_b32: lane l SENDS its data to lane (addr / 4) % 64
-static inline int ds_bpermute(int addr, int data) {
+__attribute__((always_inline)) static inline int ds_bpermute(int addr, int data) {
     const Xchg e = xchg(&data, 4);
     const int s = (addr >> 2) & 63;
     return lane_on(e, s) ? lane_get<int>(e, s) : 0;
 }
-static inline int ds_permute(int addr, int data) {
+__attribute__((always_inline)) static inline int ds_permute(int addr, int data) {
     const int pr[2] = {(addr >> 2) & 63, data};
     const Xchg e = xchg(pr, 8);
     const int me = lane_ids().lane;
@@ -204,7 +204,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
 // v_mfma_f32_32x32x2_f32: A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31]; D reg r of lane l = D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31]
-static inline v16f mfma_32x32x2f32(float a, float b, v16f c, int, int, int) {
+__attribute__((always_inline)) static inline v16f mfma_32x32x2f32(float a, float b, v16f c, int, int, int) {
     const float ab[2] = {a, b};
     const Xchg e = xchg(ab, 8);
     const int l = lane_ids().lane, j = l & 31;
@@ -222,7 +222,7 @@ static inline v16f mfma_32x32x2f32(float a, float b, v16f c, int, int, int) {
     return c;
 }
 // v_mfma_f32_16x16x4_f32: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; D reg r of lane l = D[4 (l >> 4) + r][l & 15]
-static inline v4f mfma_16x16x4f32(float a, float b, v4f c, int, int, int) {
+__attribute__((always_inline)) static inline v4f mfma_16x16x4f32(float a, float b, v4f c, int, int, int) {
     const float ab[2] = {a, b};
     const Xchg e = xchg(ab, 8);
     const int l = lane_ids().lane, j = l & 15;
@@ -240,7 +240,7 @@ static inline v4f mfma_16x16x4f32(float a, float b, v4f c, int, int, int) {
     return c;
 }
 // v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 outer products; D reg i of lane l = A[lane 4 (l / 4) + i] * B[lane l] (tools/probes/mfma4_probe.hip)
-static inline v4f mfma_4x4x1f32(float a, float b, v4f c, int, int, int) {
+__attribute__((always_inline)) static inline v4f mfma_4x4x1f32(float a, float b, v4f c, int, int, int) {
     const float ab[2] = {a, b};
     const Xchg e = xchg(ab, 8);
     const int l = lane_ids().lane;
@@ -257,7 +257,7 @@ static inline float bf(const unsigned char* p, int e) {
     return __uint_as_float((unsigned)h << 16);
 }
 // v_mfma_f32_16x16x32_bf16: A[i = l & 15][k = 8 (l >> 4) + e], B[k = 8 (l >> 4) + e][j = l & 15]; D as 16x16x4
-static inline v4f mfma_16x16x32_bf16(v8bf a, v8bf b, v4f c, int, int, int) {
+__attribute__((always_inline)) static inline v4f mfma_16x16x32_bf16(v8bf a, v8bf b, v4f c, int, int, int) {
     unsigned char ab[32];
     memcpy(ab, &a, 16); memcpy(ab + 16, &b, 16);
     const Xchg e = xchg(ab, 32);
@@ -275,7 +275,7 @@ static inline v4f mfma_16x16x32_bf16(v8bf a, v8bf b, v4f c, int, int, int) {
     return c;
 }
 // v_mfma_f32_32x32x16_bf16: A[i = l & 31][k = 8 (l >> 5) + e], B likewise; D as 32x32x2
-static inline v16f mfma_32x32x16_bf16(v8bf a, v8bf b, v16f c, int, int, int) {
+__attribute__((always_inline)) static inline v16f mfma_32x32x16_bf16(v8bf a, v8bf b, v16f c, int, int, int) {
     unsigned char ab[32];
     memcpy(ab, &a, 16); memcpy(ab + 16, &b, 16);
     const Xchg e = xchg(ab, 32);
@@ -336,13 +336,13 @@ static inline void raw_buffer_store_b128(V v, rsrc rs, int voff, int soff, int) 
 #define __builtin_amdgcn_ds_bpermute emu::ds_bpermute
 #define __builtin_amdgcn_ds_permute emu::ds_permute
 
-template <class T> static inline T __shfl_xor(T v, int m, int w = 64) { (void)w; return emu::shfl_from(v, emu::lane_ids().lane ^ m); }
-template <class T> static inline T __shfl(T v, int src, int w = 64) { const int l = emu::lane_ids().lane; return emu::shfl_from(v, (l & ~(w - 1)) + (src & (w - 1))); }
-template <class T> static inline T __shfl_up(T v, int d, int w = 64) { const int l = emu::lane_ids().lane; return emu::shfl_from(v, (l & (w - 1)) >= d ? l - d : l); }
-template <class T> static inline T __shfl_down(T v, int d, int w = 64) { const int l = emu::lane_ids().lane; return emu::shfl_from(v, (l & (w - 1)) + d < w ? l + d : l); }
-static inline unsigned long long __ballot(int p) { return emu::ballot(p != 0); }
-static inline int __any(int p) { return emu::ballot(p != 0) != 0; }
-static inline int __all(int p) { const emu::Xchg e = emu::xchg(&p, 4); for (int l = 0; l < 64; ++l) if (emu::lane_on(e, l) && !emu::lane_get<int>(e, l)) return 0; return 1; }
+template <class T> __attribute__((always_inline)) static inline T __shfl_xor(T v, int m, int w = 64) { (void)w; return emu::shfl_from(v, emu::lane_ids().lane ^ m); }
+template <class T> __attribute__((always_inline)) static inline T __shfl(T v, int src, int w = 64) { const int l = emu::lane_ids().lane; return emu::shfl_from(v, (l & ~(w - 1)) + (src & (w - 1))); }
+template <class T> __attribute__((always_inline)) static inline T __shfl_up(T v, int d, int w = 64) { const int l = emu::lane_ids().lane; return emu::shfl_from(v, (l & (w - 1)) >= d ? l - d : l); }
+template <class T> __attribute__((always_inline)) static inline T __shfl_down(T v, int d, int w = 64) { const int l = emu::lane_ids().lane; return emu::shfl_from(v, (l & (w - 1)) + d < w ? l + d : l); }
+__attribute__((always_inline)) static inline unsigned long long __ballot(int p) { return emu::ballot(p != 0); }
+__attribute__((always_inline)) static inline int __any(int p) { return emu::ballot(p != 0) != 0; }
+__attribute__((always_inline)) static inline int __all(int p) { const emu::Xchg e = emu::xchg(&p, 4); for (int l = 0; l < 64; ++l) if (emu::lane_on(e, l) && !emu::lane_get<int>(e, l)) return 0; return 1; }
 
 // ---- atomics / fences ----
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
