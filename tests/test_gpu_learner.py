@@ -937,3 +937,34 @@ def test_random_shapes_acting_path_matches_oracle(kw):
             ft = dict(ft, actions=fields["actions"][:, t - 1:t])
         qt, hc = eng.agent_forward(d1, ft, None, live, hc, first_step_zero=(t == 0))
         assert rel_err(qt[0, :, 0].cpu(), q[0, :, t].cpu()) < 1e-5, t
+
+
+def test_single_call_step_equals_the_three_calls():
+    """refil_learner_step (forward + backward + clip + RMSprop in ONE C call, what QLearner.train issues in a single process)
+    against refil_learner_forward_backward followed by refil_clip_rmsprop_step: parameters, optimiser state, gradients and
+    statistics bit-identical over three consecutive steps."""
+    from refil_amd import _lib, flat
+    from refil_amd.engine import LearnerEngine
+    g = load("refil_mid")
+    cfg, case = g["cfg"], g["case"]
+    dims = _dims(cfg, case["B"], case["T"] + 1)
+    n = flat.total(dims)
+    fields = {k: v.to(DEV) for k, v in g["batch"].items()}
+    bits = g["bits"].to(DEV)
+    res = []
+    for single in (False, True):
+        eng = LearnerEngine(DEV)
+        live = flat.pack(dims, g["agent"], g["mixer"], DEV)
+        targ = flat.pack(dims, g["tagent"], g["tmixer"], DEV)
+        sq = torch.zeros(n, device=DEV)
+        grads = torch.zeros(n + _lib.REFIL_NSTAT, device=DEV)
+        for _ in range(3):
+            if single:
+                eng.step(dims, fields, bits, live, targ, grads, sq, cfg.lr, cfg.optim_alpha, cfg.optim_eps, cfg.weight_decay, cfg.grad_norm_clip)
+            else:
+                eng.forward_backward(dims, fields, bits, live, targ, grads)
+                eng.clip_rmsprop(live, grads, sq, n, cfg.lr, cfg.optim_alpha, cfg.optim_eps, cfg.weight_decay, cfg.grad_norm_clip)
+        torch.cuda.synchronize()
+        res.append((live.clone(), sq.clone(), grads.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

@@ -371,36 +371,3 @@ def test_cfg1_training_with_ground_truth_factor_options(name, flag):
     _, groups = mac2.forward(batch2, t=None, imagine=True, group_bits=g["bits"].cuda(), **{flag.replace("train_", "use_"): True})
     assert th.equal(groups[0].cpu(), th.from_numpy(z["Wmask_noobs_t"]))
     assert th.equal(groups[1].cpu(), th.from_numpy(z["Imask_noobs_t"]))
-
-
-def test_single_call_step_equals_the_three_calls():
-    """refil_learner_step (forward + backward + clip + RMSprop in ONE C call, what QLearner.train issues in a single process)
-    against refil_learner_forward_backward followed by refil_clip_rmsprop_step: parameters, optimiser state, gradients and
-    statistics bit-identical over three consecutive steps."""
-    from golden_util import load
-    from refil_amd import _lib, flat
-    from refil_amd.engine import LearnerEngine
-    from test_gpu_learner import _dims
-    g = load("refil_mid")
-    cfg, case = g["cfg"], g["case"]
-    dims = _dims(cfg, case["B"], case["T"] + 1)
-    n = flat.total(dims)
-    fields = {k: v.to("cuda") for k, v in g["batch"].items()}
-    bits = g["bits"].to("cuda")
-    res = []
-    for single in (False, True):
-        eng = LearnerEngine("cuda")
-        live = flat.pack(dims, g["agent"], g["mixer"], "cuda")
-        targ = flat.pack(dims, g["tagent"], g["tmixer"], "cuda")
-        sq = th.zeros(n, device="cuda")
-        grads = th.zeros(n + _lib.REFIL_NSTAT, device="cuda")
-        for _ in range(3):
-            if single:
-                eng.step(dims, fields, bits, live, targ, grads, sq, cfg.lr, cfg.optim_alpha, cfg.optim_eps, cfg.weight_decay, cfg.grad_norm_clip)
-            else:
-                eng.forward_backward(dims, fields, bits, live, targ, grads)
-                eng.clip_rmsprop(live, grads, sq, n, cfg.lr, cfg.optim_alpha, cfg.optim_eps, cfg.weight_decay, cfg.grad_norm_clip)
-        th.cuda.synchronize()
-        res.append((live.clone(), sq.clone(), grads.clone()))
-    for a, b in zip(*res):
-        assert th.equal(a, b)
