@@ -95,13 +95,14 @@ def _run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, debug=True, st
     fields = {k: v.to(DEV) for k, v in batch.items()}
     out = eng.forward_backward(dims, fields, bits.to(DEV) if bits is not None else None, live, targ, grads, debug=debug)
     torch.cuda.synchronize()
-    kernels = None
+    kernels, prof = None, None
     if profile:
-        kernels = {e["name"]: e["launches"] for e in _lib.profile_collect()}
+        prof = _lib.profile_collect()       # (while the engine's workspace is alive: row-list scopes read their device-side counts here)
+        kernels = {e["name"]: e["launches"] for e in prof}
         _lib.profile_enable(False)
     stats = grads[n:].cpu().double()
     g_agent, g_mixer = flat.views(grads[:n].clone(), dims)
-    res = {"dims": dims, "kernels": kernels, "out": {k: v.cpu() for k, v in out.items()}, "stats": stats, "n": n,
+    res = {"dims": dims, "kernels": kernels, "profile": prof, "out": {k: v.cpu() for k, v in out.items()}, "stats": stats, "n": n,
            "grads": {**{"agent." + k: v.cpu() for k, v in g_agent.items()}, **{"mixer." + k: v.cpu() for k, v in g_mixer.items()}}}
     if step:
         sq = torch.zeros(n, device=DEV)

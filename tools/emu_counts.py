@@ -43,9 +43,15 @@ def main():
         cfg, batch, bits, agent, mixer, tagent, tmixer = L._oracle_case(
             kw["B"], kw["T"], kw["ne"], seed=40 + kw["B"], imagine=kw["imagine"], d=kw["d"], h=kw["d"], H=kw.get("H", 64), na=kw.get("na"),
             A=kw.get("A"), gm=kw.get("gm", False))
+        from refil_amd import _lib
         t0 = time.time()
-        L.run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, tuned=tuned or None)
+        # profile=True: the library's own profiler -- the FLOPs each launch is CREDITED with (bench.py's source)
+        r = L.run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer, tuned=tuned or None, profile=True)
+        credited = {e["name"]: e for e in r["profile"]}
         dt = time.time() - t0
+        from golden_util import live_steps
+        live = live_steps(batch)
+        live_frac = float(live.float().mean())
         n = lib.emu_counters_dump(None, 0, 0)
         buf = ctypes.create_string_buffer(n)
         lib.emu_counters_dump(buf, n, 1)
@@ -71,6 +77,29 @@ def main():
         print(f"{name[:78]:78s} {launches:8d} {c['mfma_32x32x2_f32']:11d} {c['mfma_16x16x4_f32']:11d} {c['mfma_4x4x1_f32']:10d} {c['mfma_16x16x32_bf16']:13d} "
               f"{c['mfma_32x32x16_bf16']:13d} {c['buf_load_bytes'] / 1e6:10.1f} {c['buf_store_bytes'] / 1e6:10.1f} {fl / 1e9:14.2f} {us:9.1f} {cyc / max(tot_cyc, 1):6.1%}")
     print(f"{'TOTAL':78s} {'':8s} {'':11s} {'':11s} {'':10s} {'':13s} {'':13s} {'':10s} {'':10s} {tot_fl / 1e9:14.2f} {tot_cyc / (SIMDS * CLOCK_GHZ * 1e3):9.1f}")
+    # credited (the launchers' closed forms, what bench.py prices a kernel with) against executed (counted above), per kernel family.
+    # The attention scopes credit every (b,t) row and bench.py scales them by the live-step fraction: done here as well.
+    fam = {}
+    for name, launches, wgs, c, cyc, fl in rows:
+        fam.setdefault(name.split("<")[0], [0.0, 0])[0] += fl
+    print(f"\n# credited vs executed GFLOP per step (fp32-equivalent), live-step fraction {live_frac:.3f}")
+    print(f"{'profiler scope':40s} {'launches':>8s} {'credited':>10s} {'executed':>10s} {'executed/credited':>18s}")
+    alias = {"gru_fwd_kernel": ("gru_fwd4_kernel", "gru_fwd16_kernel"), "gru_bwd_kernel": ("gru_bwd4_kernel", "gru_bwd16_kernel"),
+             "attn_fwd_mfma": ("attn_fwd_pipe",), "attn_bwd_mfma": ("attn_bwd_pipe",)}
+    seen = set()
+    for pname, e in sorted(credited.items(), key=lambda kv: -kv[1]["flops"]):
+        if e["flops"] <= 0:
+            continue
+        base = pname.split("<")[0]
+        if base in seen:
+            continue
+        cred = sum(x["flops"] for n2, x in credited.items() if n2.split("<")[0] == base)
+        nl = sum(x["launches"] for n2, x in credited.items() if n2.split("<")[0] == base)
+        if base.startswith("attn_"):
+            cred *= live_frac
+        ex = sum(fam.get(k, [0.0])[0] for k in (base,) + alias.get(base, ()))
+        seen.add(base)
+        print(f"{base:40s} {nl:8d} {cred / 1e9:10.2f} {ex / 1e9:10.2f} {ex / cred if cred else float('nan'):18.3f}")
 
 
 if __name__ == "__main__":
