@@ -246,10 +246,7 @@ __global__ __launch_bounds__(64 * qkv_waves(NJT, NAT), 1) void attn_qkv_fwd(QkvM
     const int col0 = head * hd;
 
     // the key permutation of a row (see above); identity without compaction
-    // dropped: the entities a short row leaves outside its key tiles (all of them dead as keys). A dead K / V row is a ZERO row, not an
-    // absent one (refil_attn_desc.kv_dead): where a mask leaves such a key visible it still counts in the softmax -- logit 0, value 0 --,
-    // which the core adds in closed form. (The learner's row lists mark a key dead only when every mask hides it: nothing to add there.)
-    struct QMap { int ek[NJT]; unsigned evp[NJT]; int cnt; mw_t dropped; };
+    struct QMap { int ek[NJT]; unsigned evp[NJT]; int cnt; };
     auto map_of = [&](unsigned long long kdw) -> QMap {
         QMap m;
         if (!COMPACT) {
@@ -260,7 +257,6 @@ __global__ __launch_bounds__(64 * qkv_waves(NJT, NAT), 1) void attn_qkv_fwd(QkvM
                 m.evp[jt] = e0 | ((e0 + 1) << 8) | ((e0 + 2) << 16) | ((e0 + 3) << 24);
             }
             m.cnt = 16 * NJT;
-            m.dropped = 0;
             return m;
         }
         const unsigned long long L = ~kdw & ne_bits;
@@ -268,8 +264,6 @@ __global__ __launch_bounds__(64 * qkv_waves(NJT, NAT), 1) void attn_qkv_fwd(QkvM
         const unsigned long long below = (1ull << lane) - 1ull;
         const bool live = (L >> lane) & 1ull;
         const int pos = live ? __popcll(L & below) : m.cnt + __popcll(~L & below);
-        const int ntiles = m.cnt <= 16 ? 1 : (NJT > 2 && m.cnt <= 32 ? 2 : NJT);      // (the job's dispatch below)
-        m.dropped = (mw_t)__ballot(lane < p.ne && pos >= 16 * ntiles);
         const int T = __builtin_amdgcn_ds_permute(pos << 2, lane);          // lane `pos` <- this lane's entity
 #pragma unroll
         for (int jt = 0; jt < NJT; ++jt) {
@@ -483,6 +477,17 @@ __global__ __launch_bounds__(64 * qkv_waves(NJT, NAT), 1) void attn_qkv_fwd(QkvM
             }
             QKV_TICK(t_st)
             // ---- attention core (attention_mfma.hip: attn_fwd_pipe), operands straight from the accumulators ----
+            // dropped: the entities a short row leaves outside its NT key tiles -- all of them dead as keys. A dead K / V row is a ZERO row,
+            // not an absent one (refil_attn_desc.kv_dead): where a mask leaves such a key visible it still counts in the softmax -- logit 0,
+            // value 0 --, which is added in closed form below. The tiles hold the cnt live entities and the FIRST 16 NT - cnt dead ones (in
+            // entity order): dropped = the dead-key word without its 16 NT - cnt lowest bits (scalar code; nothing is carried from row to
+            // row for it). The learner's row lists mark a key dead only when every mask hides it: nothing is ever added there.
+            mw_t dropped = 0;
+            if (COMPACT && NT < NJT) {
+                unsigned long long dk = crow.kdw & ne_bits;
+                for (int i = 16 * NT - cmap.cnt; i > 0 && dk; --i) dk &= dk - 1;
+                dropped = (mw_t)dk;
+            }
             f32x4 stt[NT][NA];
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt)
@@ -526,7 +531,7 @@ __global__ __launch_bounds__(64 * qkv_waves(NJT, NAT), 1) void attn_qkv_fwd(QkvM
                             }
                         mx = q_cross4_max(mx);
                         // visible zero rows outside the tiles: logit 0 each
-                        const int nd = NJT > 2 ? __popcll(~cw[v][ax] & cmap.dropped) : __popc((unsigned)(~cw[v][ax] & cmap.dropped));
+                        const int nd = NJT > 2 ? __popcll(~cw[v][ax] & dropped) : __popc((unsigned)(~cw[v][ax] & dropped));
                         if (nd) mx = fmaxf(mx, 0.f);
                         float sum = 0.f;
 #pragma unroll
