@@ -17,7 +17,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "refil_amd", "csrc")
-OUT = os.path.join(HERE, "_build")
+# EMU_ASAN=1: an AddressSanitizer build of the same thing (its own directory): out-of-bounds global / LDS accesses of the kernels, which the
+# GPU tolerates silently, abort with a report. Run python with LD_PRELOAD=$(clang++ -print-file-name=libclang_rt.asan-x86_64.so)
+# ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 (tools/emu_asan.sh).
+ASAN = os.environ.get("EMU_ASAN") == "1"
+OUT = os.path.join(HERE, "_build_asan" if ASAN else "_build")
 LIB = os.path.join(OUT, "librefil_emu.so")
 CLANG = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
@@ -159,6 +163,8 @@ def build(force=False, verbose=False, opt="-O1"):
     flags = [CLANG, "-x", "c++", "-std=c++17", opt, "-fPIC", "-pthread", "-fno-strict-aliasing", "-ffp-contract=off",
              "-I", os.path.join(HERE, "include"), "-I", src_dir, "-Wno-unknown-pragmas", "-Wno-pass-failed", "-Wno-unused-value",
              "-Wno-ignored-attributes", "-Wno-unknown-attributes"] + os.environ.get("EMU_EXTRA_FLAGS", "").split()
+    if ASAN:
+        flags += ["-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer", "-g1"]
     with open(os.path.join(HERE, "include", "hip", "hip_runtime.h")) as fh:
         shim = fh.read()
     with open(os.path.join(ROOT, "include", "refil_hip.h")) as fh:
@@ -204,7 +210,8 @@ def build(force=False, verbose=False, opt="-O1"):
             fh.write(dig)
     if failed:
         raise RuntimeError("emulator build failed")
-    subprocess.check_call([CLANG, "-shared", "-fPIC", "-pthread", "-o", LIB] + [obj for _, obj, _ in units] + ["-ldl", "-lm"])
+    subprocess.check_call([CLANG, "-shared", "-fPIC", "-pthread"] + (["-fsanitize=address", "-shared-libasan"] if ASAN else []) +
+                          ["-o", LIB] + [obj for _, obj, _ in units] + ["-ldl", "-lm"])
     return LIB
 
 

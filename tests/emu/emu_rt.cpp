@@ -24,6 +24,21 @@
 #include <thread>
 #include <vector>
 
+// EMU_ASAN=1 build (tests/emu/build_emu.py): AddressSanitizer has to be told about every stack switch
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define EMU_ASAN 1
+#include <sanitizer/common_interface_defs.h>
+#endif
+#endif
+#ifdef EMU_ASAN
+#define ASAN_START(save, bottom, size) __sanitizer_start_switch_fiber((save), (bottom), (size))
+#define ASAN_FINISH(save, bottom, size) __sanitizer_finish_switch_fiber((save), (bottom), (size))
+#else
+#define ASAN_START(save, bottom, size) ((void)0)
+#define ASAN_FINISH(save, bottom, size) ((void)0)
+#endif
+
 extern "C" void emu_switch(void** save_sp, void* load_sp);
 asm(R"(
 .text
@@ -79,6 +94,8 @@ struct Block;
 struct Lane {
     LaneIds ids;
     void* sp = nullptr;
+    void* asan_fake = nullptr;
+    char* stack = nullptr;
     State state = READY;
     int wait_gen = 0;
     Wave* wave = nullptr;
@@ -90,6 +107,9 @@ struct Block {
     std::vector<Wave> waves;
     int bar_gen = 0, bar_count = 0, alive = 0;
     void* sched_sp = nullptr;
+    void* asan_fake = nullptr;
+    const void* sched_stack = nullptr;
+    size_t sched_stack_size = 0;
     KernelCall call;
     const char* name;
 };
@@ -110,7 +130,10 @@ char* stack_of(size_t i) {
 
 void to_sched() {
     Lane* me = cur;
-    emu_switch(&me->sp, cur_blk->sched_sp);
+    Block* b = cur_blk;
+    ASAN_START(me->state == DONE ? nullptr : &me->asan_fake, b->sched_stack, b->sched_stack_size);
+    emu_switch(&me->sp, b->sched_sp);
+    ASAN_FINISH(me->asan_fake, nullptr, nullptr);
 }
 Result* result_get(Wave* w) {
     for (Result* r : w->pool)
@@ -170,6 +193,7 @@ bool complete_earliest(Wave* w) {
     abort();
 }
 extern "C" void emu_lane_entry() {
+    ASAN_FINISH(nullptr, &cur_blk->sched_stack, &cur_blk->sched_stack_size);       // (first time on this stack: learn where the scheduler's is)
     cur_blk->call.run(cur_blk->call.ctx);
     lane_exit();
 }
@@ -185,6 +209,7 @@ void run_block(Block& b) {
         *--sp = reinterpret_cast<void*>(&emu_lane_entry);
         for (int r = 0; r < 6; ++r) *--sp = nullptr;
         b.lanes[i].sp = sp;
+        b.lanes[i].stack = stack_of(i);
     }
     long idle_spins = 0;
     while (b.alive > 0) {
@@ -204,7 +229,9 @@ void run_block(Block& b) {
             l.state = READY;
             cur = &l;
             cur_lane_ids = &l.ids;
+            ASAN_START(&b.asan_fake, l.stack, STACK_BYTES);
             emu_switch(&b.sched_sp, l.sp);
+            ASAN_FINISH(b.asan_fake, nullptr, nullptr);
         }
         if (progressed) { idle_spins = 0; continue; }
         if (b.alive == 0) break;
