@@ -6,4 +6,5 @@ export EMU_ASAN=1
 python tests/emu/build_emu.py > /dev/null || exit 1
 export LD_PRELOAD=$RT
 export ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1:abort_on_error=1:allocator_may_return_null=1
-exec python -m pytest "${@:-tests/test_emu_ops.py tests/test_emu_learner.py tests/test_emu_replay.py}" -q -W ignore -p no:cacheprovider -x
+if [ $# -eq 0 ]; then set -- tests/test_emu_ops.py tests/test_emu_learner.py tests/test_emu_replay.py; fi
+exec python -m pytest "$@" -q -W ignore -p no:cacheprovider -x

@@ -19,6 +19,11 @@ import sys
 import time
 
 os.environ["EMU_COUNT"] = "1"
+# the library sizes grids and picks kernel variants (4-row / 16-row recurrence tiles, workgroups per weight-gradient launch) from the device's
+# CU count: emulate the MI355X's 256. The one-launch row lists would then need 256 co-resident spinning workgroups -- more than the
+# emulator's thread pool: the four-launch form builds the same lists.
+os.environ.setdefault("EMU_CUS", "256")
+os.environ.setdefault("REFIL_LISTS_FUSED", "0")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -66,7 +71,7 @@ def main():
     tot_cyc = sum(r[4] for r in rows)
     tot_fl = sum(r[5] for r in rows)
     print(f"# {which}{' +attn_qkv_wide' if '--wide' in sys.argv else ''}: B={kw['B']} T={kw['T']} ne={kw['ne']} d={kw['d']}  (one forward_backward + clip_rmsprop on the emulator, {dt:.0f} s; "
-          f"emulated device: {os.environ.get('EMU_CUS', '8')} CUs -- the counts do not depend on the grid)")
+          f"emulated device: {os.environ.get('EMU_CUS')} CUs)")
     print(f"# matrix-pipe issue floor = sum(count x issue cycles) / ({SIMDS} SIMDs x {CLOCK_GHZ} GHz); issue cycles per SIMD: {CYCLES}")
     print(f"{'kernel':78s} {'launches':>8s} {'32x32x2f32':>11s} {'16x16x4f32':>11s} {'4x4x1f32':>10s} {'16x16x32bf16':>13s} {'32x32x16bf16':>13s} "
           f"{'buf ld MB':>10s} {'buf st MB':>10s} {'GFLOP(fp32 eq)':>14s} {'floor us':>9s} {'share':>6s}")
