@@ -21,7 +21,10 @@ CSRC = os.path.join(ROOT, "refil_amd", "csrc")
 # GPU tolerates silently, abort with a report. Run python with LD_PRELOAD=$(clang++ -print-file-name=libclang_rt.asan-x86_64.so)
 # ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 (tools/emu_asan.sh).
 ASAN = os.environ.get("EMU_ASAN") == "1"
-OUT = os.path.join(HERE, "_build_asan" if ASAN else "_build")
+# EMU_UBSAN=1: the same with UndefinedBehaviorSanitizer (misaligned vector accesses, shifts past the width, signed overflow in index
+# arithmetic, out-of-range float -> int conversions): LD_PRELOAD libclang_rt.ubsan_standalone-x86_64.so, UBSAN_OPTIONS=print_stacktrace=1.
+UBSAN = os.environ.get("EMU_UBSAN") == "1"
+OUT = os.path.join(HERE, "_build_asan" if ASAN else ("_build_ubsan" if UBSAN else "_build"))
 LIB = os.path.join(OUT, "librefil_emu.so")
 CLANG = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
@@ -165,6 +168,8 @@ def build(force=False, verbose=False, opt="-O1"):
              "-Wno-ignored-attributes", "-Wno-unknown-attributes"] + os.environ.get("EMU_EXTRA_FLAGS", "").split()
     if ASAN:
         flags += ["-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer", "-g1"]
+    if UBSAN:
+        flags += ["-fsanitize=undefined", "-fno-sanitize=vptr,function", "-shared-libsan", "-fno-omit-frame-pointer", "-g1"]
     with open(os.path.join(HERE, "include", "hip", "hip_runtime.h")) as fh:
         shim = fh.read()
     with open(os.path.join(ROOT, "include", "refil_hip.h")) as fh:
@@ -210,7 +215,7 @@ def build(force=False, verbose=False, opt="-O1"):
             fh.write(dig)
     if failed:
         raise RuntimeError("emulator build failed")
-    subprocess.check_call([CLANG, "-shared", "-fPIC", "-pthread"] + (["-fsanitize=address", "-shared-libasan"] if ASAN else []) +
+    subprocess.check_call([CLANG, "-shared", "-fPIC", "-pthread"] + (["-fsanitize=address", "-shared-libasan"] if ASAN else []) + (["-fsanitize=undefined", "-shared-libsan"] if UBSAN else []) +
                           ["-o", LIB] + [obj for _, obj, _ in units] + ["-ldl", "-lm"])
     return LIB
 
