@@ -118,6 +118,8 @@ thread_local Lane* cur = nullptr;
 thread_local Block* cur_blk = nullptr;
 thread_local std::vector<char*>* stacks = nullptr;
 
+int env_int(const char* name, int dflt);
+
 char* stack_of(size_t i) {
     if (!stacks) stacks = new std::vector<char*>();
     while (stacks->size() <= i) {
@@ -211,11 +213,30 @@ void run_block(Block& b) {
         b.lanes[i].sp = sp;
         b.lanes[i].stack = stack_of(i);
     }
+    // EMU_ORDER: the order in which the scheduler visits the lanes (a kernel that is correct must not depend on it: a missing barrier
+    // between waves can pass by luck of one order) -- 0 ascending (default), 1 descending, 2 waves descending / lanes ascending,
+    // >= 3 a shuffle seeded with the value and the workgroup's id
+    static const int order_mode = env_int("EMU_ORDER", 0);
+    std::vector<unsigned> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = (unsigned)i;
+    if (order_mode == 1) for (size_t i = 0; i < n; ++i) order[i] = (unsigned)(n - 1 - i);
+    else if (order_mode == 2) {
+        const size_t nw = (n + 63) / 64;
+        size_t k = 0;
+        for (size_t w = nw; w-- > 0;)
+            for (size_t l = 64 * w; l < n && l < 64 * (w + 1); ++l) order[k++] = (unsigned)l;
+    } else if (order_mode >= 3) {
+        unsigned long long st = 0x9E3779B97F4A7C15ull * (unsigned long long)(order_mode + 1) + b.ids.bid.x * 1315423911ull + b.ids.bid.y * 2654435761ull;
+        for (size_t i = n; i > 1; --i) {
+            st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+            std::swap(order[i - 1], order[st % i]);
+        }
+    }
     long idle_spins = 0;
     while (b.alive > 0) {
         bool progressed = false, spinning = false;
-        for (size_t i = 0; i < n; ++i) {
-            Lane& l = b.lanes[i];
+        for (size_t oi = 0; oi < n; ++oi) {
+            Lane& l = b.lanes[order[oi]];
             bool run = false;
             switch (l.state) {
                 case READY: run = true; break;
