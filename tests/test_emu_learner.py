@@ -3,8 +3,9 @@ test_emu_ops.py for what that is and is not): one refil_learner_forward_backward
 emulator build -- every kernel launch of the step -- against the golden vectors generated from the reference itself and against the oracle.
 
 Default selection: every golden fixture, the 5-call reference trajectory, the oracle / degenerate-episode / config-matrix cases and a few
-fuzz shapes (~3 min). REFIL_EMU_FULL=1 adds everything of the gpu tier below production size (~10 min; the BASELINE-size cases stay on the GPU:
-hours of emulation)."""
+fuzz shapes (~3 min). REFIL_EMU_FULL=1 adds everything of the gpu tier below production size -- the bit-identity tests of the schedule variants,
+the early prologue / early target forward at engine level, all fuzz draws (~20 min); the BASELINE-size cases run offline (tools/emu_suite.sh:
+two minutes per north-star step)."""
 import os
 import shutil
 

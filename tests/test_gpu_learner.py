@@ -969,3 +969,70 @@ def test_single_call_step_equals_the_three_calls():
         res.append((live.clone(), sq.clone(), grads.clone()))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+class _ReadyEvent:
+    """refil_batch.ready_event for the engine-level early-path test: a recorded torch event on the GPU; under tests/emu (streams execute in
+    host order, events are no-ops) any non-null handle."""
+    def __init__(self):
+        if DEV == "cuda":
+            self._ev = torch.cuda.Event()
+            self._ev.record()
+            self.cuda_event = self._ev.cuda_event
+        else:
+            self.cuda_event = 1
+
+
+@pytest.mark.parametrize("et", ["1", "3", "0"])           # REFIL_EARLY_TARGET: target hypernets early (default) / + target agent / off
+def test_early_paths_engine_level_are_bit_identical(et, monkeypatch):
+    """The early prologue (refil_batch.ready_event: input assembly + row lists of step k+1 in the other workspace slot, beside the end of
+    step k) and the early target forward (refil_batch.target_version) through refil_learner_step, against the same steps without them:
+    two engines, two alternating batches (one of them twice in a row: the slot alternates even when the batch does not), target syncs
+    after steps 4 and 8 -- parameters, optimiser state and statistics bit-identical after every step, and the library's counters say the
+    early paths were taken. (The QLearner-level twin, with real events and streams, is tests/test_gpu_early.py.)"""
+    from refil_amd import _lib, flat
+    from refil_amd.engine import LearnerEngine
+    monkeypatch.delenv("REFIL_EARLY", raising=False)
+    monkeypatch.setenv("REFIL_EARLY_TARGET", et)
+    B, T, ne, d = 8, 24, 16, 64                       # the cfg2 shape at a quarter of its batch: the row-list schedule is active
+    cfg, b1, bits1, agent, mixer, tagent, tmixer = _oracle_case(B, T, ne, seed=100, imagine=True, d=d, h=d)
+    _, b2, bits2, *_ = _oracle_case(B, T, ne, seed=200, imagine=True, d=d, h=d)
+    dims = _dims(cfg, B, T + 1)
+    n = flat.total(dims)
+    batches = [({k: v.to(DEV) for k, v in b.items()}, bits.to(DEV)) for b, bits in ((b1, bits1), (b2, bits2))]
+    st0 = {k: _lib.get_stat(k) for k in ("learner_steps", "early_prologue_steps", "early_target_hypernet_steps", "early_target_agent_steps")}
+    runs = []
+    for early in (True, False):
+        eng = LearnerEngine(DEV)
+        live = flat.pack(dims, agent, mixer, DEV)
+        targ = flat.pack(dims, tagent, tmixer, DEV)
+        sq = torch.zeros(n, device=DEV)
+        grads = torch.zeros(n + _lib.REFIL_NSTAT, device=DEV)
+        version, trace = 1, []
+        for i in range(12):
+            fields, bits = batches[(0, 1, 1)[i % 3]]
+            eng.step(dims, fields, bits, live, targ, grads, sq, cfg.lr, cfg.optim_alpha, cfg.optim_eps, cfg.weight_decay, cfg.grad_norm_clip,
+                     ready_event=_ReadyEvent() if early else None, target_version=version if early else 0)
+            if i in (3, 7):                               # target sync behind steps 4 and 8: the early target forward must see it
+                targ.copy_(live)
+                version += 1
+            torch.cuda.synchronize()
+            trace.append((live.clone(), sq.clone(), grads.clone()))
+        runs.append(trace)
+    # The target agent early (et = 3) runs its recurrence in a launch of its own instead of sharing the live agent's: the 4-row / 16-row tile
+    # variant of the recurrence kernels is chosen from the rows per compute unit, so on a device with few CUs (the emulator's default 8) the
+    # two schedules may take different variants and agree to rounding only; with the MI355X's 256 CUs both take the 4-row tiles: exact.
+    import os
+    exact = et != "3" or DEV == "cuda" or os.environ.get("EMU_CUS") == "256"
+    for i, (a, b) in enumerate(zip(*runs)):
+        for x, y in zip(a, b):
+            if exact:
+                assert torch.equal(x, y), f"step {i}: max |d| = {(x - y).abs().max().item():.3e}"
+            else:
+                assert (x - y).abs().max().item() <= 1e-6 * max(1.0, y.abs().max().item()), f"step {i}"
+    st = {k: _lib.get_stat(k) - v for k, v in st0.items()}
+    # 24 steps; 11 of the first engine's with the early prologue (not its first: new workspace); the early target forward on those whose
+    # target version was on record and unchanged: not the first early step, not the two behind the syncs
+    assert st["learner_steps"] == 24 and st["early_prologue_steps"] == 11, st
+    assert st["early_target_hypernet_steps"] == (8 if et != "0" else 0) and st["early_target_agent_steps"] == (8 if et == "3" else 0), st
+    assert not torch.equal(runs[0][-1][0], flat.pack(dims, agent, mixer, DEV))
