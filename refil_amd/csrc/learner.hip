@@ -1780,8 +1780,20 @@ extern "C" int refil_learner_row_counts(const refil_dims* dims, void* workspace,
     if (int e = make_ctx(c, dims, &dummy, workspace, workspace_bytes_, CARVE_LEARNER, stream)) return e;
     out[0] = c.lists ? 1 : 0; out[5] = (int32_t)c.s.R;
     out[1] = (int32_t)c.s.NE; out[2] = (int32_t)c.s.NE; out[3] = (int32_t)c.s.NA; out[4] = (int32_t)c.s.R;
+    // make_ctx advanced the workspace's prologue slot as a learner step does (section 3a: the steps alternate between two copies of the
+    // lists). This is a query: the LAST step's lists sit in the slot it came from, and the alternation is put back as it was. (Found in
+    // round 6 by tests/test_gpu_learner.py::test_row_counts_match_the_batch: after one step the call returned the other slot's zeros;
+    // bench.py never noticed -- it trains on one batch, both slots hold the same counts.)
+    const int* counts = c.w.counts;
+    if (c.prev && c.same_layout) {
+        c.prev->slot ^= 1;
+        Arena a2{(char*)workspace, workspace_bytes_, 0, false};
+        Work w2;
+        carve(a2, *dims, w2, CARVE_LEARNER);
+        counts = c.prev->slot ? w2.alt.counts : w2.counts;
+    }
     if (c.lists) {
-        REFIL_HIP(hipMemcpyAsync(out + 1, c.w.counts, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c.st));
+        REFIL_HIP(hipMemcpyAsync(out + 1, counts, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, c.st));
         REFIL_HIP(hipStreamSynchronize(c.st));
     }
     return 0;

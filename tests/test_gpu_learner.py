@@ -1036,3 +1036,47 @@ def test_early_paths_engine_level_are_bit_identical(et, monkeypatch):
     assert st["learner_steps"] == 24 and st["early_prologue_steps"] == 11, st
     assert st["early_target_hypernet_steps"] == (8 if et != "0" else 0) and st["early_target_agent_steps"] == (8 if et == "3" else 0), st
     assert not torch.equal(runs[0][-1][0], flat.pack(dims, agent, mixer, DEV))
+
+
+@pytest.mark.parametrize("B,T,ne,d", [(8, 24, 16, 64), (8, 20, 32, 128)])
+def test_row_counts_match_the_batch(B, T, ne, d):
+    """refil_learner_row_counts -- what bench.py scales its roofline and its useful-FLOPs figure with -- against the same counts taken from
+    the batch by the definitions of DESIGN.md section 3: live steps (t <= t_last[b]), active agent rows, entity rows that some agent of the
+    agent nets can observe (or that are an active agent's own), entity rows the hypernets need (alive now or at step 0, or an active agent)."""
+    from refil_amd import _lib, flat
+    from refil_amd.engine import LearnerEngine
+    cfg, batch, bits, agent, mixer, tagent, tmixer = _oracle_case(B, T, ne, seed=7, imagine=True, d=d, h=d)
+    T1, na = T + 1, cfg.n_agents
+    dims = _dims(cfg, B, T1)
+    eng = LearnerEngine(DEV)
+    n = flat.total(dims)
+    grads = torch.zeros(n + _lib.REFIL_NSTAT, device=DEV)
+    live_p, targ_p = flat.pack(dims, agent, mixer, DEV), flat.pack(dims, tagent, tmixer, DEV)
+    _, batch2, bits2, *_ = _oracle_case(B, T, ne, seed=8, imagine=True, d=d, h=d)
+    # three steps on one workspace, another batch each time (the prologue slots alternate): the query returns the LAST step's counts
+    # every time, also when asked twice, and does not disturb the steps around it
+    for bt, bi in ((batch, bits), (batch2, bits2), (batch, bits)):
+        eng.forward_backward(dims, {k: v.to(DEV) for k, v in bt.items()}, bi.to(DEV), live_p, targ_p, grads)
+        torch.cuda.synchronize()
+        got = eng.row_counts(dims)
+        assert got == eng.row_counts(dims)
+        _check_row_counts(got, bt, B, T1, ne, na)
+    import bench
+    u = bench.qkv_useful_fraction(got, ne, na)
+    assert 0.0 < u <= 1.0
+
+
+def _check_row_counts(got, batch, B, T1, ne, na):
+    assert got["lists"] == 1, "the row-list schedule should be active at this shape"
+    live = live_steps(batch).bool()                                         # [B, T1]
+    em = batch["entity_mask"].bool()                                        # [B, T1, ne]: True = inactive
+    active_agent = ~em[:, :, :na]
+    la = torch.zeros_like(em)
+    la[:, :, :na] = active_agent
+    seen = (batch["obs_mask"][:, :, :na, :] == 0).any(dim=2)                # some agent can observe entity j
+    ka = (seen | la) & live[:, :, None]
+    kh = (~(em & em[:, :1]) | la) & live[:, :, None]
+    want = {"live_steps": int(live.sum()), "steps": B * T1, "agent_rows": int((active_agent & live[:, :, None]).sum()),
+            "entity_rows_agent": int(ka.sum()), "entity_rows_hyper": int(kh.sum()), "entity_rows": B * T1 * ne, "all_agent_rows": B * T1 * na}
+    for k, v in want.items():
+        assert got[k] == v, (k, got[k], v)
