@@ -1080,3 +1080,46 @@ def _check_row_counts(got, batch, B, T1, ne, na):
             "entity_rows_agent": int(ka.sum()), "entity_rows_hyper": int(kh.sum()), "entity_rows": B * T1 * ne, "all_agent_rows": B * T1 * na}
     for k, v in want.items():
         assert got[k] == v, (k, got[k], v)
+
+
+@pytest.mark.parametrize("B,T,ne,d", [(4, 10, 16, 64), (8, 20, 32, 128)])
+def test_mixer_grads_hook_fires_when_the_mixer_bucket_is_final(B, T, ne, d):
+    """refil_set_mixer_grads_hook (the two-bucket all-reduce of refil_amd/dp.py): the hook is called once per step, during enqueue, when every
+    kernel that writes grads[agent_total : total + REFIL_NSTAT] -- the mixer's gradients and the loss statistics -- has been enqueued on
+    the stream it is handed. A copy of that region taken ON that stream inside the hook must equal the region's final contents (nothing
+    enqueued later may touch it), the agent's gradients must not be final yet in general, and the step's results must equal a step without
+    the hook up to the summation order of the split reductions (the deferred reductions are off under the hook)."""
+    from refil_amd import _lib, flat
+    from refil_amd.engine import LearnerEngine
+    cfg, batch, bits, agent, mixer, tagent, tmixer = _oracle_case(B, T, ne, seed=31, imagine=True, d=d, h=d)
+    dims = _dims(cfg, B, T + 1)
+    n, n_agent = flat.total(dims), _lib.param_layout(dims).agent_total
+    fields = {k: v.to(DEV) for k, v in batch.items()}
+    live, targ = flat.pack(dims, agent, mixer, DEV), flat.pack(dims, tagent, tmixer, DEV)
+    plain = torch.full((n + _lib.REFIL_NSTAT,), float("nan"), device=DEV)
+    LearnerEngine(DEV).forward_backward(dims, fields, bits.to(DEV), live, targ, plain)
+    grads = torch.full((n + _lib.REFIL_NSTAT,), float("nan"), device=DEV)
+    snap = torch.zeros(n + _lib.REFIL_NSTAT - n_agent, device=DEV)
+    calls = []
+
+    def hook(user, stream):
+        calls.append(stream)
+        if DEV == "cuda":
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                snap.copy_(grads[n_agent:])
+        else:                                           # tests/emu: launches execute when they are enqueued
+            snap.copy_(grads[n_agent:])
+
+    cb = _lib.GRADS_HOOK(hook)
+    _lib.check(_lib.lib().refil_set_mixer_grads_hook(cb, None), "refil_set_mixer_grads_hook")
+    try:
+        LearnerEngine(DEV).forward_backward(dims, fields, bits.to(DEV), live, targ, grads)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().refil_set_mixer_grads_hook(_lib.GRADS_HOOK(0), None)
+    assert len(calls) == 1
+    assert torch.equal(snap, grads[n_agent:]), "the mixer bucket changed after the hook fired"
+    assert torch.isfinite(grads).all()
+    gmax = plain[:n].abs().max().item()
+    assert (grads[:n] - plain[:n]).abs().max().item() <= 5e-6 * gmax
+    assert torch.allclose(grads[n:n + 6], plain[n:n + 6], rtol=1e-6, atol=1e-6)
