@@ -30,7 +30,7 @@ _ALWAYS = ("test_learner_step_matches_reference_golden", "test_trajectory_matche
            "test_gt_factor_diagnostics_match_reference", "test_config_matrix_matches_oracle", "test_time_truncated_strided_batch_equals_contiguous",
            "test_wide_fused_attention_step_matches_oracle", "test_fused_attention_lds_fallback_is_bit_identical",
            "test_single_call_step_equals_the_three_calls", "test_row_counts_match_the_batch",
-           "test_mixer_grads_hook_fires_when_the_mixer_bucket_is_final")
+           "test_mixer_grads_hook_fires_when_the_mixer_bucket_is_final", "test_serialised_streams_and_released_streams_give_identical_steps")
 _NEVER = ("test_production_size_step_matches_oracle", "test_full_size_properties")       # BASELINE sizes: the GPU tier
 
 

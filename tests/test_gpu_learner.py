@@ -1123,3 +1123,27 @@ def test_mixer_grads_hook_fires_when_the_mixer_bucket_is_final(B, T, ne, d):
     gmax = plain[:n].abs().max().item()
     assert (grads[:n] - plain[:n]).abs().max().item() <= 5e-6 * gmax
     assert torch.allclose(grads[n:n + 6], plain[n:n + 6], rtol=1e-6, atol=1e-6)
+
+
+def test_serialised_streams_and_released_streams_give_identical_steps():
+    """refil_set_overlap(0) (one stream for everything: bench.py's isolated kernel timings, `--serial`) and refil_release_streams() between two
+    steps (the side streams and events are re-created lazily) change nothing a step computes: gradients, statistics and post-step
+    parameters bit-identical to the default four-stream schedule."""
+    from refil_amd import _lib
+    cfg, batch, bits, agent, mixer, tagent, tmixer = _oracle_case(8, 20, 32, seed=13, imagine=True, d=128, h=128)
+    base = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer)
+    try:
+        _lib.check(_lib.lib().refil_set_overlap(0), "refil_set_overlap")
+        serial = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer)
+    finally:
+        _lib.check(_lib.lib().refil_set_overlap(-1), "refil_set_overlap")
+    _lib.check(_lib.lib().refil_release_streams(), "refil_release_streams")
+    again = run_hip_step(cfg, batch, bits, agent, mixer, tagent, tmixer)
+    for other, what in ((serial, "serialised"), (again, "after refil_release_streams")):
+        for k in base["grads"]:
+            assert torch.equal(other["grads"][k], base["grads"][k]), (what, k)
+            assert torch.equal(other["post"][k], base["post"][k]), (what, k)
+        assert torch.equal(other["stats"], base["stats"]), what
+        for k in base["out"]:
+            assert torch.equal(other["out"][k], base["out"][k]), (what, k)
+    assert _lib.lib().refil_version() >= 1 and _lib.get_stat("learner_steps") >= 3 and _lib.get_stat("no such counter") == -1
