@@ -1147,3 +1147,37 @@ def test_serialised_streams_and_released_streams_give_identical_steps():
         for k in base["out"]:
             assert torch.equal(other["out"][k], base["out"][k]), (what, k)
     assert _lib.lib().refil_version() >= 1 and _lib.get_stat("learner_steps") >= 3 and _lib.get_stat("no such counter") == -1
+
+
+@pytest.mark.parametrize("B,T,ne,d,L", [(4, 12, 16, 64, 7), (8, 24, 16, 64, 15), (8, 24, 16, 64, 2)])
+def test_t_limit_equals_the_truncated_batch(B, T, ne, d, L):
+    """refil_batch.t_limit (QLearner trains a batch[:, :max_t_filled()] view through its untrimmed parent, src/run.py:269-270): the first
+    L steps of the batch count, transitions from L - 1 on carry no loss -- exactly the step on a contiguous copy of batch[:, :L]. The parent
+    is made adversarial: every episode runs on, filled and unterminated, past the cut, so without t_limit those steps WOULD carry loss."""
+    from refil_amd import _lib, flat
+    from refil_amd.engine import LearnerEngine
+    cfg, batch, bits, agent, mixer, tagent, tmixer = _oracle_case(B, T, ne, seed=17, imagine=True, d=d, h=d)
+    batch = {k: v.clone() for k, v in batch.items()}
+    batch["filled"][:, L - 1:] = 1
+    batch["terminated"][:, max(L - 2, 0):] = 0
+    T1 = T + 1
+    res = {}
+    for name, fields, t1, lim in (("parent", batch, T1, L), ("copy", {k: v[:, :L].contiguous() for k, v in batch.items()}, L, 0)):
+        dims = _dims(cfg, B, t1)
+        n = flat.total(dims)
+        grads = torch.full((n + _lib.REFIL_NSTAT,), float("nan"), device=DEV)
+        LearnerEngine(DEV).forward_backward(dims, {k: v.to(DEV) for k, v in fields.items()}, bits.to(DEV), flat.pack(dims, agent, mixer, DEV),
+                                            flat.pack(dims, tagent, tmixer, DEV), grads, t_limit=lim)
+        torch.cuda.synchronize()
+        res[name] = (grads[:n].cpu(), grads[n:n + 6].cpu().double())
+    gp, sp = res["parent"]
+    gc, sc = res["copy"]
+    assert sp[_lib.STAT_MASK_SUM] == sc[_lib.STAT_MASK_SUM] > 0
+    assert torch.allclose(sp, sc, rtol=2e-6, atol=1e-6), (sp, sc)
+    assert (gp - gc).abs().max().item() <= 5e-6 * gc.abs().max().item()
+    # and the cut matters: without t_limit the parent's extra steps do carry loss
+    dims = _dims(cfg, B, T1)
+    grads = torch.zeros(flat.total(dims) + _lib.REFIL_NSTAT, device=DEV)
+    LearnerEngine(DEV).forward_backward(dims, {k: v.to(DEV) for k, v in batch.items()}, bits.to(DEV), flat.pack(dims, agent, mixer, DEV),
+                                        flat.pack(dims, tagent, tmixer, DEV), grads)
+    assert grads[flat.total(dims) + _lib.STAT_MASK_SUM].item() > sp[_lib.STAT_MASK_SUM].item()
