@@ -14,6 +14,14 @@ from ..modules.mixers.flex_qmix import FlexQMixer, LinearFlexQMixer
 from ..modules.mixers.vdn import VDNMixer
 
 
+def _require_gpu(dev):
+    """The learner has no CPU path: its parameters must live on the GPU before the first train() / save / load. (A function of its own so
+    that the CPU test tier can run this class on tests/emu -- the kernel sources on a CPU wavefront emulator, tests/emu_util.py -- by
+    standing in for it there; nothing in the package does.)"""
+    if dev.type != "cuda":
+        raise RuntimeError("refil_amd.QLearner runs on the GPU only: call learner.cuda() first (no CPU fallback)")
+
+
 class QLearner:
     def __init__(self, mac, scheme, logger, args):
         self.args = args
@@ -53,8 +61,7 @@ class QLearner:
     def _setup_flat(self):
         """[agent | mixer] flat buffers for live / target nets, RMSprop state and gradients."""
         dev = next(self.mac.agent.parameters()).device
-        if dev.type != "cuda":
-            raise RuntimeError("refil_amd.QLearner runs on the GPU only: call learner.cuda() first (no CPU fallback)")
+        _require_gpu(dev)
         self._engine = LearnerEngine(dev)
         d0 = dims_from_args(self.args, 1, 2)
         L = _lib.param_layout(d0)

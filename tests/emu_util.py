@@ -68,20 +68,52 @@ def _host_batch(fields, group_bits=None, device=None, mask_words=None, mask_row_
     return b
 
 
+class _HostEvent:
+    """torch.cuda.Event for code that runs on the emulator: its streams execute in host order, every event has happened when it is recorded.
+    cuda_event is a non-null handle (the library passes it to hipStreamWaitEvent, a no-op there), so refil_batch.ready_event switches the
+    early-prologue code path on exactly as a real event does."""
+    cuda_event = 1
+
+    def __init__(self, *a, **k):
+        pass
+
+    def record(self, *a, **k):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def wait(self, *a, **k):
+        pass
+
+    def query(self):
+        return True
+
+    def elapsed_time(self, other):
+        return 0.0
+
+
 @contextlib.contextmanager
 def active():
-    """route refil_amd._lib.lib() to the emulator build; null stream, host batches, no device synchronisation"""
+    """route refil_amd._lib.lib() to the emulator build; null stream, host batches, no device synchronisation. For the plugin layer
+    (QLearner, the only class of the package that asks for CUDA tensors, events and pinned memory): events that have always happened,
+    pin_memory() as the identity, and the learner's GPU-only guard stood in for -- the guard itself (q_learner._require_gpu) is untouched."""
     import torch
     from refil_amd import _lib
-    saved = (_lib._lib, _lib.current_stream_ptr, _lib.make_batch, torch.cuda.synchronize)
+    from refil_amd.learners import q_learner
+    saved = (_lib._lib, _lib.current_stream_ptr, _lib.make_batch, torch.cuda.synchronize, torch.cuda.Event, torch.Tensor.pin_memory, q_learner._require_gpu)
     _lib._lib = emu_handle()
     _lib.current_stream_ptr = lambda: None
     _lib.make_batch = _host_batch
     torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.Event = _HostEvent
+    torch.Tensor.pin_memory = lambda self, *a, **k: self
+    q_learner._require_gpu = lambda dev: None
     try:
         yield _lib._lib
     finally:
-        _lib._lib, _lib.current_stream_ptr, _lib.make_batch, torch.cuda.synchronize = saved
+        (_lib._lib, _lib.current_stream_ptr, _lib.make_batch, torch.cuda.synchronize, torch.cuda.Event, torch.Tensor.pin_memory,
+         q_learner._require_gpu) = saved
 
 
 def load_copy(module, **patch):

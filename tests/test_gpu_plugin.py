@@ -7,6 +7,14 @@ import torch as th
 
 pytestmark = pytest.mark.gpu
 
+DEV = "cuda"        # (tests/test_emu_plugin.py runs a private copy of this module with DEV = "cpu" on the CPU wavefront emulator)
+
+
+def _place(learner):
+    """learner.cuda() (src/run.py:211-212) where there is a GPU"""
+    if DEV == "cuda":
+        learner.cuda()
+
 from golden_util import load, load_traj, rel_err
 from oracle import refil_oracle as orc
 from plugin_util import RecLogger, make_args, make_episode_batch
@@ -17,13 +25,13 @@ def _build(name, **over):
     from refil_amd.learners import REGISTRY as le_REGISTRY
     g = load(name)
     cfg = g["cfg"]
-    args = make_args(cfg, **over)
+    args = make_args(cfg, device=DEV, use_cuda=DEV == "cuda", **over)
     batch, groups = make_episode_batch(cfg, g["batch"])
     mac = mac_REGISTRY[args.mac](batch.scheme, groups, args)
     logger = RecLogger()
     learner = le_REGISTRY[args.learner](mac, batch.scheme, logger, args)
-    learner.cuda()
-    batch.to("cuda")
+    _place(learner)
+    batch.to(DEV)
     # load the reference's initial weights by state_dict name
     mac.agent.load_state_dict({k[len("agent0."):]: th.from_numpy(g["z"][k]) for k in g["z"].files if k.startswith("agent0.")})
     learner.mixer.load_state_dict({k[len("mixer0."):]: th.from_numpy(g["z"][k]) for k in g["z"].files if k.startswith("mixer0.")})
@@ -94,21 +102,21 @@ def test_imagine_forward_returns_groups_like_reference():
 def test_mixer_module_forward():
     g, args, batch, mac, learner, logger = _build("refil_tiny")
     z, cfg = g["z"], g["cfg"]
-    xe = orc.build_entity_inputs(cfg, g["batch"]["entities"], g["batch"]["actions"]).cuda()
+    xe = orc.build_entity_inputs(cfg, g["batch"]["entities"], g["batch"]["actions"]).to(DEV)
     em = batch["entity_mask"]
-    q = learner.mixer(th.from_numpy(z["chosen_q_real"]).cuda(), (xe[:, :-1], em[:, :-1]))
+    q = learner.mixer(th.from_numpy(z["chosen_q_real"]).to(DEV), (xe[:, :-1], em[:, :-1]))
     assert rel_err(q.cpu(), z["q_tot"]) < 1e-4
-    qi = learner.mixer(th.from_numpy(z["chosen_q_imagine"]).cuda(), (xe[:, :-1], em[:, :-1]), imagine_groups=g["bits"].cuda())
+    qi = learner.mixer(th.from_numpy(z["chosen_q_imagine"]).to(DEV), (xe[:, :-1], em[:, :-1]), imagine_groups=g["bits"].to(DEV))
     assert rel_err(qi.cpu(), z["q_tot_imagine"]) < 1e-4
     # the reference's own calling convention: imagine_groups = (Wmask, Imask) mask tensors (flex_qmix.py:85-94), as the
     # imagine agent returns them (entity_rnn_agent.py:130) and QLearner slices them (q_learner.py:137)
     T = xe.shape[1] - 1
-    Wm = th.from_numpy(z["Wmask_noobs"]).cuda()[:, None].repeat(1, T, 1, 1)
-    Im = th.from_numpy(z["Imask_noobs"]).cuda()[:, None].repeat(1, T, 1, 1)
-    qi2 = learner.mixer(th.from_numpy(z["chosen_q_imagine"]).cuda(), (xe[:, :-1], em[:, :-1]), imagine_groups=(Wm, Im))
+    Wm = th.from_numpy(z["Wmask_noobs"]).to(DEV)[:, None].repeat(1, T, 1, 1)
+    Im = th.from_numpy(z["Imask_noobs"]).to(DEV)[:, None].repeat(1, T, 1, 1)
+    qi2 = learner.mixer(th.from_numpy(z["chosen_q_imagine"]).to(DEV), (xe[:, :-1], em[:, :-1]), imagine_groups=(Wm, Im))
     assert rel_err(qi2.cpu(), z["q_tot_imagine"]) < 1e-4
     assert th.equal(qi2, qi)                       # same kernels, same mask words: bit-identical
-    qi3 = learner.mixer(th.from_numpy(z["chosen_q_imagine"]).cuda(), (xe[:, :-1], em[:, :-1]), imagine_groups=[Wm[:, :1], Im[:, :1]])
+    qi3 = learner.mixer(th.from_numpy(z["chosen_q_imagine"]).to(DEV), (xe[:, :-1], em[:, :-1]), imagine_groups=[Wm[:, :1], Im[:, :1]])
     assert th.equal(qi3, qi)
     # arbitrary masks (not derivable from a 2-way split) against the oracle's mixer
     gen = th.Generator().manual_seed(5)
@@ -118,9 +126,9 @@ def test_mixer_module_forward():
     caq = th.from_numpy(z["chosen_q_imagine"])
     _, ref_im = orc.mixer_forward(cfg, mixer_p, th.from_numpy(z["chosen_q_real"]), xe[:, :-1].cpu(), g["batch"]["entity_mask"][:, :-1],
                                   caq, (Wr[:, :, :cfg.n_agents], Ir[:, :, :cfg.n_agents]))     # (the oracle takes the agents' rows)
-    qi4 = learner.mixer(caq.cuda(), (xe[:, :-1], em[:, :-1]), imagine_groups=(Wr.cuda(), Ir.cuda()))
+    qi4 = learner.mixer(caq.to(DEV), (xe[:, :-1], em[:, :-1]), imagine_groups=(Wr.to(DEV), Ir.to(DEV)))
     assert rel_err(qi4.cpu(), ref_im) < 1e-4
-    tq = learner.target_mixer(th.from_numpy(z["target_max_q"]).cuda(), (xe[:, 1:], em[:, 1:]))
+    tq = learner.target_mixer(th.from_numpy(z["target_max_q"]).to(DEV), (xe[:, 1:], em[:, 1:]))
     assert rel_err(tq.cpu(), z["target_q_tot"]) < 1e-4
 
 
@@ -159,13 +167,13 @@ def _build_traj(name, state, **over):
     from refil_amd.learners import REGISTRY as le_REGISTRY
     g = load_traj(name)
     cfg, case = g["cfg"], g["case"]
-    args = make_args(cfg, target_update_interval=case["target_update_interval"], **over)
-    batches = [make_episode_batch(cfg, b, device="cuda")[0] for b in g["batches"]]
+    args = make_args(cfg, device=DEV, use_cuda=DEV == "cuda", target_update_interval=case["target_update_interval"], **over)
+    batches = [make_episode_batch(cfg, b, device=DEV)[0] for b in g["batches"]]
     groups = {"agents": cfg.n_agents, "entities": cfg.n_entities}
     mac = mac_REGISTRY[args.mac](batches[0].scheme, groups, args)
     logger = RecLogger()
     learner = le_REGISTRY[args.learner](mac, batches[0].scheme, logger, args)
-    learner.cuda()
+    _place(learner)
     if state is not None:
         st = g["states"][state]
         mac.agent.load_state_dict(st["agent"], strict=False)
@@ -249,14 +257,14 @@ def test_qlearner_without_mixer(tmp_path):
     from refil_amd.learners import REGISTRY as le_REGISTRY
     g = load("qmix_atten_tiny")
     cfg = dataclasses.replace(g["cfg"], mixer_none=True)
-    args = make_args(cfg)
+    args = make_args(cfg, device=DEV, use_cuda=DEV == "cuda")
     assert args.mixer is None
     batch, groups = make_episode_batch(cfg, g["batch"])
     mac = mac_REGISTRY[args.mac](batch.scheme, groups, args)
     logger = RecLogger()
     learner = le_REGISTRY[args.learner](mac, batch.scheme, logger, args)
-    learner.cuda()
-    batch.to("cuda")
+    _place(learner)
+    batch.to(DEV)
     assert learner.mixer is None and not hasattr(learner, "target_mixer")
     z = g["z"]
     agent = {k[len("agent0."):]: th.from_numpy(z[k]) for k in z.files if k.startswith("agent0.")}
@@ -368,6 +376,6 @@ def test_cfg1_training_with_ground_truth_factor_options(name, flag):
     # the groups the agent hands to the mixer are the reference's time-dependent masks
     g2, args2, batch2, mac2, _, _ = _build(name, gt_mask_avail=True)
     mac2.init_hidden(batch2.batch_size)
-    _, groups = mac2.forward(batch2, t=None, imagine=True, group_bits=g["bits"].cuda(), **{flag.replace("train_", "use_"): True})
+    _, groups = mac2.forward(batch2, t=None, imagine=True, group_bits=g["bits"].to(DEV), **{flag.replace("train_", "use_"): True})
     assert th.equal(groups[0].cpu(), th.from_numpy(z["Wmask_noobs_t"]))
     assert th.equal(groups[1].cpu(), th.from_numpy(z["Imask_noobs_t"]))
