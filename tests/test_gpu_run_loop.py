@@ -18,6 +18,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+DEV = "cuda"        # (tests/test_emu_run_loop.py runs a private copy of this module with DEV = "cpu" on the CPU wavefront emulator)
+
 NA, C, T_LIMIT = 4, 4, 10
 NE, A, ED = 2 * NA, 1 + C, 2 + C + NA
 
@@ -143,11 +145,19 @@ def test_policy_learns_through_the_whole_cycle(imagine, host_buffer):
     assert after > 0.85, (before, after, sorted(lengths))
 
 
+def test_cycle_mechanics_short():
+    """40 iterations of the same cycle (what the CPU tier runs on the emulator, where 800 take too long): every train() call happens,
+    the ring buffer wraps, the max_t_filled() trim presents several lengths -- each trained through its untrimmed parent
+    (refil_batch.t_limit) --, and the parameters stay finite. Learning itself is the 800-iteration test above."""
+    before, after, lengths, trains, iters, wrapped, finite = _cycle(True, False, iters=40)
+    assert finite and trains >= iters - 2 and wrapped and len(lengths) >= 2, (trains, wrapped, lengths)
+
+
 def _cycle(imagine, host_buffer, iters=800, lr=0.005):
     from refil_amd.components.episode_buffer import EpisodeBatch, ReplayBuffer
     from refil_amd.controllers import REGISTRY as mac_REGISTRY
     from refil_amd.learners import REGISTRY as le_REGISTRY
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", 0) if DEV == "cuda" else torch.device("cpu")
     torch.manual_seed(5)
     np.random.seed(5)
     rng = np.random.default_rng(5)
@@ -155,12 +165,13 @@ def _cycle(imagine, host_buffer, iters=800, lr=0.005):
     scheme, groups, preprocess = _scheme()
     args = _args(imagine, anneal=int(0.5 * iters * n_envs * 4.5), lr=lr)
     buffer = ReplayBuffer(scheme, groups, buffer_size, T_LIMIT + 1, preprocess=preprocess,
-                          device="cpu" if host_buffer else dev, sample_device=dev if host_buffer else None)
+                          device="cpu" if host_buffer else dev, sample_device=dev if (host_buffer and DEV == "cuda") else None)
     mac = mac_REGISTRY[args.mac](buffer.scheme, groups, args)
     from plugin_util import RecLogger
     logger = RecLogger()
     learner = le_REGISTRY[args.learner](mac, buffer.scheme, logger, args)
-    learner.cuda()
+    if DEV == "cuda":
+        learner.cuda()
     envs = MatchEnvs(n_envs, rng)
 
     def new_batch():
