@@ -204,7 +204,8 @@ def build(dims, imagine, B, T, seed, device, shard=None, dense=False, fresh=0, h
     torch.manual_seed(0)                                   # identical replicas on every rank
     mac = mac_REGISTRY[args.mac](batch.scheme, groups, args)
     learner = le_REGISTRY[args.learner](mac, batch.scheme, _Logger(), args)
-    learner.cuda()
+    if device.type == "cuda":                              # (a host device: the CPU tier's emulator runs of tests/test_gpu_early.py)
+        learner.cuda()
     learner.generator = torch.Generator().manual_seed(1234)     # the SAME stream on every rank: train() draws the global partition and slices it
     buffer = None
     if fresh > 0:
@@ -217,7 +218,7 @@ def build(dims, imagine, B, T, seed, device, shard=None, dense=False, fresh=0, h
             if dense and k:
                 dk = densify(dk)
             buffer.insert_episode_batch(episode_batch(dk))
-    if device.type == "cuda":
+    if device.type == "cuda" or getattr(torch.cuda.Event, "cuda_event", None) is not None:      # (or tests/emu_util's stand-in event)
         batch.ready_event = torch.cuda.Event()             # the batch is complete here: lets train() run its prologue early
         batch.ready_event.record()
     learner._bench_episode_batch = episode_batch           # (bench.py's second, densified timed region builds its batch with it)

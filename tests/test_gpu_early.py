@@ -8,6 +8,12 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+DEV = "cuda"        # (tests/test_emu_early.py runs a private copy of this module with DEV = "cpu" on the CPU wavefront emulator)
+
+
+def _dev():
+    return torch.device("cuda", 0) if DEV == "cuda" else torch.device("cpu")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
@@ -20,7 +26,7 @@ def test_early_prologue_is_bit_identical(cfg, et, monkeypatch):
     monkeypatch.setenv("REFIL_EARLY_TARGET", et)
     W = dict(bench.CONFIGS[cfg])
     dims = bench.workload_dims(W)
-    dev = torch.device("cuda", 0)
+    dev = _dev()
     B = 8
     _, b1, la, _, _ = bench.build(dims, W["imagine"], B, W["T"], seed=100, device=dev)
     _, b2, lb, _, _ = bench.build(dims, W["imagine"], B, W["T"], seed=200, device=dev)
@@ -71,7 +77,7 @@ def test_sampled_batches_early_gather_is_bit_identical(monkeypatch):
     import bench
     W = dict(bench.CONFIGS["cfg2"])
     dims = bench.workload_dims(W)
-    dev = torch.device("cuda", 0)
+    dev = _dev()
     B = 8
     monkeypatch.delenv("REFIL_EARLY", raising=False)
     _, _, la, _, bufa = bench.build(dims, W["imagine"], B, W["T"], seed=300, device=dev, fresh=4)
@@ -123,7 +129,7 @@ def test_first_call_autotune(monkeypatch):
     from refil_amd.learners.q_learner import QLearner
     W = dict(bench.CONFIGS["cfg2"])
     dims = bench.workload_dims(W)
-    dev = torch.device("cuda", 0)
+    dev = _dev()
     saved, measured = dict(QLearner._TUNED), QLearner._MEASURED[0]
     try:
         QLearner._TUNED.clear()
@@ -181,7 +187,7 @@ def test_unsynchronised_steps_equal_in_order_steps(cfg, B, monkeypatch):
     monkeypatch.delenv("REFIL_EARLY_TARGET", raising=False)
     W = dict(bench.CONFIGS[cfg])
     dims = bench.workload_dims(W)
-    dev = torch.device("cuda", 0)
+    dev = _dev()
     _, b1, la, _, _ = bench.build(dims, W["imagine"], B, W["T"], seed=100, device=dev)
     _, b2, lb, _, _ = bench.build(dims, W["imagine"], B, W["T"], seed=200, device=dev)
     la._check_flat(); lb._check_flat()
@@ -221,7 +227,7 @@ def test_max_t_filled_trim_trains_through_the_parent(monkeypatch):
     from refil_amd import _lib
     W = dict(bench.CONFIGS["cfg2"])
     dims = bench.workload_dims(W)
-    dev = torch.device("cuda", 0)
+    dev = _dev()
     B = 8
     learners, batches = [], []
     for _ in range(2):
@@ -268,7 +274,7 @@ def test_out_of_band_target_writes_are_seen(monkeypatch):
     monkeypatch.setenv("REFIL_EARLY_TARGET", "1")
     W = dict(bench.CONFIGS["cfg2"])
     dims = bench.workload_dims(W)
-    dev = torch.device("cuda", 0)
+    dev = _dev()
     _, b1, la, _, _ = bench.build(dims, W["imagine"], 8, W["T"], seed=100, device=dev)
     _, b2, lb, _, _ = bench.build(dims, W["imagine"], 8, W["T"], seed=100, device=dev)
     la._check_flat(); lb._check_flat()

@@ -22,7 +22,7 @@ if [ $PART = all ] || [ $PART = ops ]; then
   { hdr "CPU tier incl. the emulator tests: python -m pytest tests -q -m 'not gpu'"; run tests -m "not gpu" --durations=8; } > $OUT/${TAG}_emu_cpu_tier.txt
 fi
 if [ $PART = all ] || [ $PART = learner ]; then
-  { hdr "REFIL_EMU_FULL=1 python -m pytest tests/test_emu_learner.py tests/test_emu_plugin.py tests/test_emu_run_loop.py  (every learner-step test of the gpu tier below production size, the whole plugin suite, 40 iterations of the run loop)"; REFIL_EMU_FULL=1 run tests/test_emu_learner.py tests/test_emu_plugin.py tests/test_emu_run_loop.py --durations=8; } > $OUT/${TAG}_emu_learner_full.txt
+  { hdr "REFIL_EMU_FULL=1 python -m pytest tests/test_emu_learner.py tests/test_emu_plugin.py tests/test_emu_early.py tests/test_emu_run_loop.py  (every learner-step test of the gpu tier below production size, the whole plugin suite, 40 iterations of the run loop)"; REFIL_EMU_FULL=1 run tests/test_emu_learner.py tests/test_emu_plugin.py tests/test_emu_early.py tests/test_emu_run_loop.py --durations=8; } > $OUT/${TAG}_emu_learner_full.txt
 fi
 if [ $PART = all ] || [ $PART = production ]; then
   { hdr "tests/test_gpu_learner.py::test_production_size_step_matches_oracle on the emulator: every PRODUCTION case at full size vs the oracle"; run /tmp/test_emu_prod.py --rootdir=. --timeout 6000 --durations=0 -rA | grep -v "^PASSED"; } > $OUT/${TAG}_emu_production.txt
