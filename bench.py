@@ -218,7 +218,7 @@ def build(dims, imagine, B, T, seed, device, shard=None, dense=False, fresh=0, h
             if dense and k:
                 dk = densify(dk)
             buffer.insert_episode_batch(episode_batch(dk))
-    if device.type == "cuda" or getattr(torch.cuda.Event, "cuda_event", None) is not None:      # (or tests/emu_util's stand-in event)
+    if device.type == "cuda" or torch.cuda.Event.__name__ == "_HostEvent":      # (or tests/emu_util's stand-in event)
         batch.ready_event = torch.cuda.Event()             # the batch is complete here: lets train() run its prologue early
         batch.ready_event.record()
     learner._bench_episode_batch = episode_batch           # (bench.py's second, densified timed region builds its batch with it)
