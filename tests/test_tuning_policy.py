@@ -100,3 +100,28 @@ def test_bench_useful_fraction_of_the_fused_attention_launch():
     u = bench.qkv_useful_fraction(r05, ne, na)
     assert 0.5 < u < 0.75
     assert bench.qkv_useful_fraction(dict(live_steps=live, entity_rows_agent=0, entity_rows_hyper=0, agent_rows=0), ne, na) == 0.0
+
+
+def test_autotune_cache_round_trip_and_rejection(monkeypatch, tmp_path):
+    """REFIL_AUTOTUNE_CACHE: a measured setting is kept per (device, library version, shape bucket) and reused by later processes; an entry with a
+    value outside the parity-tested set (an old file, a hand edit) is ignored, as is an unreadable file -- the caller then measures again."""
+    import json
+    path = tmp_path / "tune.json"
+    monkeypatch.setenv("REFIL_AUTOTUNE_CACHE", str(path))
+    k1, k2 = tuning.bucket_key(_dims(32, 81)), tuning.bucket_key(_dims(32, 81, ne=16))
+    assert tuning.cache_get(k1) is None                               # no file yet
+    tuning.cache_put(k1, {"dw4_target": 96, "gru_pd": 2})
+    tuning.cache_put(k2, {})
+    assert tuning.cache_get(k1) == {"dw4_target": 96, "gru_pd": 2} and tuning.cache_get(k2) == {}
+    assert tuning.cache_get(tuning.bucket_key(_dims(64, 81))) is None    # another bucket: not measured yet
+    d = json.load(open(path))
+    d[next(k for k in d if d[k])]["dw4_target"] = 112                 # a value without parity coverage
+    json.dump(d, open(path, "w"))
+    assert tuning.cache_get(k1) is None
+    path.write_text("{ not json")
+    assert tuning.cache_get(k1) is None
+    tuning.cache_put(k1, {"gru_pd": 2})                               # an unreadable file is replaced, not fatal
+    assert tuning.cache_get(k1) == {"gru_pd": 2}
+    monkeypatch.delenv("REFIL_AUTOTUNE_CACHE")
+    tuning.cache_put(k1, {"gru_pd": 4})                               # no cache configured: nothing written, nothing read
+    assert tuning.cache_get(k1) is None
