@@ -42,13 +42,19 @@ def assert_grads_close(got, ref, scale, what=""):
     if not ref:
         return
     gmax = max(v.abs().max().item() for v in ref.values())
+    nmax = max(v.double().norm().item() for v in ref.values())
     for k, r in ref.items():
         g = got[k].double() * scale
         r = r.double()
         assert (g - r).abs().max().item() < TOL_GRAD * gmax, f"{what}{k}: max-abs"
         rn = r.norm().item()
+        # Per tensor: relative l2 error, plus the fp32 noise floor of the STEP's scale (2e-7 of the largest tensor's norm). A tensor whose whole
+        # gradient sits at that floor is rounding noise in the reference as well -- e.g. the hypernet behind a softmax over ONE agent:
+        # identically 1, its gradient exactly zero in exact arithmetic, 5.5e-7 in torch's fp32 against 1e-2 elsewhere (fuzz seed 515151,
+        # ne11 na1) -- and a relative error of noise against noise says nothing. For every other tensor the floor adds < 2e-4 to the bar.
         if rn > 1e-7:
-            assert (g - r).norm().item() / rn < TOL_GRAD_TENSOR, f"{what}{k}: relative l2 error {(g - r).norm().item() / rn:.2e} (|ref| {rn:.2e})"
+            err = (g - r).norm().item()
+            assert err <= TOL_GRAD_TENSOR * rn + 2e-7 * nmax, f"{what}{k}: relative l2 error {err / rn:.2e} (|ref| {rn:.2e}, largest tensor {nmax:.2e})"
         else:
             assert g.norm().item() < 1e-6, f"{what}{k}: reference gradient is zero, got norm {g.norm().item():.2e}"
 
