@@ -233,6 +233,7 @@ void run_block(Block& b) {
         }
     }
     long idle_spins = 0;
+    time_t spin_t0 = 0;
     while (b.alive > 0) {
         bool progressed = false, spinning = false;
         for (size_t oi = 0; oi < n; ++oi) {
@@ -256,7 +257,18 @@ void run_block(Block& b) {
         }
         if (progressed) { idle_spins = 0; continue; }
         if (b.alive == 0) break;
-        if (spinning && ++idle_spins < 2000000) { sched_yield(); continue; }
+        if (spinning) {
+            // a lane waits for ANOTHER workgroup (an OS thread that may be descheduled for a while on a loaded host): that is not a deadlock
+            // of this workgroup, and nothing here may be released on its account. Only a wall-clock limit ends it (EMU_SPIN_TIMEOUT_S, 900).
+            static const int limit_s = env_int("EMU_SPIN_TIMEOUT_S", 900);
+            if (idle_spins++ == 0) spin_t0 = time(nullptr);
+            if ((idle_spins & 0xFFF) == 0 && time(nullptr) - spin_t0 > limit_s) {
+                fprintf(stderr, "emu: kernel %s, workgroup %u: spin-wait on another workgroup for more than %d s\n", b.name, b.ids.bid.x, limit_s);
+                abort();
+            }
+            if (idle_spins > 64) { timespec ts{0, 50000}; nanosleep(&ts, nullptr); } else sched_yield();
+            continue;
+        }
         // nobody can run: a collective reached by part of a wave completes among the lanes that are there
         bool released = false;
         for (Wave& w : b.waves)
